@@ -1,0 +1,231 @@
+/*
+ * windgym_hip.h — C ABI of libwindgym_hip.so: the batched, MI355X-resident WindGym step() transition.
+ *
+ * What this boundary replaces in the reference (DTUWindEnergy/WindGym @ 2025-04-18):
+ *   - the duck-typed flow-simulation object `fs` / `fs_baseline` (external DYNAMIKS DWMFlowSimulation;
+ *     every call site is listed in SURVEY.md Appendix A: WindGym/Wind_Farm_Env.py:702-711, 734, 745,
+ *     770-782, 793, 945, 953; rotor_avg_windspeed :485-490; power() :495, :539-540),
+ *   - the sensor model `farm_mes` (WindGym/MesClass.py:354-703),
+ *   - the baseline yaw controllers (WindGym/BasicControllers/BasicControllers.py:10-73),
+ *   - and the body of WindFarmEnv.reset()/step() that strings them together
+ *     (WindGym/Wind_Farm_Env.py:680-802, 920-1034),
+ * for a batch of `n_envs` independent farms at once.  One handle == one GPU == one shard of the env axis.
+ *
+ * Conventions
+ *   - every entry point returns 0 on success or a negative wg_status; wg_last_error() gives the message
+ *     of the last failure on the calling thread.  No C++ exception crosses the boundary.
+ *   - all `*_dev` pointers are DEVICE pointers owned by the caller (PyTorch tensors' data_ptr());
+ *     the library owns only the state it allocates in wg_create(); nothing is allocated on the step path.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls on one handle must be
+ *     stream-ordered by the caller; a handle is not thread-safe; different handles are independent.
+ *   - floating point state on the device is fp32; configuration scalars are passed as double.
+ *
+ * The physics is "model M0" (DESIGN.md §2): DYNAMIKS itself is not available to this build
+ * (SURVEY.md §0.2-0.4), so parity for the flow values is against oracle/ (a CPU restatement of M0),
+ * while the glue semantics are pinned by golden vectors recorded from the reference's own code
+ * (tests/golden/).
+ */
+#ifndef WINDGYM_HIP_H
+#define WINDGYM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WG_ABI_VERSION 1
+
+typedef enum wg_status {
+    WG_OK = 0,
+    WG_ERR_INVALID = -1,      /* bad argument / inconsistent config (reference: ValueError)          */
+    WG_ERR_UNSUPPORTED = -2,  /* reference: NotImplementedError (ActionMethod "absolute", Track_power)*/
+    WG_ERR_HIP = -3,          /* a HIP runtime call failed                                            */
+    WG_ERR_NAN_POWER = -4,    /* reference: Exception("NaN Power"), Wind_Farm_Env.py:980-981           */
+    WG_ERR_STATE = -5,        /* step() on a truncated env without autoreset (reference tears fs down)*/
+    WG_ERR_NOMEM = -6
+} wg_status;
+
+/* sensor channels, order fixed by MesClass.turb_mes.get_measurements (MesClass.py:328-351) */
+enum { WG_CH_WS = 0, WG_CH_WD = 1, WG_CH_YAW = 2, WG_CH_POWER = 3, WG_N_CH = 4 };
+
+/* one `Mes` (MesClass.py:23-125) */
+typedef struct wg_channel {
+    int32_t current;       /* *_current        */
+    int32_t rolling_mean;  /* *_rolling_mean   */
+    int32_t history_n;     /* *_history_N      */
+    int32_t history_len;   /* *_history_length (deque maxlen) */
+    int32_t window_len;    /* *_window_length  */
+} wg_channel;
+
+enum { WG_ACT_YAW = 0, WG_ACT_WIND = 1 };                 /* ActionMethod, Wind_Farm_Env.py:822-864 */
+enum { WG_CTRL_LOCAL = 0, WG_CTRL_GLOBAL = 1 };           /* BaseController, BasicControllers.py    */
+enum { WG_YAWINIT_ZEROS = 0, WG_YAWINIT_RANDOM = 1, WG_YAWINIT_DEFINED = 2 }; /* :146-162, WindEnv.py */
+enum { WG_REW_BASELINE = 0, WG_REW_POWER_AVG = 1, WG_REW_NONE = 2, WG_REW_POWER_DIFF = 3 }; /* :172-194 */
+enum { WG_PEN_CHANGE = 0, WG_PEN_TOTAL = 1 };             /* _action_penalty, :804-820              */
+enum { WG_NOISE_NONE = 0, WG_NOISE_NORMAL = 1 };          /* farm_mes noise, MesClass.py:436-444    */
+enum { WG_TURB_NONE = 0, WG_TURB_RANDOM = 1, WG_TURB_BOX = 2 }; /* turbtype, :598-668               */
+
+typedef struct wg_config {
+    int32_t abi_version;       /* must be WG_ABI_VERSION */
+    /* ---- batch / discretisation ------------------------------------------------------------ */
+    int32_t n_envs;            /* B: farms simulated by this handle                                   */
+    int32_t n_turb;            /* N = nx*ny (Wind_Farm_Env.py:139)                                    */
+    int32_t n_farms;           /* F: 1, or 2 when Baseline_comp (agent farm + baseline farm, :217-220)*/
+    int32_t k_sub;             /* sim_steps_per_env_step = int(dt_env/dt_sim) (:105)                  */
+    int32_t n_particles;       /* P: wake-particle ring slots per turbine                             */
+    int32_t n_rotor_pts;       /* S: rotor quadrature points                                          */
+    double dt_sim;             /* s (:102)                                                            */
+    double rotor_diameter;     /* D, turbine.diameter() (:244)                                        */
+    double hub_height;         /* turbine.hub_height()                                                */
+    double d_particle;         /* particle spacing in D; reference hard-codes 0.2 (:116)              */
+    const double* x_pos;       /* [N] layout frame (east),  Wind_Farm_Env.py:246-252                  */
+    const double* y_pos;       /* [N] layout frame (north)                                            */
+    const double* rotor_dy;    /* [S] quadrature offsets in the rotor plane, metres                   */
+    const double* rotor_dz;    /* [S]                                                                 */
+    /* ---- turbine power / Ct table (py_wake tabular turbine; linear interpolation) ------------ */
+    int32_t n_tab;
+    const double* tab_ws;      /* [n_tab] ascending                                                   */
+    const double* tab_power;   /* [n_tab] W                                                           */
+    const double* tab_ct;      /* [n_tab]                                                             */
+    /* ---- yaw actuation ----------------------------------------------------------------------- */
+    double yaw_min, yaw_max;   /* deg (farm.yaw_min / yaw_max)                                        */
+    double yaw_step;           /* deg per sim step (:114)                                             */
+    double yaw_start;          /* 15 deg: range of yaw_init "Random" (:110, :715-720)                 */
+    int32_t action_method;     /* WG_ACT_*                                                            */
+    int32_t base_controller;   /* WG_CTRL_*                                                           */
+    int32_t yaw_init;          /* WG_YAWINIT_*                                                        */
+    const double* yaw_defined; /* [N] or NULL; used with WG_YAWINIT_DEFINED (FarmEval.set_yaw_vals)   */
+    /* ---- wind-condition sampling at reset (_set_windconditions, :557-568) --------------------- */
+    double ws_min, ws_max, ti_min, ti_max, wd_min, wd_max;
+    double n_passthrough;      /* time_max = int(t_inflow * n_passthrough) (:732)                     */
+    int32_t never_truncate;    /* FarmEval.reset: time_max = 9999999 (FarmEval.py:54-61)              */
+    /* ---- sensors (farm_mes ctor, :409-451) ---------------------------------------------------- */
+    wg_channel ch[WG_N_CH];
+    int32_t turb_ws, turb_wd, turb_ti, turb_power, farm_ws, farm_wd, farm_ti, farm_power; /* mes_level */
+    double ws_scale_min, ws_scale_max;     /* 2, 25 (:440-441)                                         */
+    double wd_scale_min, wd_scale_max;     /* wd_min-5, wd_max+5 (:443-444)                            */
+    double ti_scale_min, ti_scale_max;     /* TI_min_mes, TI_max_mes                                   */
+    double power_max;                      /* maxturbpower (:112)                                      */
+    int32_t noise;                         /* WG_NOISE_*                                               */
+    double noise_sigma[WG_N_CH];           /* 0, 2, 0, 0 (MesClass.py:436-439)                         */
+    /* ---- reward (:866-918, :989-996) ----------------------------------------------------------- */
+    int32_t reward_mode;       /* WG_REW_*                                                            */
+    int32_t power_avg;         /* deque maxlen (:142-143)                                             */
+    double power_scaling;
+    double action_penalty;
+    int32_t penalty_type;      /* WG_PEN_*                                                            */
+    /* ---- reset (:722-796) ----------------------------------------------------------------------- */
+    int32_t fill_steps_agent;  /* steps_on_reset (:229-240)                                           */
+    int32_t fill_steps_base;   /* hist_max (:784)                                                     */
+    int32_t autoreset;         /* 0: reference semantics (step after truncation is an error);         */
+                               /* 1: same-step autoreset from a pre-developed next episode            */
+    int32_t extra_timestep_inc;/* WindFarmEnvMulti.step increments timestep twice (WindEnvMulti.py:219)*/
+    /* ---- inflow --------------------------------------------------------------------------------- */
+    int32_t turb_mode;         /* WG_TURB_*                                                           */
+    /* ---- model M0 constants; 0 selects the documented default -------------------- */
+    double m0_ka, m0_kb;       /* k* = ka*TI + kb              (0.38, 0.004)                          */
+    double m0_eps;             /* sigma0/D = eps*sqrt(beta)    (0.2)                                  */
+    double m0_hill;            /* Hill-vortex deflection speed factor (0.4)                           */
+    double m0_ti_a, m0_ti_b, m0_ti_c, m0_ti_d; /* Crespo-Hernandez added TI: a*ind^b*TI^c*(x/D)^d     */
+    double m0_fc_scale;        /* meandering low-pass cut-off f_c = U/(fc_scale*D)   (2.0)            */
+} wg_config;
+
+typedef struct wg_env_s* wg_handle;
+
+/* which per-env quantity wg_get_info() copies out; names = keys of WindFarmEnv._get_info (:522-555) */
+typedef enum wg_info_field {
+    WG_INFO_YAW_AGENT = 0,        /* "yaw angles agent"            f32[B,N] */
+    WG_INFO_YAW_BASE = 1,         /* "yaw angles base"             f32[B,N] */
+    WG_INFO_WS_GLOBAL = 2,        /* "Wind speed Global"           f32[B]   */
+    WG_INFO_WD_GLOBAL = 3,        /* "Wind direction Global"       f32[B]   */
+    WG_INFO_TI_GLOBAL = 4,        /* "Turbulence intensity"        f32[B]   */
+    WG_INFO_WS_TURB = 5,          /* "Wind speed at turbines"      f32[B,N] */
+    WG_INFO_WD_TURB = 6,          /* "Wind direction at turbines"  f32[B,N] */
+    WG_INFO_POWER_TURB_AGENT = 7, /* "Power pr turbine agent"      f32[B,N] */
+    WG_INFO_POWER_TURB_BASE = 8,  /* "Power pr turbine baseline"   f32[B,N] */
+    WG_INFO_POWER_AGENT = 9,      /* "Power agent"                 f32[B]   */
+    WG_INFO_POWER_BASE = 10,      /* "Power baseline"              f32[B]   */
+    WG_INFO_WS_TURB_BASE = 11,    /* "Wind speed at turbines baseline" (u component) f32[B,N] */
+    WG_INFO_TURB_X = 12,          /* "Turbine x positions" (flow frame)  f32[B,N] */
+    WG_INFO_TURB_Y = 13,          /* "Turbine y positions"         f32[B,N] */
+    WG_INFO_TIMESTEP = 14,        /* env.timestep                  i32[B]   */
+    WG_INFO_TIME_MAX = 15,        /* env.time_max                  i32[B]   */
+    WG_INFO_FS_TIME = 16,         /* fs.time                       f32[B]   */
+    WG_INFO_EPISODE = 17,         /* episodes completed so far     i32[B]   */
+    WG_INFO_ROTOR_UVW_AGENT = 18, /* fs.windTurbines.rotor_avg_windspeed  f32[B,N,3] */
+    WG_INFO_ROTOR_UVW_BASE = 19,  /* fs_baseline ...                      f32[B,N,3] */
+    WG_INFO_RATED_POWER = 20      /* turbine.power(ws) (:700)      f32[B]   */
+} wg_info_field;
+
+/* number of floats of the episode-metric vector produced by wg_metrics (the all-reduce payload;
+ * distributed form of wrappers/recordEpisodeVals.py:31-64 and of the WindFarmMonitor callback) */
+#define WG_N_METRICS 8
+enum {
+    WG_MET_EP_RETURN_SUM = 0, WG_MET_EP_LENGTH_SUM = 1, WG_MET_EP_MEAN_POWER_SUM = 2, WG_MET_N_EPISODES = 3,
+    WG_MET_STEP_REWARD_SUM = 4, WG_MET_FARM_POWER_SUM = 5, WG_MET_BASE_POWER_SUM = 6, WG_MET_N_STEPS = 7
+};
+
+const char* wg_last_error(void);
+int wg_abi_version(void);
+
+/* Build a batch of farms on HIP device `device`.  Host arrays referenced by cfg are copied.            */
+int wg_create(const wg_config* cfg, int device, wg_handle* out);
+int wg_destroy(wg_handle h);
+
+/* Sizes derived from the config: observation length O (farm_mes.observed_variables, MesClass.py:610-618)
+ * and the per-agent observation length of the PettingZoo facade as actually produced by
+ * WindFarmEnvMulti._get_obs_multi (WindEnvMulti.py:79-103).                                          */
+int wg_obs_dim(wg_handle h, int* obs_dim, int* obs_dim_multi);
+int wg_hist_max(wg_handle h, int* hist_max);
+
+/* Optional shared frozen-turbulence box (borrowed device memory; caller keeps it alive).
+ * comps: 3 (u,v,w) planes of nx*ny*nz fp32, unit variance; spacing in metres.  Used when turb_mode==BOX. */
+int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, int ny, int nz,
+                          double dx, double dy, double dz);
+
+/* Test hook ("replay mode"): replace the flow physics of both farms by scripted tables so that the glue can
+ * be checked against golden vectors recorded from the reference.  uvw_dev: f32[F,T,B,N,3], power_dev:
+ * f32[F,T,B,N]; every flow sub-step of farm f in env b consumes row cursor[f,b]++ .  NULL disables.     */
+int wg_set_flow_script(wg_handle h, const float* uvw_dev, const float* power_dev, int n_rows);
+
+/* reset(): WindFarmEnv.reset (:680-802) for the envs whose mask byte is non-zero (NULL = all).
+ * seeds: host array [B] of uint64 or NULL.  seeds[b] == UINT64_MAX keeps env b's generator running
+ * (gymnasium reset(seed=None)); otherwise the env's PCG64 generator is re-seeded exactly like
+ * gymnasium's np_random (np.random.default_rng(seed)).  Outputs may be NULL.                            */
+int wg_reset(wg_handle h, const uint8_t* env_mask_host, const uint64_t* seeds_host,
+             float* obs_dev /*[B,O]*/, void* stream);
+
+/* step(): WindFarmEnv.step (:920-1034) for all envs.  actions_dev f32[B,N] in [-1,1].
+ * obs_dev f32[B,O] (after autoreset: first observation of the next episode), reward_dev f32[B],
+ * truncated_dev u8[B]; final_obs_dev f32[B,O] or NULL receives the last observation of the episode that
+ * ended (== obs for envs that did not truncate).  Asynchronous on `stream`.                            */
+int wg_step(wg_handle h, const float* actions_dev, float* obs_dev, float* reward_dev,
+            uint8_t* truncated_dev, float* final_obs_dev, void* stream);
+
+/* Per-agent observations of the PettingZoo facade for the current state: f32[B,N,obs_dim_multi].      */
+int wg_obs_multi(wg_handle h, float* obs_dev, void* stream);
+
+/* Lazy info dict: copy one field to out_dev (dtype/shape per wg_info_field).                           */
+int wg_get_info(wg_handle h, wg_info_field field, void* out_dev, void* stream);
+
+/* Episode-metric partial sums of this shard since the last call with reset_after != 0: f32[WG_N_METRICS]
+ * in device memory (ready for one RCCL all-reduce(sum)).                                              */
+int wg_metrics(wg_handle h, float* out_dev, int reset_after, void* stream);
+
+/* Checkpoint / golden replay: serialise the full device state.  Call with blob_host == NULL to get size. */
+int wg_get_state(wg_handle h, void* blob_host, size_t* size);
+int wg_set_state(wg_handle h, const void* blob_host, size_t size);
+
+/* HIP-event timing of the step kernels on the stream they were launched on: average milliseconds per
+ * launch of the dominant flow kernel and of the glue kernel since the last call (used by bench.py).    */
+int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, double* glue_ms_avg, int* n_launches);
+
+/* Algorithmic HBM bytes one wg_step() moves (the figure bench.py's roofline uses).       */
+int wg_algorithmic_bytes(wg_handle h, double* bytes_per_step);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WINDGYM_HIP_H */

@@ -1,0 +1,168 @@
+"""ORACLE / TEST INFRASTRUCTURE — ctypes binding of oracle/liboracle.so (see wg_oracle.c header).
+
+Only tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline`` leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+UINT64_MAX = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def build(force=False):
+    """Compile the C restatement (gcc; seconds)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("wg_oracle.c", "rng_api.c", "pcg64.h", "philox.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "windgym_hip.h"))
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+    return _LIB
+
+
+_dp = C.POINTER(C.c_double)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Oracle:
+    """Batched CPU env with the reference's semantics; ``precision`` 'f64' (default) or 'f32'."""
+
+    def __init__(self, cfg, precision="f64"):
+        self.cfg = cfg
+        self._c = cfg.to_c()
+        L = lib()
+        pre = "wgo_" if precision == "f64" else "wgof_"
+        self._f = {n: getattr(L, pre + n) for n in (
+            "create", "destroy", "obs_dim", "hist_max", "set_flow_script", "set_turbulence_box", "reset",
+            "step", "obs_multi", "get_obs", "get_info", "metrics", "get_chain", "set_threads", "max_threads")}
+        self._f["create"].restype = C.c_void_p
+        self._f["create"].argtypes = [C.c_void_p]
+        self._h = C.c_void_p(self._f["create"](C.byref(self._c)))
+        if not self._h:
+            raise RuntimeError("oracle create failed")
+        o, om = C.c_int(), C.c_int()
+        self._f["obs_dim"](self._h, C.byref(o), C.byref(om))
+        self.obs_dim, self.obs_dim_multi = o.value, om.value
+        self.B, self.N = cfg.n_envs, cfg.n_turb
+        self._script = None
+        self._box = None
+
+    def close(self):
+        if self._h:
+            self._f["destroy"](self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_threads(self, n):
+        self._f["set_threads"](C.c_int(n))
+
+    def max_threads(self):
+        return int(self._f["max_threads"]())
+
+    def set_flow_script(self, uvw, power):
+        """uvw [F,T,B,N,3], power [F,T,B,N] (float64)."""
+        if uvw is None:
+            self._f["set_flow_script"](self._h, None, None, C.c_long(0))
+            self._script = None
+            return
+        uvw = np.ascontiguousarray(uvw, dtype=np.float64)
+        power = np.ascontiguousarray(power, dtype=np.float64)
+        self._script = (uvw, power)
+        self._f["set_flow_script"](self._h, _d(uvw), _d(power), C.c_long(uvw.shape[1]))
+
+    def set_turbulence_box(self, box, spacing):
+        box = np.ascontiguousarray(box, dtype=np.float32)
+        assert box.ndim == 4 and box.shape[0] == 3
+        self._box = box
+        self._f["set_turbulence_box"](self._h, box.ctypes.data_as(C.c_void_p), C.c_int(box.shape[1]),
+                                      C.c_int(box.shape[2]), C.c_int(box.shape[3]), C.c_double(spacing[0]),
+                                      C.c_double(spacing[1]), C.c_double(spacing[2]))
+
+    def reset(self, seeds=None, mask=None):
+        obs = np.zeros((self.B, self.obs_dim))
+        sp = None
+        if seeds is not None:
+            s = np.ascontiguousarray(seeds, dtype=np.uint64)
+            sp = s.ctypes.data_as(C.c_void_p)
+        mp = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            mp = m.ctypes.data_as(C.c_void_p)
+        rc = self._f["reset"](self._h, mp, sp, _d(obs))
+        if rc:
+            raise RuntimeError(f"oracle reset rc={rc}")
+        return obs
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.B, self.N)
+        obs = np.zeros((self.B, self.obs_dim))
+        fin = np.zeros((self.B, self.obs_dim))
+        rew = np.zeros(self.B)
+        tr = np.zeros(self.B, dtype=np.uint8)
+        rc = self._f["step"](self._h, _d(a), _d(obs), _d(rew), tr.ctypes.data_as(C.c_void_p), _d(fin))
+        if rc == -5:
+            raise RuntimeError("step() on a truncated env without reset")
+        if rc == -4:
+            raise Exception("NaN Power")
+        return obs, rew, tr.astype(bool), fin
+
+    def get_obs(self):
+        obs = np.zeros((self.B, self.obs_dim))
+        self._f["get_obs"](self._h, _d(obs))
+        return obs
+
+    def obs_multi(self):
+        obs = np.zeros((self.B, self.N, self.obs_dim_multi))
+        self._f["obs_multi"](self._h, _d(obs))
+        return obs
+
+    def info(self, name):
+        from windgym_amd.config import INFO
+        f = INFO[name]
+        per_turb = name in ("yaw_agent", "yaw_base", "ws_turb", "wd_turb", "power_turb_agent",
+                            "power_turb_base", "ws_turb_base", "turb_x", "turb_y")
+        if name.startswith("rotor_uvw"):
+            out = np.zeros((self.B, self.N, 3))
+        elif per_turb:
+            out = np.zeros((self.B, self.N))
+        else:
+            out = np.zeros(self.B)
+        rc = self._f["get_info"](self._h, C.c_int(f), _d(out))
+        assert rc == 0
+        return out
+
+    def metrics(self, reset_after=False):
+        out = np.zeros(8)
+        self._f["metrics"](self._h, _d(out), C.c_int(int(reset_after)))
+        return out
+
+    def chain(self, b, farm, t):
+        P = self.cfg.n_particles
+        py, ue, ct = np.zeros(P), np.zeros(P), np.zeros(P)
+        s = C.c_double()
+        n = self._f["get_chain"](self._h, C.c_int(b), C.c_int(farm), C.c_int(t), _d(py), _d(ue), _d(ct),
+                                 C.byref(s))
+        return py[:n], ue[:n], ct[:n], s.value
