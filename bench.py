@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the batched WindGym step() on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = one batched step() over all envs of this rank (actions already resident in HBM).  Prints ONE
+JSON line on rank 0 with `value` = whole-job env-steps/s, `roofline` for the dominant kernel (k_flow) and
+`cpu_baseline` (the oracle's C port timed on the host cores, rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def make_cfg(n_envs, autoreset=True, farms2=True):
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.presets import bench_cfg2_config
+    from windgym_amd.turbine import V80
+    d = bench_cfg2_config()
+    if not farms2:
+        d["power_def"]["Power_reward"] = "Power_avg"
+    return EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_envs=n_envs, autoreset=autoreset,
+                     n_passthrough=5, n_rotor_pts=16)
+
+
+def cpu_baseline(args):
+    """The oracle's C port (OpenMP over envs) on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import oracle as om
+    om.build()
+    n = args.cpu_envs
+    cfg = make_cfg(n, autoreset=True, farms2=not args.one_farm)
+    orc = om.Oracle(cfg, "f32" if args.cpu_f32 else "f64")
+    cores = orc.max_threads()
+    orc.reset(seeds=1234 + np.arange(n))
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, size=(8, n, cfg.n_turb)).astype(np.float32)
+    for i in range(3):
+        orc.step(acts[i % 8])
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        orc.step(acts[steps % 8])
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > args.cpu_seconds or steps >= args.cpu_max_steps:
+            break
+    return {"value": n * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} envs x {steps} steps of the same 4x4 workload (oracle C port, "
+                      f"{'fp32' if args.cpu_f32 else 'fp64'}, OpenMP over envs, after reset)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (weak scaling)")
+    ap.add_argument("--one-farm", action="store_true", help="F=1 (no baseline farm)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-envs", type=int, default=64)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-max-steps", type=int, default=400)
+    ap.add_argument("--cpu-f32", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from windgym_amd import binding
+    from windgym_amd.parallel import ShardedMetrics
+    B = args.envs
+    cfg = make_cfg(B, autoreset=True, farms2=not args.one_farm)
+    env = binding.HipBatch(cfg, device=dev.index)
+    # env i of the global batch is seeded 1234 + i regardless of the number of GPUs
+    seeds = 1234 + rank * B + np.arange(B)
+    env.reset(seeds=seeds)
+    gen = torch.Generator(device="cpu").manual_seed(0 + rank)
+    n_act = 16
+    actions = (torch.rand((n_act, B, cfg.n_turb), generator=gen) * 2 - 1).to(dev).contiguous()
+    metrics = ShardedMetrics(env)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        env.step(actions[i % n_act])
+    env.check()
+    env.kernel_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        env.step(actions[i % n_act])
+    barrier()
+    el = time.perf_counter() - t0
+    flow_ms, glue_ms, n_launch = env.kernel_timing(False)
+    env.check()
+    m = metrics.all_reduce()            # the only collective on the path: 8 floats
+
+    t = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el_max = float(t.item())
+    total_envs = B * world
+    value = total_envs * args.steps / el_max
+
+    if rank == 0:
+        F = cfg.to_c().n_farms
+        alg_bytes_flow = B * F * (cfg.n_turb * cfg.n_particles * 24.0 + cfg.n_turb * 72.0)
+        achieved = alg_bytes_flow / (flow_ms * 1e-3) / 1e9 if flow_ms > 0 else 0.0
+        out = {
+            "metric": "env-steps/sec (whole node), 16-turbine farm x 4096 envs",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg2: 4x4 16-turbine grid (V80, 5.33D pitch), yaw-only action, Env1 sensors "
+                                   f"(O={env.obs_dim}), {B} envs/GPU, F={F} farms/env "
+                                   f"({'Baseline reward' if F == 2 else 'Power_avg reward'}), P={cfg.n_particles}, "
+                                   f"S={cfg.n_rotor_pts}, inflow None, same-step autoreset on",
+                       "envs_per_gpu": B, "n_turb": cfg.n_turb, "farms_per_env": F,
+                       "parallelism": f"env-axis shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None, "kernel": "k_flow",
+                         "kernel_ms": flow_ms, "glue_kernel_ms": glue_ms, "launches_timed": n_launch,
+                         "algorithmic_bytes_per_launch": alg_bytes_flow},
+            "episode_metrics": {k: float(v) for k, v in m.items()},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -204,6 +204,11 @@ int wg_reset(wg_handle h, const uint8_t* env_mask_host, const uint64_t* seeds_ho
 int wg_step(wg_handle h, const float* actions_dev, float* obs_dev, float* reward_dev,
             uint8_t* truncated_dev, float* final_obs_dev, void* stream);
 
+/* step() is asynchronous, so the errors the reference raises inside step() (Exception("NaN Power"), stepping
+ * a torn-down env) are latched in a sticky device word.  wg_check synchronises `stream` and returns it
+ * (0, WG_ERR_NAN_POWER or WG_ERR_STATE); wg_reset clears it.                                           */
+int wg_check(wg_handle h, void* stream);
+
 /* Per-agent observations of the PettingZoo facade for the current state: f32[B,N,obs_dim_multi].      */
 int wg_obs_multi(wg_handle h, float* obs_dev, void* stream);
 

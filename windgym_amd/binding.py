@@ -1,0 +1,212 @@
+"""ctypes binding of libwindgym_hip.so (C ABI in include/windgym_hip.h) on PyTorch-ROCm tensors.
+
+PyTorch is plumbing here: it owns the I/O device buffers and the HIP stream; all compute happens in the
+hand-written kernels behind the C ABI.  There is NO CPU fallback: constructing a :class:`HipBatch` without
+the built library or without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .config import INFO, INFO_INT, WG_N_METRICS, CConfig, EnvConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwindgym_hip.so")
+UINT64_MAX = 0xFFFFFFFFFFFFFFFF
+
+# every symbol include/windgym_hip.h declares (tests check the built library exports all of them)
+ABI_SYMBOLS = (
+    "wg_last_error", "wg_abi_version", "wg_create", "wg_destroy", "wg_obs_dim", "wg_hist_max",
+    "wg_set_turbulence_box", "wg_set_flow_script", "wg_reset", "wg_step", "wg_check", "wg_obs_multi",
+    "wg_get_info", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_algorithmic_bytes",
+)
+
+_lib = None
+
+
+class WindGymHipError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Load libwindgym_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WindGymHipError(
+            f"{LIB_PATH} is missing: build it with `python -m windgym_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the step() path.")
+    L = C.CDLL(LIB_PATH)
+    L.wg_last_error.restype = C.c_char_p
+    L.wg_create.argtypes = [C.POINTER(CConfig), C.c_int, C.POINTER(C.c_void_p)]
+    L.wg_destroy.argtypes = [C.c_void_p]
+    L.wg_obs_dim.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.wg_hist_max.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.wg_set_turbulence_box.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                        C.c_double, C.c_double]
+    L.wg_set_flow_script.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.wg_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.wg_step.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    L.wg_check.argtypes = [C.c_void_p, C.c_void_p]
+    L.wg_obs_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.wg_get_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.wg_metrics.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.wg_get_state.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
+    L.wg_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.wg_kernel_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_int)]
+    L.wg_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+def _chk(rc, what):
+    if rc != 0:
+        msg = load_library().wg_last_error().decode(errors="replace")
+        if rc == -4:
+            raise Exception("NaN Power")                       # Wind_Farm_Env.py:980-981
+        if rc == -2:
+            raise NotImplementedError(msg)
+        if rc == -1:
+            raise ValueError(msg)
+        raise WindGymHipError(f"{what} failed (rc={rc}): {msg}")
+
+
+class HipBatch:
+    """A batch of ``cfg.n_envs`` farms resident on one MI355X."""
+
+    def __init__(self, cfg: EnvConfig, device: int | None = None):
+        import torch
+        if not torch.cuda.is_available():
+            raise WindGymHipError("no HIP device visible: the step() path only runs on the GPU "
+                                  "(no CPU fallback; the CPU restatement under oracle/ is test-only)")
+        self.torch = torch
+        self.L = load_library()
+        self.cfg = cfg
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self._c = cfg.to_c()
+        h = C.c_void_p()
+        _chk(self.L.wg_create(C.byref(self._c), self.device_index, C.byref(h)), "wg_create")
+        self._h = h
+        o, om = C.c_int(), C.c_int()
+        self.L.wg_obs_dim(self._h, C.byref(o), C.byref(om))
+        self.obs_dim, self.obs_dim_multi = o.value, om.value
+        self.B, self.N = cfg.n_envs, cfg.n_turb
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.obs = torch.zeros((self.B, self.obs_dim), **f32)
+        self.final_obs = torch.zeros((self.B, self.obs_dim), **f32)
+        self.reward = torch.zeros(self.B, **f32)
+        self.truncated = torch.zeros(self.B, dtype=torch.uint8, device=self.device)
+        self._metrics = torch.zeros(WG_N_METRICS, **f32)
+        self._script = None
+        self._box = None
+
+    # -- lifetime -----------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.wg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- API ----------------------------------------------------------------------------------------
+    def reset(self, seeds=None, mask=None):
+        sp = mp = None
+        if seeds is not None:
+            s = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64).reshape(self.B))
+            sp = s.ctypes.data_as(C.c_void_p)
+        if mask is not None:
+            m = np.ascontiguousarray(np.asarray(mask, dtype=np.uint8).reshape(self.B))
+            mp = m.ctypes.data_as(C.c_void_p)
+        _chk(self.L.wg_reset(self._h, mp, sp, C.c_void_p(self.obs.data_ptr()), self._stream()), "wg_reset")
+        return self.obs
+
+    def step(self, actions):
+        """actions: float32 CUDA tensor [B, N].  Returns views of the persistent output tensors."""
+        assert actions.is_cuda and actions.dtype == self.torch.float32 and actions.is_contiguous()
+        _chk(self.L.wg_step(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(self.obs.data_ptr()),
+                            C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.truncated.data_ptr()),
+                            C.c_void_p(self.final_obs.data_ptr()), self._stream()), "wg_step")
+        return self.obs, self.reward, self.truncated, self.final_obs
+
+    def check(self):
+        _chk(self.L.wg_check(self._h, self._stream()), "wg_check")
+
+    def obs_multi(self):
+        out = self.torch.zeros((self.B, self.N, self.obs_dim_multi), dtype=self.torch.float32, device=self.device)
+        _chk(self.L.wg_obs_multi(self._h, C.c_void_p(out.data_ptr()), self._stream()), "wg_obs_multi")
+        return out
+
+    def info(self, name):
+        t = self.torch
+        per_turb = name in ("yaw_agent", "yaw_base", "ws_turb", "wd_turb", "power_turb_agent",
+                            "power_turb_base", "ws_turb_base", "turb_x", "turb_y")
+        if name.startswith("rotor_uvw"):
+            shape = (self.B, self.N, 3)
+        elif per_turb:
+            shape = (self.B, self.N)
+        else:
+            shape = (self.B,)
+        out = t.zeros(shape, dtype=t.int32 if name in INFO_INT else t.float32, device=self.device)
+        _chk(self.L.wg_get_info(self._h, INFO[name], C.c_void_p(out.data_ptr()), self._stream()), "wg_get_info")
+        return out
+
+    def metrics(self, reset_after=False):
+        _chk(self.L.wg_metrics(self._h, C.c_void_p(self._metrics.data_ptr()), int(reset_after), self._stream()),
+             "wg_metrics")
+        return self._metrics
+
+    def set_flow_script(self, uvw, power):
+        """Replay mode (test hook).  uvw [F,T,B,N,3], power [F,T,B,N] (array-likes)."""
+        t = self.torch
+        if uvw is None:
+            self._script = None
+            _chk(self.L.wg_set_flow_script(self._h, None, None, 0), "wg_set_flow_script")
+            return
+        u = t.as_tensor(np.ascontiguousarray(uvw, dtype=np.float32), device=self.device).contiguous()
+        p = t.as_tensor(np.ascontiguousarray(power, dtype=np.float32), device=self.device).contiguous()
+        self._script = (u, p)
+        _chk(self.L.wg_set_flow_script(self._h, C.c_void_p(u.data_ptr()), C.c_void_p(p.data_ptr()),
+                                       int(u.shape[1])), "wg_set_flow_script")
+
+    def set_turbulence_box(self, box, spacing):
+        t = self.torch
+        b = box if isinstance(box, t.Tensor) else t.as_tensor(np.ascontiguousarray(box, dtype=np.float32))
+        b = b.to(self.device, dtype=t.float32).contiguous()
+        assert b.ndim == 4 and b.shape[0] == 3
+        self._box = b
+        _chk(self.L.wg_set_turbulence_box(self._h, C.c_void_p(b.data_ptr()), int(b.shape[1]), int(b.shape[2]),
+                                          int(b.shape[3]), float(spacing[0]), float(spacing[1]),
+                                          float(spacing[2])), "wg_set_turbulence_box")
+
+    def get_state(self) -> bytes:
+        n = C.c_size_t(0)
+        _chk(self.L.wg_get_state(self._h, None, C.byref(n)), "wg_get_state")
+        buf = (C.c_char * n.value)()
+        _chk(self.L.wg_get_state(self._h, buf, C.byref(n)), "wg_get_state")
+        return bytes(buf)
+
+    def set_state(self, blob: bytes):
+        _chk(self.L.wg_set_state(self._h, blob, len(blob)), "wg_set_state")
+
+    def kernel_timing(self, enable=True):
+        f, g, n = C.c_double(), C.c_double(), C.c_int()
+        _chk(self.L.wg_kernel_timing(self._h, int(enable), C.byref(f), C.byref(g), C.byref(n)), "wg_kernel_timing")
+        return f.value, g.value, n.value
+
+    def algorithmic_bytes(self):
+        v = C.c_double()
+        _chk(self.L.wg_algorithmic_bytes(self._h, C.byref(v)), "wg_algorithmic_bytes")
+        return v.value

@@ -1,0 +1,418 @@
+// wg_api.hip — host side of libwindgym_hip.so: the C ABI declared in include/windgym_hip.h.
+// Owns the device state (allocated once in wg_create; nothing is allocated on the step path) and launches
+// the kernels of wg_kernels.hip on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "wg_state.h"
+
+extern "C" {
+void wg_launch_flow(const WgParams*, const WgPtrs*, int, const float*, const uint8_t*, int, hipStream_t);
+void wg_launch_glue(const WgParams*, const WgPtrs*, int, const uint8_t*, float*, float*, uint8_t*, float*, hipStream_t);
+void wg_launch_init(const WgParams*, const WgPtrs*, const uint8_t*, const uint64_t*, hipStream_t);
+void wg_launch_create(const WgParams*, const WgPtrs*, hipStream_t);
+void wg_launch_obs_multi(const WgParams*, const WgPtrs*, float*, hipStream_t);
+void wg_launch_info(const WgParams*, const WgPtrs*, int, void*, hipStream_t);
+void wg_launch_metrics(const WgParams*, const WgPtrs*, float*, int, hipStream_t);
+}
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t _e = (x);                                                                        \
+        if (_e != hipSuccess)                                                                       \
+            return fail(WG_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e));                \
+    } while (0)
+
+struct Alloc {
+    void* ptr;
+    size_t bytes;
+};
+
+struct wg_env_s {
+    WgParams p;
+    WgPtrs d;
+    int device;
+    std::vector<Alloc> allocs;      // everything owned by the handle (state blob = allocs flagged `state`)
+    std::vector<size_t> state_idx;  // indices into allocs that make up the serialisable state
+    uint8_t* mask_dev = nullptr;
+    uint64_t* seeds_dev = nullptr;
+    int reset_launches = 0;         // upper bound of RESET-mode flow launches needed to develop any episode
+    int reset_chunk = 32;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;     // pairs (start, stop) around flow launches, then glue launches
+    std::vector<int> ev_kind;
+    size_t ev_used = 0;
+    double alg_bytes = 0;
+};
+
+template <typename T>
+static int dev_alloc(wg_env_s* h, T** out, size_t n, bool state, bool zero = true) {
+    size_t bytes = sizeof(T) * (n ? n : 1);
+    void* ptr = nullptr;
+    hipError_t e = hipMalloc(&ptr, bytes);
+    if (e != hipSuccess) return fail(WG_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (zero) {
+        e = hipMemset(ptr, 0, bytes);
+        if (e != hipSuccess) return fail(WG_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
+    }
+    h->allocs.push_back({ptr, bytes});
+    if (state) h->state_idx.push_back(h->allocs.size() - 1);
+    *out = (T*)ptr;
+    return 0;
+}
+template <typename T, typename S>
+static int dev_upload(wg_env_s* h, const T** out, const S* src, size_t n) {
+    std::vector<T> tmp(n ? n : 1);
+    for (size_t i = 0; i < n; ++i) tmp[i] = (T)src[i];
+    T* p = nullptr;
+    int rc = dev_alloc(h, &p, n, false, false);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(p, tmp.data(), sizeof(T) * (n ? n : 1), hipMemcpyHostToDevice));
+    *out = p;
+    return 0;
+}
+
+static double defd(double v, double dflt) { return v == 0.0 ? dflt : v; }
+
+static int ch_count(const wg_channel& c, int on) { return (c.current && on) + (c.rolling_mean && on) * c.history_n; }
+
+extern "C" const char* wg_last_error(void) { return g_err.c_str(); }
+extern "C" int wg_abi_version(void) { return WG_ABI_VERSION; }
+
+extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
+    if (!c || !out) return fail(WG_ERR_INVALID, "null argument");
+    if (c->abi_version != WG_ABI_VERSION) return fail(WG_ERR_INVALID, "abi_version mismatch");
+    if (c->n_envs < 1 || c->n_turb < 1) return fail(WG_ERR_INVALID, "n_envs and n_turb must be >= 1");
+    if (c->n_farms != 1 && c->n_farms != 2) return fail(WG_ERR_INVALID, "n_farms must be 1 or 2");
+    if (c->k_sub < 1) return fail(WG_ERR_INVALID, "dt_env must be a multiple of dt_sim");
+    if (c->n_particles < 8 || c->n_particles % 4) return fail(WG_ERR_INVALID, "n_particles must be a multiple of 4 (>= 8)");
+    if (c->n_rotor_pts < 1 || c->n_rotor_pts > 64) return fail(WG_ERR_INVALID, "n_rotor_pts must be in [1, 64]");
+    if (!c->x_pos || !c->y_pos || !c->rotor_dy || !c->rotor_dz || !c->tab_ws || !c->tab_power || !c->tab_ct || c->n_tab < 2)
+        return fail(WG_ERR_INVALID, "layout / rotor points / turbine table missing");
+    if (c->action_method != WG_ACT_YAW && c->action_method != WG_ACT_WIND)
+        return fail(WG_ERR_UNSUPPORTED, "The ActionMethod must be yaw or wind (absolute is not implemented)");
+    if (c->reward_mode < 0 || c->reward_mode > 3)
+        return fail(WG_ERR_INVALID, "The Power_reward must be either Baseline, Power_avg, None or Power_diff");
+    if (c->reward_mode == WG_REW_POWER_DIFF && c->power_avg < 40)
+        return fail(WG_ERR_INVALID, "The Power_avg must be larger then 40 for the Power_diff reward");
+    if (c->reward_mode == WG_REW_BASELINE && c->n_farms != 2)
+        return fail(WG_ERR_INVALID, "Baseline reward needs the baseline farm (n_farms = 2)");
+    if (c->power_avg < 1) return fail(WG_ERR_INVALID, "Power_avg must be >= 1");
+    if (c->turb_mode != WG_TURB_NONE) return fail(WG_ERR_UNSUPPORTED, "only turbtype \"None\" is implemented in this build");
+    for (int i = 0; i < WG_N_CH; ++i)
+        if (c->ch[i].history_len < 1 || c->ch[i].window_len < 1 || c->ch[i].history_n < 1)
+            return fail(WG_ERR_INVALID, "sensor history/window lengths must be >= 1");
+    HIPCHK(hipSetDevice(device));
+    wg_env_s* h = new wg_env_s();
+    h->device = device;
+    WgParams& p = h->p;
+    memset(&p, 0, sizeof(p));
+    p.B = c->n_envs; p.N = c->n_turb; p.F = c->n_farms; p.K = c->k_sub; p.P = c->n_particles; p.S = c->n_rotor_pts;
+    p.NP = p.N * p.P;
+    p.dt = (float)c->dt_sim; p.dt_d = c->dt_sim;
+    p.D = (float)c->rotor_diameter; p.D_d = c->rotor_diameter; p.inv_D = 1.0f / (float)c->rotor_diameter;
+    p.hub = (float)c->hub_height; p.hub_d = c->hub_height;
+    p.dpart = c->d_particle * c->rotor_diameter;
+    p.yaw_min = (float)c->yaw_min; p.yaw_max = (float)c->yaw_max; p.yaw_step = (float)c->yaw_step;
+    p.yaw_min_d = c->yaw_min; p.yaw_max_d = c->yaw_max; p.yaw_step_d = c->yaw_step; p.yaw_start = c->yaw_start;
+    p.action_method = c->action_method; p.base_controller = c->base_controller; p.yaw_init = c->yaw_init;
+    p.has_yaw_defined = c->yaw_defined != nullptr;
+    p.ws_min = c->ws_min; p.ws_max = c->ws_max; p.ti_min = c->ti_min; p.ti_max = c->ti_max;
+    p.wd_min = c->wd_min; p.wd_max = c->wd_max; p.n_passthrough = c->n_passthrough;
+    p.never_truncate = c->never_truncate;
+    for (int i = 0; i < WG_N_CH; ++i) p.ch[i] = c->ch[i];
+    p.turb_on[WG_CH_WS] = c->turb_ws; p.turb_on[WG_CH_WD] = c->turb_wd; p.turb_on[WG_CH_YAW] = 1;
+    p.turb_on[WG_CH_POWER] = c->turb_power;
+    p.farm_on[WG_CH_WS] = c->farm_ws; p.farm_on[WG_CH_WD] = c->farm_wd; p.farm_on[WG_CH_YAW] = 0;
+    p.farm_on[WG_CH_POWER] = c->farm_power;
+    p.turb_ti = c->turb_ti; p.farm_ti = c->farm_ti;
+    const double mn[WG_N_CH] = {c->ws_scale_min, c->wd_scale_min, c->yaw_min, 0.0};
+    const double mx[WG_N_CH] = {c->ws_scale_max, c->wd_scale_max, c->yaw_max, c->power_max};
+    for (int i = 0; i < WG_N_CH; ++i) { p.sc_min[i] = (float)mn[i]; p.sc_rng[i] = (float)(mx[i] - mn[i]); }
+    p.sc_rng_farm_power = (float)(c->power_max * c->n_turb);
+    p.ti_min_f = (float)c->ti_scale_min; p.ti_rng_f = (float)(c->ti_scale_max - c->ti_scale_min);
+    p.noise = c->noise;
+    for (int i = 0; i < WG_N_CH; ++i) p.noise_sigma[i] = (float)c->noise_sigma[i];
+    p.reward_mode = c->reward_mode; p.power_avg = c->power_avg; p.power_scaling = c->power_scaling;
+    p.action_penalty = c->action_penalty; p.penalty_type = c->penalty_type;
+    p.fill_a = c->fill_steps_agent; p.fill_b = c->fill_steps_base; p.autoreset = c->autoreset;
+    p.extra_inc = c->extra_timestep_inc; p.turb_mode = c->turb_mode;
+    p.ka = (float)defd(c->m0_ka, 0.38); p.kb = (float)defd(c->m0_kb, 0.004); p.eps0 = (float)defd(c->m0_eps, 0.2);
+    p.hill = (float)defd(c->m0_hill, 0.4);
+    p.tia = (float)defd(c->m0_ti_a, 0.73); p.tib = (float)defd(c->m0_ti_b, 0.8325);
+    p.tic = (float)defd(c->m0_ti_c, 0.0325); p.tid = (float)defd(c->m0_ti_d, -0.32);
+    p.fc_scale = defd(c->m0_fc_scale, 2.0);
+    p.n_tab = c->n_tab;
+    p.turb_obs = ch_count(c->ch[WG_CH_WS], c->turb_ws) + ch_count(c->ch[WG_CH_WD], c->turb_wd) +
+                 ch_count(c->ch[WG_CH_YAW], 1) + (c->turb_ti ? 1 : 0) + ch_count(c->ch[WG_CH_POWER], c->turb_power);
+    p.farm_obs = ch_count(c->ch[WG_CH_WS], c->farm_ws) + ch_count(c->ch[WG_CH_WD], c->farm_wd) +
+                 (c->farm_ti ? 1 : 0) + ch_count(c->ch[WG_CH_POWER], c->farm_power);
+    p.obs_dim = p.turb_obs * p.N + p.farm_obs;
+    p.obs_dim_multi = p.turb_obs + p.farm_obs;
+    p.hist_max = std::max(c->ch[WG_CH_WS].history_len, std::max(c->ch[WG_CH_WD].history_len, c->ch[WG_CH_YAW].history_len));
+    int off = 0, foff = 0;
+    for (int i = 0; i < WG_N_CH; ++i) {
+        p.ring_off[i] = off; off += p.N * c->ch[i].history_len;
+        p.fring_off[i] = foff; foff += c->ch[i].history_len;
+    }
+    p.ring_stride = off; p.fring_stride = foff;
+
+    WgPtrs& d = h->d;
+    memset(&d, 0, sizeof(d));
+    const size_t n_slots = (size_t)p.B * 2 * p.F, n_ctx = (size_t)p.B * 2;
+    int rc = 0;
+#define A(field, n, st) if (!rc) rc = dev_alloc(h, &d.field, (n), (st))
+    A(py, n_slots * p.NP, true); A(ct_e, n_slots * p.NP, true); A(k_e, n_slots * p.NP, true);
+    A(eps_e, n_slots * p.NP, true); A(hv_e, n_slots * p.NP, true); A(u_e, n_slots * p.NP, true);
+    A(yaw, n_slots * p.N, true); A(u, n_slots * p.N, true); A(v, n_slots * p.N, true); A(w, n_slots * p.N, true);
+    A(ti_loc, n_slots * p.N, true); A(power, n_slots * p.N, true); A(ct, n_slots * p.N, true);
+    A(slot, n_slots, true); A(ctx, n_ctx, true); A(env, (size_t)p.B, true);
+    A(xr, n_ctx * p.N, true); A(yr, n_ctx * p.N, true);
+    A(ring, n_ctx * p.ring_stride, true); A(fring, n_ctx * p.fring_stride, true);
+    A(cur_ws, n_ctx * p.N, true); A(cur_wd, n_ctx * p.N, true);
+    A(pend_farm, n_ctx * p.power_avg, true); A(pend_base, n_ctx * p.power_avg, true);
+    A(farm_pow, (size_t)p.B * p.power_avg, true); A(base_pow, (size_t)p.B * p.power_avg, true);
+    A(old_yaw, (size_t)p.B * p.N, true);
+    A(step_farm_pow, (size_t)p.B, true); A(step_base_pow, (size_t)p.B, true);
+    A(metrics, (size_t)p.B * WG_N_METRICS, true);
+    A(status, 1, true);
+#undef A
+    if (!rc) rc = dev_alloc(h, &h->mask_dev, (size_t)p.B, false);
+    if (!rc) rc = dev_alloc(h, &h->seeds_dev, (size_t)p.B, false);
+    if (!rc) rc = dev_upload<double>(h, &d.x_pos, c->x_pos, p.N);
+    if (!rc) rc = dev_upload<double>(h, &d.y_pos, c->y_pos, p.N);
+    if (!rc && c->yaw_defined) rc = dev_upload<double>(h, &d.yaw_defined, c->yaw_defined, p.N);
+    if (!rc) rc = dev_upload<float>(h, &d.rotor_dy, c->rotor_dy, p.S);
+    if (!rc) rc = dev_upload<float>(h, &d.rotor_dz, c->rotor_dz, p.S);
+    if (!rc) rc = dev_upload<float>(h, &d.tab_ws, c->tab_ws, p.n_tab);
+    if (!rc) rc = dev_upload<float>(h, &d.tab_power, c->tab_power, p.n_tab);
+    if (!rc) rc = dev_upload<float>(h, &d.tab_ct, c->tab_ct, p.n_tab);
+    if (!rc) rc = dev_upload<double>(h, &d.tab_ws_d, c->tab_ws, p.n_tab);
+    if (!rc) rc = dev_upload<double>(h, &d.tab_power_d, c->tab_power, p.n_tab);
+    if (rc) {
+        wg_destroy(h);
+        return rc;
+    }
+    // how many RESET-mode launches develop the slowest possible episode: the chain needs
+    // int(2 * dist / ws) steps (dist <= layout diagonal, ws >= ws_min) plus the window fill
+    double ext_x = 0, ext_y = 0, xmn = 1e300, xmx = -1e300, ymn = 1e300, ymx = -1e300;
+    for (int t = 0; t < p.N; ++t) {
+        xmn = std::min(xmn, c->x_pos[t]); xmx = std::max(xmx, c->x_pos[t]);
+        ymn = std::min(ymn, c->y_pos[t]); ymx = std::max(ymx, c->y_pos[t]);
+    }
+    ext_x = xmx - xmn; ext_y = ymx - ymn;
+    const double diag = std::sqrt(ext_x * ext_x + ext_y * ext_y);
+    const double ws_lo = std::max(1e-3, std::min(c->ws_min, c->ws_max));
+    const long max_dev = (long)std::ceil(2.0 * diag / ws_lo / c->dt_sim) + 2;
+    const long max_work = max_dev + (long)p.K * (std::max(p.fill_a, p.fill_b) + 1);
+    h->reset_chunk = 32;
+    h->reset_launches = (int)((max_work + h->reset_chunk - 1) / h->reset_chunk) + 1;
+
+    // algorithmic bytes of one step(): advection streams py r/w + 4 record floats per particle;
+    // per turbine 7 floats r/w (+ positions); glue: rings, obs, actions, reward/flag
+    const double per_farm_step = (double)p.NP * (4 + 4 + 16) + (double)p.N * (7 * 4 * 2 + 16);
+    h->alg_bytes = (double)p.B * ((double)p.K * p.F * per_farm_step + 20.0 * p.N + 12.0 * p.obs_dim + 20.0);
+
+    wg_launch_create(&p, &d, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    *out = h;
+    return 0;
+}
+
+extern "C" int wg_destroy(wg_handle h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    for (auto& e : h->ev) hipEventDestroy(e);
+    for (auto& a : h->allocs) hipFree(a.ptr);
+    delete h;
+    return 0;
+}
+
+extern "C" int wg_obs_dim(wg_handle h, int* obs_dim, int* obs_dim_multi) {
+    if (!h) return fail(WG_ERR_INVALID, "null handle");
+    if (obs_dim) *obs_dim = h->p.obs_dim;
+    if (obs_dim_multi) *obs_dim_multi = h->p.obs_dim_multi;
+    return 0;
+}
+extern "C" int wg_hist_max(wg_handle h, int* hist_max) {
+    if (!h || !hist_max) return fail(WG_ERR_INVALID, "null argument");
+    *hist_max = h->p.hist_max;
+    return 0;
+}
+
+extern "C" int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, int ny, int nz, double dx,
+                                     double dy, double dz) {
+    if (!h) return fail(WG_ERR_INVALID, "null handle");
+    h->d.box = box_dev;
+    h->p.bnx = nx; h->p.bny = ny; h->p.bnz = nz; h->p.bdx = dx; h->p.bdy = dy; h->p.bdz = dz;
+    return 0;
+}
+
+extern "C" int wg_set_flow_script(wg_handle h, const float* uvw_dev, const float* power_dev, int n_rows) {
+    if (!h) return fail(WG_ERR_INVALID, "null handle");
+    h->d.script_uvw = uvw_dev;
+    h->d.script_power = power_dev;
+    h->p.script_rows = n_rows;
+    return 0;
+}
+
+static void time_begin(wg_env_s* h, int kind, hipStream_t st) {
+    if (!h->timing) return;
+    if (h->ev_used + 2 > h->ev.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            hipEventCreate(&e);
+            h->ev.push_back(e);
+        }
+        h->ev_kind.push_back(kind);
+    } else {
+        h->ev_kind[h->ev_used / 2] = kind;
+    }
+    hipEventRecord(h->ev[h->ev_used], st);
+}
+static void time_end(wg_env_s* h, hipStream_t st) {
+    if (!h->timing) return;
+    hipEventRecord(h->ev[h->ev_used + 1], st);
+    h->ev_used += 2;
+}
+
+extern "C" int wg_reset(wg_handle h, const uint8_t* env_mask_host, const uint64_t* seeds_host, float* obs_dev,
+                        void* stream) {
+    if (!h) return fail(WG_ERR_INVALID, "null handle");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(h->device));
+    const uint8_t* mask = nullptr;
+    const uint64_t* seeds = nullptr;
+    if (env_mask_host) {
+        HIPCHK(hipMemcpyAsync(h->mask_dev, env_mask_host, (size_t)h->p.B, hipMemcpyHostToDevice, st));
+        mask = h->mask_dev;
+    }
+    if (seeds_host) {
+        HIPCHK(hipMemcpyAsync(h->seeds_dev, seeds_host, sizeof(uint64_t) * (size_t)h->p.B, hipMemcpyHostToDevice, st));
+        seeds = h->seeds_dev;
+    }
+    HIPCHK(hipMemsetAsync(h->d.status, 0, sizeof(int), st));
+    wg_launch_init(&h->p, &h->d, mask, seeds, st);
+    const int n_launch = h->d.script_uvw ? ((h->p.K * (std::max(h->p.fill_a, h->p.fill_b) + 1)) / h->reset_chunk + 2)
+                                         : h->reset_launches;
+    for (int i = 0; i < n_launch; ++i) wg_launch_flow(&h->p, &h->d, WG_MODE_RESET, nullptr, mask, h->reset_chunk, st);
+    wg_launch_glue(&h->p, &h->d, 1, mask, obs_dev, nullptr, nullptr, nullptr, st);
+    HIPCHK(hipGetLastError());
+    // the host staging buffers must not be reused before the copies above are done
+    if (env_mask_host || seeds_host) HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int wg_step(wg_handle h, const float* actions_dev, float* obs_dev, float* reward_dev,
+                       uint8_t* truncated_dev, float* final_obs_dev, void* stream) {
+    if (!h || !actions_dev || !obs_dev) return fail(WG_ERR_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    time_begin(h, 0, st);
+    wg_launch_flow(&h->p, &h->d, WG_MODE_STEP, actions_dev, nullptr, 0, st);
+    time_end(h, st);
+    time_begin(h, 1, st);
+    wg_launch_glue(&h->p, &h->d, 0, nullptr, obs_dev, reward_dev, truncated_dev, final_obs_dev, st);
+    time_end(h, st);
+    return 0;
+}
+
+extern "C" int wg_check(wg_handle h, void* stream) {
+    if (!h) return fail(WG_ERR_INVALID, "null handle");
+    int status = 0;
+    HIPCHK(hipMemcpyAsync(&status, h->d.status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(hipGetLastError());
+    if (status == WG_ERR_NAN_POWER) return fail(status, "NaN Power");
+    if (status == WG_ERR_STATE) return fail(status, "step() on a truncated env without reset (or background episode not ready)");
+    return status;
+}
+
+extern "C" int wg_obs_multi(wg_handle h, float* obs_dev, void* stream) {
+    if (!h || !obs_dev) return fail(WG_ERR_INVALID, "null argument");
+    wg_launch_obs_multi(&h->p, &h->d, obs_dev, (hipStream_t)stream);
+    return 0;
+}
+
+extern "C" int wg_get_info(wg_handle h, wg_info_field field, void* out_dev, void* stream) {
+    if (!h || !out_dev) return fail(WG_ERR_INVALID, "null argument");
+    if ((int)field < 0 || (int)field > WG_INFO_RATED_POWER) return fail(WG_ERR_INVALID, "unknown info field");
+    wg_launch_info(&h->p, &h->d, (int)field, out_dev, (hipStream_t)stream);
+    return 0;
+}
+
+extern "C" int wg_metrics(wg_handle h, float* out_dev, int reset_after, void* stream) {
+    if (!h || !out_dev) return fail(WG_ERR_INVALID, "null argument");
+    wg_launch_metrics(&h->p, &h->d, out_dev, reset_after, (hipStream_t)stream);
+    return 0;
+}
+
+extern "C" int wg_get_state(wg_handle h, void* blob_host, size_t* size) {
+    if (!h || !size) return fail(WG_ERR_INVALID, "null argument");
+    size_t total = 0;
+    for (size_t i : h->state_idx) total += h->allocs[i].bytes;
+    if (!blob_host) {
+        *size = total;
+        return 0;
+    }
+    if (*size < total) return fail(WG_ERR_INVALID, "state buffer too small");
+    HIPCHK(hipDeviceSynchronize());
+    char* o = (char*)blob_host;
+    for (size_t i : h->state_idx) {
+        HIPCHK(hipMemcpy(o, h->allocs[i].ptr, h->allocs[i].bytes, hipMemcpyDeviceToHost));
+        o += h->allocs[i].bytes;
+    }
+    *size = total;
+    return 0;
+}
+extern "C" int wg_set_state(wg_handle h, const void* blob_host, size_t size) {
+    if (!h || !blob_host) return fail(WG_ERR_INVALID, "null argument");
+    size_t total = 0;
+    for (size_t i : h->state_idx) total += h->allocs[i].bytes;
+    if (size != total) return fail(WG_ERR_INVALID, "state size mismatch");
+    HIPCHK(hipDeviceSynchronize());
+    const char* o = (const char*)blob_host;
+    for (size_t i : h->state_idx) {
+        HIPCHK(hipMemcpy(h->allocs[i].ptr, o, h->allocs[i].bytes, hipMemcpyHostToDevice));
+        o += h->allocs[i].bytes;
+    }
+    return 0;
+}
+
+extern "C" int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, double* glue_ms_avg, int* n_launches) {
+    if (!h) return fail(WG_ERR_INVALID, "null handle");
+    double fsum = 0, gsum = 0;
+    int nf = 0, ng = 0;
+    if (h->ev_used) {
+        HIPCHK(hipDeviceSynchronize());
+        for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) != hipSuccess) continue;
+            if (h->ev_kind[i / 2] == 0) { fsum += ms; nf++; } else { gsum += ms; ng++; }
+        }
+    }
+    if (flow_ms_avg) *flow_ms_avg = nf ? fsum / nf : 0.0;
+    if (glue_ms_avg) *glue_ms_avg = ng ? gsum / ng : 0.0;
+    if (n_launches) *n_launches = nf;
+    h->ev_used = 0;
+    h->timing = enable != 0;
+    return 0;
+}
+
+extern "C" int wg_algorithmic_bytes(wg_handle h, double* bytes_per_step) {
+    if (!h || !bytes_per_step) return fail(WG_ERR_INVALID, "null argument");
+    *bytes_per_step = h->alg_bytes;
+    return 0;
+}

@@ -1,0 +1,133 @@
+// wg_state.h — device-resident state of libwindgym_hip.so (internal; the public ABI is include/windgym_hip.h).
+//
+// Data layout in HBM.  B envs; every env owns TWO episode contexts ("ctx"): the live episode
+// and the next one, which is developed in the background so that autoreset never stalls the batch
+// (reference: WindFarmEnv.reset runs hundreds of hidden flow steps, Wind_Farm_Env.py:722-796).
+// Every ctx owns F farm "slots" (agent farm, baseline farm).  slot id = (env*2 + ctx)*F + farm.
+//
+//   particle SoA, fp32, [n_slots][N*P] each, ring index fastest -> a workgroup streams contiguous memory:
+//       py                      transverse position of the wake particle (r/w every step)
+//       ct_e, k_e, eps_e, hv_e  frozen emission record (read every step by the advection pass)
+//       u_e                     rotor wind speed at emission (gathered by the deficit pass only)
+//       pz, vlp, wlp            vertical position + low-pass filtered transverse turbulence (box inflow only)
+//   turbine SoA, fp32, [n_slots][N]: yaw, u, v, w, ti_loc, power, ct
+//   sensors, fp32, per ctx: ring[ch][N][H_ch], farm ring[ch][H_ch]   (MesClass deques)
+#pragma once
+#include <stdint.h>
+
+#include "../../include/windgym_hip.h"
+
+#define WG_BLOCK 256
+#define WG_WAVE 64
+#define WG_NWAVES (WG_BLOCK / WG_WAVE)
+
+typedef unsigned __int128 wg_u128;
+
+enum { WG_MODE_STEP = 0, WG_MODE_RESET = 1 };
+
+struct WgParams {
+    int B, N, F, K, P, S, NP;
+    float dt, D, inv_D, hub;
+    double dt_d, dpart, D_d, hub_d;
+    float yaw_min, yaw_max, yaw_step;
+    double yaw_min_d, yaw_max_d, yaw_step_d, yaw_start;
+    int action_method, base_controller, yaw_init, has_yaw_defined;
+    double ws_min, ws_max, ti_min, ti_max, wd_min, wd_max, n_passthrough;
+    int never_truncate;
+    wg_channel ch[WG_N_CH];
+    int turb_on[WG_N_CH];   // level flags per channel for the turbine block (yaw always on)
+    int farm_on[WG_N_CH];   // level flags for the farm block (yaw never)
+    int turb_ti, farm_ti;
+    float sc_min[WG_N_CH], sc_rng[WG_N_CH];  // (float)min, (float)(max-min) of _scale_val per channel (turbine)
+    float sc_rng_farm_power;                 // (float)(power_max*N - 0)
+    float ti_min_f, ti_rng_f;
+    int noise;
+    float noise_sigma[WG_N_CH];
+    int reward_mode, power_avg;
+    double power_scaling, action_penalty;
+    int penalty_type;
+    int fill_a, fill_b, autoreset, extra_inc, turb_mode;
+    float ka, kb, eps0, hill, tia, tib, tic, tid;
+    double fc_scale;
+    int n_tab;
+    int obs_dim, obs_dim_multi, hist_max, turb_obs, farm_obs;
+    int ring_off[WG_N_CH];   // float offset of channel ch inside a ctx's turbine-ring block
+    int ring_stride;         // floats per ctx of turbine rings
+    int fring_off[WG_N_CH];
+    int fring_stride;
+    // frozen turbulence box
+    int bnx, bny, bnz;
+    double bdx, bdy, bdz;
+    // replay mode
+    int script_rows;
+};
+
+// per farm slot
+struct WgSlot {
+    double s_off;       // distance travelled by the newest particle since its emission
+    double time;        // fs.time
+    int head;           // ring slot of the newest particle (all turbines of a farm emit together)
+    int n_valid;        // particles emitted so far (saturates at P)
+    int dev_remaining;  // flow-development steps still to run (fs.run(t_developed))
+    int fill_remaining; // window-fill env steps still to run
+    int cursor;         // replay mode row
+    int pad;
+};
+
+// per episode context
+struct WgCtx {
+    double ws, wd, ti;
+    double dist, t_inflow;
+    float rated_power;
+    int t_developed, time_max;
+    int n_pushed;        // add_measurements calls so far (all MesClass deques advance together)
+    uint32_t turb_seed;
+    int episode_tag;     // episode index this ctx belongs to (noise counter)
+    // fill pushes into the env-level power deques are deferred until the ctx goes live
+    int pend_farm_n, pend_base_n;
+};
+
+// per env
+struct WgEnv {
+    wg_u128 rng_state, rng_inc;   // PCG64 (numpy Generator behind gymnasium's np_random)
+    uint32_t rng_has32, rng_u32;
+    uint64_t noise_key;
+    int live;            // which ctx is the running episode
+    int timestep;
+    int episode;         // episodes finished
+    int done;            // truncated and not reset (autoreset off)  -> step() is an error
+    int shadow_iters;    // flow sub-steps the background ctx advances during the next step()
+    int farm_pow_n, base_pow_n;   // total pushes into farm_pow_deq / base_pow_deq
+    int steps_done;      // step() calls in the running episode
+    float ep_return, ep_power_sum;
+    int ep_len;
+    int pad[3];
+};
+
+struct WgPtrs {
+    // particles
+    float *py, *ct_e, *k_e, *eps_e, *hv_e, *u_e, *pz, *vlp, *wlp;
+    // turbines [n_slots][N]
+    float *yaw, *u, *v, *w, *ti_loc, *power, *ct;
+    WgSlot* slot;
+    WgCtx* ctx;
+    WgEnv* env;
+    double *xr, *yr;          // [B*2][N] flow-frame positions
+    float *ring, *fring;      // [B*2][ring_stride], [B*2][fring_stride]
+    float *cur_ws, *cur_wd;   // [B*2][N] last sub-step measurement (info dict)
+    float *pend_farm, *pend_base;   // [B*2][power_avg]
+    float *farm_pow, *base_pow;     // [B][power_avg]
+    float *old_yaw;           // [B][N]
+    float *step_farm_pow, *step_base_pow;   // [B] produced by the flow kernel, consumed by the glue kernel
+    float* metrics;           // [B][WG_N_METRICS] running per-env sums
+    int* status;              // sticky error word
+    // config tables
+    const double *x_pos, *y_pos, *yaw_defined;
+    const float *rotor_dy, *rotor_dz;
+    const float *tab_ws, *tab_power, *tab_ct;
+    const double *tab_ws_d, *tab_power_d;
+    // inflow
+    const float* box;
+    // replay
+    const float *script_uvw, *script_power;
+};
