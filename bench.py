@@ -115,7 +115,7 @@ def main():
         env.step(actions[i % n_act])
     barrier()
     el = time.perf_counter() - t0
-    flow_ms, glue_ms, n_launch = env.kernel_timing(False)
+    flow_ms, glue_ms, n_launch, flow_steps = env.kernel_timing(False)
     env.check()
     m = metrics.all_reduce()            # the only collective on the path: 8 floats
 
@@ -128,7 +128,11 @@ def main():
 
     if rank == 0:
         F = cfg.to_c().n_farms
-        alg_bytes_flow = B * F * (cfg.n_turb * cfg.n_particles * 24.0 + cfg.n_turb * 72.0)
+        # algorithmic bytes of one k_flow launch = farm flow-steps it executed (live farms + background
+        # development of the next episodes, counted on the device) x bytes per farm flow-step:
+        # per particle: py read+write (8) + record ct,k,eps,hv read (16); per turbine: state r/w + positions
+        bytes_per_flow_step = cfg.n_turb * cfg.n_particles * 24.0 + cfg.n_turb * 72.0
+        alg_bytes_flow = flow_steps * bytes_per_flow_step
         achieved = alg_bytes_flow / (flow_ms * 1e-3) / 1e9 if flow_ms > 0 else 0.0
         out = {
             "metric": "env-steps/sec (whole node), 16-turbine farm x 4096 envs",
@@ -144,7 +148,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None, "kernel": "k_flow",
                          "kernel_ms": flow_ms, "glue_kernel_ms": glue_ms, "launches_timed": n_launch,
-                         "algorithmic_bytes_per_launch": alg_bytes_flow},
+                         "algorithmic_bytes_per_launch": alg_bytes_flow, "farm_flow_steps_per_launch": flow_steps,
+                         "bytes_per_farm_flow_step": bytes_per_flow_step},
             "episode_metrics": {k: float(v) for k, v in m.items()},
         }
         if world == 1 and not args.no_cpu:

@@ -224,8 +224,11 @@ int wg_get_state(wg_handle h, void* blob_host, size_t* size);
 int wg_set_state(wg_handle h, const void* blob_host, size_t size);
 
 /* HIP-event timing of the step kernels on the stream they were launched on: average milliseconds per
- * launch of the dominant flow kernel and of the glue kernel since the last call (used by bench.py).    */
-int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, double* glue_ms_avg, int* n_launches);
+ * launch of the dominant flow kernel and of the glue kernel since the last call, and the average number of
+ * farm flow-steps one flow launch executed (live farms + background episode development) — the unit
+ * count behind bench.py's roofline.                                                                    */
+int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, double* glue_ms_avg, int* n_launches,
+                     double* flow_steps_per_launch);
 
 /* Algorithmic HBM bytes one wg_step() moves (the figure bench.py's roofline uses).       */
 int wg_algorithmic_bytes(wg_handle h, double* bytes_per_step);

@@ -27,10 +27,10 @@ static inline void wgo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-/* standard normal from two 32-bit words: u1 in (0,1], u2 in [0,1) */
+/* standard normal from the top 24 bits of two 32-bit words: u1 in (0,1], u2 in [0,1) */
 static inline double wgo_normal_from_u32(uint32_t a, uint32_t b) {
-    double u1 = ((double)a + 1.0) * (1.0 / 4294967296.0);
-    double u2 = (double)b * (1.0 / 4294967296.0);
+    double u1 = ((double)(a >> 8) + 1.0) * (1.0 / 16777216.0);
+    double u2 = (double)(b >> 8) * (1.0 / 16777216.0);
     return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925 * u2);
 }
 static inline double wgo_noise_normal(uint64_t key, uint32_t push_idx, uint32_t turbine, uint32_t channel,

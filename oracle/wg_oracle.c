@@ -337,7 +337,10 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
     farm_t* f = &x->farm[fi];
     const int N = o->N, P = o->P, S = o->S;
     const real D = (real)c->rotor_diameter, dt = (real)c->dt_sim;
+    const real inv_D = (real)1 / D;
     const double dpart = c->d_particle * c->rotor_diameter;
+    const double inv_dpart = 1.0 / dpart;
+    const real R_rot = (real)0.5 * D;
     const real hub = (real)c->hub_height;
 
     /* (1) emission records of this step */
@@ -357,8 +360,8 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
             int j = f->head - r; if (j < 0) j += P;      /* age index of ring slot r */
             if (j >= f->n_valid) continue;
             size_t i = (size_t)t * P + r;
-            real xrel = (real)(f->s_off + (double)j * dpart);
-            real sp = m0_sigma_over_d(f->k_e[i], f->eps_e[i], xrel / D);
+            real xrel = (real)f->s_off + (real)j * (real)dpart;
+            real sp = m0_sigma_over_d(f->k_e[i], f->eps_e[i], xrel * inv_D);
             real cf = m0_cfrac(f->ct_e[i], sp);
             real vy = f->hv_e[i] * cf;
             real vz = 0;
@@ -399,7 +402,7 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
             if (s2 == t) continue;
             double dx = x->xr[t] - x->xr[s2];
             if (!(dx > 0.0)) continue;
-            double xi = (dx - f->s_off) / dpart;
+            double xi = (dx - f->s_off) * inv_dpart;
             double jf = floor(xi);
             real wgt = (real)(xi - jf);
             long j = (long)jf;
@@ -415,10 +418,15 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
             real kv = w0 * f->k_e[i0] + w1 * f->k_e[i1];
             real epv = w0 * f->eps_e[i0] + w1 * f->eps_e[i1];
             real uev = w0 * f->u_e[i0] + w1 * f->u_e[i1];
-            real xd = (real)dx / D;
+            real xd = (real)dx * inv_D;
             real sp = m0_sigma_over_d(kv, epv, xd);
             real cf = m0_cfrac(ctv, sp);
             real sig = sp * D;
+            /* lateral cut-off: a wake whose centre is farther than R + 5 sigma from the rotor centre is
+             * neglected (its Gaussian tail is < exp(-12.5) of the centreline deficit) */
+            real rc2 = ((real)x->yr[t] - yc) * ((real)x->yr[t] - yc) + (hub - zc) * (hub - zc);
+            real rcut = R_rot + (real)5 * sig;
+            if (rc2 > rcut * rcut) continue;
             real inv2s2 = (real)1 / ((real)2 * sig * sig);
             real amp = uev * cf;
             for (int s = 0; s < S; ++s) {
@@ -430,7 +438,6 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
             /* wake-added turbulence (Crespo & Hernandez 1996), weighted by the Gaussian at the hub */
             real ind = (real)0.5 * ((real)1 - R_SQRT((real)1 - ctv));
             real xdc = xd < (real)1 ? (real)1 : xd;
-            real rc2 = ((real)x->yr[t] - yc) * ((real)x->yr[t] - yc) + (hub - zc) * (hub - zc);
             real tia = (real)c->m0_ti_a * R_POW(ind, (real)c->m0_ti_b) * R_POW((real)x->ti, (real)c->m0_ti_c) *
                        R_POW(xdc, (real)c->m0_ti_d) * R_EXP(-rc2 * inv2s2);
             if (tia > tiadd_max) tiadd_max = tia;

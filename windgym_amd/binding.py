@@ -58,7 +58,7 @@ def load_library():
     L.wg_get_state.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
     L.wg_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.wg_kernel_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
-                                   C.POINTER(C.c_int)]
+                                   C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.wg_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     _lib = L
     return L
@@ -202,9 +202,11 @@ class HipBatch:
         _chk(self.L.wg_set_state(self._h, blob, len(blob)), "wg_set_state")
 
     def kernel_timing(self, enable=True):
-        f, g, n = C.c_double(), C.c_double(), C.c_int()
-        _chk(self.L.wg_kernel_timing(self._h, int(enable), C.byref(f), C.byref(g), C.byref(n)), "wg_kernel_timing")
-        return f.value, g.value, n.value
+        """-> (flow kernel ms/launch, glue kernel ms/launch, launches timed, farm flow-steps per launch)"""
+        f, g, n, fs = C.c_double(), C.c_double(), C.c_int(), C.c_double()
+        _chk(self.L.wg_kernel_timing(self._h, int(enable), C.byref(f), C.byref(g), C.byref(n), C.byref(fs)),
+             "wg_kernel_timing")
+        return f.value, g.value, n.value, fs.value
 
     def algorithmic_bytes(self):
         v = C.c_double()

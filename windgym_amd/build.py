@@ -8,8 +8,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwindgym_hip.so")
-SOURCES = ["wg_kernels.hip", "wg_api.hip"]
-HEADERS = ["wg_state.h", "wg_device.h", os.path.join("..", "..", "include", "windgym_hip.h")]
+SOURCES = ["wg_flow.hip", "wg_kernels.hip", "wg_api.hip"]
+HEADERS = ["wg_state.h", "wg_device.h", "wg_flow.h", os.path.join("..", "..", "include", "windgym_hip.h")]
 
 
 def needs_build() -> bool:
@@ -23,7 +23,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    extra = os.environ.get("WG_HIPCC_FLAGS", "").split()
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra + [
            "-Wno-unused-result", "-Wno-unused-value", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -11,9 +11,10 @@
 #include <vector>
 
 #include "wg_state.h"
+#include "wg_flow.h"
 
 extern "C" {
-void wg_launch_flow(const WgParams*, const WgPtrs*, int, const float*, const uint8_t*, int, hipStream_t);
+void wg_launch_flow(const FlowP*, const FlowPtrs*, int, const float*, const uint8_t*, int, hipStream_t);
 void wg_launch_glue(const WgParams*, const WgPtrs*, int, const uint8_t*, float*, float*, uint8_t*, float*, hipStream_t);
 void wg_launch_init(const WgParams*, const WgPtrs*, const uint8_t*, const uint64_t*, hipStream_t);
 void wg_launch_create(const WgParams*, const WgPtrs*, hipStream_t);
@@ -42,6 +43,10 @@ struct Alloc {
 struct wg_env_s {
     WgParams p;
     WgPtrs d;
+    FlowP fp;
+    FlowPtrs fd;
+    unsigned long long* flow_steps_dev = nullptr;
+    unsigned long long flow_steps_mark = 0;
     int device;
     std::vector<Alloc> allocs;      // everything owned by the handle (state blob = allocs flagged `state`)
     std::vector<size_t> state_idx;  // indices into allocs that make up the serialisable state
@@ -189,6 +194,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     A(metrics, (size_t)p.B * WG_N_METRICS, true);
     A(status, 1, true);
 #undef A
+    if (!rc) rc = dev_alloc(h, &h->flow_steps_dev, 1, false);
     if (!rc) rc = dev_alloc(h, &h->mask_dev, (size_t)p.B, false);
     if (!rc) rc = dev_alloc(h, &h->seeds_dev, (size_t)p.B, false);
     if (!rc) rc = dev_upload<double>(h, &d.x_pos, c->x_pos, p.N);
@@ -205,6 +211,74 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         wg_destroy(h);
         return rc;
     }
+    // ---- k_flow parameter block -------------------------------------------------------------------
+    {
+        // turbine table on a uniform grid (O(1) lookup in the kernel); tables that are already uniform
+        // (V80: 1 m/s; as_tabular: 0.5 m/s) are used as they are, others are resampled on 1024 points
+        bool uniform = true;
+        const double dx0 = c->tab_ws[1] - c->tab_ws[0];
+        for (int i = 2; i < c->n_tab; ++i)
+            if (std::fabs((c->tab_ws[i] - c->tab_ws[i - 1]) - dx0) > 1e-9 * std::fabs(dx0)) uniform = false;
+        std::vector<float> pu, cu;
+        int nu = c->n_tab;
+        double x0 = c->tab_ws[0], dxu = dx0;
+        if (uniform) {
+            for (int i = 0; i < nu; ++i) { pu.push_back((float)c->tab_power[i]); cu.push_back((float)c->tab_ct[i]); }
+        } else {
+            nu = 1024;
+            dxu = (c->tab_ws[c->n_tab - 1] - x0) / (nu - 1);
+            int k = 0;
+            for (int i = 0; i < nu; ++i) {
+                const double x = std::min(x0 + i * dxu, c->tab_ws[c->n_tab - 1]);
+                while (k + 2 < c->n_tab && c->tab_ws[k + 1] <= x) ++k;
+                const double f = (x - c->tab_ws[k]) / (c->tab_ws[k + 1] - c->tab_ws[k]);
+                pu.push_back((float)(c->tab_power[k] + f * (c->tab_power[k + 1] - c->tab_power[k])));
+                cu.push_back((float)(c->tab_ct[k] + f * (c->tab_ct[k + 1] - c->tab_ct[k])));
+            }
+        }
+        const float* tpu = nullptr;
+        const float* tcu = nullptr;
+        rc = dev_upload<float>(h, &tpu, pu.data(), (size_t)nu);
+        if (!rc) rc = dev_upload<float>(h, &tcu, cu.data(), (size_t)nu);
+        if (rc) { wg_destroy(h); return rc; }
+        FlowP& f = h->fp;
+        memset(&f, 0, sizeof(f));
+        f.B = p.B; f.N = p.N; f.F = p.F; f.K = p.K; f.P = p.P; f.S = p.S; f.NP = p.NP; f.n_tab = nu;
+        f.S_pad = 1; f.S_shift = 0;
+        while (f.S_pad < p.S) { f.S_pad <<= 1; f.S_shift++; }
+        f.autoreset = p.autoreset; f.action_method = p.action_method; f.base_controller = p.base_controller;
+        f.power_avg = p.power_avg; f.script_rows = 0; f.noise = (p.noise == WG_NOISE_NORMAL);
+        int tc = 1024 / p.N; if (tc < 1) tc = 1; if (tc > p.N) tc = p.N;
+        // phase B maps one thread per (target, sample): keep a chunk's items a multiple of the sample group
+        f.target_chunk = tc;
+        size_t off = sizeof(float) * 4 * (size_t)tc * p.N;
+        f.lds_off_turb = (int)off; off += (size_t)WG_TURB_LDS_BYTES * p.N;
+        off = (off + 15) & ~(size_t)15;
+        f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S);
+        f.lds_bytes = (int)((off + 15) & ~(size_t)15);
+        f.dt = p.dt; f.D = p.D; f.inv_D = p.inv_D; f.hub = p.hub; f.dpart_f = (float)p.dpart; f.R_rot = 0.5f * p.D;
+        f.inv_N = 1.0f / (float)p.N; f.inv_S = 1.0f / (float)p.S;
+        f.dt_d = p.dt_d; f.dpart = p.dpart; f.inv_dpart = 1.0 / p.dpart;
+        f.yaw_min = p.yaw_min; f.yaw_max = p.yaw_max; f.yaw_step = p.yaw_step;
+        f.ka = p.ka; f.kb = p.kb; f.eps0 = p.eps0; f.hill = p.hill; f.tia = p.tia; f.tib = p.tib; f.tic = p.tic; f.tid = p.tid;
+        f.tab_x0 = (float)x0; f.tab_inv_dx = (float)(1.0 / dxu);
+        for (int i = 0; i < WG_N_CH; ++i) {
+            f.hlen[i] = p.ch[i].history_len; f.ring_off[i] = p.ring_off[i]; f.fring_off[i] = p.fring_off[i];
+            f.noise_sigma[i] = p.noise_sigma[i];
+        }
+        f.ring_stride = p.ring_stride; f.fring_stride = p.fring_stride;
+        FlowPtrs& g = h->fd;
+        memset(&g, 0, sizeof(g));
+        g.py = d.py; g.ct_e = d.ct_e; g.k_e = d.k_e; g.eps_e = d.eps_e; g.hv_e = d.hv_e; g.u_e = d.u_e;
+        g.yaw = d.yaw; g.u = d.u; g.v = d.v; g.w = d.w; g.ti_loc = d.ti_loc; g.power = d.power; g.ct = d.ct;
+        g.slot = d.slot; g.ctx = d.ctx; g.env = d.env; g.xr = d.xr; g.yr = d.yr;
+        g.ring = d.ring; g.fring = d.fring; g.cur_ws = d.cur_ws; g.cur_wd = d.cur_wd;
+        g.pend_farm = d.pend_farm; g.pend_base = d.pend_base; g.old_yaw = d.old_yaw;
+        g.step_farm_pow = d.step_farm_pow; g.step_base_pow = d.step_base_pow;
+        g.rotor_dy = d.rotor_dy; g.rotor_dz = d.rotor_dz; g.tab_power = tpu; g.tab_ct = tcu;
+        g.flow_steps = h->flow_steps_dev;
+    }
+
     // how many RESET-mode launches develop the slowest possible episode: the chain needs
     // int(2 * dist / ws) steps (dist <= layout diagonal, ws >= ws_min) plus the window fill
     double ext_x = 0, ext_y = 0, xmn = 1e300, xmx = -1e300, ymn = 1e300, ymx = -1e300;
@@ -266,6 +340,9 @@ extern "C" int wg_set_flow_script(wg_handle h, const float* uvw_dev, const float
     h->d.script_uvw = uvw_dev;
     h->d.script_power = power_dev;
     h->p.script_rows = n_rows;
+    h->fd.script_uvw = uvw_dev;
+    h->fd.script_power = power_dev;
+    h->fp.script_rows = n_rows;
     return 0;
 }
 
@@ -308,7 +385,7 @@ extern "C" int wg_reset(wg_handle h, const uint8_t* env_mask_host, const uint64_
     wg_launch_init(&h->p, &h->d, mask, seeds, st);
     const int n_launch = h->d.script_uvw ? ((h->p.K * (std::max(h->p.fill_a, h->p.fill_b) + 1)) / h->reset_chunk + 2)
                                          : h->reset_launches;
-    for (int i = 0; i < n_launch; ++i) wg_launch_flow(&h->p, &h->d, WG_MODE_RESET, nullptr, mask, h->reset_chunk, st);
+    for (int i = 0; i < n_launch; ++i) wg_launch_flow(&h->fp, &h->fd, WG_MODE_RESET, nullptr, mask, h->reset_chunk, st);
     wg_launch_glue(&h->p, &h->d, 1, mask, obs_dev, nullptr, nullptr, nullptr, st);
     HIPCHK(hipGetLastError());
     // the host staging buffers must not be reused before the copies above are done
@@ -321,7 +398,7 @@ extern "C" int wg_step(wg_handle h, const float* actions_dev, float* obs_dev, fl
     if (!h || !actions_dev || !obs_dev) return fail(WG_ERR_INVALID, "null argument");
     hipStream_t st = (hipStream_t)stream;
     time_begin(h, 0, st);
-    wg_launch_flow(&h->p, &h->d, WG_MODE_STEP, actions_dev, nullptr, 0, st);
+    wg_launch_flow(&h->fp, &h->fd, WG_MODE_STEP, actions_dev, nullptr, 0, st);
     time_end(h, st);
     time_begin(h, 1, st);
     wg_launch_glue(&h->p, &h->d, 0, nullptr, obs_dev, reward_dev, truncated_dev, final_obs_dev, st);
@@ -391,8 +468,12 @@ extern "C" int wg_set_state(wg_handle h, const void* blob_host, size_t size) {
     return 0;
 }
 
-extern "C" int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, double* glue_ms_avg, int* n_launches) {
+extern "C" int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, double* glue_ms_avg, int* n_launches,
+                                double* flow_steps_per_launch) {
     if (!h) return fail(WG_ERR_INVALID, "null handle");
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long fs_now = 0;
+    HIPCHK(hipMemcpy(&fs_now, h->flow_steps_dev, sizeof(fs_now), hipMemcpyDeviceToHost));
     double fsum = 0, gsum = 0;
     int nf = 0, ng = 0;
     if (h->ev_used) {
@@ -406,6 +487,8 @@ extern "C" int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, do
     if (flow_ms_avg) *flow_ms_avg = nf ? fsum / nf : 0.0;
     if (glue_ms_avg) *glue_ms_avg = ng ? gsum / ng : 0.0;
     if (n_launches) *n_launches = nf;
+    if (flow_steps_per_launch) *flow_steps_per_launch = nf ? (double)(fs_now - h->flow_steps_mark) / nf : 0.0;
+    h->flow_steps_mark = fs_now;
     h->ev_used = 0;
     h->timing = enable != 0;
     return 0;

@@ -116,9 +116,10 @@ __device__ inline float wg_noise_normal(uint64_t key, uint32_t push_idx, uint32_
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
-    double u1 = ((double)c0 + 1.0) * (1.0 / 4294967296.0);
-    double u2 = (double)c1 * (1.0 / 4294967296.0);
-    return (float)(sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925 * u2));
+    // 24-bit uniforms keep everything in float32: u1 in (0,1], u2 in [0,1)
+    const float u1 = ((float)(c0 >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    const float u2 = (float)(c1 >> 8) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853071795864f * u2);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,38 @@
+// wg_flow.h — slim parameter block of k_flow (see wg_flow.hip for why it is separate from WgParams).
+#pragma once
+#include "wg_state.h"
+
+#ifndef WG_FLOW_WAVES
+#define WG_FLOW_WAVES 6   // min waves/SIMD the register allocator must leave room for (6 -> <= 80 VGPRs)
+#endif
+
+struct FlowP {
+    int B, N, F, K, P, S, S_pad, S_shift, NP, n_tab;
+    int autoreset, action_method, base_controller, power_avg, script_rows, noise;
+    int target_chunk;             // targets whose pair parameters are staged in LDS at once
+    int lds_off_turb, lds_off_tab, lds_bytes;
+    float dt, D, inv_D, hub, dpart_f, R_rot, inv_N, inv_S;
+    double dt_d, dpart, inv_dpart;
+    float yaw_min, yaw_max, yaw_step;
+    float ka, kb, eps0, hill, tia, tib, tic, tid;
+    float tab_x0, tab_inv_dx;     // uniform-grid turbine table
+    int hlen[WG_N_CH], ring_off[WG_N_CH], fring_off[WG_N_CH];
+    int ring_stride, fring_stride;
+    float noise_sigma[WG_N_CH];
+};
+
+struct FlowPtrs {
+    float *py, *ct_e, *k_e, *eps_e, *hv_e, *u_e;
+    float *yaw, *u, *v, *w, *ti_loc, *power, *ct;
+    WgSlot* slot;
+    WgCtx* ctx;
+    const WgEnv* env;
+    const double *xr, *yr;
+    float *ring, *fring, *cur_ws, *cur_wd, *pend_farm, *pend_base, *old_yaw, *step_farm_pow, *step_base_pow;
+    const float *rotor_dy, *rotor_dz, *tab_power, *tab_ct;   // tab_*: resampled on the uniform grid
+    const float *script_uvw, *script_power;
+    unsigned long long* flow_steps;   // total flow_step() executions (for the roofline accounting)
+};
+
+// sizeof(TurbLds) in wg_flow.hip; kept here so the host can size the dynamic LDS
+#define WG_TURB_LDS_BYTES 88

@@ -1,12 +1,6 @@
 // wg_kernels.hip — HIP kernels of the batched WindGym step() transition for MI355X (gfx950, wave64).
 //
-//   k_flow   one 256-thread workgroup per farm slot (env x ctx x farm).  Streams the slot's wake-particle
-//            SoA through HBM with 16-byte coalesced accesses (advection + emission), then the 4 waves
-//            evaluate the Gaussian deficit superposition at the rotor sample points with the per-pair wake
-//            parameters staged in LDS, look up power/Ct, and push the sensor rings.
-//            Replaces DWMFlowSimulation.step() + rotor_avg_windspeed + power() + the baseline controllers
-//            + _take_measurements + farm_mes.add_measurements
-//            (Wind_Farm_Env.py:480-495, 822-864, 943-979; BasicControllers.py:10-73; MesClass.py:568-591).
+//   (k_flow, the dominant kernel, lives in wg_flow.hip)
 //   k_glue   one wave per env: power deques, observation (MesClass windows / TI / scaling / clip), reward,
 //            penalty, truncation, same-step autoreset by swapping in the pre-developed next episode, and
 //            sampling of the episode after that (Wind_Farm_Env.py:513-520, 557-568, 680-732, 804-820,
@@ -16,470 +10,6 @@
 #include <hip/hip_runtime.h>
 
 #include "wg_device.h"
-
-// ===================================================================================================
-// model M0 pieces
-// ===================================================================================================
-__device__ __forceinline__ float m0_cfrac(float ct, float sp) {
-    float m = __builtin_amdgcn_rcpf(8.0f * sp * sp);
-    m = fminf(m, 1.0f);
-    float a = fmaxf(1.0f - ct * m, 0.0f);
-    return 1.0f - __builtin_amdgcn_sqrtf(a);
-}
-
-struct FlowLds {
-    double *xr, *yr;
-    float *yaw, *u, *v, *w, *ti, *pow, *ct, *cg;
-    float *rct, *rk, *reps, *rhv, *rue;
-    float *sws, *swd, *syaw, *sp;
-    float *tabws, *tabp, *tabct;
-    float *rdy, *rdz;
-    float4* pair;
-};
-
-__host__ __device__ inline size_t flow_lds_bytes(int N, int S, int n_tab) {
-    size_t b = 0;
-    b += sizeof(double) * 2 * N;
-    b += sizeof(float) * (8 + 5 + 4) * N;
-    b += sizeof(float) * 3 * n_tab;
-    b += sizeof(float) * 2 * S;
-    b = (b + 15) & ~(size_t)15;
-    b += sizeof(float4) * WG_NWAVES * N;
-    return b;
-}
-
-__device__ inline FlowLds flow_lds_carve(char* smem, int N, int S, int n_tab) {
-    FlowLds L;
-    L.xr = (double*)smem;
-    L.yr = L.xr + N;
-    float* f = (float*)(L.yr + N);
-    L.yaw = f; f += N; L.u = f; f += N; L.v = f; f += N; L.w = f; f += N;
-    L.ti = f; f += N; L.pow = f; f += N; L.ct = f; f += N; L.cg = f; f += N;
-    L.rct = f; f += N; L.rk = f; f += N; L.reps = f; f += N; L.rhv = f; f += N; L.rue = f; f += N;
-    L.sws = f; f += N; L.swd = f; f += N; L.syaw = f; f += N; L.sp = f; f += N;
-    L.tabws = f; f += n_tab; L.tabp = f; f += n_tab; L.tabct = f; f += n_tab;
-    L.rdy = f; f += S; L.rdz = f; f += S;
-    size_t off = ((char*)f - smem + 15) & ~(size_t)15;
-    L.pair = (float4*)(smem + off);
-    return L;
-}
-
-// One DWMFlowSimulation.step() of model M0 for the slot owned by this workgroup.  Slot scalars live in
-// registers (uniform across the block); turbine state lives in LDS.
-template <int TURB>
-__device__ inline void flow_step(const WgParams& p, const WgPtrs& d, const FlowLds& L, size_t pbase, double ws,
-                                 double ti_amb, int& head, int& n_valid, double& s_off, double& time) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = p.N, P = p.P, S = p.S, NP = p.NP;
-
-    // (1) emission records of this step + cos(yaw)
-    for (int t = tid; t < N; t += WG_BLOCK) {
-        float g = L.yaw[t] * WG_DEG2RAD_F;
-        const float sg = sinf(g), cg = cosf(g);
-        float wsn = fmaxf(L.u[t] * cg + L.v[t] * sg, 0.0f);
-        float ct0 = wg_tab_interp<float>(L.tabws, L.tabct, p.n_tab, wsn);
-        float ctx = fminf(fmaxf(ct0 * cg * cg, 0.0f), 0.96f);
-        float q = sqrtf(1.0f - ctx);
-        float beta = 0.5f * (1.0f + q) / q;
-        L.rct[t] = ctx;
-        L.rk[t] = p.ka * L.ti[t] + p.kb;
-        L.reps[t] = p.eps0 * sqrtf(beta);
-        L.rhv[t] = -p.hill * sg * L.u[t];
-        L.rue[t] = L.u[t];
-        L.cg[t] = cg;
-    }
-    __syncthreads();
-
-    // (2)+(3) advect every particle over dt, release the new particles (streaming pass over the SoA)
-    double s_new = s_off + ws * p.dt_d;
-    int n_emit = 0;
-    while (s_new >= p.dpart) { s_new -= p.dpart; ++n_emit; }
-    if (n_emit > P) n_emit = P;
-    int new_head = (head + n_emit) % P;
-    int new_valid = n_valid + n_emit; if (new_valid > P) new_valid = P;
-
-    float* __restrict__ gpy = d.py + pbase;
-    float* __restrict__ gct = d.ct_e + pbase;
-    float* __restrict__ gk = d.k_e + pbase;
-    float* __restrict__ geps = d.eps_e + pbase;
-    float* __restrict__ ghv = d.hv_e + pbase;
-    float* __restrict__ gue = d.u_e + pbase;
-    for (int i4 = tid * 4; i4 < NP; i4 += WG_BLOCK * 4) {
-        const int t = i4 / P;
-        const int r0 = i4 - t * P;
-        float4 py4 = *reinterpret_cast<const float4*>(gpy + i4);
-        float4 ct4 = *reinterpret_cast<const float4*>(gct + i4);
-        float4 k4 = *reinterpret_cast<const float4*>(gk + i4);
-        float4 ep4 = *reinterpret_cast<const float4*>(geps + i4);
-        float4 hv4 = *reinterpret_cast<const float4*>(ghv + i4);
-        float pyv[4] = {py4.x, py4.y, py4.z, py4.w};
-        float ctv[4] = {ct4.x, ct4.y, ct4.z, ct4.w};
-        float kv[4] = {k4.x, k4.y, k4.z, k4.w};
-        float epv[4] = {ep4.x, ep4.y, ep4.z, ep4.w};
-        float hvv[4] = {hv4.x, hv4.y, hv4.z, hv4.w};
-        bool any_emit = false;
-        bool em[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = r0 + q;
-            int ei = r - head - 1; if (ei < 0) ei += P;
-            em[q] = ei < n_emit;
-            any_emit |= em[q];
-            if (em[q]) {
-                pyv[q] = (float)L.yr[t];
-                ctv[q] = L.rct[t]; kv[q] = L.rk[t]; epv[q] = L.reps[t]; hvv[q] = L.rhv[t];
-            } else {
-                int j = head - r; if (j < 0) j += P;
-                if (j < n_valid) {
-                    float xrel = (float)(s_off + (double)j * p.dpart);
-                    float sp = kv[q] * (xrel * p.inv_D) + epv[q];
-                    float cf = m0_cfrac(ctv[q], sp);
-                    pyv[q] += hvv[q] * cf * p.dt;
-                }
-            }
-        }
-        *reinterpret_cast<float4*>(gpy + i4) = make_float4(pyv[0], pyv[1], pyv[2], pyv[3]);
-        if (any_emit) {
-            *reinterpret_cast<float4*>(gct + i4) = make_float4(ctv[0], ctv[1], ctv[2], ctv[3]);
-            *reinterpret_cast<float4*>(gk + i4) = make_float4(kv[0], kv[1], kv[2], kv[3]);
-            *reinterpret_cast<float4*>(geps + i4) = make_float4(epv[0], epv[1], epv[2], epv[3]);
-            *reinterpret_cast<float4*>(ghv + i4) = make_float4(hvv[0], hvv[1], hvv[2], hvv[3]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (em[q]) gue[i4 + q] = L.rue[t];
-        }
-    }
-    head = new_head;
-    n_valid = new_valid;
-    s_off = s_new;
-    time += p.dt_d;
-    __syncthreads();   // particle stores of this workgroup are visible to its own gathers below
-
-    // (4) rotor-averaged inflow: one wave per target turbine; wake parameters of every upstream chain are
-    // staged in LDS (pair[]), then the lanes sweep the (source, sample) pairs.
-    float4* pair = L.pair + wave * N;
-    const float ws_f = (float)ws, ti_f = (float)ti_amb;
-    const float inv_S = 1.0f / (float)S;
-    for (int t = wave; t < N; t += WG_NWAVES) {
-        const double xt = L.xr[t];
-        const float yt = (float)L.yr[t];
-        const float cgt = L.cg[t];
-        float tia_max = 0.f;
-        for (int s2 = lane; s2 < N; s2 += WG_WAVE) {
-            float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
-            const double dx = xt - L.xr[s2];
-            if (s2 != t && dx > 0.0) {
-                const double xi = (dx - s_off) / p.dpart;
-                const double jf = floor(xi);
-                float wgt = (float)(xi - jf);
-                long j = (long)jf;
-                if (j < 0) { j = 0; wgt = 0.f; }
-                if (j + 1 <= (long)n_valid - 1) {
-                    int r0 = (int)(((long)head - j) % P); if (r0 < 0) r0 += P;
-                    int r1 = r0 - 1; if (r1 < 0) r1 += P;
-                    const size_t i0 = (size_t)s2 * P + r0, i1 = (size_t)s2 * P + r1;
-                    const float w0 = 1.0f - wgt, w1 = wgt;
-                    const float yc = w0 * gpy[i0] + w1 * gpy[i1];
-                    const float ctv = w0 * gct[i0] + w1 * gct[i1];
-                    const float kv = w0 * gk[i0] + w1 * gk[i1];
-                    const float epv = w0 * geps[i0] + w1 * geps[i1];
-                    const float uev = w0 * gue[i0] + w1 * gue[i1];
-                    const float xd = (float)dx * p.inv_D;
-                    const float sp = kv * xd + epv;
-                    const float cf = m0_cfrac(ctv, sp);
-                    const float sig = sp * p.D;
-                    const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sig * sig);
-                    pp = make_float4(yc, p.hub, inv2s2, uev * cf);
-                    // wake-added turbulence (Crespo-Hernandez), Gaussian-weighted at the hub
-                    const float ind = 0.5f * (1.0f - __builtin_amdgcn_sqrtf(1.0f - ctv));
-                    const float xdc = fmaxf(xd, 1.0f);
-                    const float rc2 = (yt - yc) * (yt - yc);
-                    const float tia = p.tia * __powf(ind, p.tib) * __powf(ti_f, p.tic) * __powf(xdc, p.tid) *
-                                      __expf(-rc2 * inv2s2);
-                    tia_max = fmaxf(tia_max, tia);
-                }
-            }
-            pair[s2] = pp;
-        }
-        float acc = 0.f;
-        {
-            const int total = N * S;
-            int s2 = lane / S, s = lane - s2 * S;
-            const int d2 = WG_WAVE / S, ds = WG_WAVE - d2 * S;
-            for (int idx = lane; idx < total; idx += WG_WAVE) {
-                const float4 pp = pair[s2];
-                if (pp.w != 0.f) {
-                    const float ys = yt + L.rdy[s] * cgt;
-                    const float zs = p.hub + L.rdz[s];
-                    const float r2 = (ys - pp.x) * (ys - pp.x) + (zs - pp.y) * (zs - pp.y);
-                    acc += pp.w * __expf(-r2 * pp.z);
-                }
-                s2 += d2; s += ds;
-                if (s >= S) { s -= S; ++s2; }
-            }
-        }
-        acc = wg_wave_sum(acc);
-        tia_max = wg_wave_max(tia_max);
-        if (lane == 0) {
-            L.u[t] = ws_f - acc * inv_S;
-            L.v[t] = 0.f;
-            L.w[t] = 0.f;
-            L.ti[t] = sqrtf(ti_f * ti_f + tia_max * tia_max);
-        }
-    }
-    __syncthreads();
-
-    // (5) power / thrust with the current yaw
-    for (int t = tid; t < N; t += WG_BLOCK) {
-        const float g = L.yaw[t] * WG_DEG2RAD_F;
-        const float sg = sinf(g), cg = L.cg[t];
-        const float wsn = fmaxf(L.u[t] * cg + L.v[t] * sg, 0.0f);
-        L.pow[t] = wg_tab_interp<float>(L.tabws, L.tabp, p.n_tab, wsn);
-        L.ct[t] = wg_tab_interp<float>(L.tabws, L.tabct, p.n_tab, wsn) * cg * cg;
-    }
-    __syncthreads();
-}
-
-// replay mode (test hook): consume one scripted row instead of the physics
-__device__ inline void script_step(const WgParams& p, const WgPtrs& d, const FlowLds& L, int e, int farm,
-                                   int& cursor, double& time, bool advance) {
-    if (advance) { ++cursor; time += p.dt_d; }
-    int row = cursor < p.script_rows ? cursor : p.script_rows - 1;
-    size_t base = (((size_t)farm * p.script_rows + row) * p.B + e) * p.N;
-    for (int t = threadIdx.x; t < p.N; t += WG_BLOCK) {
-        L.u[t] = d.script_uvw[(base + t) * 3 + 0];
-        L.v[t] = d.script_uvw[(base + t) * 3 + 1];
-        L.w[t] = d.script_uvw[(base + t) * 3 + 2];
-        L.pow[t] = d.script_power[base + t];
-    }
-    __syncthreads();
-}
-
-// WindFarmEnv._take_measurements (Wind_Farm_Env.py:480-495), accumulated over the k sub-steps
-__device__ inline void take_measurements(const WgParams& p, const WgPtrs& d, const FlowLds& L, int ctx_id,
-                                         float wd_env) {
-    for (int t = threadIdx.x; t < p.N; t += WG_BLOCK) {
-        const float u = L.u[t], v = L.v[t], w = L.w[t];
-        const float ws = sqrtf(u * u + v * v + w * w);
-        const float wd = atanf(v / u) * WG_RAD2DEG_F + wd_env;
-        d.cur_ws[(size_t)ctx_id * p.N + t] = ws;
-        d.cur_wd[(size_t)ctx_id * p.N + t] = wd;
-        L.sws[t] += ws; L.swd[t] += wd; L.syaw[t] += L.yaw[t]; L.sp[t] += L.pow[t];
-    }
-}
-
-// farm_mes.add_measurements (MesClass.py:568-591): noise, ring push, farm-level mean/mean/sum.
-// Returns (to thread 0) the farm power pushed to farm_pow_deq (Wind_Farm_Env.py:766, :975).
-__device__ inline float push_measurements(const WgParams& p, const WgPtrs& d, const FlowLds& L, int ctx_id,
-                                          WgCtx& cx, uint64_t noise_key) {
-    const int N = p.N;
-    const int n_pushed = cx.n_pushed;
-    const float inv_k = 1.0f / (float)p.K;
-    float* rbase = d.ring + (size_t)ctx_id * p.ring_stride;
-    for (int t = threadIdx.x; t < N; t += WG_BLOCK) {
-        float val[WG_N_CH] = {L.sws[t] * inv_k, L.swd[t] * inv_k, L.syaw[t] * inv_k, L.sp[t] * inv_k};
-        if (p.K == 1) { val[0] = L.sws[t]; val[1] = L.swd[t]; val[2] = L.syaw[t]; val[3] = L.sp[t]; }
-        if (p.noise == WG_NOISE_NORMAL) {
-#pragma unroll
-            for (int ch = 0; ch < WG_N_CH; ++ch)
-                if (p.noise_sigma[ch] != 0.f)
-                    val[ch] += p.noise_sigma[ch] *
-                               wg_noise_normal(noise_key, (uint32_t)n_pushed, (uint32_t)t, (uint32_t)ch,
-                                               (uint32_t)cx.episode_tag);
-        }
-#pragma unroll
-        for (int ch = 0; ch < WG_N_CH; ++ch) {
-            const int H = p.ch[ch].history_len;
-            rbase[p.ring_off[ch] + (size_t)t * H + (n_pushed % H)] = val[ch];
-        }
-        L.sws[t] = val[0]; L.swd[t] = val[1]; L.sp[t] = val[3];
-    }
-    __syncthreads();
-    float tot = 0.f;
-    if (threadIdx.x == 0) {
-        float sws = 0.f, swd = 0.f;
-        for (int t = 0; t < N; ++t) { sws += L.sws[t]; swd += L.swd[t]; tot += L.sp[t]; }
-        float* fbase = d.fring + (size_t)ctx_id * p.fring_stride;
-        fbase[p.fring_off[WG_CH_WS] + n_pushed % p.ch[WG_CH_WS].history_len] = sws / (float)N;
-        fbase[p.fring_off[WG_CH_WD] + n_pushed % p.ch[WG_CH_WD].history_len] = swd / (float)N;
-        fbase[p.fring_off[WG_CH_POWER] + n_pushed % p.ch[WG_CH_POWER].history_len] = tot;
-        cx.n_pushed = n_pushed + 1;
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < N; t += WG_BLOCK) { L.sws[t] = 0.f; L.swd[t] = 0.f; L.syaw[t] = 0.f; L.sp[t] = 0.f; }
-    __syncthreads();
-    return tot;
-}
-
-// BasicControllers.local_yaw_controller / global_yaw_controller (BasicControllers.py:10-73)
-__device__ inline void base_controller(const WgParams& p, const FlowLds& L) {
-    for (int t = threadIdx.x; t < p.N; t += WG_BLOCK) {
-        float yaw = L.yaw[t];
-        if (p.base_controller == WG_CTRL_LOCAL) {
-            const float wdir = atanf(L.v[t] / L.u[t]) * WG_RAD2DEG_F;
-            const float off = wdir - yaw;
-            const float sgn = (float)((off > 0.f) - (off < 0.f));
-            yaw = yaw + sgn * fminf(fabsf(off), p.yaw_step);
-        } else {
-            const float sgn = (float)((yaw > 0.f) - (yaw < 0.f));
-            yaw = yaw - sgn * fminf(fabsf(yaw), p.yaw_step);
-        }
-        L.yaw[t] = yaw;
-    }
-    __syncthreads();
-}
-
-// WindFarmEnv._adjust_yaws (Wind_Farm_Env.py:822-864), float32 like numpy evaluates it on a float32 action
-__device__ inline void adjust_yaws(const WgParams& p, const WgPtrs& d, const FlowLds& L, int e,
-                                   const float* __restrict__ actions) {
-    for (int t = threadIdx.x; t < p.N; t += WG_BLOCK) {
-        float yaw = L.yaw[t];
-        d.old_yaw[(size_t)e * p.N + t] = yaw;          // :932
-        const float a = actions[(size_t)e * p.N + t];
-        if (p.action_method == WG_ACT_YAW) {
-            yaw = fminf(fmaxf(yaw + a * p.yaw_step, p.yaw_min), p.yaw_max);
-        } else {
-            float tf = a + 1.0f;
-            tf = tf / 2.0f;
-            tf = tf * (p.yaw_max - p.yaw_min);
-            tf = tf + p.yaw_min;
-            float ny = fminf(fmaxf(tf, yaw - p.yaw_step), yaw + p.yaw_step);
-            yaw = fminf(fmaxf(ny, p.yaw_min), p.yaw_max);
-        }
-        L.yaw[t] = yaw;
-    }
-    __syncthreads();
-}
-
-template <int TURB>
-__global__ void __launch_bounds__(WG_BLOCK)
-k_flow(const WgParams p, const WgPtrs d, const int mode, const float* __restrict__ actions,
-       const uint8_t* __restrict__ mask, const int chunk) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int F = p.F, N = p.N;
-    const int bid = blockIdx.x;
-    const int farm = bid % F;
-    const int ec = bid / F;
-    const int c = ec & 1;
-    const int e = ec >> 1;
-    const int tid = threadIdx.x;
-    const int ctx_id = e * 2 + c;
-    const int slot_id = ctx_id * F + farm;
-
-    const WgEnv& env = d.env[e];
-    const bool is_live = (c == env.live);
-    WgSlot& slot = d.slot[slot_id];
-    const bool ready = (slot.dev_remaining == 0 && slot.fill_remaining == 0);
-    int budget = 0;
-    if (mode == WG_MODE_STEP) {
-        if (is_live) {
-            if (env.done) return;
-        } else {
-            if (!p.autoreset || ready) return;
-            budget = env.shadow_iters;
-            if (budget <= 0) return;
-        }
-    } else {
-        if (!is_live || ready || (mask && !mask[e])) return;
-        budget = chunk;
-    }
-
-    FlowLds L = flow_lds_carve(smem, N, p.S, p.n_tab);
-    WgCtx& cx = d.ctx[ctx_id];
-    const double ws = cx.ws, ti_amb = cx.ti;
-    const float wd_env = (float)cx.wd;
-    const size_t tb = (size_t)slot_id * N;
-    const size_t pbase = (size_t)slot_id * p.NP;
-    for (int t = tid; t < N; t += WG_BLOCK) {
-        L.xr[t] = d.xr[(size_t)ctx_id * N + t];
-        L.yr[t] = d.yr[(size_t)ctx_id * N + t];
-        L.yaw[t] = d.yaw[tb + t]; L.u[t] = d.u[tb + t]; L.v[t] = d.v[tb + t]; L.w[t] = d.w[tb + t];
-        L.ti[t] = d.ti_loc[tb + t]; L.pow[t] = d.power[tb + t]; L.ct[t] = d.ct[tb + t];
-        L.sws[t] = 0.f; L.swd[t] = 0.f; L.syaw[t] = 0.f; L.sp[t] = 0.f;
-    }
-    for (int i = tid; i < p.n_tab; i += WG_BLOCK) {
-        L.tabws[i] = d.tab_ws[i]; L.tabp[i] = d.tab_power[i]; L.tabct[i] = d.tab_ct[i];
-    }
-    for (int i = tid; i < p.S; i += WG_BLOCK) { L.rdy[i] = d.rotor_dy[i]; L.rdz[i] = d.rotor_dz[i]; }
-    __syncthreads();
-
-    int head = slot.head, n_valid = slot.n_valid, cursor = slot.cursor;
-    double s_off = slot.s_off, time = slot.time;
-    int dev_rem = slot.dev_remaining, fill_rem = slot.fill_remaining;
-    const bool replay = d.script_uvw != nullptr;
-
-    if (mode == WG_MODE_STEP && is_live) {
-        // ---- one env step of the running episode (Wind_Farm_Env.py:932-979) ----
-        if (farm == 0) adjust_yaws(p, d, L, e, actions);
-        float base_acc = 0.f;
-        for (int k = 0; k < p.K; ++k) {
-            if (farm == 1) base_controller(p, L);
-            if (replay) script_step(p, d, L, e, farm, cursor, time, true);
-            else flow_step<TURB>(p, d, L, pbase, ws, ti_amb, head, n_valid, s_off, time);
-            if (farm == 0) {
-                take_measurements(p, d, L, ctx_id, wd_env);
-                __syncthreads();
-            } else if (tid == 0) {
-                float tot = 0.f;
-                for (int t = 0; t < N; ++t) tot += L.pow[t];
-                base_acc += tot;
-            }
-        }
-        if (farm == 0) {
-            float tot = push_measurements(p, d, L, ctx_id, cx, env.noise_key);
-            if (tid == 0) d.step_farm_pow[e] = tot;
-        } else if (tid == 0) {
-            d.step_base_pow[e] = p.K == 1 ? base_acc : base_acc / (float)p.K;
-        }
-    } else {
-        // ---- background development of a not-yet-live episode (Wind_Farm_Env.py:722-796) ----
-        while (budget > 0 && (dev_rem > 0 || fill_rem > 0)) {
-            if (dev_rem > 0) {
-                flow_step<TURB>(p, d, L, pbase, ws, ti_amb, head, n_valid, s_off, time);
-                --dev_rem; --budget;
-            } else {
-                float base_acc = 0.f;
-                for (int k = 0; k < p.K; ++k) {
-                    if (replay) script_step(p, d, L, e, farm, cursor, time, true);
-                    else flow_step<TURB>(p, d, L, pbase, ws, ti_amb, head, n_valid, s_off, time);
-                    if (farm == 0) {
-                        take_measurements(p, d, L, ctx_id, wd_env);
-                        __syncthreads();
-                    } else if (tid == 0) {
-                        float tot = 0.f;
-                        for (int t = 0; t < N; ++t) tot += L.pow[t];
-                        base_acc += tot;
-                    }
-                }
-                if (farm == 0) {
-                    float tot = push_measurements(p, d, L, ctx_id, cx, env.noise_key);
-                    if (tid == 0) {
-                        d.pend_farm[(size_t)ctx_id * p.power_avg + cx.pend_farm_n % p.power_avg] = tot;
-                        cx.pend_farm_n += 1;
-                    }
-                } else if (tid == 0) {
-                    d.pend_base[(size_t)ctx_id * p.power_avg + cx.pend_base_n % p.power_avg] =
-                        p.K == 1 ? base_acc : base_acc / (float)p.K;
-                    cx.pend_base_n += 1;
-                }
-                --fill_rem; budget -= p.K;
-            }
-        }
-    }
-
-    // write the slot back
-    for (int t = tid; t < N; t += WG_BLOCK) {
-        d.yaw[tb + t] = L.yaw[t]; d.u[tb + t] = L.u[t]; d.v[tb + t] = L.v[t]; d.w[tb + t] = L.w[t];
-        d.ti_loc[tb + t] = L.ti[t]; d.power[tb + t] = L.pow[t]; d.ct[tb + t] = L.ct[t];
-    }
-    if (tid == 0) {
-        slot.head = head; slot.n_valid = n_valid; slot.s_off = s_off; slot.time = time; slot.cursor = cursor;
-        slot.dev_remaining = dev_rem; slot.fill_remaining = fill_rem;
-    }
-}
-
-template __global__ void k_flow<WG_TURB_NONE>(const WgParams, const WgPtrs, const int, const float*,
-                                              const uint8_t*, const int);
 
 // ===================================================================================================
 // episode context initialisation (wave-cooperative): WindFarmEnv.reset up to fs.run (:689-732)
@@ -1000,12 +530,6 @@ __global__ void __launch_bounds__(WG_BLOCK) k_metrics(const WgParams p, const Wg
 }
 
 // host-visible launch helpers (defined here so that the <<<>>> syntax stays in one translation unit)
-extern "C" void wg_launch_flow(const WgParams* p, const WgPtrs* d, int mode, const float* actions,
-                               const uint8_t* mask, int chunk, hipStream_t st) {
-    const int grid = p->B * 2 * p->F;
-    const size_t lds = flow_lds_bytes(p->N, p->S, p->n_tab);
-    hipLaunchKernelGGL(k_flow<WG_TURB_NONE>, dim3(grid), dim3(WG_BLOCK), lds, st, *p, *d, mode, actions, mask, chunk);
-}
 extern "C" void wg_launch_glue(const WgParams* p, const WgPtrs* d, int phase, const uint8_t* mask, float* obs,
                                float* reward, uint8_t* trunc, float* final_obs, hipStream_t st) {
     const int grid = (p->B + WG_NWAVES - 1) / WG_NWAVES;
