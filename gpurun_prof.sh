@@ -1,4 +1,4 @@
-# usage: bash gpurun_prof.sh <tag> [bench args...]
+# usage: bash gpurun_prof.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/summary.txt
 cd $GRAFT_REPO_ROOT
 TAG=$1; shift
 export TMPDIR=/tmp
@@ -7,24 +7,29 @@ mkdir -p $OUT
 BENCH="python bench.py --steps 100 --warmup 10 --no-cpu $@"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $BENCH > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $OUT/pmc1 -o p -- $BENCH > $OUT/bench_pmc1.log 2>&1
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM -d $OUT/pmc2 -o p -- $BENCH > $OUT/bench_pmc2.log 2>&1
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM -d $OUT/pmc2 -o p -- $BENCH > $OUT/bench_pmc2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc3 -o p -- $BENCH > $OUT/bench_pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc4 -o p -- $BENCH > $OUT/bench_pmc4.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc5 -o p -- $BENCH > $OUT/bench_pmc5.log 2>&1
-find $OUT -name "*.csv" | head -30
-python - <<PY
-import csv, glob, collections, os
+rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum -d $OUT/pmc5 -o p -- $BENCH > $OUT/bench_pmc5.log 2>&1
+rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_32B_sum -d $OUT/pmc6 -o p -- $BENCH > $OUT/bench_pmc6.log 2>&1
+python - > $OUT/summary.txt <<PY
+import sqlite3, collections, glob
 out = "$OUT"
-for f in sorted(glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)):
-    print("==", f); print(open(f).read()[:3000])
-for d in ("pmc1","pmc2","pmc3","pmc4","pmc5"):
-    for f in glob.glob(out + f"/{d}/**/*counter_collection.csv", recursive=True):
-        acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
-        for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"][:40]
-            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            cnt[(k, r["Counter_Name"])] += 1
-        for k, v in acc.items():
-            if "k_flow" in k or "k_glue" in k:
-                print(d, k, {c: round(val / cnt[(k, c)], 1) for c, val in v.items()})
+db = sqlite3.connect(out + '/trace/t_results.db'); cur = db.cursor()
+print("# rocprofv3 --kernel-trace --stats : top kernels (name, calls, total_us, avg_us, pct)")
+for r in cur.execute("select * from top_kernels limit 8"): print(r)
+rows = list(cur.execute("select name, start, end from kernels order by start"))
+fl = [(e-s)/1e3 for n,s,e in rows if 'k_flow' in n]
+gl = [(e-s)/1e3 for n,s,e in rows if 'k_glue' in n]
+print("# k_flow STEP-mode launches (last 100): avg_us %.2f min %.2f max %.2f ; k_glue avg_us %.2f" % (sum(fl[-100:])/100, min(fl[-100:]), max(fl[-100:]), sum(gl[-100:])/100))
+print("# k_flow RESET-mode launches (first ones) us:", [round(x) for x in fl[:len(fl)-110]])
+print("# PMC counters, k_flow STEP-mode launches, average per launch (last 100 dispatches)")
+for n in sorted(glob.glob(out + '/pmc*/p_results.db')):
+    db = sqlite3.connect(n); cur = db.cursor()
+    acc = collections.defaultdict(list)
+    for r in cur.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection order by dispatch_id"):
+        if 'k_flow' in r[0]: acc[r[1]].append(r[2])
+    for k,v in sorted(acc.items()):
+        v = v[-100:]; print(k, round(sum(v)/len(v),1))
 PY
+cat $OUT/summary.txt; tail -1 $OUT/bench_trace.log | cut -c1-600

@@ -45,7 +45,6 @@ struct wg_env_s {
     WgPtrs d;
     FlowP fp;
     FlowPtrs fd;
-    unsigned long long* flow_steps_dev = nullptr;
     unsigned long long flow_steps_mark = 0;
     int device;
     std::vector<Alloc> allocs;      // everything owned by the handle (state blob = allocs flagged `state`)
@@ -104,6 +103,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     if (c->k_sub < 1) return fail(WG_ERR_INVALID, "dt_env must be a multiple of dt_sim");
     if (c->n_particles < 8 || c->n_particles % 4) return fail(WG_ERR_INVALID, "n_particles must be a multiple of 4 (>= 8)");
     if (c->n_rotor_pts < 1 || c->n_rotor_pts > 64) return fail(WG_ERR_INVALID, "n_rotor_pts must be in [1, 64]");
+    if (c->n_turb > 32 * WG_MASK_WORDS) return fail(WG_ERR_UNSUPPORTED, "n_turb > 128 is not supported by this build");
     if (!c->x_pos || !c->y_pos || !c->rotor_dy || !c->rotor_dz || !c->tab_ws || !c->tab_power || !c->tab_ct || c->n_tab < 2)
         return fail(WG_ERR_INVALID, "layout / rotor points / turbine table missing");
     if (c->action_method != WG_ACT_YAW && c->action_method != WG_ACT_WIND)
@@ -194,7 +194,6 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     A(metrics, (size_t)p.B * WG_N_METRICS, true);
     A(status, 1, true);
 #undef A
-    if (!rc) rc = dev_alloc(h, &h->flow_steps_dev, 1, false);
     if (!rc) rc = dev_alloc(h, &h->mask_dev, (size_t)p.B, false);
     if (!rc) rc = dev_alloc(h, &h->seeds_dev, (size_t)p.B, false);
     if (!rc) rc = dev_upload<double>(h, &d.x_pos, c->x_pos, p.N);
@@ -251,10 +250,14 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         int tc = 1024 / p.N; if (tc < 1) tc = 1; if (tc > p.N) tc = p.N;
         // phase B maps one thread per (target, sample): keep a chunk's items a multiple of the sample group
         f.target_chunk = tc;
+        // workgroup size: small farms are latency-bound around their phase boundaries -> more, smaller
+        // workgroups per CU (a single-wave workgroup needs no barriers at all); big farms want more lanes
+        f.block = p.NP <= 1024 ? 64 : (p.NP <= 8192 ? 128 : 256);   // measured on cfg2 (NP = 2048): 128 best
+        if (const char* ev = getenv("WG_FLOW_BLOCK")) { int b = atoi(ev); if (b == 64 || b == 128 || b == 256) f.block = b; }
         size_t off = sizeof(float) * 4 * (size_t)tc * p.N;
         f.lds_off_turb = (int)off; off += (size_t)WG_TURB_LDS_BYTES * p.N;
         off = (off + 15) & ~(size_t)15;
-        f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S);
+        f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S) + sizeof(unsigned) * WG_MASK_WORDS * (size_t)tc;
         f.lds_bytes = (int)((off + 15) & ~(size_t)15);
         f.dt = p.dt; f.D = p.D; f.inv_D = p.inv_D; f.hub = p.hub; f.dpart_f = (float)p.dpart; f.R_rot = 0.5f * p.D;
         f.inv_N = 1.0f / (float)p.N; f.inv_S = 1.0f / (float)p.S;
@@ -276,7 +279,6 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         g.pend_farm = d.pend_farm; g.pend_base = d.pend_base; g.old_yaw = d.old_yaw;
         g.step_farm_pow = d.step_farm_pow; g.step_base_pow = d.step_base_pow;
         g.rotor_dy = d.rotor_dy; g.rotor_dz = d.rotor_dz; g.tab_power = tpu; g.tab_ct = tcu;
-        g.flow_steps = h->flow_steps_dev;
     }
 
     // how many RESET-mode launches develop the slowest possible episode: the chain needs
@@ -473,7 +475,12 @@ extern "C" int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, do
     if (!h) return fail(WG_ERR_INVALID, "null handle");
     HIPCHK(hipDeviceSynchronize());
     unsigned long long fs_now = 0;
-    HIPCHK(hipMemcpy(&fs_now, h->flow_steps_dev, sizeof(fs_now), hipMemcpyDeviceToHost));
+    {
+        const size_t n_slots = (size_t)h->p.B * 2 * h->p.F;
+        std::vector<WgSlot> slots(n_slots);
+        HIPCHK(hipMemcpy(slots.data(), h->d.slot, sizeof(WgSlot) * n_slots, hipMemcpyDeviceToHost));
+        for (const WgSlot& s : slots) fs_now += s.flow_count;
+    }
     double fsum = 0, gsum = 0;
     int nf = 0, ng = 0;
     if (h->ev_used) {

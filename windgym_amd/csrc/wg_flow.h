@@ -9,6 +9,7 @@
 struct FlowP {
     int B, N, F, K, P, S, S_pad, S_shift, NP, n_tab;
     int autoreset, action_method, base_controller, power_avg, script_rows, noise;
+    int block;                    // threads per workgroup: 64, 128 or 256
     int target_chunk;             // targets whose pair parameters are staged in LDS at once
     int lds_off_turb, lds_off_tab, lds_bytes;
     float dt, D, inv_D, hub, dpart_f, R_rot, inv_N, inv_S;
@@ -31,8 +32,9 @@ struct FlowPtrs {
     float *ring, *fring, *cur_ws, *cur_wd, *pend_farm, *pend_base, *old_yaw, *step_farm_pow, *step_base_pow;
     const float *rotor_dy, *rotor_dz, *tab_power, *tab_ct;   // tab_*: resampled on the uniform grid
     const float *script_uvw, *script_power;
-    unsigned long long* flow_steps;   // total flow_step() executions (for the roofline accounting)
 };
 
 // sizeof(TurbLds) in wg_flow.hip; kept here so the host can size the dynamic LDS
 #define WG_TURB_LDS_BYTES 88
+// per-target bit mask of contributing sources: 32-bit words per target (N <= 32 * WG_MASK_WORDS)
+#define WG_MASK_WORDS 4

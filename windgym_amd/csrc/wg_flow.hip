@@ -36,6 +36,11 @@ __device__ __forceinline__ float m0_cfrac(float ct, float sp) {
     return 1.0f - __builtin_amdgcn_sqrtf(a);
 }
 
+// x^y for x >= 0 via v_log_f32 / v_exp_f32 (HIP's __powf expands to the full-precision routine)
+__device__ __forceinline__ float fast_pow(float x, float y) {
+    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+}
+
 // uniform-grid table lookup (linear interpolation, 0 outside)
 __device__ __forceinline__ float tab_lookup(const float* __restrict__ ys, const FlowP& p, float x) {
     const float fx = (x - p.tab_x0) * p.tab_inv_dx;
@@ -51,34 +56,56 @@ struct SlotRegs {
     int head, n_valid;
 };
 
+// barrier that orders LDS traffic only: does NOT wait for outstanding global stores (a plain
+// __syncthreads() drains vmcnt and exposes the full store latency at every phase boundary)
+template <int NT>
+__device__ __forceinline__ void lds_barrier() {
+    if (NT > WG_WAVE) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // single-wave workgroup: program order suffices
+}
+// barrier that also makes this workgroup's global stores visible to its own later loads
+template <int NT>
+__device__ __forceinline__ void full_barrier() {
+    if (NT > WG_WAVE) __syncthreads();
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+#ifndef WG_ABLATE
+#define WG_ABLATE 0   // profiling only: 1 = no advection pass, 2 = no deficit phases
+#endif
+
+// One DWMFlowSimulation.step() of model M0 up to the new rotor inflow (T[t].u/v/w/ti); power and the
+// measurement are done by the caller's per-turbine tail.
+template <int NT>
 __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, TurbLds* __restrict__ T,
-                                          const float* __restrict__ tabp, const float* __restrict__ tabct,
+                                          const float* __restrict__ tabct,
                                           const float* __restrict__ rdy, const float* __restrict__ rdz,
-                                          float4* __restrict__ pair, const size_t pbase, const double ws,
+                                          float4* __restrict__ pair, unsigned* __restrict__ tmask,
+                                          const size_t pbase, const double ws,
                                           const float ti_f, const float ti_pow, SlotRegs& sr) {
     const int tid = threadIdx.x;
     const int N = p.N, P = p.P;
+    const int TC = p.target_chunk;
 
-    // (1) emission records of this step, sin/cos of the yaw
-    if (tid < N) {
-        for (int t = tid; t < N; t += WG_BLOCK) {
-            TurbLds& q = T[t];
-            const float g = q.yaw * WG_DEG2RAD_F;
-            const float sg = __sinf(g), cg = __cosf(g);
-            const float wsn = fmaxf(q.u * cg + q.v * sg, 0.0f);
-            const float ctx = fminf(fmaxf(tab_lookup(tabct, p, wsn) * cg * cg, 0.0f), 0.96f);
-            const float rq = __builtin_amdgcn_sqrtf(1.0f - ctx);
-            const float beta = 0.5f * (1.0f + rq) * __builtin_amdgcn_rcpf(rq);
-            q.rct = ctx;
-            q.rk = p.ka * q.ti + p.kb;
-            q.reps = p.eps0 * __builtin_amdgcn_sqrtf(beta);
-            q.rhv = -p.hill * sg * q.u;
-            q.rue = q.u;
-            q.cg = cg;
-            q.sg = sg;
-        }
+    // (1) emission records of this step, sin/cos of the yaw; clear the source masks
+    for (int t = tid; t < N; t += NT) {
+        TurbLds& q = T[t];
+        const float g = q.yaw * WG_DEG2RAD_F;
+        const float sg = __sinf(g), cg = __cosf(g);
+        const float wsn = fmaxf(q.u * cg + q.v * sg, 0.0f);
+        const float ctx = fminf(fmaxf(tab_lookup(tabct, p, wsn) * cg * cg, 0.0f), 0.96f);
+        const float rq = __builtin_amdgcn_sqrtf(1.0f - ctx);
+        const float beta = 0.5f * (1.0f + rq) * __builtin_amdgcn_rcpf(rq);
+        q.rct = ctx;
+        q.rk = p.ka * q.ti + p.kb;
+        q.reps = p.eps0 * __builtin_amdgcn_sqrtf(beta);
+        q.rhv = -p.hill * sg * q.u;
+        q.rue = q.u;
+        q.cg = cg;
+        q.sg = sg;
     }
-    __syncthreads();
+    for (int i = tid; i < TC * WG_MASK_WORDS; i += NT) tmask[i] = 0u;
+    lds_barrier<NT>();
 
     // (2) streaming pass over the particle SoA: advect over dt, release the new particles
     const int head = sr.head, n_valid = sr.n_valid;
@@ -96,12 +123,12 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     float* __restrict__ geps = d.eps_e + pbase;
     float* __restrict__ ghv = d.hv_e + pbase;
     float* __restrict__ gue = d.u_e + pbase;
-    {
+    if (!(WG_ABLATE & 1)) {
         // thread -> 4 consecutive ring slots of one turbine (P % 4 == 0); (t, r0) advance incrementally
         int t = (tid * 4) / P;
         int r0 = tid * 4 - t * P;
-        const int dt_ = (WG_BLOCK * 4) / P, dr_ = (WG_BLOCK * 4) - dt_ * P;
-        for (int i4 = tid * 4; i4 < p.NP; i4 += WG_BLOCK * 4) {
+        const int dt_ = (NT * 4) / P, dr_ = (NT * 4) - dt_ * P;
+        for (int i4 = tid * 4; i4 < p.NP; i4 += NT * 4) {
             float4 py4 = *reinterpret_cast<const float4*>(gpy + i4);
             const float4 hv4 = *reinterpret_cast<const float4*>(ghv + i4);
             int j0 = head - r0; if (j0 < 0) j0 += P;              // age of ring slot r0 (slot r0+q: j0-q)
@@ -151,16 +178,19 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         }
     }
     sr.head = new_head; sr.n_valid = new_valid; sr.s_off = s_new; sr.time += p.dt_d;
-    __syncthreads();   // this workgroup's particle stores are visible to its own gathers below (same CU)
+    full_barrier<NT>();   // this workgroup's particle stores are visible to its own gathers below
 
     // (3)+(4) rotor-averaged inflow
-    const int TC = p.target_chunk;
     const float ws_f = (float)ws;
-    for (int t0 = 0; t0 < N; t0 += TC) {
+    for (int t0 = 0; t0 < ((WG_ABLATE & 2) ? 0 : N); t0 += TC) {
         const int nt = (N - t0) < TC ? (N - t0) : TC;
         const int npairs = nt * N;
-        // phase A: one thread per (target, source) pair
-        for (int i = tid; i < npairs; i += WG_BLOCK) {
+        if (t0 > 0) {
+            for (int i = tid; i < nt * WG_MASK_WORDS; i += NT) tmask[i] = 0u;
+            lds_barrier<NT>();
+        }
+        // phase A: one thread per (target, source) pair; contributing sources are flagged in tmask[target]
+        for (int i = tid; i < npairs; i += NT) {
             const int tl = (int)(((float)i + 0.5f) * p.inv_N);
             const int s2 = i - tl * N;
             const int t = t0 + tl;
@@ -175,11 +205,14 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 if (j + 1 <= new_valid - 1) {
                     int r0 = new_head - j; if (r0 < 0) r0 += P;
                     int r1 = r0 - 1; if (r1 < 0) r1 += P;
-                    const int i0 = s2 * P + r0, i1 = s2 * P + r1;
+                    const unsigned i0 = (unsigned)(s2 * P + r0), i1 = (unsigned)(s2 * P + r1);
+                    // one round of gathers (L2 hits: this workgroup wrote these lines a moment ago)
+                    const float py0 = gpy[i0], py1 = gpy[i1], k0 = gk[i0], k1 = gk[i1], e0 = geps[i0], e1 = geps[i1];
+                    const float c0 = gct[i0], c1 = gct[i1], u0 = gue[i0], u1 = gue[i1];
                     const float w0 = 1.0f - wgt, w1 = wgt;
-                    const float yc = w0 * gpy[i0] + w1 * gpy[i1];
-                    const float kv = w0 * gk[i0] + w1 * gk[i1];
-                    const float epv = w0 * geps[i0] + w1 * geps[i1];
+                    const float yc = w0 * py0 + w1 * py1;
+                    const float kv = w0 * k0 + w1 * k1;
+                    const float epv = w0 * e0 + w1 * e1;
                     const float xd = (float)dx * p.inv_D;
                     const float sp = kv * xd + epv;
                     const float sig = sp * p.D;
@@ -187,24 +220,25 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     const float rc2 = (yt - yc) * (yt - yc);
                     const float rcut = p.R_rot + 5.0f * sig;
                     if (rc2 <= rcut * rcut) {
-                        const float ctv = w0 * gct[i0] + w1 * gct[i1];
-                        const float uev = w0 * gue[i0] + w1 * gue[i1];
+                        const float ctv = w0 * c0 + w1 * c1;
+                        const float uev = w0 * u0 + w1 * u1;
                         const float cf = m0_cfrac(ctv, sp);
                         const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sig * sig);
                         // wake-added turbulence (Crespo-Hernandez), Gaussian-weighted at the hub
                         const float ind = 0.5f * (1.0f - __builtin_amdgcn_sqrtf(1.0f - ctv));
-                        const float tia = p.tia * __powf(ind, p.tib) * ti_pow * __powf(fmaxf(xd, 1.0f), p.tid) *
+                        const float tia = p.tia * fast_pow(ind, p.tib) * ti_pow * fast_pow(fmaxf(xd, 1.0f), p.tid) *
                                           __expf(-rc2 * inv2s2);
                         pp = make_float4(yc, inv2s2, uev * cf, tia);
+                        atomicOr(&tmask[tl * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
                     }
                 }
             }
             pair[i] = pp;
         }
-        __syncthreads();
+        lds_barrier<NT>();
         // phase B: one thread per (target, sample); S_pad = S rounded up to a power of two
         const int nitems = nt << p.S_shift;
-        for (int it = tid; it < ((nitems + WG_BLOCK - 1) & ~(WG_BLOCK - 1)); it += WG_BLOCK) {
+        for (int it = tid; it < ((nitems + NT - 1) & ~(NT - 1)); it += NT) {
             const int tl = it >> p.S_shift;
             const int s = it & (p.S_pad - 1);
             const bool live = (it < nitems) && (s < p.S);
@@ -215,10 +249,13 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 const float ys = (float)T[t].yr + rdy[s] * T[t].cg;
                 const float dz = rdz[s];
                 const float dz2 = dz * dz;
-                for (int s2 = 0; s2 < N; ++s2) {
-                    const float4 pp = pr[s2];
-                    tia_max = fmaxf(tia_max, pp.w);
-                    if (pp.z != 0.f) {
+                for (int wd = 0; wd * 32 < N; ++wd) {
+                    unsigned m = tmask[tl * WG_MASK_WORDS + wd];
+                    while (m) {                       // ascending source order -> deterministic sum
+                        const int s2 = wd * 32 + __builtin_ctz(m);
+                        m &= m - 1;
+                        const float4 pp = pr[s2];
+                        tia_max = fmaxf(tia_max, pp.w);
                         const float dy = ys - pp.x;
                         acc += pp.z * __expf(-(dy * dy + dz2) * pp.y);
                     }
@@ -233,39 +270,38 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 q.ti = __builtin_amdgcn_sqrtf(ti_f * ti_f + tia_max * tia_max);
             }
         }
-        __syncthreads();
+        lds_barrier<NT>();
     }
-
-    // (5) power / thrust with the current yaw
-    if (tid < N) {
-        for (int t = tid; t < N; t += WG_BLOCK) {
-            TurbLds& q = T[t];
-            const float wsn = fmaxf(q.u * q.cg + q.v * q.sg, 0.0f);
-            q.pow = tab_lookup(tabp, p, wsn);
-            q.ct = tab_lookup(tabct, p, wsn) * q.cg * q.cg;
-        }
-    }
-    __syncthreads();
 }
 
 // replay mode (test hook): consume one scripted row instead of the physics
+template <int NT>
 __device__ __forceinline__ void script_step(const FlowP& p, const FlowPtrs& d, TurbLds* T, int e, int farm,
                                             int& cursor, double& time) {
     ++cursor;
     time += p.dt_d;
     const int row = cursor < p.script_rows ? cursor : p.script_rows - 1;
     const size_t base = (((size_t)farm * p.script_rows + row) * p.B + e) * p.N;
-    for (int t = threadIdx.x; t < p.N; t += WG_BLOCK) {
+    for (int t = threadIdx.x; t < p.N; t += NT) {
         T[t].u = d.script_uvw[(base + t) * 3 + 0];
         T[t].v = d.script_uvw[(base + t) * 3 + 1];
         T[t].w = d.script_uvw[(base + t) * 3 + 2];
         T[t].pow = d.script_power[base + t];
     }
-    __syncthreads();
+    lds_barrier<NT>();
 }
 
-template <bool REPLAY, bool NOISE>
-__global__ void __launch_bounds__(WG_BLOCK, WG_FLOW_WAVES)
+// sum of a per-turbine LDS field over all turbines, by wave 0 (fixed shuffle tree -> deterministic);
+// result valid in every lane of wave 0
+#define WG_TURB_SUM(field)                                                                  \
+    ([&]() {                                                                                \
+        float _s = 0.f;                                                                     \
+        for (int _t = (int)(threadIdx.x & 63); _t < N; _t += WG_WAVE) _s += T[_t].field;    \
+        return wg_wave_sum(_s);                                                             \
+    }())
+
+template <int NT, bool REPLAY, bool NOISE>
+__global__ void __launch_bounds__(NT, WG_FLOW_WAVES)
 k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict__ actions,
        const uint8_t* __restrict__ mask, const int chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -278,68 +314,90 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     const int tid = threadIdx.x;
     const int ctx_id = e * 2 + c;
     const int slot_id = ctx_id * F + farm;
+    const size_t tb = (size_t)slot_id * N;
+    const size_t pbase = (size_t)slot_id * p.NP;
 
+    // ---- prologue: issue every independent global load up front (ONE exposed memory round trip) -------
     const WgEnv& env = d.env[e];
-    const bool is_live = (c == env.live);
+    const int env_live = env.live, env_done = env.done, env_shadow_iters = env.shadow_iters;
+    const uint64_t noise_key = env.noise_key;
     WgSlot& slot = d.slot[slot_id];
     int dev_rem = slot.dev_remaining, fill_rem = slot.fill_remaining;
+    SlotRegs sr{slot.s_off, slot.time, slot.head, slot.n_valid};
+    int cursor = slot.cursor;
+    WgCtx& cx = d.ctx[ctx_id];
+    const double ws = cx.ws;
+    const float ti_f = (float)cx.ti;
+    const float wd_env = (float)cx.wd;
+    int n_pushed = cx.n_pushed;
+    int pend_farm_n = cx.pend_farm_n, pend_base_n = cx.pend_base_n;
+    const uint32_t episode_tag = (uint32_t)cx.episode_tag;
+    const uint8_t masked_out = (mode == WG_MODE_RESET && mask) ? (uint8_t)(mask[e] == 0) : (uint8_t)0;
+    double l_xr = 0, l_yr = 0;
+    float l_yaw = 0, l_u = 0, l_v = 0, l_w = 0, l_ti = 0, l_pow = 0, l_ct = 0, l_act = 0;
+    const int t_own = tid < N ? tid : 0;
+    {
+        l_xr = d.xr[(size_t)ctx_id * N + t_own];
+        l_yr = d.yr[(size_t)ctx_id * N + t_own];
+        l_yaw = d.yaw[tb + t_own]; l_u = d.u[tb + t_own]; l_v = d.v[tb + t_own]; l_w = d.w[tb + t_own];
+        l_ti = d.ti_loc[tb + t_own]; l_pow = d.power[tb + t_own]; l_ct = d.ct[tb + t_own];
+        if (mode == WG_MODE_STEP && farm == 0) l_act = actions[(size_t)e * N + t_own];
+    }
+
+    const bool is_live = (c == env_live);
     const bool ready = (dev_rem == 0 && fill_rem == 0);
     int budget = 0;
     const bool live_step = (mode == WG_MODE_STEP) && is_live;
     if (mode == WG_MODE_STEP) {
         if (is_live) {
-            if (env.done) return;
+            if (env_done) return;
         } else {
             if (!p.autoreset || ready) return;
-            budget = env.shadow_iters;
+            budget = env_shadow_iters;
             if (budget <= 0) return;
         }
     } else {
-        if (!is_live || ready || (mask && !mask[e])) return;
+        if (!is_live || ready || masked_out) return;
         budget = chunk;
     }
 
-    // LDS carve: pair[target_chunk * N] | T[N] | tabp[n_tab] | tabct[n_tab] | rdy[S] | rdz[S]
+    // LDS carve: pair[target_chunk * N] | T[N] | tabp[n_tab] | tabct[n_tab] | rdy[S] | rdz[S] | tmask
     float4* pair = reinterpret_cast<float4*>(smem);
     TurbLds* T = reinterpret_cast<TurbLds*>(smem + p.lds_off_turb);
     float* tabp = reinterpret_cast<float*>(smem + p.lds_off_tab);
     float* tabct = tabp + p.n_tab;
     float* rdy = tabct + p.n_tab;
     float* rdz = rdy + p.S;
+    unsigned* tmask = reinterpret_cast<unsigned*>(rdz + p.S);
 
-    WgCtx& cx = d.ctx[ctx_id];
-    const double ws = cx.ws;
-    const float ti_f = (float)cx.ti;
-    const float wd_env = (float)cx.wd;
-    const size_t tb = (size_t)slot_id * N;
-    const size_t pbase = (size_t)slot_id * p.NP;
-    for (int t = tid; t < N; t += WG_BLOCK) {
+    for (int t = tid; t < N; t += NT) {
         TurbLds& q = T[t];
-        q.xr = d.xr[(size_t)ctx_id * N + t];
-        q.yr = d.yr[(size_t)ctx_id * N + t];
-        q.yaw = d.yaw[tb + t]; q.u = d.u[tb + t]; q.v = d.v[tb + t]; q.w = d.w[tb + t];
-        q.ti = d.ti_loc[tb + t]; q.pow = d.power[tb + t]; q.ct = d.ct[tb + t];
+        if (t == tid && tid < N) {
+            q.xr = l_xr; q.yr = l_yr; q.yaw = l_yaw; q.u = l_u; q.v = l_v; q.w = l_w; q.ti = l_ti; q.pow = l_pow; q.ct = l_ct;
+        }
+        if (t >= NT) {   // N > 256 (not the common case): remaining turbines loaded the slow way
+            q.xr = d.xr[(size_t)ctx_id * N + t]; q.yr = d.yr[(size_t)ctx_id * N + t];
+            q.yaw = d.yaw[tb + t]; q.u = d.u[tb + t]; q.v = d.v[tb + t]; q.w = d.w[tb + t];
+            q.ti = d.ti_loc[tb + t]; q.pow = d.power[tb + t]; q.ct = d.ct[tb + t];
+        }
         q.sws = 0.f; q.swd = 0.f; q.syaw = 0.f; q.sp = 0.f;
     }
-    for (int i = tid; i < p.n_tab; i += WG_BLOCK) { tabp[i] = d.tab_power[i]; tabct[i] = d.tab_ct[i]; }
-    for (int i = tid; i < p.S; i += WG_BLOCK) { rdy[i] = d.rotor_dy[i]; rdz[i] = d.rotor_dz[i]; }
-    __syncthreads();
+    for (int i = tid; i < p.n_tab; i += NT) { tabp[i] = d.tab_power[i]; tabct[i] = d.tab_ct[i]; }
+    for (int i = tid; i < p.S; i += NT) { rdy[i] = d.rotor_dy[i]; rdz[i] = d.rotor_dz[i]; }
 
-    SlotRegs sr{slot.s_off, slot.time, slot.head, slot.n_valid};
-    int cursor = slot.cursor;
-    const float ti_pow = __powf(ti_f, p.tic);
+    const float ti_pow = fast_pow(ti_f, p.tic);
 
     // WindFarmEnv._adjust_yaws (Wind_Farm_Env.py:822-864), float32 like numpy evaluates it on a float32 action
     if (live_step && farm == 0) {
-        for (int t = tid; t < N; t += WG_BLOCK) {
-            float yaw = T[t].yaw;
+        for (int t = tid; t < N; t += NT) {
+            float yaw = t < NT ? l_yaw : d.yaw[tb + t];
             d.old_yaw[(size_t)e * N + t] = yaw;          // :932
-            const float a = actions[(size_t)e * N + t];
+            const float a = t < NT ? l_act : actions[(size_t)e * N + t];
             if (p.action_method == WG_ACT_YAW) {
                 yaw = fminf(fmaxf(yaw + a * p.yaw_step, p.yaw_min), p.yaw_max);
             } else {
                 float tf = a + 1.0f;
-                tf = tf / 2.0f;
+                tf = tf * 0.5f;
                 tf = tf * (p.yaw_max - p.yaw_min);
                 tf = tf + p.yaw_min;
                 const float ny = fminf(fmaxf(tf, yaw - p.yaw_step), yaw + p.yaw_step);
@@ -347,20 +405,21 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             }
             T[t].yaw = yaw;
         }
-        __syncthreads();
     }
+    lds_barrier<NT>();   // publishes T, the tables and the rotor offsets
 
     // live:   one env step = K sub-steps with measurement (Wind_Farm_Env.py:932-979)
     // else:   background development of a not-yet-live episode: flow-development steps (fs.run), then
     //         window-fill env steps (Wind_Farm_Env.py:722-796)
     int sub = 0, n_flow = 0;
     float base_acc = 0.f;
+    const float inv_k = 1.0f / (float)p.K;
     for (;;) {
         if (!live_step && sub == 0 && (budget <= 0 || (dev_rem == 0 && fill_rem == 0))) break;
         const bool is_dev = !live_step && dev_rem > 0;
         if (live_step && farm == 1) {
             // BasicControllers.local_yaw_controller / global_yaw_controller (BasicControllers.py:10-73)
-            for (int t = tid; t < N; t += WG_BLOCK) {
+            for (int t = tid; t < N; t += NT) {
                 float yaw = T[t].yaw;
                 if (p.base_controller == WG_CTRL_LOCAL) {
                     const float wdir = atanf(T[t].v / T[t].u) * WG_RAD2DEG_F;
@@ -373,89 +432,95 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
                 }
                 T[t].yaw = yaw;
             }
-            __syncthreads();
         }
-        if (REPLAY && !is_dev) script_step(p, d, T, e, farm, cursor, sr.time);
-        else { flow_step(p, d, T, tabp, tabct, rdy, rdz, pair, pbase, ws, ti_f, ti_pow, sr); ++n_flow; }
+        if (REPLAY && !is_dev) {
+            lds_barrier<NT>();
+            // sin/cos are not needed in replay mode: power comes from the script
+            script_step<NT>(p, d, T, e, farm, cursor, sr.time);
+        } else {
+            flow_step<NT>(p, d, T, tabct, rdy, rdz, pair, tmask, pbase, ws, ti_f, ti_pow, sr);
+            ++n_flow;
+        }
         --budget;
-        if (is_dev) { --dev_rem; continue; }
-        if (farm == 0) {
-            // WindFarmEnv._take_measurements (Wind_Farm_Env.py:480-495), accumulated over the k sub-steps
-            for (int t = tid; t < N; t += WG_BLOCK) {
-                TurbLds& q = T[t];
+        const bool measuring = !is_dev;
+        const bool unit_end = measuring && (sub + 1 == p.K);
+        // per-turbine tail (thread t owns turbine t): power / thrust with the current yaw (model M0 step 5),
+        // WindFarmEnv._take_measurements (Wind_Farm_Env.py:480-495) accumulated over the k sub-steps and, at
+        // the end of the env step, farm_mes.add_measurements' ring push (MesClass.py:568-591)
+        float* __restrict__ rbase = d.ring + (size_t)ctx_id * p.ring_stride;
+        for (int t = tid; t < N; t += NT) {
+            TurbLds& q = T[t];
+            if (!(REPLAY && !is_dev)) {
+                const float wsn = fmaxf(q.u * q.cg + q.v * q.sg, 0.0f);
+                q.pow = tab_lookup(tabp, p, wsn);
+                q.ct = tab_lookup(tabct, p, wsn) * q.cg * q.cg;
+            }
+            if (measuring && farm == 0) {
                 const float wsm = __builtin_amdgcn_sqrtf(q.u * q.u + q.v * q.v + q.w * q.w);
                 const float wdm = atanf(q.v / q.u) * WG_RAD2DEG_F + wd_env;
-                d.cur_ws[(size_t)ctx_id * N + t] = wsm;
-                d.cur_wd[(size_t)ctx_id * N + t] = wdm;
-                q.sws += wsm; q.swd += wdm; q.syaw += q.yaw; q.sp += q.pow;
+                float val[WG_N_CH] = {q.sws + wsm, q.swd + wdm, q.syaw + q.yaw, q.sp + q.pow};
+                if (unit_end) {
+                    d.cur_ws[(size_t)ctx_id * N + t] = wsm;
+                    d.cur_wd[(size_t)ctx_id * N + t] = wdm;
+                    if (p.K != 1) {
+#pragma unroll
+                        for (int ch = 0; ch < WG_N_CH; ++ch) val[ch] *= inv_k;
+                    }
+                    if (NOISE) {
+#pragma unroll
+                        for (int ch = 0; ch < WG_N_CH; ++ch)
+                            if (p.noise_sigma[ch] != 0.f)
+                                val[ch] += p.noise_sigma[ch] * wg_noise_normal(noise_key, (uint32_t)n_pushed, (uint32_t)t,
+                                                                               (uint32_t)ch, episode_tag);
+                    }
+#pragma unroll
+                    for (int ch = 0; ch < WG_N_CH; ++ch) {
+                        const int H = p.hlen[ch];
+                        rbase[p.ring_off[ch] + t * H + (n_pushed % H)] = val[ch];
+                    }
+                    // stage the pushed values for the farm-level mean / mean / sum
+                    q.sws = val[0]; q.swd = val[1]; q.sp = val[3];
+                } else {
+                    q.sws = val[0]; q.swd = val[1]; q.syaw = val[2]; q.sp = val[3];
+                }
             }
-            __syncthreads();
-        } else if (tid == 0) {
-            float tot = 0.f;
-            for (int t = 0; t < N; ++t) tot += T[t].pow;
-            base_acc += tot;
         }
+        if (is_dev) { --dev_rem; continue; }
+        if (farm == 1 || unit_end) lds_barrier<NT>();
+        if (farm == 1 && tid < WG_WAVE) base_acc += WG_TURB_SUM(pow);   // fs_baseline...power().sum() (:954)
         if (++sub < p.K) continue;
         sub = 0;
         if (farm == 0) {
-            // farm_mes.add_measurements (MesClass.py:568-591): noise, ring push, farm-level mean/mean/sum
-            const int n_pushed = cx.n_pushed;
-            const float inv_k = 1.0f / (float)p.K;
-            float* __restrict__ rbase = d.ring + (size_t)ctx_id * p.ring_stride;
-            for (int t = tid; t < N; t += WG_BLOCK) {
-                TurbLds& q = T[t];
-                float val[WG_N_CH] = {q.sws, q.swd, q.syaw, q.sp};
-                if (p.K != 1) {
-#pragma unroll
-                    for (int ch = 0; ch < WG_N_CH; ++ch) val[ch] *= inv_k;
+            if (tid < WG_WAVE) {
+                const float sws = WG_TURB_SUM(sws), swd = WG_TURB_SUM(swd), tot = WG_TURB_SUM(sp);
+                if (tid == 0) {
+                    float* fbase = d.fring + (size_t)ctx_id * p.fring_stride;
+                    fbase[p.fring_off[WG_CH_WS] + n_pushed % p.hlen[WG_CH_WS]] = sws * p.inv_N;
+                    fbase[p.fring_off[WG_CH_WD] + n_pushed % p.hlen[WG_CH_WD]] = swd * p.inv_N;
+                    fbase[p.fring_off[WG_CH_POWER] + n_pushed % p.hlen[WG_CH_POWER]] = tot;
+                    if (live_step) d.step_farm_pow[e] = tot;
+                    else d.pend_farm[(size_t)ctx_id * p.power_avg + pend_farm_n % p.power_avg] = tot;
                 }
-                if (NOISE) {
-#pragma unroll
-                    for (int ch = 0; ch < WG_N_CH; ++ch)
-                        if (p.noise_sigma[ch] != 0.f)
-                            val[ch] += p.noise_sigma[ch] * wg_noise_normal(env.noise_key, (uint32_t)n_pushed, (uint32_t)t,
-                                                                           (uint32_t)ch, (uint32_t)cx.episode_tag);
-                }
-#pragma unroll
-                for (int ch = 0; ch < WG_N_CH; ++ch) {
-                    const int H = p.hlen[ch];
-                    rbase[p.ring_off[ch] + t * H + (n_pushed % H)] = val[ch];
-                }
-                q.sws = val[0]; q.swd = val[1]; q.sp = val[3];
             }
-            __syncthreads();
+            ++n_pushed;
+            if (!live_step) ++pend_farm_n;
+            lds_barrier<NT>();
+            for (int t = tid; t < N; t += NT) { T[t].sws = 0.f; T[t].swd = 0.f; T[t].syaw = 0.f; T[t].sp = 0.f; }
+        } else {
             if (tid == 0) {
-                float sws = 0.f, swd = 0.f, tot = 0.f;
-                for (int t = 0; t < N; ++t) { sws += T[t].sws; swd += T[t].swd; tot += T[t].sp; }
-                float* fbase = d.fring + (size_t)ctx_id * p.fring_stride;
-                fbase[p.fring_off[WG_CH_WS] + n_pushed % p.hlen[WG_CH_WS]] = sws * p.inv_N;
-                fbase[p.fring_off[WG_CH_WD] + n_pushed % p.hlen[WG_CH_WD]] = swd * p.inv_N;
-                fbase[p.fring_off[WG_CH_POWER] + n_pushed % p.hlen[WG_CH_POWER]] = tot;
-                cx.n_pushed = n_pushed + 1;
-                if (live_step) d.step_farm_pow[e] = tot;
-                else {
-                    d.pend_farm[(size_t)ctx_id * p.power_avg + cx.pend_farm_n % p.power_avg] = tot;
-                    cx.pend_farm_n += 1;
-                }
+                const float bp = p.K == 1 ? base_acc : base_acc * inv_k;
+                if (live_step) d.step_base_pow[e] = bp;
+                else d.pend_base[(size_t)ctx_id * p.power_avg + pend_base_n % p.power_avg] = bp;
             }
-            __syncthreads();
-            for (int t = tid; t < N; t += WG_BLOCK) { T[t].sws = 0.f; T[t].swd = 0.f; T[t].syaw = 0.f; T[t].sp = 0.f; }
-            __syncthreads();
-        } else if (tid == 0) {
-            const float bp = p.K == 1 ? base_acc : base_acc / (float)p.K;
-            if (live_step) d.step_base_pow[e] = bp;
-            else {
-                d.pend_base[(size_t)ctx_id * p.power_avg + cx.pend_base_n % p.power_avg] = bp;
-                cx.pend_base_n += 1;
-            }
+            if (!live_step) ++pend_base_n;
             base_acc = 0.f;
         }
         if (live_step) break;
         --fill_rem;
     }
 
-    // write the slot back
-    for (int t = tid; t < N; t += WG_BLOCK) {
+    // epilogue: write the slot back (thread t owns turbine t; no barrier needed for its own T[t])
+    for (int t = tid; t < N; t += NT) {
         const TurbLds& q = T[t];
         d.yaw[tb + t] = q.yaw; d.u[tb + t] = q.u; d.v[tb + t] = q.v; d.w[tb + t] = q.w;
         d.ti_loc[tb + t] = q.ti; d.power[tb + t] = q.pow; d.ct[tb + t] = q.ct;
@@ -464,20 +529,31 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         slot.head = sr.head; slot.n_valid = sr.n_valid; slot.s_off = sr.s_off; slot.time = sr.time;
         slot.cursor = cursor;
         slot.dev_remaining = dev_rem; slot.fill_remaining = fill_rem;
-        if (n_flow) atomicAdd(d.flow_steps, (unsigned long long)n_flow);
+        if (farm == 0) { cx.n_pushed = n_pushed; cx.pend_farm_n = pend_farm_n; }
+        else cx.pend_base_n = pend_base_n;
+        slot.flow_count += (unsigned)n_flow;   // NOT a global atomic: one hot word serialises the whole grid
     }
 }
 
-extern "C" void wg_launch_flow(const FlowP* p, const FlowPtrs* d, int mode, const float* actions,
-                               const uint8_t* mask, int chunk, hipStream_t st) {
+template <int NT>
+static void launch_nt(const FlowP* p, const FlowPtrs* d, int mode, const float* actions, const uint8_t* mask,
+                      int chunk, hipStream_t st) {
     const int grid = p->B * 2 * p->F;
     const size_t lds = p->lds_bytes;
     const bool replay = d->script_uvw != nullptr, noise = p->noise != 0;
     if (replay) {
-        if (noise) hipLaunchKernelGGL((k_flow<true, true>), dim3(grid), dim3(WG_BLOCK), lds, st, *p, *d, mode, actions, mask, chunk);
-        else hipLaunchKernelGGL((k_flow<true, false>), dim3(grid), dim3(WG_BLOCK), lds, st, *p, *d, mode, actions, mask, chunk);
+        if (noise) hipLaunchKernelGGL((k_flow<NT, true, true>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk);
+        else hipLaunchKernelGGL((k_flow<NT, true, false>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk);
     } else {
-        if (noise) hipLaunchKernelGGL((k_flow<false, true>), dim3(grid), dim3(WG_BLOCK), lds, st, *p, *d, mode, actions, mask, chunk);
-        else hipLaunchKernelGGL((k_flow<false, false>), dim3(grid), dim3(WG_BLOCK), lds, st, *p, *d, mode, actions, mask, chunk);
+        if (noise) hipLaunchKernelGGL((k_flow<NT, false, true>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk);
+        else hipLaunchKernelGGL((k_flow<NT, false, false>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk);
     }
+}
+
+// one workgroup per farm slot; its size (64 / 128 / 256 threads) is chosen on the host (FlowP.block)
+extern "C" void wg_launch_flow(const FlowP* p, const FlowPtrs* d, int mode, const float* actions,
+                               const uint8_t* mask, int chunk, hipStream_t st) {
+    if (p->block == 64) launch_nt<64>(p, d, mode, actions, mask, chunk, st);
+    else if (p->block == 128) launch_nt<128>(p, d, mode, actions, mask, chunk, st);
+    else launch_nt<256>(p, d, mode, actions, mask, chunk, st);
 }

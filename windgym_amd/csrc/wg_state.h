@@ -71,7 +71,7 @@ struct WgSlot {
     int dev_remaining;  // flow-development steps still to run (fs.run(t_developed))
     int fill_remaining; // window-fill env steps still to run
     int cursor;         // replay mode row
-    int pad;
+    unsigned flow_count; // flow_step() executions of this slot (roofline accounting; summed on the host)
 };
 
 // per episode context
