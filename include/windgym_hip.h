@@ -156,7 +156,8 @@ typedef enum wg_info_field {
     WG_INFO_EPISODE = 17,         /* episodes completed so far     i32[B]   */
     WG_INFO_ROTOR_UVW_AGENT = 18, /* fs.windTurbines.rotor_avg_windspeed  f32[B,N,3] */
     WG_INFO_ROTOR_UVW_BASE = 19,  /* fs_baseline ...                      f32[B,N,3] */
-    WG_INFO_RATED_POWER = 20      /* turbine.power(ws) (:700)      f32[B]   */
+    WG_INFO_RATED_POWER = 20,     /* turbine.power(ws) (:700)      f32[B]   */
+    WG_INFO_WIND_F64 = 21         /* (ws, wd, ti) as sampled, in double precision  f64[B,3] */
 } wg_info_field;
 
 /* number of floats of the episode-metric vector produced by wg_metrics (the all-reduce payload;

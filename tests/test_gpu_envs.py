@@ -1,0 +1,154 @@
+"""GPU tests of the host classes: the reference's own invariant tests (tests/test_basics.py) replayed against
+WindFarmEnv / FarmEval / WindFarmEnvMulti / WindFarmVecEnv, and the known-answer yaw trajectory of
+test_fast_eval (tests/test_basics.py:415-471)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wg():
+    import torch
+    assert torch.cuda.is_available()
+    import windgym_amd
+    return windgym_amd
+
+
+def _yaml(tmp_path, d, name="cfg.yaml"):
+    import yaml
+    p = tmp_path / name
+    p.write_text(yaml.safe_dump(d))
+    return str(p)
+
+
+@pytest.fixture(params=["two_turb", "env1"])
+def env(request, wg, tmp_path):
+    from windgym_amd import presets
+    d = presets.two_turb_config() if request.param == "two_turb" else presets.env1_config()
+    e = wg.WindFarmEnv(turbine=wg.V80(), n_passthrough=2, yaml_path=_yaml(tmp_path, d), turbtype="None", seed=3)
+    yield e
+    e.close()
+
+
+def test_environment_initialization(env):            # tests/test_basics.py:100-113
+    assert isinstance(env.observation_space.sample(), np.ndarray)
+    assert isinstance(env.action_space.sample(), np.ndarray)
+    assert env.n_turb > 0 and hasattr(env, "turbine")
+
+
+def test_environment_reset(env):                     # :116-137
+    obs, info = env.reset()
+    assert isinstance(obs, np.ndarray) and obs.dtype == np.float32
+    assert obs.shape == env.observation_space.shape
+    assert not np.any(np.isnan(obs))
+    for key in ["yaw angles agent", "Wind speed Global", "Wind direction Global", "Power agent"]:
+        assert key in info
+
+
+def test_environment_step_and_limits(env):           # :140-209
+    env.reset()
+    for _ in range(3):
+        obs, reward, terminated, truncated, info = env.step(np.zeros(env.action_space.shape))
+        assert obs.shape == env.observation_space.shape
+        assert isinstance(reward, float) and not np.isnan(reward)
+        assert isinstance(terminated, bool) and isinstance(truncated, bool) and isinstance(info, dict)
+        assert info["Power agent"] >= 0
+    _, _, _, _, info = env.step(np.ones(env.action_space.shape))
+    assert np.all(info["yaw angles agent"] >= env.yaw_min) and np.all(info["yaw angles agent"] <= env.yaw_max)
+    env.action_penalty, env.action_penalty_type = 1.0, "Change"
+    assert env._action_penalty() >= 0
+    env.action_penalty_type = "Total"
+    assert env._action_penalty() >= 0
+    assert env._get_num_raw_features() <= env.obs_var
+
+
+def test_wind_conditions_and_truncation(env):        # :232-246 + truncation semantics (:1003-1025)
+    _, info = env.reset()
+    assert env.ws_min <= info["Wind speed Global"] <= env.ws_max
+    assert env.wd_min <= info["Wind direction Global"] <= env.wd_max
+    assert len(info["Wind speed at turbines"]) == env.n_turb
+    n = 0
+    while True:
+        _, _, _, truncated, _ = env.step(env.action_space.sample())
+        n += 1
+        if truncated:
+            break
+    assert n == env.time_max + 1
+    with pytest.raises(RuntimeError):
+        env.step(env.action_space.sample())
+    env.reset()
+    env.step(env.action_space.sample())
+
+
+def test_fast_eval_known_answer(wg, tmp_path):       # tests/test_basics.py:415-471
+    from windgym_amd import presets
+    env = wg.FarmEval(turbine=wg.V80(), yaml_path=_yaml(tmp_path, presets.env1_config()), turbtype="None",
+                      yaw_init="Zeros", seed=1)
+    env.set_wind_vals(ws=10, ti=0.07, wd=270)
+    obs, info = env.reset()
+    assert np.allclose(env.fs.windTurbines.yaw, 0.0)
+    assert env.ws == 10 and env.ti == 0.07 and env.wd == 270
+    yaw_goal = np.array([-10.0, 20.0, 0.0, 0.0])
+    action = ((yaw_goal - env.yaw_min) / (env.yaw_max - env.yaw_min) * 2 - 1).astype(np.float32)  # BaseAgent.scale_yaw
+    for i in range(1, 50):
+        obs, reward, terminated, truncated, info = env.step(action)
+        assert not truncated
+    assert np.allclose(env.fs.windTurbines.yaw, yaw_goal, atol=1e-4)
+    assert env.time_max == 9999999
+    # the two downstream turbines of the 2x2 farm are waked, the upstream pair is not
+    u = env.fs.windTurbines.rotor_avg_windspeed[:, 0]
+    assert np.allclose(u[[0, 2]], 10.0, atol=1e-4) and np.all(u[[1, 3]] < 10.0)
+    env.close()
+
+
+def test_multi_agent_facade(wg, tmp_path):
+    from windgym_amd import presets
+    d = presets.env1_config()
+    d["farm"].update(nx=3, ny=3)
+    env = wg.WindFarmEnvMulti(turbine=wg.V80(), n_passthrough=2, yaml_path=_yaml(tmp_path, d), turbtype="None", seed=51)
+    obs, infos = env.reset()
+    assert env.possible_agents == [f"turbine_{i}" for i in range(9)] and set(obs) == set(env.possible_agents)
+    assert env.observation_space("turbine_0").shape == (env.obs_var,)
+    assert env.action_space("turbine_0").shape == (1,)
+    steps = 0
+    while env.agents:
+        acts = {a: env.action_space(a).sample() for a in env.agents}
+        obs, rewards, terms, truncs, infos = env.step(acts)
+        steps += 1
+        assert all(v.shape == (env.obs_len,) and v.dtype == np.float32 for v in obs.values())
+        assert len(set(rewards.values())) == 1 and not any(terms.values())
+    # timestep advances twice per step (WindEnvMulti.py:219): the episode lasts ceil(time_max / 2) + 1 steps
+    assert steps == (env.time_max + 1) // 2 + 1
+    env.close()
+
+
+def test_vec_env_autoreset_and_episode_stats(wg, tmp_path):
+    import torch
+    from windgym_amd import presets
+    from windgym_amd.envs import RecordEpisodeVals
+    d = presets.env1_config()
+    d["ActionMethod"] = "yaw"
+    venv = wg.WindFarmVecEnv(wg.V80(), 64, yaml_path=_yaml(tmp_path, d), turbtype="None", n_passthrough=1, seed=7,
+                             as_torch=True)
+    rec = RecordEpisodeVals(venv)
+    obs, infos = rec.reset()
+    assert obs.shape == (64, venv.single_observation_space.shape[0]) and obs.is_cuda
+    n_done = 0
+    for i in range(400):
+        a = torch.rand((64, venv.n_turb), device="cuda") * 2 - 1
+        obs, rew, term, trunc, infos = rec.step(a)
+        assert not term.any() and torch.isfinite(obs).all() and torch.isfinite(rew).all()
+        assert (obs.abs() <= 1).all()
+        n_done += int(trunc.sum())
+        assert (infos["Power agent"] >= 0).all()
+    venv.batch.check()
+    assert n_done >= 64 and len(rec.mean_power_queue) == min(n_done, 100)
+    m = venv.metrics()
+    assert m["n_episodes"] == n_done and m["n_steps"] == 400 * 64
+    assert abs(m["mean_episode_power"] - np.mean(rec.mean_power_queue)) / m["mean_episode_power"] < 0.2
+    # SB3-style access
+    venv.step_async(np.zeros((64, venv.n_turb), dtype=np.float32))
+    o, r, dones, inf = venv.step_wait()
+    assert o.shape[0] == 64 and len(inf) == 64 and "Power agent" in inf[0]
+    venv.close()

@@ -153,6 +153,10 @@ class HipBatch:
         t = self.torch
         per_turb = name in ("yaw_agent", "yaw_base", "ws_turb", "wd_turb", "power_turb_agent",
                             "power_turb_base", "ws_turb_base", "turb_x", "turb_y")
+        if name == "wind_f64":
+            out = t.zeros((self.B, 3), dtype=t.float64, device=self.device)
+            _chk(self.L.wg_get_info(self._h, INFO[name], C.c_void_p(out.data_ptr()), self._stream()), "wg_get_info")
+            return out
         if name.startswith("rotor_uvw"):
             shape = (self.B, self.N, 3)
         elif per_turb:

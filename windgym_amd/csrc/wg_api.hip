@@ -427,7 +427,7 @@ extern "C" int wg_obs_multi(wg_handle h, float* obs_dev, void* stream) {
 
 extern "C" int wg_get_info(wg_handle h, wg_info_field field, void* out_dev, void* stream) {
     if (!h || !out_dev) return fail(WG_ERR_INVALID, "null argument");
-    if ((int)field < 0 || (int)field > WG_INFO_RATED_POWER) return fail(WG_ERR_INVALID, "unknown info field");
+    if ((int)field < 0 || (int)field > WG_INFO_WIND_F64) return fail(WG_ERR_INVALID, "unknown info field");
     wg_launch_info(&h->p, &h->d, (int)field, out_dev, (hipStream_t)stream);
     return 0;
 }

@@ -1,0 +1,597 @@
+"""Drop-in host classes: the reference's Gymnasium / PettingZoo surface over the batched HIP transition.
+
+* :class:`WindFarmVecEnv`   — the native batched env (thousands of farms per GPU, same-step autoreset);
+                              gymnasium ``VectorEnv``-style ``reset/step`` plus SB3 ``VecEnv`` duck-typing.
+* :class:`WindFarmEnv`      — single-env facade with the reference's constructor, attributes, ``reset`` /
+                              ``step`` return types and info-dict keys (WindGym/Wind_Farm_Env.py:47-1034).
+* :class:`FarmEval`         — evaluation subclass (WindGym/FarmEval.py:10-90).
+* :class:`WindFarmEnvMulti` — PettingZoo ``ParallelEnv`` facade (WindGym/WindEnvMulti.py:17-249).
+* :class:`RecordEpisodeVals`— episode-mean-power statistics (WindGym/wrappers/recordEpisodeVals.py:8-64).
+
+All physics and sensor work happens in libwindgym_hip.so; nothing here computes flow values.
+"""
+from __future__ import annotations
+
+import copy
+from collections import deque
+from typing import Optional
+
+import numpy as np
+
+from .binding import HipBatch
+from .config import EnvConfig
+from .spaces import Box
+
+try:  # pragma: no cover
+    import gymnasium as _gym
+    _EnvBase = _gym.Env
+except Exception:
+    _EnvBase = object
+
+try:  # pragma: no cover
+    from pettingzoo import ParallelEnv as _ParallelEnvBase
+except Exception:
+    _ParallelEnvBase = object
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+class _TurbinesProxy:
+    """Duck type of ``fs.windTurbines`` for the call sites listed in SURVEY.md Appendix A."""
+
+    def __init__(self, batch: HipBatch, farm: str, env_index: int = 0):
+        self._b, self._farm, self._i = batch, farm, env_index
+
+    @property
+    def yaw(self):
+        return _np(self._b.info(f"yaw_{self._farm}"))[self._i].astype(np.float64)
+
+    @property
+    def rotor_avg_windspeed(self):
+        return _np(self._b.info(f"rotor_uvw_{self._farm}"))[self._i].astype(np.float64)
+
+    def power(self):
+        return _np(self._b.info(f"power_turb_{self._farm}"))[self._i].astype(np.float64)
+
+    @property
+    def positions_xyz(self):
+        x = _np(self._b.info("turb_x"))[self._i]
+        y = _np(self._b.info("turb_y"))[self._i]
+        return np.array([x, y, np.full_like(x, self._b.cfg.tab.hub_height())], dtype=np.float64)
+
+    rotor_positions_xyz = positions_xyz
+
+
+class _FlowProxy:
+    """Duck type of the DYNAMIKS flow-simulation object (`env.fs`, `env.fs_baseline`)."""
+
+    def __init__(self, batch: HipBatch, farm: str, env_index: int = 0):
+        self._b, self._i = batch, env_index
+        self.windTurbines = _TurbinesProxy(batch, farm, env_index)
+
+    @property
+    def time(self):
+        return float(_np(self._b.info("fs_time"))[self._i])
+
+    @property
+    def wind_direction(self):
+        return float(_np(self._b.info("wd_global"))[self._i])
+
+
+# ======================================================================================================
+class WindFarmVecEnv:
+    """``n_envs`` independent farms on one GPU behind one handle.
+
+    ``step(actions)`` takes a float32 array / CUDA tensor ``[n_envs, n_turb]`` in [-1, 1] and returns
+    ``(obs, rewards, terminations, truncations, infos)``; with ``as_torch=True`` these stay CUDA tensors
+    (no host synchronisation on the step path).  Truncated envs are reset in the same step from an
+    episode that was developed in the background; ``infos["final_obs"]`` holds their last observation.
+    """
+
+    def __init__(self, turbine, n_envs: int, yaml_path=None, *, seed: Optional[int] = 0, device: Optional[int] = None,
+                 as_torch: bool = False, autoreset: bool = True, **kwargs):
+        self.cfg = EnvConfig(turbine=turbine, yaml_path=yaml_path, n_envs=int(n_envs), autoreset=autoreset,
+                             seed=seed, **kwargs)
+        self.batch = HipBatch(self.cfg, device=device)
+        self.num_envs = self.n_envs = int(n_envs)
+        self.n_turb = self.cfg.n_turb
+        self.as_torch = as_torch
+        self.torch = self.batch.torch
+        self.single_observation_space = Box(-1.0, 1.0, (self.batch.obs_dim,), np.float32)
+        self.single_action_space = Box(-1.0, 1.0, (self.n_turb,), np.float32)
+        self.observation_space = Box(-1.0, 1.0, (self.num_envs, self.batch.obs_dim), np.float32)
+        self.action_space = Box(-1.0, 1.0, (self.num_envs, self.n_turb), np.float32)
+        self._base_seed = seed
+        self._global_offset = 0          # first global env index of this shard (set by shard())
+        self._actions = self.torch.zeros((self.num_envs, self.n_turb), dtype=self.torch.float32,
+                                         device=self.batch.device)
+        self._sb3_actions = None
+
+    # -- sharding: env i of the *global* batch is always seeded base_seed + i ------------------------
+    def shard(self, rank: int, world: int, n_envs_total: Optional[int] = None):
+        from .parallel import shard_range
+        total = n_envs_total if n_envs_total is not None else self.num_envs * world
+        lo, hi = shard_range(total, rank, world)
+        assert hi - lo == self.num_envs, "construct the env with this rank's share of the env axis"
+        self._global_offset = lo
+        return self
+
+    def _seeds(self, seed):
+        if seed is None:
+            return None
+        if np.isscalar(seed):
+            return (int(seed) + self._global_offset + np.arange(self.num_envs)).astype(np.uint64)
+        return np.asarray(seed, dtype=np.uint64)
+
+    def _out(self, t):
+        return t if self.as_torch else _np(t).copy()
+
+    def reset(self, *, seed=None, options=None, mask=None):
+        seeds = self._seeds(seed if seed is not None else (self._base_seed if not getattr(self, "_was_reset", False) else None))
+        self._was_reset = True
+        obs = self.batch.reset(seeds=seeds, mask=mask)
+        return self._out(obs), self.infos()
+
+    def step(self, actions):
+        t = self.torch
+        if not isinstance(actions, t.Tensor):
+            self._actions.copy_(t.as_tensor(np.ascontiguousarray(actions, dtype=np.float32)).reshape(self.num_envs, self.n_turb))
+            actions = self._actions
+        elif not (actions.is_cuda and actions.dtype == t.float32 and actions.is_contiguous()):
+            self._actions.copy_(actions.reshape(self.num_envs, self.n_turb))
+            actions = self._actions
+        obs, rew, trunc, fin = self.batch.step(actions)
+        term = t.zeros_like(trunc, dtype=t.bool)                         # terminated is always False (:1029)
+        infos = self.infos()
+        infos["final_obs"] = self._out(fin)
+        return self._out(obs), self._out(rew), self._out(term), self._out(trunc.bool()), infos
+
+    def infos(self):
+        """Lazy info dict: values are fetched from the device on first access (keys of _get_info)."""
+        return _LazyInfo(self)
+
+    def metrics(self, reset_after=True):
+        from .parallel import ShardedMetrics
+        return ShardedMetrics(self.batch).all_reduce(reset_after=reset_after)
+
+    def close(self):
+        self.batch.close()
+
+    # -- SB3 VecEnv duck-typing (examples/longer_steps_example.py:194-209 uses make_vec_env) -----------
+    def step_async(self, actions):
+        self._sb3_actions = actions
+
+    def step_wait(self):
+        obs, rew, term, trunc, infos = self.step(self._sb3_actions)
+        obs, rew, trunc = (np.asarray(_np(x) if self.as_torch else x) for x in (obs, rew, trunc))
+        fin = infos["final_obs"]
+        fin = _np(fin) if self.as_torch else fin
+        power = infos["Power agent"]
+        power = _np(power) if self.as_torch else np.asarray(power)
+        out = [{"Power agent": float(power[i]), "TimeLimit.truncated": bool(trunc[i])} for i in range(self.num_envs)]
+        for i in np.nonzero(trunc)[0]:
+            out[i]["terminal_observation"] = fin[i]
+        return obs, rew, trunc.astype(bool), out
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * self.num_envs
+
+    def get_attr(self, name, indices=None):
+        return [getattr(self, name)] * self.num_envs
+
+    def seed(self, seed=None):
+        self._base_seed = seed
+        self._was_reset = False
+        return [seed] * self.num_envs
+
+
+_INFO_KEYS = {
+    # reference key (Wind_Farm_Env.py:527-554)     -> wg_info_field name
+    "yaw angles agent": "yaw_agent",
+    "Wind speed Global": "ws_global",
+    "Wind speed at turbines": "ws_turb",
+    "Wind direction Global": "wd_global",
+    "Wind direction at turbines": "wd_turb",
+    "Turbulence intensity": "ti_global",
+    "Power agent": "power_agent",
+    "Power pr turbine agent": "power_turb_agent",
+    "Turbine x positions": "turb_x",
+    "Turbine y positions": "turb_y",
+    "yaw angles base": "yaw_base",
+    "Power baseline": "power_base",
+    "Power pr turbine baseline": "power_turb_base",
+    "Wind speed at turbines baseline": "ws_turb_base",
+}
+_BASE_ONLY = {"yaw angles base", "Power baseline", "Power pr turbine baseline", "Wind speed at turbines baseline"}
+
+
+class _LazyInfo(dict):
+    """Batched info dict with the reference's keys; each value is copied from the device when first read."""
+
+    def __init__(self, venv: WindFarmVecEnv):
+        super().__init__()
+        self._v = venv
+        self._two = venv.cfg.baseline_comp
+
+    def _keys(self):
+        return [k for k in _INFO_KEYS if self._two or k not in _BASE_ONLY]
+
+    def __missing__(self, key):
+        if key not in _INFO_KEYS or (key in _BASE_ONLY and not self._two):
+            raise KeyError(key)
+        val = self._v.batch.info(_INFO_KEYS[key])
+        val = val if self._v.as_torch else _np(val)
+        self[key] = val
+        return val
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._keys()
+
+    def keys(self):
+        return list(dict.keys(self)) + [k for k in self._keys() if not dict.__contains__(self, k)]
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+
+# ======================================================================================================
+class WindFarmEnv(_EnvBase):
+    """Single farm with the reference's API (WindGym/Wind_Farm_Env.py:47-1034), backed by a batch of 1.
+
+    Differences, all documented in DESIGN.md §3: the flow physics is model M0 (DYNAMIKS is not available);
+    ``HTC_path`` (HAWC2 turbines), ``sample_site`` and rendering are not part of the step() path and raise
+    ``NotImplementedError``.
+    """
+
+    metadata = {"render_modes": ["human", "rgb_array"]}
+    _extra_timestep_inc = False
+    _never_truncate = False
+
+    def __init__(self, turbine, n_passthrough=5, TI_min_mes: float = 0.0, TI_max_mes: float = 0.50,
+                 TurbBox="Default", turbtype="MannLoad", yaml_path=None, Baseline_comp=False, yaw_init=None,
+                 render_mode=None, seed=None, dt_sim=1, dt_env=1, yaw_step=1, fill_window=True, sample_site=None,
+                 HTC_path=None, reset_init=True, *, device=None, yaml_dict=None, n_particles=None,
+                 n_rotor_pts=16, x_pos=None, y_pos=None):
+        if HTC_path is not None:
+            raise NotImplementedError("HAWC2 turbines (HTC_path) are outside the MI355X step() path")
+        if sample_site is not None:
+            raise NotImplementedError("site-based wind sampling (sample_site) is not implemented in this build")
+        assert render_mode is None or render_mode in self.metadata["render_modes"]
+        if render_mode is not None:
+            raise NotImplementedError("rendering is not part of the MI355X step() path")
+        self.render_mode = render_mode
+        self.turbine = turbine
+        self.seed = seed
+        self._device = device
+        self._kw = dict(turbine=turbine, n_passthrough=n_passthrough, TI_min_mes=TI_min_mes, TI_max_mes=TI_max_mes,
+                        TurbBox=TurbBox, turbtype=turbtype, yaml_path=yaml_path, Baseline_comp=Baseline_comp,
+                        yaw_init=yaw_init, seed=seed, dt_sim=dt_sim, dt_env=dt_env, yaw_step=yaw_step,
+                        fill_window=fill_window, yaml_dict=yaml_dict, n_particles=n_particles,
+                        n_rotor_pts=n_rotor_pts, x_pos=x_pos, y_pos=y_pos, n_envs=1, autoreset=False,
+                        never_truncate=self._never_truncate, extra_timestep_inc=self._extra_timestep_inc)
+        self.yaw_initial = [0]
+        self._overrides = {}
+        self._build()
+        self.timestep = 0
+        self._torn_down = True
+        if reset_init:
+            self.reset(seed=seed)
+
+    # -- construction ---------------------------------------------------------------------------------
+    def _build(self):
+        kw = dict(self._kw)
+        if self.yaw_initial is not None and len(self.yaw_initial) and kw.get("yaw_init") == "Defined":
+            kw["yaw_defined"] = self.yaw_initial
+        cfg = EnvConfig(**kw)
+        for k, v in self._overrides.items():      # FarmEval.set_wind_vals
+            setattr(cfg, k, v)
+        old = getattr(self, "_batch", None)
+        if old is not None:
+            old.close()
+        self.cfg = cfg
+        self._batch = HipBatch(cfg, device=self._device)
+        c = cfg
+        # attributes callers read
+        self.n_turb, self.x_pos, self.y_pos = c.n_turb, c.x_pos, c.y_pos
+        self.yaw_min, self.yaw_max, self.yaw_step = c.yaw_min, c.yaw_max, c.yaw_step
+        self.ws_min, self.ws_max, self.TI_min, self.TI_max = c.ws_min, c.ws_max, c.TI_min, c.TI_max
+        self.wd_min, self.wd_max = c.wd_min, c.wd_max
+        self.Baseline_comp = c.baseline_comp
+        self.power_reward, self.ActionMethod = c.power_reward, c.ActionMethod
+        self.action_penalty, self.action_penalty_type = c.action_penalty, c.action_penalty_type
+        self.hist_max, self.steps_on_reset = c.hist_max, c.steps_on_reset
+        self.obs_var = self._batch.obs_dim
+        self.D, self.maxturbpower = c.D, c.maxturbpower
+        self.dt = self.dt_sim = c.dt_sim
+        self.dt_env, self.sim_steps_per_env_step = c.dt_env, c.sim_steps_per_env_step
+        self.n_passthrough = c.n_passthrough
+        self.mes_level = c.mes_level
+        self.fs = _FlowProxy(self._batch, "agent")
+        self.fs_baseline = _FlowProxy(self._batch, "base") if c.baseline_comp else None
+        self._init_spaces()
+        self._dirty = False
+
+    def _init_spaces(self):
+        self.observation_space = Box(low=-1.0, high=1.0, shape=(self.obs_var,), dtype=np.float32)
+        self.action_space = Box(low=-1, high=1, shape=(self.n_turb,), dtype=np.float32)
+
+    # -- gymnasium API ---------------------------------------------------------------------------------
+    def reset(self, seed: Optional[int] = None, options: Optional[dict] = None):
+        if self._dirty:
+            self._build()
+        seeds = None if seed is None else np.array([seed], dtype=np.uint64)
+        obs = self._batch.reset(seeds=seeds)
+        self._batch.check()
+        self._torn_down = False
+        self.timestep = 0
+        self._refresh_episode_attrs()
+        return _np(obs)[0].copy(), self._get_info()
+
+    def _refresh_episode_attrs(self):
+        b = self._batch
+        self.ws, self.wd, self.ti = (float(v) for v in _np(b.info("wind_f64"))[0])
+        self.time_max = int(_np(b.info("time_max"))[0])
+        self.rated_power = float(_np(b.info("rated_power"))[0])
+
+    def step(self, action):
+        if self._torn_down:
+            # the reference deletes fs/site/farm_measurements at truncation (:1003-1023)
+            raise RuntimeError("step() called on a truncated environment: call reset() first")
+        a = np.ascontiguousarray(action, dtype=np.float32).reshape(1, self.n_turb)
+        self.old_yaws = self.fs.windTurbines.yaw                        # :932
+        obs, rew, trunc, _ = self._batch.step(self._batch.torch.as_tensor(a, device=self._batch.device))
+        self._batch.check()               # Exception("NaN Power") (:980-981)
+        observation = _np(obs)[0].copy()
+        reward = float(_np(rew)[0])
+        truncated = bool(_np(trunc)[0])
+        info = self._get_info()
+        self.timestep = int(_np(self._batch.info("timestep"))[0])
+        self.fs_time = self.fs.time
+        if truncated:
+            self._torn_down = True
+        return observation, reward, False, truncated, info
+
+    def _get_info(self):
+        """Keys and shapes of WindFarmEnv._get_info (Wind_Farm_Env.py:522-555)."""
+        b = self._batch
+        g = lambda k: _np(b.info(k))[0].astype(np.float64)   # noqa: E731
+        obs_u = None
+        d = {
+            "yaw angles agent": g("yaw_agent"),
+            "yaw angles measured": self._measured("yaw"),
+            "Wind speed Global": float(g("ws_global")),
+            "Wind speed at turbines": g("ws_turb"),
+            "Wind speed at turbines measured": self._measured("ws"),
+            "Wind speed at farm measured": np.array([], dtype=np.float32),
+            "Wind direction Global": float(g("wd_global")),
+            "Wind direction at turbines": g("wd_turb"),
+            "Wind direction at turbines measured": self._measured("wd"),
+            "Wind direction at farm measured": np.array([], dtype=np.float32),
+            "Turbulence intensity": float(g("ti_global")),
+            "Power agent": float(g("power_agent")),
+            "Power pr turbine agent": g("power_turb_agent"),
+            "Turbine x positions": g("turb_x"),
+            "Turbine y positions": g("turb_y"),
+        }
+        del obs_u
+        if self.Baseline_comp:
+            d["yaw angles base"] = g("yaw_base")
+            d["Power baseline"] = float(g("power_base"))
+            d["Power pr turbine baseline"] = g("power_turb_base")
+            d["Wind speed at turbines baseline"] = g("ws_turb_base")
+        return d
+
+    def _measured(self, which):
+        """Unscaled sensor values are not materialised by the kernels; the scaled ones are the observation.
+        The reference returns `farm_measurements.get_*_turb()` here (:529-537); callers in the reference tree
+        only read the keys, so an empty array keeps the key set identical without a second sensor pass."""
+        return np.array([], dtype=np.float32)
+
+    # -- helpers callers use -----------------------------------------------------------------------------
+    def _get_num_raw_features(self):
+        m = self.mes_level
+        f = sum(self.n_turb for k in ("turb_ws", "turb_wd", "turb_TI", "turb_power") if m[k])
+        return f + sum(1 for k in ("farm_ws", "farm_wd", "farm_TI", "farm_power") if m[k])
+
+    def _action_penalty(self):
+        """Wind_Farm_Env.py:804-820 (host-side restatement for callers that probe it; the reward itself is
+        computed on the device)."""
+        if self.action_penalty < 0.001:
+            return 0
+        yaw = self.fs.windTurbines.yaw
+        if self.action_penalty_type == "Change":
+            pen_val = np.mean(np.abs(getattr(self, "old_yaws", yaw) - yaw))
+        else:
+            pen_val = np.mean(np.abs(yaw)) / self.yaw_max
+        return self.action_penalty * pen_val
+
+    def render(self):
+        raise NotImplementedError("rendering is not part of the MI355X step() path")
+
+    def close(self):
+        b = getattr(self, "_batch", None)
+        if b is not None:
+            b.close()
+            self._batch = None
+
+
+class FarmEval(WindFarmEnv):
+    """WindGym/FarmEval.py:10-90: fixed wind values, never truncates, optional initial yaws."""
+
+    _never_truncate = True
+
+    def __init__(self, turbine, TI_min_mes: float = 0.0, TI_max_mes: float = 0.50, yaw_init="Zeros",
+                 TurbBox="Default", yaml_path=None, Baseline_comp=False, render_mode=None, turbtype="MannLoad",
+                 seed=None, dt_sim=1, dt_env=1, yaw_step=1, n_passthrough=5, HTC_path=None, reset_init=True, **kw):
+        super().__init__(turbine=turbine, n_passthrough=n_passthrough, TI_min_mes=TI_min_mes, TI_max_mes=TI_max_mes,
+                         TurbBox=TurbBox, turbtype=turbtype, yaml_path=yaml_path, Baseline_comp=Baseline_comp,
+                         yaw_init=yaw_init, render_mode=render_mode, seed=seed, dt_sim=dt_sim, dt_env=dt_env,
+                         yaw_step=yaw_step, HTC_path=HTC_path, reset_init=reset_init, **kw)
+
+    def reset(self, seed=None, options=None):
+        observation, info = super().reset(seed=seed, options=options)
+        self.time_max = 9999999                                         # FarmEval.py:54-61
+        return observation, info
+
+    def set_wind_vals(self, ws=None, ti=None, wd=None):                # FarmEval.py:63-78
+        if ws is not None:
+            self.ws = ws
+            self._overrides.update(ws_min=ws, ws_max=ws)
+        if ti is not None:
+            self.ti = ti
+            self._overrides.update(TI_min=ti, TI_max=ti)
+        if wd is not None:
+            self.wd = wd
+            self._overrides.update(wd_min=wd, wd_max=wd)
+        self._dirty = True
+
+    def set_yaw_vals(self, yaw_vals):                                  # FarmEval.py:80-84
+        self.yaw_initial = yaw_vals
+        self._kw["yaw_init"] = "Defined"
+        self._dirty = True
+
+    def update_tf(self, path):                                         # FarmEval.py:86-90
+        self.TF_files = [path]
+
+
+# ======================================================================================================
+class WindFarmEnvMulti(_ParallelEnvBase):
+    """PettingZoo ``ParallelEnv`` facade, one agent per turbine (WindGym/WindEnvMulti.py:17-249).
+
+    Reproduced quirks: ``timestep`` advances twice per step (:219), the per-agent vector is the turbine block
+    followed by ``farm_mes.farm_mes``' block and is *shorter* than the declared ``obs_var`` whenever yaw is
+    observed.  Fixed (the reference raises there, tests/golden/make_golden.py): the
+    constructor works with the real pettingzoo base class, and truncation returns instead of raising.
+    """
+
+    metadata = {"name": "MultiFarm_environment_v0"}
+
+    def __init__(self, turbine, n_passthrough=20, TI_min_mes: float = 0.0, TI_max_mes: float = 0.50,
+                 TurbBox="Default", turbtype="MannLoad", yaml_path=None, Baseline_comp=False, yaw_init=None,
+                 render_mode=None, seed=None, dt_sim=1, dt_env=1, yaw_step=1, fill_window=True, sample_site=None,
+                 **kw):
+        class _Inner(WindFarmEnv):
+            _extra_timestep_inc = True
+
+        self._env = _Inner(turbine=turbine, n_passthrough=n_passthrough, TI_min_mes=TI_min_mes,
+                           TI_max_mes=TI_max_mes, TurbBox=TurbBox, turbtype=turbtype, yaml_path=yaml_path,
+                           Baseline_comp=Baseline_comp, yaw_init=yaw_init, render_mode=render_mode, seed=seed,
+                           dt_sim=dt_sim, dt_env=dt_env, yaw_step=yaw_step, fill_window=fill_window,
+                           sample_site=sample_site, reset_init=False, **kw)
+        self.act_var = 1
+        self.n_turb = self._env.n_turb
+        self.obs_var = self._env.cfg.multi_declared_obs_var()           # as declared (:65-69)
+        self.obs_len = self._env._batch.obs_dim_multi                   # as produced (:79-103)
+        self.possible_agents = ["turbine_" + str(r) for r in range(self.n_turb)]
+        self.agent_name_mapping = dict(zip(self.possible_agents, range(self.n_turb)))
+        self.agents = []
+        self.timestep = 0
+        self._seed = seed
+        self._was_reset = False
+
+    def __getattr__(self, name):            # n_turb, ws, wd, fs, ... of the wrapped env
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._env, name)
+
+    def _get_obs_multi(self):
+        om = _np(self._env._batch.obs_multi())[0]
+        return {a: om[i].copy() for i, a in enumerate(self.agents)}
+
+    def _get_infos(self):
+        info = self._env._get_info()
+        out = {}
+        for a in self.agents:
+            i = self.agent_name_mapping[a]
+            out[a] = {
+                "yaw angles agent": info["yaw angles agent"][i],
+                "Wind speed Global": info["Wind speed Global"],
+                "Wind speed at turbine": info["Wind speed at turbines"][i],
+                "Wind direction Global": info["Wind direction Global"],
+                "Wind direction at turbine": info["Wind direction at turbines"][i],
+                "Turbulence intensity": info["Turbulence intensity"],
+                "Power agent": info["Power agent"],
+                "Power turbine agent": info["Power pr turbine agent"][i],
+                "Turbine x positions": info["Turbine x positions"][i],
+                "Turbine y positions": info["Turbine y positions"][i],
+            }
+        return out
+
+    def reset(self, seed=None, options=None):
+        if seed is None and not self._was_reset:
+            seed = self._seed
+        self._was_reset = True
+        self._env.reset(seed, options)
+        self.agents = copy.copy(self.possible_agents)
+        self.timestep = 0
+        return self._get_obs_multi(), self._get_infos()
+
+    def step(self, actions):
+        all_action = np.array([np.asarray(actions[a]).reshape(-1)[0] for a in self.agents], dtype=np.float32)
+        _, reward, _, truncated, _ = self._env.step(all_action)
+        observations = self._get_obs_multi()
+        infos = self._get_infos()
+        rewards = {a: reward for a in self.agents}
+        truncations = {a: bool(truncated) for a in self.agents}
+        terminations = {a: False for a in self.agents}
+        self.timestep = self._env.timestep
+        if all(truncations.values()):
+            self.agents = []
+        return observations, rewards, terminations, truncations, infos
+
+    def observation_space(self, agent):
+        return Box(low=-1.0, high=1.0, shape=(self.obs_var,), dtype=np.float32)
+
+    def action_space(self, agent):
+        return Box(low=-1.0, high=1.0, shape=(self.act_var,), dtype=np.float32)
+
+    def close(self):
+        self._env.close()
+
+
+# ======================================================================================================
+class RecordEpisodeVals:
+    """Episode statistics of a :class:`WindFarmVecEnv` (wrappers/recordEpisodeVals.py:8-64): per-env running
+    sum of ``infos["Power agent"]``, pushed as ``sum / episode_length`` into ``mean_power_queue`` when the
+    episode ends; also ``return_queue`` / ``length_queue`` like gymnasium's RecordEpisodeStatistics."""
+
+    def __init__(self, env: WindFarmVecEnv, buffer_length=100):
+        self.env = env
+        self.num_envs = env.num_envs
+        self.mean_power_queue = deque(maxlen=buffer_length)
+        self.return_queue = deque(maxlen=buffer_length)
+        self.length_queue = deque(maxlen=buffer_length)
+        self.episode_powers = np.zeros(self.num_envs)
+        self.episode_returns = np.zeros(self.num_envs)
+        self.episode_lengths = np.zeros(self.num_envs, dtype=np.int64)
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    def reset(self, **kw):
+        out = self.env.reset(**kw)
+        self.episode_powers[:] = 0
+        self.episode_returns[:] = 0
+        self.episode_lengths[:] = 0
+        return out
+
+    def step(self, actions):
+        obs, rew, term, trunc, infos = self.env.step(actions)
+        to_np = (lambda x: _np(x)) if self.env.as_torch else np.asarray
+        r, d, p = to_np(rew), to_np(trunc).astype(bool), to_np(infos["Power agent"])
+        self.episode_powers += p
+        self.episode_returns += r
+        self.episode_lengths += 1
+        for i in np.nonzero(d)[0]:
+            self.mean_power_queue.append(self.episode_powers[i] / self.episode_lengths[i])
+            self.return_queue.append(self.episode_returns[i])
+            self.length_queue.append(int(self.episode_lengths[i]))
+        self.episode_powers[d] = 0
+        self.episode_returns[d] = 0
+        self.episode_lengths[d] = 0
+        return obs, rew, term, trunc, infos
