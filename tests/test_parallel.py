@@ -1,0 +1,89 @@
+"""Multi-process (gloo, world_size 2, CPU) tests of the env-axis sharding and of the one collective on the
+path: the all-reduce(sum) of the 8-float episode-metric vector (windgym_amd/parallel.py).  The per-rank env is
+the oracle here (no GPU in this container); the GPU path uses the same ShardedMetrics / seeding helpers."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(n_envs):
+    sys.path.insert(0, ROOT), sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.presets import env1_config
+    from windgym_amd.turbine import V80
+    d = env1_config()
+    d["ActionMethod"] = "yaw"
+    return EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_envs=n_envs, autoreset=True, n_passthrough=1,
+                     n_rotor_pts=4)
+
+
+class _OracleBatch:
+    """Adapter with the two methods ShardedMetrics needs."""
+
+    def __init__(self, orc):
+        self.orc = orc
+
+    def metrics(self, reset_after=False):
+        return torch.tensor(self.orc.metrics(reset_after), dtype=torch.float64)
+
+
+def _run_rank(rank, world, port, total, steps, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as om
+    from windgym_amd import parallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = parallel.shard_range(total, rank, world)
+    cfg = _cfg(hi - lo)
+    orc = om.Oracle(cfg)
+    orc.set_threads(1)
+    seeds = parallel.global_seeds(100, total, rank, world)
+    obs = orc.reset(seeds=seeds)
+    rng = np.random.default_rng(5)
+    acts = rng.uniform(-1, 1, size=(steps, total, cfg.n_turb)).astype(np.float32)   # global action tensor
+    for s in range(steps):
+        obs, rew, tr, _ = orc.step(acts[s, lo:hi])
+    m = parallel.ShardedMetrics(_OracleBatch(orc)).all_reduce(reset_after=True)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), obs=obs, lo=lo, hi=hi, **{k: v for k, v in m.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_covers_axis():
+    from windgym_amd.parallel import global_seeds, shard_range
+    for total, world in [(4096, 8), (10, 3), (7, 2)]:
+        spans = [shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        seeds = np.concatenate([global_seeds(1234, total, r, world) for r in range(world)])
+        assert np.array_equal(seeds, 1234 + np.arange(total))
+
+
+def test_two_rank_gloo_matches_single_process(tmp_path, oracle_lib):
+    total, steps, world = 6, 150, 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_run_rank, args=(world, port, total, steps, str(tmp_path)), nprocs=world, join=True)
+    # single-process reference over the whole env axis
+    from windgym_amd import parallel
+    cfg = _cfg(total)
+    orc = oracle_lib.Oracle(cfg)
+    obs = orc.reset(seeds=parallel.global_seeds(100, total, 0, 1))
+    rng = np.random.default_rng(5)
+    acts = rng.uniform(-1, 1, size=(steps, total, cfg.n_turb)).astype(np.float32)
+    for s in range(steps):
+        obs, *_ = orc.step(acts[s])
+    ref = parallel.derive(orc.metrics())
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    got_obs = np.concatenate([p["obs"] for p in parts])
+    np.testing.assert_array_equal(got_obs, obs)            # sharding does not change any env's trajectory
+    for p in parts:                                        # every rank holds the same reduced metrics
+        for k in ("n_steps", "n_episodes", "ep_return_sum", "farm_power_sum", "mean_episode_power"):
+            assert np.isclose(float(p[k]), ref[k], rtol=1e-12), k
+    assert ref["n_steps"] == total * steps and ref["n_episodes"] > 0
