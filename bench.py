@@ -134,6 +134,15 @@ def main():
         bytes_per_flow_step = cfg.n_turb * cfg.n_particles * 24.0 + cfg.n_turb * 72.0
         alg_bytes_flow = flow_steps * bytes_per_flow_step
         achieved = alg_bytes_flow / (flow_ms * 1e-3) / 1e9 if flow_ms > 0 else 0.0
+        # HBM bytes per k_flow launch from the rocprofv3 PMC passes of this same command (separate runs:
+        # tools/profile_kflow.sh -> profiles/r01_kflow_traffic.json); only quoted for the profiled workload
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_kflow_traffic.json")
+        if os.path.exists(tf) and B == 4096 and F == 2 and world == 1:
+            try:
+                traffic = json.load(open(tf))["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
         out = {
             "metric": "env-steps/sec (whole node), 16-turbine farm x 4096 envs",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -146,7 +155,7 @@ def main():
                        "envs_per_gpu": B, "n_turb": cfg.n_turb, "farms_per_env": F,
                        "parallelism": f"env-axis shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None, "kernel": "k_flow",
+                         "frac": achieved / 8000.0, "traffic": traffic, "kernel": "k_flow",
                          "kernel_ms": flow_ms, "glue_kernel_ms": glue_ms, "launches_timed": n_launch,
                          "algorithmic_bytes_per_launch": alg_bytes_flow, "farm_flow_steps_per_launch": flow_steps,
                          "bytes_per_farm_flow_step": bytes_per_flow_step},

@@ -3,7 +3,7 @@
 #include "wg_state.h"
 
 #ifndef WG_FLOW_WAVES
-#define WG_FLOW_WAVES 6   // min waves/SIMD the register allocator must leave room for (6 -> <= 80 VGPRs)
+#define WG_FLOW_WAVES 4   // min waves/SIMD the register allocator must leave room for (4 -> <= 128 VGPRs, no spills)
 #endif
 
 struct FlowP {

@@ -124,57 +124,84 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     float* __restrict__ ghv = d.hv_e + pbase;
     float* __restrict__ gue = d.u_e + pbase;
     if (!(WG_ABLATE & 1)) {
-        // thread -> 4 consecutive ring slots of one turbine (P % 4 == 0); (t, r0) advance incrementally
-        int t = (tid * 4) / P;
-        int r0 = tid * 4 - t * P;
-        const int dt_ = (NT * 4) / P, dr_ = (NT * 4) - dt_ * P;
-        for (int i4 = tid * 4; i4 < p.NP; i4 += NT * 4) {
-            float4 py4 = *reinterpret_cast<const float4*>(gpy + i4);
-            const float4 hv4 = *reinterpret_cast<const float4*>(ghv + i4);
-            int j0 = head - r0; if (j0 < 0) j0 += P;              // age of ring slot r0 (slot r0+q: j0-q)
-            int e0 = r0 - head - 1; if (e0 < 0) e0 += P;          // emission index of slot r0 (r0+q: e0+q)
-            const bool emits = (e0 < n_emit) || (n_emit > 0 && e0 + 3 >= P);   // slots r0..r0+3 wrap past e = P-1 -> 0
-            const bool moves = (hv4.x != 0.f) | (hv4.y != 0.f) | (hv4.z != 0.f) | (hv4.w != 0.f);
-            if (moves || emits) {
-                float4 ct4 = *reinterpret_cast<const float4*>(gct + i4);
-                float4 k4 = *reinterpret_cast<const float4*>(gk + i4);
-                float4 ep4 = *reinterpret_cast<const float4*>(geps + i4);
-                float pyv[4] = {py4.x, py4.y, py4.z, py4.w};
-                const float hvv[4] = {hv4.x, hv4.y, hv4.z, hv4.w};
-                const float ctv[4] = {ct4.x, ct4.y, ct4.z, ct4.w};
-                const float kv[4] = {k4.x, k4.y, k4.z, k4.w};
-                const float epv[4] = {ep4.x, ep4.y, ep4.z, ep4.w};
+        // thread -> quads of 4 consecutive ring slots of one turbine (P % 4 == 0).  A thread owns QB quads per
+        // batch, strided by NT*4 floats so that every load instruction of the wave is one contiguous 1 KiB.
+        // Two stages keep many loads in flight per lane (the pass is latency-bound otherwise):
+        //   stage 1: hv of all QB quads            -> which quads move (any hv != 0) or receive a new particle
+        //   stage 2: py, ct, k, eps of those quads -> all issued before the first use
+        // A quad that neither moves nor emits costs only its hv read.
+#ifndef WG_QB
+#define WG_QB 2
+#endif
+        constexpr int QB = WG_QB;
+        const int stride = NT * 4;
+        for (int b0 = tid * 4; b0 < p.NP; b0 += stride * QB) {
+            float4 hv[QB];
+            bool need[QB], emits[QB];
+            int j0s[QB], e0s[QB], ts[QB];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int j = j0 - q; if (j < 0) j += P;
+            for (int q = 0; q < QB; ++q) {
+                const int i4 = b0 + q * stride;
+                hv[q] = (i4 < p.NP) ? *reinterpret_cast<const float4*>(ghv + i4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const int i4 = b0 + q * stride;
+                const int t = i4 / P;                              // P is a multiple of 4: the quad has one owner
+                const int r0 = i4 - t * P;
+                int j0 = head - r0; if (j0 < 0) j0 += P;           // age of ring slot r0 (slot r0+i: j0-i)
+                int e0 = r0 - head - 1; if (e0 < 0) e0 += P;       // emission index of slot r0 (r0+i: e0+i)
+                emits[q] = (i4 < p.NP) && ((e0 < n_emit) || (n_emit > 0 && e0 + 3 >= P));   // wraps past P-1 -> 0
+                need[q] = emits[q] || (hv[q].x != 0.f) | (hv[q].y != 0.f) | (hv[q].z != 0.f) | (hv[q].w != 0.f);
+                j0s[q] = j0; e0s[q] = e0; ts[q] = t;
+            }
+            float4 py[QB], ct[QB], kk[QB], ep[QB];
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const int i4 = b0 + q * stride;
+                if (need[q]) {
+                    py[q] = *reinterpret_cast<const float4*>(gpy + i4);
+                    ct[q] = *reinterpret_cast<const float4*>(gct + i4);
+                    kk[q] = *reinterpret_cast<const float4*>(gk + i4);
+                    ep[q] = *reinterpret_cast<const float4*>(geps + i4);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                if (!need[q]) continue;
+                const int i4 = b0 + q * stride;
+                float pyv[4] = {py[q].x, py[q].y, py[q].z, py[q].w};
+                float hvv[4] = {hv[q].x, hv[q].y, hv[q].z, hv[q].w};
+                float ctv[4] = {ct[q].x, ct[q].y, ct[q].z, ct[q].w};
+                float kv[4] = {kk[q].x, kk[q].y, kk[q].z, kk[q].w};
+                float epv[4] = {ep[q].x, ep[q].y, ep[q].z, ep[q].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int j = j0s[q] - i; if (j < 0) j += P;
                     if (j < n_valid) {
                         const float xrel = s_off_f + (float)j * p.dpart_f;
-                        const float sp = kv[q] * (xrel * p.inv_D) + epv[q];
-                        pyv[q] += hvv[q] * m0_cfrac(ctv[q], sp) * p.dt;
+                        const float sp = kv[i] * (xrel * p.inv_D) + epv[i];
+                        pyv[i] += hvv[i] * m0_cfrac(ctv[i], sp) * p.dt;
                     }
                 }
-                if (emits) {
-                    const TurbLds& tq = T[t];
+                if (emits[q]) {
+                    const TurbLds& tq = T[ts[q]];
                     const float y0 = (float)tq.yr;
-                    float c4[4] = {ctv[0], ctv[1], ctv[2], ctv[3]}, kk[4] = {kv[0], kv[1], kv[2], kv[3]};
-                    float e4[4] = {epv[0], epv[1], epv[2], epv[3]}, h4[4] = {hvv[0], hvv[1], hvv[2], hvv[3]};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        int ei = e0 + q; if (ei >= P) ei -= P;
+                    for (int i = 0; i < 4; ++i) {
+                        int ei = e0s[q] + i; if (ei >= P) ei -= P;
                         if (ei < n_emit) {
-                            pyv[q] = y0; c4[q] = tq.rct; kk[q] = tq.rk; e4[q] = tq.reps; h4[q] = tq.rhv;
-                            gue[i4 + q] = tq.rue;
+                            pyv[i] = y0; ctv[i] = tq.rct; kv[i] = tq.rk; epv[i] = tq.reps; hvv[i] = tq.rhv;
+                            gue[i4 + i] = tq.rue;
                         }
                     }
-                    *reinterpret_cast<float4*>(gct + i4) = make_float4(c4[0], c4[1], c4[2], c4[3]);
-                    *reinterpret_cast<float4*>(gk + i4) = make_float4(kk[0], kk[1], kk[2], kk[3]);
-                    *reinterpret_cast<float4*>(geps + i4) = make_float4(e4[0], e4[1], e4[2], e4[3]);
-                    *reinterpret_cast<float4*>(ghv + i4) = make_float4(h4[0], h4[1], h4[2], h4[3]);
+                    *reinterpret_cast<float4*>(gct + i4) = make_float4(ctv[0], ctv[1], ctv[2], ctv[3]);
+                    *reinterpret_cast<float4*>(gk + i4) = make_float4(kv[0], kv[1], kv[2], kv[3]);
+                    *reinterpret_cast<float4*>(geps + i4) = make_float4(epv[0], epv[1], epv[2], epv[3]);
+                    *reinterpret_cast<float4*>(ghv + i4) = make_float4(hvv[0], hvv[1], hvv[2], hvv[3]);
                 }
                 *reinterpret_cast<float4*>(gpy + i4) = make_float4(pyv[0], pyv[1], pyv[2], pyv[3]);
             }
-            t += dt_; r0 += dr_;
-            if (r0 >= P) { r0 -= P; ++t; }
         }
     }
     sr.head = new_head; sr.n_valid = new_valid; sr.s_off = s_new; sr.time += p.dt_d;
