@@ -195,3 +195,78 @@ def test_step_after_truncation_is_an_error(hip):
     env.step(a)
     with pytest.raises(Exception):
         env.check()
+
+
+def test_horns_rev_80_turbines_matches_oracle(hip, oracle_lib):
+    """BASELINE.json configs[2] at test size: Horns Rev 1 layout (N = 80 > one wave, P = 416, target chunking
+    in phase A), B = 3, autoreset on."""
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.presets import horns_rev1_layout, horns_rev_config
+    from windgym_amd.turbine import V80
+    x, y = horns_rev1_layout()
+    cfg = EnvConfig(turbine=V80(), yaml_dict=horns_rev_config(), turbtype="None", n_envs=3, autoreset=True,
+                    n_passthrough=0.2, x_pos=x, y_pos=y)
+    assert cfg.n_turb == 80
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    seeds = 500 + np.arange(3)
+    np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=OBS_ATOL)
+    rng = np.random.default_rng(4)
+    n_tr = 0
+    for step in range(260):
+        a = rng.uniform(-1, 1, size=(3, 80)).astype(np.float32)
+        _compare_step(env, orc, a, step, check_flow=(step % 20 == 0))
+        n_tr += int(env.truncated.sum().item())
+    env.check()
+    assert n_tr >= 3
+    u = env.info("rotor_uvw_agent").cpu().numpy()[..., 0]
+    assert (u.min(axis=1) < env.info("ws_global").cpu().numpy() - 0.3).all()      # downstream rows are waked
+
+
+def test_multi_agent_3x3_batched_matches_oracle(hip, oracle_lib):
+    """BASELINE.json configs[3] at test size: per-turbine-agent packing [B, 9, o_t + o_f] for a batch."""
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.presets import multi_3x3_config
+    from windgym_amd.turbine import V80
+    d = multi_3x3_config()
+    d["mes_level"].update(turb_wd=True, farm_ws=True, farm_power=True, farm_TI=True, turb_TI=True)
+    d["wd_mes"]["wd_rolling_mean"] = True
+    d["power_mes"]["power_rolling_mean"] = True
+    cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_envs=7, autoreset=True, n_passthrough=1,
+                    extra_timestep_inc=True)
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    seeds = 900 + np.arange(7)
+    env.reset(seeds=seeds), orc.reset(seeds=seeds)
+    np.testing.assert_allclose(env.obs_multi().cpu().numpy(), orc.obs_multi(), rtol=0, atol=OBS_ATOL)
+    rng = np.random.default_rng(6)
+    for step in range(150):
+        a = rng.uniform(-1, 1, size=(7, 9)).astype(np.float32)
+        _compare_step(env, orc, a, step, check_flow=False)
+        if step % 10 == 0:
+            np.testing.assert_allclose(env.obs_multi().cpu().numpy(), orc.obs_multi(), rtol=0, atol=OBS_ATOL)
+    env.check()
+
+
+def test_noise_normal_matches_oracle_stream(hip, oracle_lib):
+    """noise: "Normal" (2turb.yaml / 4turb.yaml): the Philox/Box-Muller stream is the same on both sides; the
+    kernel evaluates log/cos in fast fp32 -> tolerance 2e-3 deg on the 2-deg wd noise (1e-4 of the wd scale)."""
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.presets import four_turb_config
+    from windgym_amd.turbine import V80
+    d = four_turb_config()
+    d["mes_level"].update(turb_wd=True)
+    d["wd_mes"].update(wd_current=True, wd_rolling_mean=True)
+    cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_envs=5, autoreset=True, n_passthrough=1)
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    seeds = 11 + np.arange(5)
+    g0, o0 = env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds)
+    np.testing.assert_allclose(g0, o0, rtol=0, atol=5e-4)
+    assert np.std(g0) > 0
+    rng = np.random.default_rng(8)
+    import torch
+    for step in range(120):
+        a = rng.uniform(-1, 1, size=(5, 4)).astype(np.float32)
+        obs, rew, tr, _ = env.step(torch.as_tensor(a, device="cuda"))
+        o_obs, o_rew, o_tr, _ = orc.step(a)
+        np.testing.assert_array_equal(tr.cpu().numpy().astype(bool), o_tr)
+        np.testing.assert_allclose(obs.cpu().numpy(), o_obs, rtol=0, atol=5e-4)
+    env.check()

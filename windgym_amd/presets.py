@@ -63,3 +63,26 @@ def bench_cfg2_config() -> dict:
     """BASELINE.json configs[1] / the headline metric: 4x4 16-turbine grid, yaw-only action, Env1 sensors and
     wind ranges, Baseline reward (two farms per env, as every shipped YAML implies)."""
     return _upd(env1_config(), ActionMethod="yaw", farm=dict(nx=4, ny=4))
+
+
+def horns_rev1_layout():
+    """Horns Rev 1: 80 turbines, 10 columns x 8 rows on a parallelogram, 7 D = 560 m pitch, columns skewed by
+    about 7.2 degrees (regenerated analytically; py_wake's wt_x / wt_y table is not available here).  Returns
+    (x_pos, y_pos) in metres.  The reference can only express nx x ny rectangles (Wind_Farm_Env.py:246-252);
+    the build accepts an explicit layout through the x_pos / y_pos keyword arguments."""
+    import numpy as np
+    pitch, skew = 560.0, np.deg2rad(7.2)
+    col, row = np.meshgrid(np.arange(10), np.arange(8), indexing="xy")
+    x = col * pitch + row * pitch * np.sin(skew)
+    y = -row * pitch * np.cos(skew)
+    return x.ravel().astype(float), (y - y.min()).ravel().astype(float)
+
+
+def horns_rev_config() -> dict:
+    """BASELINE.json configs[2]: Horns Rev 1 (80 turbines), Env1 sensors, yaw action."""
+    return _upd(env1_config(), ActionMethod="yaw", farm=dict(nx=10, ny=8))
+
+
+def multi_3x3_config() -> dict:
+    """BASELINE.json configs[3]: 3x3 farm for the per-turbine-agent PettingZoo facade."""
+    return _upd(env1_config(), ActionMethod="yaw", farm=dict(nx=3, ny=3))
