@@ -65,7 +65,10 @@ enum { WG_YAWINIT_ZEROS = 0, WG_YAWINIT_RANDOM = 1, WG_YAWINIT_DEFINED = 2 }; /*
 enum { WG_REW_BASELINE = 0, WG_REW_POWER_AVG = 1, WG_REW_NONE = 2, WG_REW_POWER_DIFF = 3 }; /* :172-194 */
 enum { WG_PEN_CHANGE = 0, WG_PEN_TOTAL = 1 };             /* _action_penalty, :804-820              */
 enum { WG_NOISE_NONE = 0, WG_NOISE_NORMAL = 1 };          /* farm_mes noise, MesClass.py:436-444    */
-enum { WG_TURB_NONE = 0, WG_TURB_RANDOM = 1, WG_TURB_BOX = 2 }; /* turbtype, :598-668               */
+/* turbtype (:598-668): "None" -> NONE; "Random" -> RANDOM (draws a seed, :642); "MannFixed" -> BOX (the same
+ * frozen box every episode, no draw, :646-657); "MannGenerate"/"MannLoad" -> BOX_SHIFT (draws a seed like :623
+ * and uses it as a random horizontal offset into the one shared box instead of generating 0.8 GB per env). */
+enum { WG_TURB_NONE = 0, WG_TURB_RANDOM = 1, WG_TURB_BOX = 2, WG_TURB_BOX_SHIFT = 3 };
 
 typedef struct wg_config {
     int32_t abi_version;       /* must be WG_ABI_VERSION */

@@ -41,4 +41,21 @@ static inline double wgo_noise_normal(uint64_t key, uint32_t push_idx, uint32_t 
     wgo_philox4x32_10(ctr, k, o);
     return wgo_normal_from_u32(o[0], o[1]);
 }
+/* inflow streams of model M0: standard normal keyed by the episode's turbulence seed */
+static inline double wgo_turb_normal(uint32_t turb_seed, uint32_t step, uint32_t index, uint32_t comp, uint32_t kind) {
+    uint32_t ctr[4] = {step, index, comp, kind};
+    uint32_t k[2] = {turb_seed, 0x57474d30u};
+    uint32_t o[4];
+    wgo_philox4x32_10(ctr, k, o);
+    return wgo_normal_from_u32(o[0], o[1]);
+}
+/* horizontal offset (fractions of the box length) of an episode into the shared frozen box */
+static inline void wgo_turb_offset(uint32_t turb_seed, double* fx, double* fy) {
+    uint32_t ctr[4] = {0, 0, 0, 0x4f};
+    uint32_t k[2] = {turb_seed, 0x57474d30u};
+    uint32_t o[4];
+    wgo_philox4x32_10(ctr, k, o);
+    *fx = (double)o[0] * (1.0 / 4294967296.0);
+    *fy = (double)o[1] * (1.0 / 4294967296.0);
+}
 #endif

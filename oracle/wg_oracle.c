@@ -65,6 +65,7 @@ typedef struct farm_t {
     int n_valid;                         /* particles emitted so far, saturating at P                   */
     double s_off;                        /* distance travelled by the newest particle since emission    */
     double time;                         /* fs.time                                                     */
+    uint32_t istep;                      /* flow steps since the farm was built (inflow stream counter)  */
     /* turbines [N] */
     real *yaw, *u, *v, *w, *ti_loc, *power, *ct;
     long cursor;                         /* replay mode: row of the scripted table                      */
@@ -77,6 +78,7 @@ typedef struct ctx_t {
     int t_developed, time_max;
     double rated_power;
     uint32_t turb_seed;
+    double box_ox, box_oy;               /* horizontal offset of this episode into the shared box (m)   */
     farm_t farm[2];
     /* MesClass state: rings [4][N][H_c] + farm-level rings ws, wd, power */
     double* ring[WG_N_CH];
@@ -275,37 +277,37 @@ static inline real m0_cfrac(real ct, real sp) {
     return (real)1 - R_SQRT(a);
 }
 
-/* trilinear, periodic lookup of one component of the frozen box at (x,y,z) metres */
+/* trilinear, periodic lookup of one component of the frozen box at (x,y,z) metres; cell coordinates are
+ * formed in double precision (x - U t reaches 1e5 m), the interpolation weights in `real` */
 static inline real box_lookup(const oracle_t* o, int comp, double x, double y, double z) {
     double fx = x / o->bdx, fy = y / o->bdy, fz = z / o->bdz;
     double ix = floor(fx), iy = floor(fy), iz = floor(fz);
     real tx = (real)(fx - ix), ty = (real)(fy - iy), tz = (real)(fz - iz);
-    long i0 = (long)ix % o->bnx; if (i0 < 0) i0 += o->bnx;
-    long j0 = (long)iy % o->bny; if (j0 < 0) j0 += o->bny;
-    long k0 = (long)iz % o->bnz; if (k0 < 0) k0 += o->bnz;
+    long i0 = (long)fmod(ix, (double)o->bnx); if (i0 < 0) i0 += o->bnx;
+    long j0 = (long)fmod(iy, (double)o->bny); if (j0 < 0) j0 += o->bny;
+    long k0 = (long)fmod(iz, (double)o->bnz); if (k0 < 0) k0 += o->bnz;
     long i1 = (i0 + 1) % o->bnx, j1 = (j0 + 1) % o->bny, k1 = (k0 + 1) % o->bnz;
     const float* p = o->box + (size_t)comp * o->bnx * o->bny * o->bnz;
 #define BX(i, j, k) ((real)p[((size_t)(i) * o->bny + (j)) * o->bnz + (k)])
-    real c00 = BX(i0, j0, k0) * (1 - tx) + BX(i1, j0, k0) * tx;
-    real c10 = BX(i0, j1, k0) * (1 - tx) + BX(i1, j1, k0) * tx;
-    real c01 = BX(i0, j0, k1) * (1 - tx) + BX(i1, j0, k1) * tx;
-    real c11 = BX(i0, j1, k1) * (1 - tx) + BX(i1, j1, k1) * tx;
+    real c00 = BX(i0, j0, k0) + tx * (BX(i1, j0, k0) - BX(i0, j0, k0));
+    real c10 = BX(i0, j1, k0) + tx * (BX(i1, j1, k0) - BX(i0, j1, k0));
+    real c01 = BX(i0, j0, k1) + tx * (BX(i1, j0, k1) - BX(i0, j0, k1));
+    real c11 = BX(i0, j1, k1) + tx * (BX(i1, j1, k1) - BX(i0, j1, k1));
 #undef BX
-    real c0 = c00 * (1 - ty) + c10 * ty;
-    real c1 = c01 * (1 - ty) + c11 * ty;
-    return c0 * (1 - tz) + c1 * tz;
+    real c0 = c00 + ty * (c10 - c00);
+    real c1 = c01 + ty * (c11 - c01);
+    return c0 + tz * (c1 - c0);
 }
 
-/* ambient velocity fluctuation (u',v',w') at a point of the flow frame at time `time` (Taylor's frozen
- * turbulence: the box is advected with U_inf).  turb_mode NONE -> 0. */
-static void ambient_fluct(const oracle_t* o, const ctx_t* x, double time, double px, double py, double pz,
-                          real out[3]) {
-    out[0] = out[1] = out[2] = 0;
-    if (o->cfg.turb_mode == WG_TURB_BOX && o->box) {
-        double scale = x->ti * x->ws; /* unit-variance box scaled to TI*U (MannTurbulenceField.scale_TI) */
-        double xb = px - x->ws * time;
-        for (int c = 0; c < 3; ++c) out[c] = (real)scale * box_lookup(o, c, xb, py, pz);
-    }
+static inline int has_box(const oracle_t* o) {
+    return (o->cfg.turb_mode == WG_TURB_BOX || o->cfg.turb_mode == WG_TURB_BOX_SHIFT) && o->box;
+}
+
+/* frozen-box fluctuation (one component) at a point of the flow frame at time `time`: Taylor's hypothesis,
+ * the unit-variance box is scaled to TI*U (MannTurbulenceField.scale_TI, Wind_Farm_Env.py:617, :637, :658) */
+static inline real box_fluct(const oracle_t* o, const ctx_t* x, int comp, double time, double px, double py,
+                             double pz) {
+    return (real)(x->ti * x->ws) * box_lookup(o, comp, px - x->ws * time + x->box_ox, py + x->box_oy, pz);
 }
 
 /* what a particle emitted *now* by turbine t would carry (uses the turbine's last rotor wind and its
@@ -349,9 +351,12 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
 
     /* (2) advect every particle over dt: Hill-vortex-style lateral self-induced speed hv*C(x) plus the
      * low-pass filtered ambient transverse velocity at the particle (meandering) */
-    const int box = (c->turb_mode == WG_TURB_BOX && o->box);
+    const int box = has_box(o);
+    const int rnd = (c->turb_mode == WG_TURB_RANDOM);
+    const real sig_amb = (real)(x->ti * x->ws);
     real alpha = 0;
-    if (box) {
+    if (box || rnd) {
+        /* meandering: first-order low pass of the transverse inflow at the particle, cut-off U/(2D) (DWM) */
         double fc = x->ws / (c->m0_fc_scale * c->rotor_diameter);
         alpha = (real)(1.0 - exp(-2.0 * PI_D * fc * c->dt_sim));
     }
@@ -365,11 +370,17 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
             real cf = m0_cfrac(f->ct_e[i], sp);
             real vy = f->hv_e[i] * cf;
             real vz = 0;
-            if (box) {
-                real fl[3];
-                ambient_fluct(o, x, f->time, x->xr[t] + (double)xrel, (double)f->py[i], (double)f->pz[i], fl);
-                f->vlp[i] += alpha * (fl[1] - f->vlp[i]);
-                f->wlp[i] += alpha * (fl[2] - f->wlp[i]);
+            if (box || rnd) {
+                real fv, fw;
+                if (box) {
+                    fv = box_fluct(o, x, 1, f->time, x->xr[t] + (double)xrel, (double)f->py[i], (double)f->pz[i]);
+                    fw = box_fluct(o, x, 2, f->time, x->xr[t] + (double)xrel, (double)f->py[i], (double)f->pz[i]);
+                } else {
+                    fv = sig_amb * (real)wgo_turb_normal(x->turb_seed, f->istep, (uint32_t)i, 1, 0x50);
+                    fw = sig_amb * (real)wgo_turb_normal(x->turb_seed, f->istep, (uint32_t)i, 2, 0x50);
+                }
+                f->vlp[i] += alpha * (fv - f->vlp[i]);
+                f->wlp[i] += alpha * (fw - f->wlp[i]);
                 vy += f->vlp[i];
                 vz += f->wlp[i];
             }
@@ -380,6 +391,7 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
     /* (3) travel + emission: particles are released every d_particle*D of travel, at the exact distance,
      * so a chain stays equispaced: particle of age j sits at x_t + s_off + j*dpart */
     f->time += c->dt_sim;
+    f->istep += 1;
     f->s_off += x->ws * c->dt_sim;
     while (f->s_off >= dpart) {
         f->s_off -= dpart;
@@ -444,13 +456,16 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
         }
         real amb[3] = {0, 0, 0};
         if (box) {
-            for (int s = 0; s < S; ++s) {
-                real fl[3];
-                ambient_fluct(o, x, f->time, x->xr[t], x->yr[t] + o->rotor_dy[s] * (double)cg,
-                              c->hub_height + o->rotor_dz[s], fl);
-                amb[0] += fl[0]; amb[1] += fl[1]; amb[2] += fl[2];
-            }
+            for (int s = 0; s < S; ++s)
+                for (int cc = 0; cc < 3; ++cc)
+                    amb[cc] += box_fluct(o, x, cc, f->time, x->xr[t], x->yr[t] + (double)((real)o->rotor_dy[s] * cg),
+                                         c->hub_height + o->rotor_dz[s]);
             amb[0] /= (real)S; amb[1] /= (real)S; amb[2] /= (real)S;
+        } else if (rnd) {
+            /* i.i.d. gusts at the S rotor points: their mean is one normal of variance sigma^2 / S */
+            const real sc = sig_amb / R_SQRT((real)S);
+            for (int cc = 0; cc < 3; ++cc)
+                amb[cc] = sc * (real)wgo_turb_normal(x->turb_seed, f->istep, (uint32_t)t, (uint32_t)cc, 0x52);
         }
         f->u[t] = (real)x->ws + amb[0] - dsum / (real)S;
         f->v[t] = amb[1];
@@ -808,7 +823,7 @@ static double compute_reward(const oracle_t* o, env_t* e) {
 }
 
 static void farm_init(const oracle_t* o, ctx_t* x, farm_t* f, const real* yaw0) {
-    f->head = o->P - 1; f->n_valid = 0; f->s_off = 0.0; f->time = 0.0;
+    f->head = o->P - 1; f->n_valid = 0; f->s_off = 0.0; f->time = 0.0; f->istep = 0;
     for (int t = 0; t < o->N; ++t) {
         f->yaw[t] = yaw0[t];
         f->u[t] = (real)x->ws; f->v[t] = 0; f->w[t] = 0;
@@ -830,7 +845,15 @@ static void reset_env(oracle_t* o, int b, uint64_t seed, int reseed) {
     x->ti = wgo_pcg64_uniform(&e->rng, c->ti_min, c->ti_max);
     x->wd = wgo_pcg64_uniform(&e->rng, c->wd_min, c->wd_max);
     /* _def_site (:598-678): "Random" draws a turbulence seed; "None"/"MannFixed" draw nothing */
-    if (c->turb_mode == WG_TURB_RANDOM) x->turb_seed = wgo_pcg64_integers(&e->rng, 100000);
+    x->turb_seed = 0; x->box_ox = 0; x->box_oy = 0;
+    if (c->turb_mode == WG_TURB_RANDOM || c->turb_mode == WG_TURB_BOX_SHIFT)
+        x->turb_seed = wgo_pcg64_integers(&e->rng, 100000);
+    if (c->turb_mode == WG_TURB_BOX_SHIFT && o->box) {
+        double fx, fy;
+        wgo_turb_offset(x->turb_seed, &fx, &fy);
+        x->box_ox = fx * o->bnx * o->bdx;
+        x->box_oy = fy * o->bny * o->bdy;
+    }
     /* flow frame (model M0): rotate the layout by theta = 270 - wd about the farm centre */
     double th = (270.0 - x->wd) * (PI_D / 180.0), cx = 0, cy = 0;
     for (int t = 0; t < N; ++t) { cx += o->x_pos[t]; cy += o->y_pos[t]; }

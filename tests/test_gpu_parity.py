@@ -270,3 +270,85 @@ def test_noise_normal_matches_oracle_stream(hip, oracle_lib):
         np.testing.assert_array_equal(tr.cpu().numpy().astype(bool), o_tr)
         np.testing.assert_allclose(obs.cpu().numpy(), o_obs, rtol=0, atol=5e-4)
     env.check()
+
+
+def _turb_cfg(turbtype, n_envs, autoreset=True, n_passthrough=1.0, nx=3, ny=2):
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.presets import env1_config
+    from windgym_amd.turbine import V80
+    d = env1_config()
+    d["ActionMethod"] = "yaw"
+    d["farm"].update(nx=nx, ny=ny)
+    d["mes_level"].update(turb_wd=True, turb_TI=True)
+    d["wd_mes"].update(wd_rolling_mean=True)
+    return EnvConfig(turbine=V80(), yaml_dict=d, turbtype=turbtype, n_envs=n_envs, autoreset=autoreset,
+                     n_passthrough=n_passthrough, n_rotor_pts=16)
+
+
+@pytest.fixture(scope="module")
+def small_mann_box():
+    from windgym_amd.mann import generate_mann_box
+    return generate_mann_box((256, 64, 32), (3.0, 3.0, 3.0), seed=1234), (3.0, 3.0, 3.0)
+
+
+# with turbulence the rotor wind speeds fluctuate by O(1 m/s); fast fp32 log/cos in the Box-Muller transform and
+# fp32 trilinear weights move individual samples by ~1e-4 relative, hence slightly wider bars than for steady inflow
+TURB_OBS_ATOL = 5e-4
+
+
+def _compare_turb(env, orc, steps, rng, n_turb, B):
+    import torch
+    n_tr = 0
+    for step in range(steps):
+        a = rng.uniform(-1, 1, size=(B, n_turb)).astype(np.float32)
+        obs, rew, tr, fin = env.step(torch.as_tensor(a, device="cuda"))
+        o_obs, o_rew, o_tr, o_fin = orc.step(a)
+        np.testing.assert_array_equal(tr.cpu().numpy().astype(bool), o_tr, err_msg=f"step {step}")
+        np.testing.assert_allclose(obs.cpu().numpy(), o_obs, rtol=0, atol=TURB_OBS_ATOL, err_msg=f"obs step {step}")
+        np.testing.assert_allclose(rew.cpu().numpy(), o_rew, rtol=1e-3, atol=1e-3, err_msg=f"reward step {step}")
+        if step % 20 == 0:
+            np.testing.assert_allclose(env.info("rotor_uvw_agent").cpu().numpy(), orc.info("rotor_uvw_agent"),
+                                       rtol=2e-4, atol=2e-3, err_msg=f"uvw step {step}")
+            np.testing.assert_allclose(env.info("yaw_base").cpu().numpy(), orc.info("yaw_base"), atol=2e-2)
+        n_tr += int(tr.sum().item())
+    return n_tr
+
+
+def test_random_inflow_matches_oracle(hip, oracle_lib):
+    """turbtype "Random": counter-based gusts at the rotors and at the wake particles (meandering)."""
+    B = 6
+    cfg = _turb_cfg("Random", B)
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    seeds = 300 + np.arange(B)
+    np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=TURB_OBS_ATOL)
+    v = env.info("rotor_uvw_agent").cpu().numpy()[..., 1]
+    assert np.std(v) > 0.01                      # the lateral component is alive -> wd sensors and controller work
+    n_tr = _compare_turb(env, orc, 300, np.random.default_rng(9), cfg.n_turb, B)
+    env.check()
+    assert n_tr >= B
+
+
+@pytest.mark.parametrize("turbtype", ["MannFixed", "MannGenerate"])
+def test_mann_box_inflow_matches_oracle(hip, oracle_lib, small_mann_box, turbtype):
+    """BASELINE.json configs[4] at test size: frozen Mann box (trilinear, periodic, Taylor advection), DWM
+    meandering of the wake particles through the low-pass filtered transverse inflow."""
+    box, spacing = small_mann_box
+    B = 5
+    cfg = _turb_cfg(turbtype, B)
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    env.set_turbulence_box(box, spacing), orc.set_turbulence_box(box, spacing)
+    seeds = 700 + np.arange(B)
+    np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=TURB_OBS_ATOL)
+    n_tr = _compare_turb(env, orc, 260, np.random.default_rng(10), cfg.n_turb, B)
+    env.check()
+    assert n_tr >= B
+    # the wake centre lines meander: particle positions leave the hub height / the turbine's y
+    u = env.info("rotor_uvw_agent").cpu().numpy()
+    assert np.std(u[..., 0]) > 0.05 and np.std(u[..., 2]) > 0.005
+
+
+def test_mann_box_required(hip):
+    cfg = _turb_cfg("MannFixed", 2)
+    env = hip.HipBatch(cfg)
+    with pytest.raises(ValueError):
+        env.reset(seeds=[1, 2])

@@ -31,7 +31,7 @@ PEN = {"Change": 0, "Total": 1}
 NOISE = {"None": 0, "Normal": 1}
 # turbtype -> inflow mode of the build.  The three Mann variants share one frozen box per GPU
 # (DESIGN.md §2.5); "Random" = i.i.d. gusts; "None" = uniform inflow.
-TURB = {"None": 0, "Random": 1, "MannLoad": 2, "MannGenerate": 2, "MannFixed": 2}
+TURB = {"None": 0, "Random": 1, "MannFixed": 2, "MannGenerate": 3, "MannLoad": 3}
 
 # wg_info_field
 INFO = dict(

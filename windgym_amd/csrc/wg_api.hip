@@ -115,7 +115,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     if (c->reward_mode == WG_REW_BASELINE && c->n_farms != 2)
         return fail(WG_ERR_INVALID, "Baseline reward needs the baseline farm (n_farms = 2)");
     if (c->power_avg < 1) return fail(WG_ERR_INVALID, "Power_avg must be >= 1");
-    if (c->turb_mode != WG_TURB_NONE) return fail(WG_ERR_UNSUPPORTED, "only turbtype \"None\" is implemented in this build");
+    if (c->turb_mode < WG_TURB_NONE || c->turb_mode > WG_TURB_BOX_SHIFT) return fail(WG_ERR_INVALID, "Invalid turbulence type specified");
     for (int i = 0; i < WG_N_CH; ++i)
         if (c->ch[i].history_len < 1 || c->ch[i].window_len < 1 || c->ch[i].history_n < 1)
             return fail(WG_ERR_INVALID, "sensor history/window lengths must be >= 1");
@@ -181,6 +181,9 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
 #define A(field, n, st) if (!rc) rc = dev_alloc(h, &d.field, (n), (st))
     A(py, n_slots * p.NP, true); A(ct_e, n_slots * p.NP, true); A(k_e, n_slots * p.NP, true);
     A(eps_e, n_slots * p.NP, true); A(hv_e, n_slots * p.NP, true); A(u_e, n_slots * p.NP, true);
+    if (p.turb_mode != WG_TURB_NONE) {
+        A(pz, n_slots * p.NP, true); A(vlp, n_slots * p.NP, true); A(wlp, n_slots * p.NP, true);
+    }
     A(yaw, n_slots * p.N, true); A(u, n_slots * p.N, true); A(v, n_slots * p.N, true); A(w, n_slots * p.N, true);
     A(ti_loc, n_slots * p.N, true); A(power, n_slots * p.N, true); A(ct, n_slots * p.N, true);
     A(slot, n_slots, true); A(ctx, n_ctx, true); A(env, (size_t)p.B, true);
@@ -257,7 +260,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         size_t off = sizeof(float) * 4 * (size_t)tc * p.N;
         f.lds_off_turb = (int)off; off += (size_t)WG_TURB_LDS_BYTES * p.N;
         off = (off + 15) & ~(size_t)15;
-        f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S) + sizeof(unsigned) * WG_MASK_WORDS * (size_t)tc;
+        f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S) + sizeof(unsigned) * WG_MASK_WORDS * (size_t)tc + sizeof(float) * (size_t)tc * p.N;
         f.lds_bytes = (int)((off + 15) & ~(size_t)15);
         f.dt = p.dt; f.D = p.D; f.inv_D = p.inv_D; f.hub = p.hub; f.dpart_f = (float)p.dpart; f.R_rot = 0.5f * p.D;
         f.inv_N = 1.0f / (float)p.N; f.inv_S = 1.0f / (float)p.S;
@@ -270,9 +273,12 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             f.noise_sigma[i] = p.noise_sigma[i];
         }
         f.ring_stride = p.ring_stride; f.fring_stride = p.fring_stride;
+        f.turb_mode = p.turb_mode; f.fc_scale = p.fc_scale; f.D_d = p.D_d; f.hub_d = p.hub_d;
+        f.inv_sqrt_S = 1.0f / std::sqrt((float)p.S);
         FlowPtrs& g = h->fd;
         memset(&g, 0, sizeof(g));
         g.py = d.py; g.ct_e = d.ct_e; g.k_e = d.k_e; g.eps_e = d.eps_e; g.hv_e = d.hv_e; g.u_e = d.u_e;
+        g.pz = d.pz; g.vlp = d.vlp; g.wlp = d.wlp;
         g.yaw = d.yaw; g.u = d.u; g.v = d.v; g.w = d.w; g.ti_loc = d.ti_loc; g.power = d.power; g.ct = d.ct;
         g.slot = d.slot; g.ctx = d.ctx; g.env = d.env; g.xr = d.xr; g.yr = d.yr;
         g.ring = d.ring; g.fring = d.fring; g.cur_ws = d.cur_ws; g.cur_wd = d.cur_wd;
@@ -298,7 +304,11 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
 
     // algorithmic bytes of one step(): advection streams py r/w + 4 record floats per particle;
     // per turbine 7 floats r/w (+ positions); glue: rings, obs, actions, reward/flag
-    const double per_farm_step = (double)p.NP * (4 + 4 + 16) + (double)p.N * (7 * 4 * 2 + 16);
+    // inflow None: py r/w + 4 record floats; turbulent: + pz, vlp, wlp r/w (24) and, for the box, 8 corners x
+    // 2 components gathered per particle (64) and 8 x 3 per rotor point (96)
+    const bool turb = p.turb_mode != WG_TURB_NONE, boxm = p.turb_mode >= WG_TURB_BOX;
+    const double per_farm_step = (double)p.NP * (4 + 4 + 16 + (turb ? 24 : 0) + (boxm ? 64 : 0)) +
+                                 (double)p.N * (7 * 4 * 2 + 16) + (boxm ? (double)p.N * p.S * 96 : 0.0);
     h->alg_bytes = (double)p.B * ((double)p.K * p.F * per_farm_step + 20.0 * p.N + 12.0 * p.obs_dim + 20.0);
 
     wg_launch_create(&p, &d, nullptr);
@@ -332,8 +342,13 @@ extern "C" int wg_hist_max(wg_handle h, int* hist_max) {
 extern "C" int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, int ny, int nz, double dx,
                                      double dy, double dz) {
     if (!h) return fail(WG_ERR_INVALID, "null handle");
+    if (!box_dev || nx < 2 || ny < 2 || nz < 2 || !(dx > 0) || !(dy > 0) || !(dz > 0))
+        return fail(WG_ERR_INVALID, "turbulence box: null pointer or bad dimensions");
     h->d.box = box_dev;
     h->p.bnx = nx; h->p.bny = ny; h->p.bnz = nz; h->p.bdx = dx; h->p.bdy = dy; h->p.bdz = dz;
+    h->fd.box = box_dev;
+    h->fp.bnx = nx; h->fp.bny = ny; h->fp.bnz = nz;
+    h->fp.inv_bdx = 1.0 / dx; h->fp.inv_bdy = 1.0 / dy; h->fp.inv_bdz = 1.0 / dz;
     return 0;
 }
 
@@ -373,6 +388,8 @@ extern "C" int wg_reset(wg_handle h, const uint8_t* env_mask_host, const uint64_
     if (!h) return fail(WG_ERR_INVALID, "null handle");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->device));
+    if ((h->p.turb_mode == WG_TURB_BOX || h->p.turb_mode == WG_TURB_BOX_SHIFT) && !h->d.box)
+        return fail(WG_ERR_INVALID, "turbtype Mann*: call wg_set_turbulence_box before wg_reset");
     const uint8_t* mask = nullptr;
     const uint64_t* seeds = nullptr;
     if (env_mask_host) {

@@ -122,6 +122,32 @@ __device__ inline float wg_noise_normal(uint64_t key, uint32_t push_idx, uint32_
     return sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853071795864f * u2);
 }
 
+// inflow streams of model M0: standard normal keyed by the episode's turbulence seed
+__device__ inline void wg_philox_turb(uint32_t turb_seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                      uint32_t& o0, uint32_t& o1) {
+    uint32_t k0 = turb_seed, k1 = 0x57474d30u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1;
+}
+__device__ inline float wg_turb_normal(uint32_t turb_seed, uint32_t step, uint32_t index, uint32_t comp, uint32_t kind) {
+    uint32_t a, b;
+    wg_philox_turb(turb_seed, step, index, comp, kind, a, b);
+    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853071795864f * u2);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // tabular turbine: linear interpolation, 0 outside the table
 // ---------------------------------------------------------------------------------------------------

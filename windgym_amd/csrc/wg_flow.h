@@ -20,10 +20,15 @@ struct FlowP {
     int hlen[WG_N_CH], ring_off[WG_N_CH], fring_off[WG_N_CH];
     int ring_stride, fring_stride;
     float noise_sigma[WG_N_CH];
+    // turbulent inflow (Random / frozen Mann box)
+    int turb_mode, bnx, bny, bnz;
+    double inv_bdx, inv_bdy, inv_bdz, fc_scale, D_d, hub_d;
+    float inv_sqrt_S;
 };
 
 struct FlowPtrs {
-    float *py, *ct_e, *k_e, *eps_e, *hv_e, *u_e;
+    float *py, *ct_e, *k_e, *eps_e, *hv_e, *u_e, *pz, *vlp, *wlp;
+    const float* box;
     float *yaw, *u, *v, *w, *ti_loc, *power, *ct;
     WgSlot* slot;
     WgCtx* ctx;

@@ -54,7 +54,47 @@ __device__ __forceinline__ float tab_lookup(const float* __restrict__ ys, const 
 struct SlotRegs {
     double s_off, time;
     int head, n_valid;
+    unsigned istep;
 };
+
+// per-episode inflow context (uniform over the workgroup)
+struct TurbCtx {
+    uint32_t seed;
+    double ox, oy;       // offset of the episode into the shared box (m)
+    float sig;           // TI * U: standard deviation the unit-variance inflow is scaled to
+    float alpha;         // low-pass coefficient of the meandering filter
+    double ws;
+};
+
+// trilinear, periodic lookup of NC consecutive components (from c0) of the frozen box at (x, y, z) metres.
+// Cell coordinates in double precision (x - U t reaches 1e5 m), weights in fp32 — as the oracle does.
+template <int NC>
+__device__ __forceinline__ void box_lookup(const float* __restrict__ box, const FlowP& p, int c0, double x, double y,
+                                           double z, float* __restrict__ out) {
+    const double fx = x * p.inv_bdx, fy = y * p.inv_bdy, fz = z * p.inv_bdz;
+    const double ix = floor(fx), iy = floor(fy), iz = floor(fz);
+    const float tx = (float)(fx - ix), ty = (float)(fy - iy), tz = (float)(fz - iz);
+    long long i0 = (long long)ix % p.bnx; if (i0 < 0) i0 += p.bnx;
+    long long j0 = (long long)iy % p.bny; if (j0 < 0) j0 += p.bny;
+    long long k0 = (long long)iz % p.bnz; if (k0 < 0) k0 += p.bnz;
+    const int i1 = (int)((i0 + 1) % p.bnx), j1 = (int)((j0 + 1) % p.bny), k1 = (int)((k0 + 1) % p.bnz);
+    const size_t plane = (size_t)p.bnx * p.bny * p.bnz;
+    const size_t a00 = ((size_t)i0 * p.bny + j0) * p.bnz, a10 = ((size_t)i0 * p.bny + j1) * p.bnz;
+    const size_t b00 = ((size_t)i1 * p.bny + j0) * p.bnz, b10 = ((size_t)i1 * p.bny + j1) * p.bnz;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float* __restrict__ q = box + (size_t)(c0 + c) * plane;
+        const float v000 = q[a00 + k0], v100 = q[b00 + k0], v010 = q[a10 + k0], v110 = q[b10 + k0];
+        const float v001 = q[a00 + k1], v101 = q[b00 + k1], v011 = q[a10 + k1], v111 = q[b10 + k1];
+        const float c00 = v000 + tx * (v100 - v000);
+        const float c10 = v010 + tx * (v110 - v010);
+        const float c01 = v001 + tx * (v101 - v001);
+        const float c11 = v011 + tx * (v111 - v011);
+        const float d0 = c00 + ty * (c10 - c00);
+        const float d1 = c01 + ty * (c11 - c01);
+        out[c] = d0 + tz * (d1 - d0);
+    }
+}
 
 // barrier that orders LDS traffic only: does NOT wait for outstanding global stores (a plain
 // __syncthreads() drains vmcnt and exposes the full store latency at every phase boundary)
@@ -76,13 +116,14 @@ __device__ __forceinline__ void full_barrier() {
 
 // One DWMFlowSimulation.step() of model M0 up to the new rotor inflow (T[t].u/v/w/ti); power and the
 // measurement are done by the caller's per-turbine tail.
-template <int NT>
+template <int NT, int TURB>
 __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, TurbLds* __restrict__ T,
                                           const float* __restrict__ tabct,
                                           const float* __restrict__ rdy, const float* __restrict__ rdz,
-                                          float4* __restrict__ pair, unsigned* __restrict__ tmask,
+                                          float4* __restrict__ pair, float* __restrict__ tiap,
+                                          unsigned* __restrict__ tmask,
                                           const size_t pbase, const double ws,
-                                          const float ti_f, const float ti_pow, SlotRegs& sr) {
+                                          const float ti_f, const float ti_pow, const TurbCtx& tc, SlotRegs& sr) {
     const int tid = threadIdx.x;
     const int N = p.N, P = p.P;
     const int TC = p.target_chunk;
@@ -123,7 +164,74 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     float* __restrict__ geps = d.eps_e + pbase;
     float* __restrict__ ghv = d.hv_e + pbase;
     float* __restrict__ gue = d.u_e + pbase;
-    if (!(WG_ABLATE & 1)) {
+    if (TURB != WG_TURB_NONE) {
+        // turbulent inflow: every valid particle meanders -> all state arrays are streamed (py, pz, vlp, wlp r/w,
+        // record read) and the transverse inflow at the particle is looked up (frozen box: 8 corners x 2
+        // components, L2/MALL-resident shared box; "Random": counter-based normals)
+        float* __restrict__ gpz = d.pz + pbase;
+        float* __restrict__ gvl = d.vlp + pbase;
+        float* __restrict__ gwl = d.wlp + pbase;
+        const double xshift = tc.ox - tc.ws * sr.time;
+        for (int i4 = tid * 4; i4 < p.NP; i4 += NT * 4) {
+            const int t = i4 / P;
+            const int r0 = i4 - t * P;
+            float4 py4 = *reinterpret_cast<const float4*>(gpy + i4);
+            float4 pz4 = *reinterpret_cast<const float4*>(gpz + i4);
+            float4 vl4 = *reinterpret_cast<const float4*>(gvl + i4);
+            float4 wl4 = *reinterpret_cast<const float4*>(gwl + i4);
+            float4 hv4 = *reinterpret_cast<const float4*>(ghv + i4);
+            float4 ct4 = *reinterpret_cast<const float4*>(gct + i4);
+            float4 k4 = *reinterpret_cast<const float4*>(gk + i4);
+            float4 ep4 = *reinterpret_cast<const float4*>(geps + i4);
+            float pyv[4] = {py4.x, py4.y, py4.z, py4.w}, pzv[4] = {pz4.x, pz4.y, pz4.z, pz4.w};
+            float vlv[4] = {vl4.x, vl4.y, vl4.z, vl4.w}, wlv[4] = {wl4.x, wl4.y, wl4.z, wl4.w};
+            float hvv[4] = {hv4.x, hv4.y, hv4.z, hv4.w}, ctv[4] = {ct4.x, ct4.y, ct4.z, ct4.w};
+            float kv[4] = {k4.x, k4.y, k4.z, k4.w}, epv[4] = {ep4.x, ep4.y, ep4.z, ep4.w};
+            int j0 = head - r0; if (j0 < 0) j0 += P;
+            int e0 = r0 - head - 1; if (e0 < 0) e0 += P;
+            const bool emits = (e0 < n_emit) || (n_emit > 0 && e0 + 3 >= P);
+            const TurbLds& tq = T[t];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int j = j0 - i; if (j < 0) j += P;
+                if (j < n_valid) {
+                    const float xrel = s_off_f + (float)j * p.dpart_f;
+                    const float sp = kv[i] * (xrel * p.inv_D) + epv[i];
+                    float fvw[2];
+                    if (TURB == WG_TURB_RANDOM) {
+                        fvw[0] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)(i4 + i), 1u, 0x50u);
+                        fvw[1] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)(i4 + i), 2u, 0x50u);
+                    } else {
+                        box_lookup<2>(d.box, p, 1, tq.xr + (double)xrel + xshift, (double)pyv[i] + tc.oy, (double)pzv[i], fvw);
+                    }
+                    vlv[i] += tc.alpha * (tc.sig * fvw[0] - vlv[i]);
+                    wlv[i] += tc.alpha * (tc.sig * fvw[1] - wlv[i]);
+                    pyv[i] += (hvv[i] * m0_cfrac(ctv[i], sp) + vlv[i]) * p.dt;
+                    pzv[i] += wlv[i] * p.dt;
+                }
+            }
+            if (emits) {
+                const float y0 = (float)tq.yr;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int ei = e0 + i; if (ei >= P) ei -= P;
+                    if (ei < n_emit) {
+                        pyv[i] = y0; pzv[i] = p.hub; vlv[i] = 0.f; wlv[i] = 0.f;
+                        ctv[i] = tq.rct; kv[i] = tq.rk; epv[i] = tq.reps; hvv[i] = tq.rhv;
+                        gue[i4 + i] = tq.rue;
+                    }
+                }
+                *reinterpret_cast<float4*>(gct + i4) = make_float4(ctv[0], ctv[1], ctv[2], ctv[3]);
+                *reinterpret_cast<float4*>(gk + i4) = make_float4(kv[0], kv[1], kv[2], kv[3]);
+                *reinterpret_cast<float4*>(geps + i4) = make_float4(epv[0], epv[1], epv[2], epv[3]);
+                *reinterpret_cast<float4*>(ghv + i4) = make_float4(hvv[0], hvv[1], hvv[2], hvv[3]);
+            }
+            *reinterpret_cast<float4*>(gpy + i4) = make_float4(pyv[0], pyv[1], pyv[2], pyv[3]);
+            *reinterpret_cast<float4*>(gpz + i4) = make_float4(pzv[0], pzv[1], pzv[2], pzv[3]);
+            *reinterpret_cast<float4*>(gvl + i4) = make_float4(vlv[0], vlv[1], vlv[2], vlv[3]);
+            *reinterpret_cast<float4*>(gwl + i4) = make_float4(wlv[0], wlv[1], wlv[2], wlv[3]);
+        }
+    } else if (!(WG_ABLATE & 1)) {
         // thread -> quads of 4 consecutive ring slots of one turbine (P % 4 == 0).  A thread owns QB quads per
         // batch, strided by NT*4 floats so that every load instruction of the wave is one contiguous 1 KiB.
         // Two stages keep many loads in flight per lane (the pass is latency-bound otherwise):
@@ -204,7 +312,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             }
         }
     }
-    sr.head = new_head; sr.n_valid = new_valid; sr.s_off = s_new; sr.time += p.dt_d;
+    sr.head = new_head; sr.n_valid = new_valid; sr.s_off = s_new; sr.time += p.dt_d; sr.istep += 1u;
     full_barrier<NT>();   // this workgroup's particle stores are visible to its own gathers below
 
     // (3)+(4) rotor-averaged inflow
@@ -238,13 +346,15 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     const float c0 = gct[i0], c1 = gct[i1], u0 = gue[i0], u1 = gue[i1];
                     const float w0 = 1.0f - wgt, w1 = wgt;
                     const float yc = w0 * py0 + w1 * py1;
+                    float zc = p.hub;
+                    if (TURB != WG_TURB_NONE) zc = w0 * d.pz[pbase + i0] + w1 * d.pz[pbase + i1];
                     const float kv = w0 * k0 + w1 * k1;
                     const float epv = w0 * e0 + w1 * e1;
                     const float xd = (float)dx * p.inv_D;
                     const float sp = kv * xd + epv;
                     const float sig = sp * p.D;
                     const float yt = (float)T[t].yr;
-                    const float rc2 = (yt - yc) * (yt - yc);
+                    const float rc2 = (yt - yc) * (yt - yc) + (p.hub - zc) * (p.hub - zc);
                     const float rcut = p.R_rot + 5.0f * sig;
                     if (rc2 <= rcut * rcut) {
                         const float ctv = w0 * c0 + w1 * c1;
@@ -255,7 +365,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                         const float ind = 0.5f * (1.0f - __builtin_amdgcn_sqrtf(1.0f - ctv));
                         const float tia = p.tia * fast_pow(ind, p.tib) * ti_pow * fast_pow(fmaxf(xd, 1.0f), p.tid) *
                                           __expf(-rc2 * inv2s2);
-                        pp = make_float4(yc, inv2s2, uev * cf, tia);
+                        pp = make_float4(yc, zc, inv2s2, uev * cf);
+                        tiap[i] = tia;
                         atomicOr(&tmask[tl * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
                     }
                 }
@@ -270,30 +381,51 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             const int s = it & (p.S_pad - 1);
             const bool live = (it < nitems) && (s < p.S);
             float acc = 0.f, tia_max = 0.f;
+            float amb[3] = {0.f, 0.f, 0.f};
             if (live) {
                 const int t = t0 + tl;
                 const float4* __restrict__ pr = pair + tl * N;
                 const float ys = (float)T[t].yr + rdy[s] * T[t].cg;
-                const float dz = rdz[s];
-                const float dz2 = dz * dz;
+                const float zs = p.hub + rdz[s];
                 for (int wd = 0; wd * 32 < N; ++wd) {
                     unsigned m = tmask[tl * WG_MASK_WORDS + wd];
                     while (m) {                       // ascending source order -> deterministic sum
                         const int s2 = wd * 32 + __builtin_ctz(m);
                         m &= m - 1;
                         const float4 pp = pr[s2];
-                        tia_max = fmaxf(tia_max, pp.w);
-                        const float dy = ys - pp.x;
-                        acc += pp.z * __expf(-(dy * dy + dz2) * pp.y);
+                        tia_max = fmaxf(tia_max, tiap[tl * N + s2]);
+                        const float dy = ys - pp.x, dz = zs - pp.y;
+                        acc += pp.w * __expf(-(dy * dy + dz * dz) * pp.z);
                     }
+                }
+                if (TURB == WG_TURB_BOX) {
+                    // ambient fluctuation at this rotor point (8 corners x 3 components of the frozen box)
+                    box_lookup<3>(d.box, p, 0, T[t].xr - tc.ws * sr.time + tc.ox,
+                                  T[t].yr + (double)(rdy[s] * T[t].cg) + tc.oy, p.hub_d + (double)rdz[s], amb);
                 }
             }
             for (int o = p.S_pad >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (TURB == WG_TURB_BOX) {
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+                    for (int o = p.S_pad >> 1; o > 0; o >>= 1) amb[cc] += __shfl_xor(amb[cc], o, 64);
+            }
             if (live && s == 0) {
                 TurbLds& q = T[t0 + tl];
-                q.u = ws_f - acc * p.inv_S;
-                q.v = 0.f;
-                q.w = 0.f;
+                float au = 0.f, av = 0.f, aw = 0.f;
+                if (TURB == WG_TURB_BOX) {
+                    au = tc.sig * amb[0] * p.inv_S; av = tc.sig * amb[1] * p.inv_S; aw = tc.sig * amb[2] * p.inv_S;
+                } else if (TURB == WG_TURB_RANDOM) {
+                    // i.i.d. gusts at the S rotor points: their mean is one normal of variance sigma^2 / S
+                    const float sc = tc.sig * p.inv_sqrt_S;
+                    const uint32_t tt = (uint32_t)(t0 + tl);
+                    au = sc * wg_turb_normal(tc.seed, sr.istep, tt, 0u, 0x52u);
+                    av = sc * wg_turb_normal(tc.seed, sr.istep, tt, 1u, 0x52u);
+                    aw = sc * wg_turb_normal(tc.seed, sr.istep, tt, 2u, 0x52u);
+                }
+                q.u = ws_f + au - acc * p.inv_S;
+                q.v = av;
+                q.w = aw;
                 q.ti = __builtin_amdgcn_sqrtf(ti_f * ti_f + tia_max * tia_max);
             }
         }
@@ -327,7 +459,7 @@ __device__ __forceinline__ void script_step(const FlowP& p, const FlowPtrs& d, T
         return wg_wave_sum(_s);                                                             \
     }())
 
-template <int NT, bool REPLAY, bool NOISE>
+template <int NT, int TURB, bool REPLAY, bool NOISE>
 __global__ void __launch_bounds__(NT, WG_FLOW_WAVES)
 k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict__ actions,
        const uint8_t* __restrict__ mask, const int chunk) {
@@ -350,7 +482,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     const uint64_t noise_key = env.noise_key;
     WgSlot& slot = d.slot[slot_id];
     int dev_rem = slot.dev_remaining, fill_rem = slot.fill_remaining;
-    SlotRegs sr{slot.s_off, slot.time, slot.head, slot.n_valid};
+    SlotRegs sr{slot.s_off, slot.time, slot.head, slot.n_valid, slot.istep};
     int cursor = slot.cursor;
     WgCtx& cx = d.ctx[ctx_id];
     const double ws = cx.ws;
@@ -359,6 +491,11 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     int n_pushed = cx.n_pushed;
     int pend_farm_n = cx.pend_farm_n, pend_base_n = cx.pend_base_n;
     const uint32_t episode_tag = (uint32_t)cx.episode_tag;
+    TurbCtx tc;
+    tc.seed = cx.turb_seed; tc.ox = cx.box_ox; tc.oy = cx.box_oy; tc.ws = ws;
+    tc.sig = (float)(cx.ti * ws);
+    tc.alpha = TURB == WG_TURB_NONE ? 0.f
+                                    : (float)(1.0 - exp(-2.0 * WG_PI_D * (ws / (p.fc_scale * p.D_d)) * p.dt_d));
     const uint8_t masked_out = (mode == WG_MODE_RESET && mask) ? (uint8_t)(mask[e] == 0) : (uint8_t)0;
     double l_xr = 0, l_yr = 0;
     float l_yaw = 0, l_u = 0, l_v = 0, l_w = 0, l_ti = 0, l_pow = 0, l_ct = 0, l_act = 0;
@@ -396,6 +533,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     float* rdy = tabct + p.n_tab;
     float* rdz = rdy + p.S;
     unsigned* tmask = reinterpret_cast<unsigned*>(rdz + p.S);
+    float* tiap = reinterpret_cast<float*>(tmask + p.target_chunk * WG_MASK_WORDS);
 
     for (int t = tid; t < N; t += NT) {
         TurbLds& q = T[t];
@@ -465,7 +603,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             // sin/cos are not needed in replay mode: power comes from the script
             script_step<NT>(p, d, T, e, farm, cursor, sr.time);
         } else {
-            flow_step<NT>(p, d, T, tabct, rdy, rdz, pair, tmask, pbase, ws, ti_f, ti_pow, sr);
+            flow_step<NT, TURB>(p, d, T, tabct, rdy, rdz, pair, tiap, tmask, pbase, ws, ti_f, ti_pow, tc, sr);
             ++n_flow;
         }
         --budget;
@@ -554,6 +692,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     }
     if (tid == 0) {
         slot.head = sr.head; slot.n_valid = sr.n_valid; slot.s_off = sr.s_off; slot.time = sr.time;
+        slot.istep = sr.istep;
         slot.cursor = cursor;
         slot.dev_remaining = dev_rem; slot.fill_remaining = fill_rem;
         if (farm == 0) { cx.n_pushed = n_pushed; cx.pend_farm_n = pend_farm_n; }
@@ -568,13 +707,19 @@ static void launch_nt(const FlowP* p, const FlowPtrs* d, int mode, const float* 
     const int grid = p->B * 2 * p->F;
     const size_t lds = p->lds_bytes;
     const bool replay = d->script_uvw != nullptr, noise = p->noise != 0;
-    if (replay) {
-        if (noise) hipLaunchKernelGGL((k_flow<NT, true, true>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk);
-        else hipLaunchKernelGGL((k_flow<NT, true, false>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk);
+#define WG_LAUNCH(TURB, REPLAY, NOISE) \
+    hipLaunchKernelGGL((k_flow<NT, TURB, REPLAY, NOISE>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk)
+    const int turb = (p->turb_mode == WG_TURB_BOX_SHIFT) ? WG_TURB_BOX : p->turb_mode;
+    if (replay) {                       // replay mode ignores the physics
+        if (noise) WG_LAUNCH(WG_TURB_NONE, true, true); else WG_LAUNCH(WG_TURB_NONE, true, false);
+    } else if (turb == WG_TURB_NONE) {
+        if (noise) WG_LAUNCH(WG_TURB_NONE, false, true); else WG_LAUNCH(WG_TURB_NONE, false, false);
+    } else if (turb == WG_TURB_RANDOM) {
+        if (noise) WG_LAUNCH(WG_TURB_RANDOM, false, true); else WG_LAUNCH(WG_TURB_RANDOM, false, false);
     } else {
-        if (noise) hipLaunchKernelGGL((k_flow<NT, false, true>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk);
-        else hipLaunchKernelGGL((k_flow<NT, false, false>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk);
+        if (noise) WG_LAUNCH(WG_TURB_BOX, false, true); else WG_LAUNCH(WG_TURB_BOX, false, false);
     }
+#undef WG_LAUNCH
 }
 
 // one workgroup per farm slot; its size (64 / 128 / 256 threads) is chosen on the host (FlowP.block)

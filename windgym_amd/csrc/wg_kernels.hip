@@ -25,7 +25,15 @@ __device__ inline void ctx_init(const WgParams& p, const WgPtrs& d, int e, int c
         ti = wg_pcg_uniform(env, p.ti_min, p.ti_max);
         wd = wg_pcg_uniform(env, p.wd_min, p.wd_max);
         uint32_t tseed = 0;
-        if (p.turb_mode == WG_TURB_RANDOM) tseed = wg_pcg_integers(env, 100000);   // _def_site (:640-644)
+        if (p.turb_mode == WG_TURB_RANDOM || p.turb_mode == WG_TURB_BOX_SHIFT)
+            tseed = wg_pcg_integers(env, 100000);                                  // _def_site (:623, :642)
+        cx.box_ox = 0.0; cx.box_oy = 0.0;
+        if (p.turb_mode == WG_TURB_BOX_SHIFT && p.bnx > 0) {
+            uint32_t a, b;
+            wg_philox_turb(tseed, 0u, 0u, 0u, 0x4fu, a, b);
+            cx.box_ox = (double)a * (1.0 / 4294967296.0) * p.bnx * p.bdx;
+            cx.box_oy = (double)b * (1.0 / 4294967296.0) * p.bny * p.bdy;
+        }
         for (int t = 0; t < N; ++t) {                     // yaw init (:715-720)
             float y0 = 0.f;
             if (p.yaw_init == WG_YAWINIT_RANDOM) y0 = (float)wg_pcg_uniform(env, -p.yaw_start, p.yaw_start);
@@ -63,7 +71,7 @@ __device__ inline void ctx_init(const WgParams& p, const WgPtrs& d, int e, int c
         if (d.script_uvw) n_dev = 0;
         for (int f = 0; f < F; ++f) {
             WgSlot& s = d.slot[ctx_id * F + f];
-            s.head = p.P - 1; s.n_valid = 0; s.s_off = 0.0; s.time = 0.0;
+            s.head = p.P - 1; s.n_valid = 0; s.s_off = 0.0; s.time = 0.0; s.istep = 0;
             s.dev_remaining = n_dev;
             s.fill_remaining = f == 0 ? p.fill_a : p.fill_b;
         }

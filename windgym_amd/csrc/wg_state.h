@@ -72,6 +72,8 @@ struct WgSlot {
     int fill_remaining; // window-fill env steps still to run
     int cursor;         // replay mode row
     unsigned flow_count; // flow_step() executions of this slot (roofline accounting; summed on the host)
+    unsigned istep;      // flow steps since the farm was built (counter of the inflow random stream)
+    int pad;
 };
 
 // per episode context
@@ -82,6 +84,7 @@ struct WgCtx {
     int t_developed, time_max;
     int n_pushed;        // add_measurements calls so far (all MesClass deques advance together)
     uint32_t turb_seed;
+    double box_ox, box_oy;   // horizontal offset of this episode into the shared turbulence box (m)
     int episode_tag;     // episode index this ctx belongs to (noise counter)
     // fill pushes into the env-level power deques are deferred until the ctx goes live
     int pend_farm_n, pend_base_n;

@@ -1,0 +1,72 @@
+"""Mann (1994/1998) spectral-tensor turbulence boxes — host-side generator (numpy FFT).
+
+Stands in for ``MannTurbulenceField.generate(alphaepsilon, L, Gamma, Nxyz, dxyz, seed)`` of
+dynamiks/hipersim (Wind_Farm_Env.py:624-637, :649-658; tests/test_basics.py:38-45), which are not
+installable here.  The algorithm is the published one: an isotropic von Karman field with random complex
+Gaussian amplitudes is distorted by rapid-distortion shear with the eddy-lifetime parameter Gamma and
+transformed back with an inverse FFT.  The box is returned normalised to unit standard deviation of the u
+component (the reference rescales with ``scale_TI(TI, U)``, :617/:637/:658 — the kernels multiply by TI*U per
+env instead).  Layout: float32 [3, Nx, Ny, Nz], z fastest — what ``wg_set_turbulence_box`` expects.
+
+One box is generated per process and shared by every env of the GPU (a per-env 0.8 GB box is not an option at
+thousands of envs); episodes differ by a random horizontal offset (WG_TURB_BOX_SHIFT).  A hipFFT generator
+on the device is the "next" row f2 of SURVEY.md §8.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _eddy_lifetime_beta(kL, Gamma):
+    from scipy.special import hyp2f1
+    kL = np.maximum(kL, 1e-12)
+    return Gamma * kL ** (-2.0 / 3.0) / np.sqrt(hyp2f1(1.0 / 3.0, 17.0 / 6.0, 4.0 / 3.0, -kL ** (-2.0)))
+
+
+def generate_mann_box(Nxyz=(1024, 128, 32), dxyz=(3.0, 3.0, 3.0), alphaepsilon=0.1, L=33.6, Gamma=3.9, seed=1234):
+    Nx, Ny, Nz = (int(n) for n in Nxyz)
+    dx, dy, dz = (float(d) for d in dxyz)
+    rng = np.random.default_rng(seed)
+    k1 = 2 * np.pi * np.fft.fftfreq(Nx, dx)[:, None, None]
+    k2 = 2 * np.pi * np.fft.fftfreq(Ny, dy)[None, :, None]
+    k3 = 2 * np.pi * np.fft.fftfreq(Nz, dz)[None, None, :]
+    k1 = np.broadcast_to(k1, (Nx, Ny, Nz)).astype(np.float64)
+    k2 = np.broadcast_to(k2, (Nx, Ny, Nz)).astype(np.float64)
+    k3 = np.broadcast_to(k3, (Nx, Ny, Nz)).astype(np.float64)
+    kk = np.sqrt(k1 ** 2 + k2 ** 2 + k3 ** 2)
+    beta = _eddy_lifetime_beta(kk * L, Gamma)
+    k30 = k3 + beta * k1
+    k0 = np.sqrt(k1 ** 2 + k2 ** 2 + k30 ** 2)
+    k0 = np.where(k0 == 0, 1e-12, k0)
+    kk_s = np.where(kk == 0, 1e-12, kk)
+    # von Karman energy spectrum at the undistorted wave number
+    E0 = alphaepsilon * L ** (5.0 / 3.0) * (k0 * L) ** 4 / (1.0 + (k0 * L) ** 2) ** (17.0 / 6.0)
+    amp = np.sqrt(E0 / (4.0 * np.pi)) / k0 ** 2
+    # rapid-distortion coefficients (Mann 1998, eqs. 3.16-3.18)
+    k12 = k1 ** 2 + k2 ** 2
+    k12s = np.where(k12 == 0, 1e-12, k12)
+    C1 = beta * k1 ** 2 * (k0 ** 2 - 2 * k30 ** 2 + beta * k1 * k30) / (kk_s ** 2 * k12s)
+    C2 = k2 * k0 ** 2 / k12s ** 1.5 * np.arctan2(beta * k1 * np.sqrt(k12s), k0 ** 2 - k30 * k1 * beta)
+    k1s = np.where(k1 == 0, 1e-12, k1)
+    zeta1 = C1 - k2 / k1s * C2
+    zeta2 = k2 / k1s * C1 + C2
+    zeta1 = np.where(k1 == 0, -beta, zeta1)
+    zeta2 = np.where(k1 == 0, 0.0, zeta2)
+    # random complex Gaussian white noise
+    n = (rng.standard_normal((3, Nx, Ny, Nz)) + 1j * rng.standard_normal((3, Nx, Ny, Nz))) / np.sqrt(2.0)
+    # isotropic incompressible field dZ_iso = amp * (k0 x n), then sheared
+    a1 = amp * (k2 * n[2] - k30 * n[1])
+    a2 = amp * (k30 * n[0] - k1 * n[2])
+    a3 = amp * (k1 * n[1] - k2 * n[0])
+    r = (k0 / kk_s) ** 2
+    dZ1 = a1 + zeta1 * a3
+    dZ2 = a2 + zeta2 * a3
+    dZ3 = r * a3
+    dV = (2 * np.pi) ** 3 / (Nx * dx * Ny * dy * Nz * dz)
+    out = np.empty((3, Nx, Ny, Nz), dtype=np.float32)
+    for c, dZ in enumerate((dZ1, dZ2, dZ3)):
+        dZ = dZ.copy()
+        dZ[0, 0, 0] = 0.0
+        out[c] = (np.fft.ifftn(dZ) * (Nx * Ny * Nz) * np.sqrt(dV)).real.astype(np.float32)
+    out /= float(out[0].std())
+    return np.ascontiguousarray(out)
