@@ -152,3 +152,34 @@ def test_vec_env_autoreset_and_episode_stats(wg, tmp_path):
     o, r, dones, inf = venv.step_wait()
     assert o.shape[0] == 64 and len(inf) == 64 and "Power agent" in inf[0]
     venv.close()
+
+
+def test_mann_box_generators_agree_statistically(wg):
+    """hipFFT (torch) generator vs the numpy reference implementation of the same algorithm."""
+    import torch
+    from windgym_amd.mann import generate_mann_box, generate_mann_box_torch
+    a = generate_mann_box((256, 64, 32), (3.0, 3.0, 3.0), seed=5)
+    b = generate_mann_box_torch((256, 64, 32), (3.0, 3.0, 3.0), seed=5).cpu().numpy()
+    assert a.shape == b.shape == (3, 256, 64, 32)
+    for arr in (a, b):
+        assert abs(arr[0].std() - 1.0) < 1e-3
+        assert 0.6 < arr[1].std() < 0.95 and 0.5 < arr[2].std() < 0.95
+        assert np.mean(arr[0] * arr[2]) < -0.1                     # shear: negative uw covariance
+    assert abs(a[1].std() - b[1].std()) < 0.08 and abs(a[2].std() - b[2].std()) < 0.08
+    ac = lambda u, k: np.mean(u[:-k] * u[k:])                      # noqa: E731
+    assert abs(ac(a[0], 10) - ac(b[0], 10)) < 0.15
+
+
+def test_mannfixed_env_with_reference_box_size(wg, tmp_path):
+    """turbtype='MannFixed' end to end: the 2048x512x64 box (0.8 GB) is generated on the GPU and the env steps."""
+    from windgym_amd import presets
+    d = presets.env1_config()
+    env = wg.WindFarmEnv(turbine=wg.V80(), n_passthrough=1, yaml_path=_yaml(tmp_path, d), turbtype="MannFixed", seed=2)
+    obs, info = env.reset()
+    assert np.isfinite(obs).all() and np.std(info["Wind direction at turbines"]) > 0
+    u0 = env.fs.windTurbines.rotor_avg_windspeed.copy()
+    for _ in range(5):
+        obs, r, term, trunc, info = env.step(env.action_space.sample())
+    assert np.isfinite(obs).all() and np.isfinite(r)
+    assert np.abs(env.fs.windTurbines.rotor_avg_windspeed - u0).max() > 1e-3    # unsteady inflow
+    env.close()

@@ -38,6 +38,22 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+def _attach_box(batch: HipBatch, cfg: EnvConfig, turbulence_box=None):
+    """Mann turbtypes need the frozen box on the device (MannTurbulenceField.generate / from_netcdf,
+    Wind_Farm_Env.py:611-659).  `turbulence_box` = (array-like [3,Nx,Ny,Nz], (dx,dy,dz)) or None: generate the
+    reference's box for this turbtype on the GPU (hipFFT)."""
+    if cfg.turbtype not in ("MannFixed", "MannGenerate", "MannLoad"):
+        return
+    if turbulence_box is None:
+        from .mann import generate_mann_box_torch, reference_box_spec
+        spec = reference_box_spec(cfg.turbtype, cfg.D)
+        box = generate_mann_box_torch(device=batch.device, **spec)
+        spacing = spec["dxyz"]
+    else:
+        box, spacing = turbulence_box
+    batch.set_turbulence_box(box, spacing)
+
+
 class _TurbinesProxy:
     """Duck type of ``fs.windTurbines`` for the call sites listed in SURVEY.md Appendix A."""
 
@@ -91,10 +107,11 @@ class WindFarmVecEnv:
     """
 
     def __init__(self, turbine, n_envs: int, yaml_path=None, *, seed: Optional[int] = 0, device: Optional[int] = None,
-                 as_torch: bool = False, autoreset: bool = True, **kwargs):
+                 as_torch: bool = False, autoreset: bool = True, turbulence_box=None, **kwargs):
         self.cfg = EnvConfig(turbine=turbine, yaml_path=yaml_path, n_envs=int(n_envs), autoreset=autoreset,
                              seed=seed, **kwargs)
         self.batch = HipBatch(self.cfg, device=device)
+        _attach_box(self.batch, self.cfg, turbulence_box)
         self.num_envs = self.n_envs = int(n_envs)
         self.n_turb = self.cfg.n_turb
         self.as_torch = as_torch
@@ -256,7 +273,7 @@ class WindFarmEnv(_EnvBase):
                  TurbBox="Default", turbtype="MannLoad", yaml_path=None, Baseline_comp=False, yaw_init=None,
                  render_mode=None, seed=None, dt_sim=1, dt_env=1, yaw_step=1, fill_window=True, sample_site=None,
                  HTC_path=None, reset_init=True, *, device=None, yaml_dict=None, n_particles=None,
-                 n_rotor_pts=16, x_pos=None, y_pos=None):
+                 n_rotor_pts=16, x_pos=None, y_pos=None, turbulence_box=None):
         if HTC_path is not None:
             raise NotImplementedError("HAWC2 turbines (HTC_path) are outside the MI355X step() path")
         if sample_site is not None:
@@ -276,6 +293,7 @@ class WindFarmEnv(_EnvBase):
                         never_truncate=self._never_truncate, extra_timestep_inc=self._extra_timestep_inc)
         self.yaw_initial = [0]
         self._overrides = {}
+        self._turbulence_box = turbulence_box
         self._build()
         self.timestep = 0
         self._torn_down = True
@@ -295,6 +313,11 @@ class WindFarmEnv(_EnvBase):
             old.close()
         self.cfg = cfg
         self._batch = HipBatch(cfg, device=self._device)
+        if self._turbulence_box is None and cfg.turbtype in ("MannFixed", "MannGenerate", "MannLoad"):
+            from .mann import generate_mann_box_torch, reference_box_spec      # generated once, reused on rebuilds
+            spec = reference_box_spec(cfg.turbtype, cfg.D)
+            self._turbulence_box = (generate_mann_box_torch(device=self._batch.device, **spec), spec["dxyz"])
+        _attach_box(self._batch, cfg, self._turbulence_box)
         c = cfg
         # attributes callers read
         self.n_turb, self.x_pos, self.y_pos = c.n_turb, c.x_pos, c.y_pos

@@ -70,3 +70,67 @@ def generate_mann_box(Nxyz=(1024, 128, 32), dxyz=(3.0, 3.0, 3.0), alphaepsilon=0
         out[c] = (np.fft.ifftn(dZ) * (Nx * Ny * Nz) * np.sqrt(dV)).real.astype(np.float32)
     out /= float(out[0].std())
     return np.ascontiguousarray(out)
+
+
+def generate_mann_box_torch(Nxyz=(2048, 512, 64), dxyz=(3.0, 3.0, 3.0), alphaepsilon=0.1, L=33.6, Gamma=3.9,
+                            seed=1234, device="cuda"):
+    """Same algorithm on the GPU: the three inverse FFTs run in hipFFT (torch.fft on ROCm), so the reference's
+    box sizes (2048x512x64 = 0.8 GB, Wind_Farm_Env.py:654; 4096x512x64, :629-633) take seconds instead of minutes.
+    The eddy-lifetime factor (a 2F1 hypergeometric function of |k|L only) is tabulated on the host with scipy and
+    interpolated on the device.  Returns a float32 CUDA tensor [3, Nx, Ny, Nz], unit std of u."""
+    import torch
+    Nx, Ny, Nz = (int(n) for n in Nxyz)
+    dx, dy, dz = (float(d) for d in dxyz)
+    dev = torch.device(device)
+    f32, c64 = torch.float32, torch.complex64
+    g = torch.Generator(device=dev).manual_seed(int(seed))
+    k1 = (2 * np.pi * torch.fft.fftfreq(Nx, dx, device=dev, dtype=f32))[:, None, None]
+    k2 = (2 * np.pi * torch.fft.fftfreq(Ny, dy, device=dev, dtype=f32))[None, :, None]
+    k3 = (2 * np.pi * torch.fft.fftfreq(Nz, dz, device=dev, dtype=f32))[None, None, :]
+    kk = torch.sqrt(k1 ** 2 + k2 ** 2 + k3 ** 2)
+    # beta(|k| L) table: log-spaced, linear interpolation in log space
+    kl_tab = np.logspace(-6, 6, 4096)
+    beta_tab = torch.as_tensor(_eddy_lifetime_beta(kl_tab, Gamma), dtype=f32, device=dev)
+    lk = torch.log10(torch.clamp(kk * L, min=1e-6, max=1e6))
+    pos = (lk + 6.0) / 12.0 * (len(kl_tab) - 1)
+    i0 = torch.clamp(pos.floor().long(), 0, len(kl_tab) - 2)
+    w = pos - i0.to(f32)
+    beta = beta_tab[i0] * (1 - w) + beta_tab[i0 + 1] * w
+    del lk, pos, i0, w
+    k30 = k3 + beta * k1
+    k0 = torch.sqrt(k1 ** 2 + k2 ** 2 + k30 ** 2).clamp_min(1e-12)
+    kks = kk.clamp_min(1e-12)
+    E0 = alphaepsilon * L ** (5.0 / 3.0) * (k0 * L) ** 4 / (1.0 + (k0 * L) ** 2) ** (17.0 / 6.0)
+    amp = torch.sqrt(E0 / (4.0 * np.pi)) / k0 ** 2
+    del E0
+    k12 = (k1 ** 2 + k2 ** 2).expand(Nx, Ny, Nz)
+    k12s = k12.clamp_min(1e-12)
+    C1 = beta * k1 ** 2 * (k0 ** 2 - 2 * k30 ** 2 + beta * k1 * k30) / (kks ** 2 * k12s)
+    C2 = k2 * k0 ** 2 / k12s ** 1.5 * torch.atan2(beta * k1 * torch.sqrt(k12s), k0 ** 2 - k30 * k1 * beta)
+    k1s = torch.where(k1 == 0, torch.full_like(k1, 1e-12), k1)
+    zeta1 = torch.where(k1 == 0, -beta, C1 - k2 / k1s * C2)
+    zeta2 = torch.where(k1 == 0, torch.zeros_like(beta), k2 / k1s * C1 + C2)
+    del C1, C2, k12, k12s
+    shape = (Nx, Ny, Nz)
+    n = [torch.complex(torch.randn(shape, generator=g, device=dev, dtype=f32),
+                       torch.randn(shape, generator=g, device=dev, dtype=f32)) / np.sqrt(2.0) for _ in range(3)]
+    a3 = amp * (k1 * n[1] - k2 * n[0])
+    dZ = [amp * (k2 * n[2] - k30 * n[1]) + zeta1 * a3, amp * (k30 * n[0] - k1 * n[2]) + zeta2 * a3,
+          (k0 / kks) ** 2 * a3]
+    del n, a3, amp, zeta1, zeta2
+    dV = (2 * np.pi) ** 3 / (Nx * dx * Ny * dy * Nz * dz)
+    out = torch.empty((3, Nx, Ny, Nz), dtype=f32, device=dev)
+    for c in range(3):
+        z = dZ[c].to(c64)
+        z[0, 0, 0] = 0
+        out[c] = torch.fft.ifftn(z).real * (Nx * Ny * Nz * np.sqrt(dV))
+        dZ[c] = None
+    out /= out[0].std()
+    return out.contiguous()
+
+
+# the reference's box definitions per turbtype (Wind_Farm_Env.py:624-637, :649-658)
+def reference_box_spec(turbtype: str, D: float):
+    if turbtype == "MannFixed":
+        return dict(Nxyz=(2048, 512, 64), dxyz=(3.0, 3.0, 3.0), seed=1234)
+    return dict(Nxyz=(4096, 512, 64), dxyz=(D / 20, D / 10, D / 10), seed=1234)
