@@ -19,15 +19,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def make_cfg(n_envs, autoreset=True, farms2=True):
+WORKLOADS = {
+    # name: (default envs per GPU, description)            -- BASELINE.json `configs`
+    "cfg2": (4096, "4x4 16-turbine grid (V80, 5.33D pitch), yaw-only action, Env1 sensors, inflow None"),
+    "cfg3": (512, "Horns Rev 1 layout (80 turbines), yaw action, Env1 sensors, inflow None"),
+    "cfg4": (2048, "3x3 farm, WindFarmEnvMulti per-turbine-agent observations [B,9,o_t+o_f], inflow None"),
+    "cfg5": (1024, "4x4 16-turbine grid, frozen Mann box 2048x512x64 @ 3 m + DWM meandering"),
+}
+
+
+def make_cfg(n_envs, autoreset=True, farms2=True, workload="cfg2"):
+    from windgym_amd import presets
     from windgym_amd.config import EnvConfig
-    from windgym_amd.presets import bench_cfg2_config
     from windgym_amd.turbine import V80
-    d = bench_cfg2_config()
+    kw = {}
+    turbtype = "None"
+    if workload == "cfg3":
+        d = presets.horns_rev_config()
+        kw["x_pos"], kw["y_pos"] = presets.horns_rev1_layout()
+    elif workload == "cfg4":
+        d = presets.multi_3x3_config()
+        kw["extra_timestep_inc"] = True
+    else:
+        d = presets.bench_cfg2_config()
+        if workload == "cfg5":
+            turbtype = "MannGenerate"
     if not farms2:
         d["power_def"]["Power_reward"] = "Power_avg"
-    return EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_envs=n_envs, autoreset=autoreset,
-                     n_passthrough=5, n_rotor_pts=16)
+    return EnvConfig(turbine=V80(), yaml_dict=d, turbtype=turbtype, n_envs=n_envs, autoreset=autoreset,
+                     n_passthrough=5, n_rotor_pts=16, **kw)
 
 
 def cpu_baseline(args):
@@ -36,8 +56,11 @@ def cpu_baseline(args):
     from oracle import oracle as om
     om.build()
     n = args.cpu_envs
-    cfg = make_cfg(n, autoreset=True, farms2=not args.one_farm)
+    cfg = make_cfg(n, autoreset=True, farms2=not args.one_farm, workload=args.workload)
     orc = om.Oracle(cfg, "f32" if args.cpu_f32 else "f64")
+    if args.workload == "cfg5":
+        from windgym_amd.mann import generate_mann_box
+        orc.set_turbulence_box(generate_mann_box((512, 128, 32), (3.0, 3.0, 3.0), seed=1234), (3.0, 3.0, 3.0))
     cores = orc.max_threads()
     orc.reset(seeds=1234 + np.arange(n))
     rng = np.random.default_rng(0)
@@ -53,7 +76,7 @@ def cpu_baseline(args):
         if el > args.cpu_seconds or steps >= args.cpu_max_steps:
             break
     return {"value": n * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {steps} steps of the same 4x4 workload (oracle C port, "
+            "sample": f"{n} envs x {steps} steps of the same {args.workload} workload (oracle C port, "
                       f"{'fp32' if args.cpu_f32 else 'fp64'}, OpenMP over envs, after reset)"}
 
 
@@ -62,7 +85,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (weak scaling)")
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (weak scaling); default per workload")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
+                    help="cfg2 is the headline metric; the others are BASELINE.json's remaining GPU configs")
     ap.add_argument("--one-farm", action="store_true", help="F=1 (no baseline farm)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=64)
@@ -88,9 +113,13 @@ def main():
 
     from windgym_amd import binding
     from windgym_amd.parallel import ShardedMetrics
-    B = args.envs
-    cfg = make_cfg(B, autoreset=True, farms2=not args.one_farm)
+    B = args.envs if args.envs else WORKLOADS[args.workload][0]
+    cfg = make_cfg(B, autoreset=True, farms2=not args.one_farm, workload=args.workload)
     env = binding.HipBatch(cfg, device=dev.index)
+    if args.workload == "cfg5":
+        from windgym_amd.mann import generate_mann_box_torch, reference_box_spec
+        spec = reference_box_spec("MannFixed", cfg.D)
+        env.set_turbulence_box(generate_mann_box_torch(device=dev, **spec), spec["dxyz"])
     # env i of the global batch is seeded 1234 + i regardless of the number of GPUs
     seeds = 1234 + rank * B + np.arange(B)
     env.reset(seeds=seeds)
@@ -105,14 +134,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    multi_out = None
+
+    def one_step(i):
         env.step(actions[i % n_act])
+        if args.workload == "cfg4":      # the PettingZoo facade packs per-agent observations every step
+            nonlocal multi_out
+            multi_out = env.obs_multi()
+
+    for i in range(args.warmup):
+        one_step(i)
     env.check()
     env.kernel_timing(True)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        env.step(actions[i % n_act])
+        one_step(i)
     barrier()
     el = time.perf_counter() - t0
     flow_ms, glue_ms, n_launch, flow_steps = env.kernel_timing(False)
@@ -131,27 +168,30 @@ def main():
         # algorithmic bytes of one k_flow launch = farm flow-steps it executed (live farms + background
         # development of the next episodes, counted on the device) x bytes per farm flow-step:
         # per particle: py read+write (8) + record ct,k,eps,hv read (16); per turbine: state r/w + positions
-        bytes_per_flow_step = cfg.n_turb * cfg.n_particles * 24.0 + cfg.n_turb * 72.0
+        per_particle = 24.0 + (88.0 if args.workload == "cfg5" else 0.0)       # + pz,vlp,wlp r/w + 16 box corners
+        bytes_per_flow_step = (cfg.n_turb * cfg.n_particles * per_particle + cfg.n_turb * 72.0
+                               + (cfg.n_turb * cfg.n_rotor_pts * 96.0 if args.workload == "cfg5" else 0.0))
         alg_bytes_flow = flow_steps * bytes_per_flow_step
         achieved = alg_bytes_flow / (flow_ms * 1e-3) / 1e9 if flow_ms > 0 else 0.0
         # HBM bytes per k_flow launch from the rocprofv3 PMC passes of this same command (separate runs:
         # tools/profile_kflow.sh -> profiles/r01_kflow_traffic.json); only quoted for the profiled workload
         traffic = None
         tf = os.path.join(ROOT, "profiles", "r01_kflow_traffic.json")
-        if os.path.exists(tf) and B == 4096 and F == 2 and world == 1:
+        if os.path.exists(tf) and B == 4096 and F == 2 and world == 1 and args.workload == "cfg2":
             try:
                 traffic = json.load(open(tf))["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
         out = {
-            "metric": "env-steps/sec (whole node), 16-turbine farm x 4096 envs",
+            "metric": "env-steps/sec (whole node), 16-turbine farm x 4096 envs" if args.workload == "cfg2"
+                      else f"env-steps/sec (whole node), {args.workload}",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cfg2: 4x4 16-turbine grid (V80, 5.33D pitch), yaw-only action, Env1 sensors "
+            "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload][1]} "
                                    f"(O={env.obs_dim}), {B} envs/GPU, F={F} farms/env "
                                    f"({'Baseline reward' if F == 2 else 'Power_avg reward'}), P={cfg.n_particles}, "
-                                   f"S={cfg.n_rotor_pts}, inflow None, same-step autoreset on",
+                                   f"S={cfg.n_rotor_pts}, same-step autoreset on",
                        "envs_per_gpu": B, "n_turb": cfg.n_turb, "farms_per_env": F,
                        "parallelism": f"env-axis shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
