@@ -193,10 +193,16 @@ __device__ inline double wg_wave_max_d(double v) {
 struct WgRing {
     const float* data;
     int n_pushed, hlen;
-    __device__ int avail() const { return n_pushed < hlen ? n_pushed : hlen; }
+    int n_avail, start;      // start = physical slot of the oldest sample (one modulo per ring, not per element)
+    __device__ WgRing() {}
+    __device__ WgRing(const float* d_, int n_pushed_, int hlen_) : data(d_), n_pushed(n_pushed_), hlen(hlen_) {
+        n_avail = n_pushed < hlen ? n_pushed : hlen;
+        start = (n_pushed - n_avail) % hlen;
+    }
+    __device__ int avail() const { return n_avail; }
     __device__ float at(int q) const {   // q = 0 oldest
-        int a = avail();
-        int phys = (n_pushed - a + q) % hlen;
+        int phys = start + q;
+        if (phys >= hlen) phys -= hlen;
         return data[phys];
     }
 };
@@ -277,14 +283,12 @@ __device__ inline int wg_turb_block(const WgParams& p, const WgPtrs& d, int ctx_
         const int H = p.ch[ch].history_len;
         bool on = farm_level ? (p.farm_on[ch] != 0) : (p.turb_on[ch] != 0);
         WgRing r;
-        r.hlen = H;
         if (farm_level) {
-            r.data = fbase + p.fring_off[ch];
-            r.n_pushed = (ch == WG_CH_YAW) ? 0 : n_pushed;   // the farm object's yaw deque is never filled
-            if (ch == WG_CH_YAW) on = true;                   // flags would allow it; the empty deque yields []
+            // the farm object's yaw deque is never filled: the flags would allow it, the empty deque yields []
+            r = WgRing(fbase + p.fring_off[ch], (ch == WG_CH_YAW) ? 0 : n_pushed, H);
+            if (ch == WG_CH_YAW) on = true;
         } else {
-            r.data = rbase + p.ring_off[ch] + (size_t)t * H;
-            r.n_pushed = n_pushed;
+            r = WgRing(rbase + p.ring_off[ch] + (size_t)t * H, n_pushed, H);
         }
         float rng = (farm_level && ch == WG_CH_POWER) ? p.sc_rng_farm_power : p.sc_rng[ch];
         n += wg_mes_get(p.ch[ch], p.ch[ch].current && on, p.ch[ch].rolling_mean && on, r, p.sc_min[ch], rng,

@@ -14,10 +14,9 @@
 // ===================================================================================================
 // episode context initialisation (wave-cooperative): WindFarmEnv.reset up to fs.run (:689-732)
 // ===================================================================================================
-__device__ inline void ctx_init(const WgParams& p, const WgPtrs& d, int e, int c, int lane, int episode_tag) {
+__device__ inline void ctx_init(const WgParams& p, const WgPtrs& d, WgEnv& env, int e, int c, int lane, int episode_tag) {
     const int N = p.N, F = p.F;
     const int ctx_id = e * 2 + c;
-    WgEnv& env = d.env[e];
     WgCtx& cx = d.ctx[ctx_id];
     double ws = 0, ti = 0, wd = 0;
     if (lane == 0) {
@@ -100,7 +99,7 @@ __device__ inline void ctx_init(const WgParams& p, const WgPtrs& d, int e, int c
 // observation (farm_mes.get_measurements(scaled=True) + clip, MesClass.py:679-703, Wind_Farm_Env.py:513-520)
 // ===================================================================================================
 __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id, int lane, float* __restrict__ obs,
-                                 float* __restrict__ obs2) {
+                                 float* __restrict__ obs2, const float* rbase, const float* fbase) {
     const int N = p.N;
     const int n_pushed = d.ctx[ctx_id].n_pushed;
     float ti_sum = 0.f;
@@ -109,17 +108,16 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
         // turbine block written straight to its place (block length is fixed = turb_obs)
         float* o = obs + (size_t)t * p.turb_obs;
         int n = 0;
-        const float* rbase = d.ring + (size_t)ctx_id * p.ring_stride;
         for (int ch = 0; ch < WG_N_CH; ++ch) {
             const int H = p.ch[ch].history_len;
             if (ch == WG_CH_POWER && p.turb_ti) {
-                WgRing r{rbase + p.ring_off[WG_CH_WS] + (size_t)t * p.ch[WG_CH_WS].history_len, n_pushed,
-                         p.ch[WG_CH_WS].history_len};
+                WgRing r(rbase + p.ring_off[WG_CH_WS] + (size_t)t * p.ch[WG_CH_WS].history_len, n_pushed,
+                         p.ch[WG_CH_WS].history_len);
                 float v = wg_clip1(wg_scale(wg_calc_ti(r), p.ti_min_f, p.ti_rng_f));
                 o[n] = v; if (obs2) obs2[(size_t)t * p.turb_obs + n] = v;
                 ++n;
             }
-            WgRing r{rbase + p.ring_off[ch] + (size_t)t * H, n_pushed, H};
+            WgRing r(rbase + p.ring_off[ch] + (size_t)t * H, n_pushed, H);
             const bool on = p.turb_on[ch] != 0;
             const bool cur_on = p.ch[ch].current && on, rol_on = p.ch[ch].rolling_mean && on;
             // stream the values out one at a time (window count is unbounded: history_N up to 100s)
@@ -151,8 +149,8 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
             }
         }
         if (p.farm_ti) {   // farm TI = mean of the *scaled* turbine TIs (MesClass.py:670-673)
-            WgRing r{rbase + p.ring_off[WG_CH_WS] + (size_t)t * p.ch[WG_CH_WS].history_len, n_pushed,
-                     p.ch[WG_CH_WS].history_len};
+            WgRing r(rbase + p.ring_off[WG_CH_WS] + (size_t)t * p.ch[WG_CH_WS].history_len, n_pushed,
+                     p.ch[WG_CH_WS].history_len);
             ti_sum += wg_scale(wg_calc_ti(r), p.ti_min_f, p.ti_rng_f);
         }
     }
@@ -161,7 +159,6 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
         float* o = obs + (size_t)N * p.turb_obs;
         float* o2 = obs2 ? obs2 + (size_t)N * p.turb_obs : nullptr;
         int n = 0;
-        const float* fbase = d.fring + (size_t)ctx_id * p.fring_stride;
         const int chs[3] = {WG_CH_WS, WG_CH_WD, WG_CH_POWER};
         for (int ci = 0; ci < 3; ++ci) {
             const int ch = chs[ci];
@@ -171,7 +168,7 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
                 ++n;
             }
             if (!p.farm_on[ch]) continue;
-            WgRing r{fbase + p.fring_off[ch], n_pushed, p.ch[ch].history_len};
+            WgRing r(fbase + p.fring_off[ch], n_pushed, p.ch[ch].history_len);
             const float rng = ch == WG_CH_POWER ? p.sc_rng_farm_power : p.sc_rng[ch];
             // farm windows are few: reuse the generic helper through a small buffer when it fits
             const int cnt = (p.ch[ch].current ? 1 : 0) + (p.ch[ch].rolling_mean ? p.ch[ch].history_n : 0);
@@ -205,6 +202,33 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
     }
 }
 
+// copy one context's sensor rings into this wave's LDS region with coalesced loads (the window loops of
+// build_obs would otherwise issue long chains of dependent global loads); returns the bases to read from
+__device__ inline void stage_rings(const WgParams& p, const WgPtrs& d, int ctx_id, int lane, float* lds,
+                                   const float*& rbase, const float*& fbase) {
+    const float* gr = d.ring + (size_t)ctx_id * p.ring_stride;
+    const float* gf = d.fring + (size_t)ctx_id * p.fring_stride;
+    if (lds == nullptr) { rbase = gr; fbase = gf; return; }
+    // 16 loads in flight per lane (a plain copy loop waits for every load before its LDS store)
+    constexpr int U = 16;
+    for (int b0 = lane; b0 < p.ring_stride; b0 += WG_WAVE * U) {
+        float v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) { const int i = b0 + k * WG_WAVE; v[k] = i < p.ring_stride ? gr[i] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < U; ++k) { const int i = b0 + k * WG_WAVE; if (i < p.ring_stride) lds[i] = v[k]; }
+    }
+    for (int b0 = lane; b0 < p.fring_stride; b0 += WG_WAVE * U) {
+        float v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) { const int i = b0 + k * WG_WAVE; v[k] = i < p.fring_stride ? gf[i] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < U; ++k) { const int i = b0 + k * WG_WAVE; if (i < p.fring_stride) lds[p.ring_stride + i] = v[k]; }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // single wave: program order suffices
+    rbase = lds; fbase = lds + p.ring_stride;
+}
+
 __device__ inline double deque_mean(const float* dq, int n_total, int maxlen) {
     const int n = n_total < maxlen ? n_total : maxlen;
     double s = 0;
@@ -218,8 +242,7 @@ __device__ inline float deque_at(const float* dq, int n_total, int maxlen, int q
 
 // plan how many flow sub-steps the background episode must advance during the next step() so that it is
 // ready exactly when the running episode truncates
-__device__ inline int plan_shadow(const WgParams& p, const WgPtrs& d, int e) {
-    const WgEnv& env = d.env[e];
+__device__ inline int plan_shadow(const WgParams& p, const WgPtrs& d, const WgEnv& env, int e) {
     const int live = env.live, sh = live ^ 1;
     int work = 0;
     for (int f = 0; f < p.F; ++f) {
@@ -242,13 +265,16 @@ __device__ inline int plan_shadow(const WgParams& p, const WgPtrs& d, int e) {
 __global__ void __launch_bounds__(WG_BLOCK)
 k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restrict__ mask,
        float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out,
-       float* __restrict__ final_obs_out) {
+       float* __restrict__ final_obs_out, const int lds_floats_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) float glue_lds[];
     const int lane = threadIdx.x & 63;
     const int e = blockIdx.x * WG_NWAVES + (threadIdx.x >> 6);
     if (e >= p.B) return;
     WgEnv& env = d.env[e];
     const int N = p.N;
     float* obs = obs_out ? obs_out + (size_t)e * p.obs_dim : nullptr;
+    float* my_lds = lds_floats_per_wave > 0 ? glue_lds + (size_t)(threadIdx.x >> 6) * lds_floats_per_wave : nullptr;
+    const float *rbase, *fbase;
 
     if (phase == 1) {
         if (mask && !mask[e]) return;
@@ -271,9 +297,12 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
             cx.pend_farm_n = 0; cx.pend_base_n = 0;
             env.timestep = 0; env.done = 0; env.steps_done = 0;
             env.ep_return = 0.f; env.ep_power_sum = 0.f; env.ep_len = 0;
-            env.shadow_iters = p.autoreset ? plan_shadow(p, d, e) : 0;
+            env.shadow_iters = p.autoreset ? plan_shadow(p, d, env, e) : 0;
         }
-        if (obs) build_obs(p, d, ctx_id, lane, obs, nullptr);
+        if (obs) {
+            stage_rings(p, d, ctx_id, lane, my_lds, rbase, fbase);
+            build_obs(p, d, ctx_id, lane, obs, nullptr, rbase, fbase);
+        }
         return;
     }
 
@@ -281,29 +310,92 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         if (lane == 0) atomicMin(d.status, (int)WG_ERR_STATE);
         return;
     }
-    const int live = env.live;
+    // Work on a register copy of the env header: through the reference every field access is a dependent
+    // global round trip (the kernel was a ~25-deep latency chain).  All lanes apply the same scalar updates to
+    // their copies; lane 0 alone consumes random numbers and writes the header back.
+#ifndef WG_GLUE_ABLATE
+#define WG_GLUE_ABLATE 0
+#endif
+    if (WG_GLUE_ABLATE == 1) return;
+    WgEnv ev = env;
+    const int live = ev.live;
     const int ctx_id = e * 2 + live;
     WgCtx& cx = d.ctx[ctx_id];
+    const int time_max = cx.time_max;
+    const float rated_power = cx.rated_power;
     const size_t tb_a = (size_t)(ctx_id * p.F) * N;
+    const float fp = d.step_farm_pow[e];
+    const float bp = p.F == 2 ? d.step_base_pow[e] : 0.f;
+    float* fq = d.farm_pow + (size_t)e * p.power_avg;
+    float* bq = d.base_pow + (size_t)e * p.power_avg;
 
-    // power deques (:975-981)
-    if (lane == 0) {
-        const float fp = d.step_farm_pow[e];
-        d.farm_pow[(size_t)e * p.power_avg + env.farm_pow_n % p.power_avg] = fp;
-        env.farm_pow_n++;
-        if (p.F == 2) {
-            d.base_pow[(size_t)e * p.power_avg + env.base_pow_n % p.power_avg] = d.step_base_pow[e];
-            env.base_pow_n++;
+    // ---- issue every remaining global load now: they all depend only on (e, live), so they share ONE memory
+    // round trip with the ring staging below instead of forming a chain of dependent round trips ----
+    float l_yaw = 0.f, l_old = 0.f, l_pow = 0.f, l_powb = 0.f;
+    if (lane < N) {
+        l_yaw = d.yaw[tb_a + lane]; l_old = d.old_yaw[(size_t)e * N + lane]; l_pow = d.power[tb_a + lane];
+        if (p.F == 2) l_powb = d.power[tb_a + N + lane];
+    }
+    float* met = d.metrics + (size_t)e * WG_N_METRICS;
+    float l_met = lane < WG_N_METRICS ? met[lane] : 0.f;
+    int l_work = 0;                       // background-episode work of farm `lane` (plan_shadow)
+    if (p.autoreset && lane < p.F) {
+        const WgSlot& sl = d.slot[(e * 2 + (live ^ 1)) * p.F + lane];
+        l_work = sl.dev_remaining + p.K * sl.fill_remaining;
+    }
+
+    // power deques (:975-981): one lane per deque element, the new value patched in registers
+    const int fslot = ev.farm_pow_n % p.power_avg, bslot = ev.base_pow_n % p.power_avg;
+    ev.farm_pow_n++;
+    if (p.F == 2) ev.base_pow_n++;
+    double fsum = 0.0, bsum = 0.0, fl = 0.0, fo = 0.0;
+    int nl = 0, no = 0;
+    {
+        const int nf = ev.farm_pow_n < p.power_avg ? ev.farm_pow_n : p.power_avg;
+        const int nb = ev.base_pow_n < p.power_avg ? ev.base_pow_n : p.power_avg;
+        const int wsz = p.power_avg / 10;
+        for (int i = lane; i < p.power_avg; i += WG_WAVE) {
+            const float fv = i == fslot ? fp : fq[i];
+            if (i < nf) fsum += (double)fv;
+            if (p.F == 2) {
+                const float bv = i == bslot ? bp : bq[i];
+                if (i < nb) bsum += (double)bv;
+            }
+            if (p.reward_mode == WG_REW_POWER_DIFF && i < nf) {
+                // logical index (0 = oldest) of physical slot i in the ring
+                int q = i - (ev.farm_pow_n - nf) % p.power_avg; if (q < 0) q += p.power_avg;
+                if (q >= p.power_avg - wsz && q < p.power_avg) { fl += (double)fv; nl++; }
+                if (q < wsz) { fo += (double)fv; no++; }
+            }
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            fsum += __shfl_xor(fsum, o, 64); bsum += __shfl_xor(bsum, o, 64);
+            fl += __shfl_xor(fl, o, 64); fo += __shfl_xor(fo, o, 64);
+            nl += __shfl_xor(nl, o, 64); no += __shfl_xor(no, o, 64);
+        }
+        fsum /= (double)nf; bsum /= (double)nb;
+    }
+    if (lane == 0) {
+        fq[fslot] = fp;
+        if (p.F == 2) bq[bslot] = bp;
         if (fp != fp) atomicMin(d.status, (int)WG_ERR_NAN_POWER);
     }
     // observation (:983)
     float* fin = final_obs_out ? final_obs_out + (size_t)e * p.obs_dim : nullptr;
-    build_obs(p, d, ctx_id, lane, obs, fin);
+    if (WG_GLUE_ABLATE == 2) return;
+    stage_rings(p, d, ctx_id, lane, my_lds, rbase, fbase);
+    if (WG_GLUE_ABLATE == 3) return;
+    build_obs(p, d, ctx_id, lane, obs, fin, rbase, fbase);
+    if (WG_GLUE_ABLATE == 4) return;
 
     // action penalty sums (:804-820) and current farm powers ("Power agent", :539)
     float pen_s = 0.f, pnow = 0.f, pbase = 0.f;
-    for (int t = lane; t < N; t += WG_WAVE) {
+    if (lane < N) {
+        pen_s = p.penalty_type == WG_PEN_CHANGE ? fabsf(l_old - l_yaw) : fabsf(l_yaw);
+        pnow = l_pow; pbase = l_powb;
+    }
+    for (int t = lane + WG_WAVE; t < N; t += WG_WAVE) {      // farms with more than 64 turbines
         const float y = d.yaw[tb_a + t];
         pen_s += p.penalty_type == WG_PEN_CHANGE ? fabsf(d.old_yaw[(size_t)e * N + t] - y) : fabsf(y);
         pnow += d.power[tb_a + t];
@@ -311,95 +403,99 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     }
     pen_s = wg_wave_sum(pen_s); pnow = wg_wave_sum(pnow); pbase = wg_wave_sum(pbase);
 
-    int truncated = 0;
+    double pr = 0.0;
+    switch (p.reward_mode) {
+    case WG_REW_BASELINE: pr = fsum / bsum - 1.0; break;                              // :882-891
+    case WG_REW_POWER_AVG: pr = fsum / N / (double)rated_power; break;                // :896-897
+    case WG_REW_NONE: pr = 0.0; break;
+    case WG_REW_POWER_DIFF: pr = (fl / (double)nl - fo / (double)no) / N; break;      // :904-918
+    }
+    double pen = 0.0;
+    if (p.action_penalty >= 0.001) {
+        pen = p.penalty_type == WG_PEN_CHANGE ? p.action_penalty * ((double)pen_s / N)
+                                              : p.action_penalty * ((double)pen_s / N / p.yaw_max_d);
+    }
+    const float reward = (float)(pr * p.power_scaling + 0.0 - pen);                   // :989-996
+    const int truncated = ev.timestep >= time_max;                                    // :1003
+    ev.timestep += 1 + (p.extra_inc ? 1 : 0);                                         // :1027
+    ev.steps_done += 1;
+    // episode metrics (recordEpisodeVals.py:31-64; longer_steps_example.py:39-124)
+    ev.ep_return += reward; ev.ep_power_sum += pnow; ev.ep_len += 1;
     if (lane == 0) {
-        double pr = 0.0;
-        const float* fq = d.farm_pow + (size_t)e * p.power_avg;
-        const float* bq = d.base_pow + (size_t)e * p.power_avg;
-        switch (p.reward_mode) {
-        case WG_REW_BASELINE:
-            pr = deque_mean(fq, env.farm_pow_n, p.power_avg) / deque_mean(bq, env.base_pow_n, p.power_avg) - 1.0;
-            break;
-        case WG_REW_POWER_AVG:
-            pr = deque_mean(fq, env.farm_pow_n, p.power_avg) / N / (double)cx.rated_power;
-            break;
-        case WG_REW_NONE: pr = 0.0; break;
-        case WG_REW_POWER_DIFF: {
-            const int wsz = p.power_avg / 10;
-            const int n = env.farm_pow_n < p.power_avg ? env.farm_pow_n : p.power_avg;
-            double sl = 0, so = 0; int nl = 0, no = 0;
-            for (int q = p.power_avg - wsz; q < p.power_avg && q < n; ++q) { sl += deque_at(fq, env.farm_pow_n, p.power_avg, q); nl++; }
-            for (int q = 0; q < wsz && q < n; ++q) { so += deque_at(fq, env.farm_pow_n, p.power_avg, q); no++; }
-            pr = (sl / (double)nl - so / (double)no) / N;
-            break;
-        }
-        }
-        double pen = 0.0;
-        if (p.action_penalty >= 0.001) {
-            pen = p.penalty_type == WG_PEN_CHANGE ? p.action_penalty * ((double)pen_s / N)
-                                                  : p.action_penalty * ((double)pen_s / N / p.yaw_max_d);
-        }
-        const float reward = (float)(pr * p.power_scaling + 0.0 - pen);             // :989-996
-        truncated = env.timestep >= cx.time_max;                                    // :1003
-        env.timestep += 1 + (p.extra_inc ? 1 : 0);                                  // :1027
-        env.steps_done += 1;
         if (reward_out) reward_out[e] = reward;
         if (trunc_out) trunc_out[e] = (uint8_t)truncated;
-        // episode metrics (recordEpisodeVals.py:31-64; longer_steps_example.py:39-124)
-        float* met = d.metrics + (size_t)e * WG_N_METRICS;
-        env.ep_return += reward; env.ep_power_sum += pnow; env.ep_len += 1;
-        met[WG_MET_STEP_REWARD_SUM] += reward;
-        met[WG_MET_FARM_POWER_SUM] += pnow;
-        met[WG_MET_BASE_POWER_SUM] += pbase;
-        met[WG_MET_N_STEPS] += 1.f;
-        if (truncated) {
-            met[WG_MET_EP_RETURN_SUM] += env.ep_return;
-            met[WG_MET_EP_LENGTH_SUM] += (float)env.ep_len;
-            met[WG_MET_EP_MEAN_POWER_SUM] += env.ep_power_sum / (float)env.ep_len;
-            met[WG_MET_N_EPISODES] += 1.f;
-            env.ep_return = 0.f; env.ep_power_sum = 0.f; env.ep_len = 0;
-            env.episode += 1;
-        }
     }
-    truncated = __shfl(truncated, 0, 64);
+    if (lane < WG_N_METRICS) {            // lane m owns metric m
+        float add = 0.f;
+        switch (lane) {
+        case WG_MET_STEP_REWARD_SUM: add = reward; break;
+        case WG_MET_FARM_POWER_SUM: add = pnow; break;
+        case WG_MET_BASE_POWER_SUM: add = pbase; break;
+        case WG_MET_N_STEPS: add = 1.f; break;
+        case WG_MET_EP_RETURN_SUM: add = truncated ? ev.ep_return : 0.f; break;
+        case WG_MET_EP_LENGTH_SUM: add = truncated ? (float)ev.ep_len : 0.f; break;
+        case WG_MET_EP_MEAN_POWER_SUM: add = truncated ? ev.ep_power_sum / (float)ev.ep_len : 0.f; break;
+        case WG_MET_N_EPISODES: add = truncated ? 1.f : 0.f; break;
+        }
+        met[lane] = l_met + add;
+    }
     if (truncated) {
+        ev.ep_return = 0.f; ev.ep_power_sum = 0.f; ev.ep_len = 0;
+        ev.episode += 1;
         if (!p.autoreset) {
-            if (lane == 0) env.done = 1;
+            ev.done = 1;
+            if (lane == 0) env = ev;
             return;
         }
         // same-step autoreset: the next episode was developed in the background; make it live
         const int nxt = live ^ 1;
         const int nctx = e * 2 + nxt;
         WgCtx& ncx = d.ctx[nctx];
+        const int pfn = ncx.pend_farm_n, pbn = ncx.pend_base_n;
+        const int nf = pfn < p.power_avg ? pfn : p.power_avg;
+        const int nb = pbn < p.power_avg ? pbn : p.power_avg;
         if (lane == 0) {
             bool ok = true;
             for (int f = 0; f < p.F; ++f) {
-                const WgSlot& s = d.slot[nctx * p.F + f];
-                ok = ok && s.dev_remaining == 0 && s.fill_remaining == 0;
+                const WgSlot& sl = d.slot[nctx * p.F + f];
+                ok = ok && sl.dev_remaining == 0 && sl.fill_remaining == 0;
             }
             if (!ok) atomicMin(d.status, (int)WG_ERR_STATE);
-            const int nf = ncx.pend_farm_n < p.power_avg ? ncx.pend_farm_n : p.power_avg;
-            for (int q = 0; q < nf; ++q) {
-                float v = deque_at(d.pend_farm + (size_t)nctx * p.power_avg, ncx.pend_farm_n, p.power_avg, q);
-                d.farm_pow[(size_t)e * p.power_avg + env.farm_pow_n % p.power_avg] = v;
-                env.farm_pow_n++;
-            }
-            const int nb = ncx.pend_base_n < p.power_avg ? ncx.pend_base_n : p.power_avg;
-            for (int q = 0; q < nb; ++q) {
-                float v = deque_at(d.pend_base + (size_t)nctx * p.power_avg, ncx.pend_base_n, p.power_avg, q);
-                d.base_pow[(size_t)e * p.power_avg + env.base_pow_n % p.power_avg] = v;
-                env.base_pow_n++;
-            }
+            for (int q = 0; q < nf; ++q)
+                fq[(ev.farm_pow_n + q) % p.power_avg] = deque_at(d.pend_farm + (size_t)nctx * p.power_avg, pfn, p.power_avg, q);
+            for (int q = 0; q < nb; ++q)
+                bq[(ev.base_pow_n + q) % p.power_avg] = deque_at(d.pend_base + (size_t)nctx * p.power_avg, pbn, p.power_avg, q);
             ncx.pend_farm_n = 0; ncx.pend_base_n = 0;
-            env.live = nxt; env.timestep = 0; env.steps_done = 0;
         }
+        ev.farm_pow_n += nf; ev.base_pow_n += nb;
+        ev.live = nxt; ev.timestep = 0; ev.steps_done = 0;
         __threadfence_block();
-        if (obs) build_obs(p, d, nctx, lane, obs, nullptr);
-        // the retired context starts developing the episode after the next one
-        ctx_init(p, d, e, live, lane, env.episode + 1);
+        if (obs) {
+            stage_rings(p, d, nctx, lane, my_lds, rbase, fbase);
+            build_obs(p, d, nctx, lane, obs, nullptr, rbase, fbase);
+        }
+        // the retired context starts developing the episode after the next one (lane 0 draws from ev's PCG64)
+        ctx_init(p, d, ev, e, live, lane, ev.episode + 1);
         __threadfence_block();
     }
-    if (lane == 0) env.shadow_iters = p.autoreset ? plan_shadow(p, d, e) : 0;
+    if (!p.autoreset) {
+        ev.shadow_iters = 0;
+    } else if (truncated) {
+        ev.shadow_iters = plan_shadow(p, d, ev, e);               // contexts were swapped / re-initialised
+    } else {
+        int work = l_work;                                        // max over the farms of the background ctx
+        for (int o = 1; o < 4; o <<= 1) work = max(work, __shfl_xor(work, o, 64));
+        work = __shfl(work, 0, 64);
+        if (work == 0) ev.shadow_iters = 0;
+        else {
+            const int inc = 1 + (p.extra_inc ? 1 : 0);
+            const long total = (long)((time_max + inc - 1) / inc) + 1;
+            long left = total - ev.steps_done;
+            if (left < 1) left = 1;
+            ev.shadow_iters = (int)((work + left - 1) / left);
+        }
+    }
+    if (lane == 0) env = ev;
 }
 
 // ===================================================================================================
@@ -421,8 +517,8 @@ k_init(const WgParams p, const WgPtrs d, const uint8_t* __restrict__ mask, const
     }
     __threadfence_block();
     const int live = env.live;
-    ctx_init(p, d, e, live, lane, env.episode);
-    if (p.autoreset) ctx_init(p, d, e, live ^ 1, lane, env.episode + 1);
+    ctx_init(p, d, env, e, live, lane, env.episode);
+    if (p.autoreset) ctx_init(p, d, env, e, live ^ 1, lane, env.episode + 1);
 }
 
 // fresh-handle initialisation: generator state of np.random.default_rng(b)
@@ -542,7 +638,11 @@ __global__ void __launch_bounds__(WG_BLOCK) k_metrics(const WgParams p, const Wg
 extern "C" void wg_launch_glue(const WgParams* p, const WgPtrs* d, int phase, const uint8_t* mask, float* obs,
                                float* reward, uint8_t* trunc, float* final_obs, hipStream_t st) {
     const int grid = (p->B + WG_NWAVES - 1) / WG_NWAVES;
-    hipLaunchKernelGGL(k_glue, dim3(grid), dim3(WG_BLOCK), 0, st, *p, *d, phase, mask, obs, reward, trunc, final_obs);
+    // rings of one env staged in LDS when they fit (<= 16 KiB per wave); otherwise read from global memory
+    int per_wave = p->ring_stride + p->fring_stride;
+    if (per_wave * 4 > 16384) per_wave = 0;
+    hipLaunchKernelGGL(k_glue, dim3(grid), dim3(WG_BLOCK), (size_t)per_wave * 4 * WG_NWAVES, st, *p, *d, phase, mask,
+                       obs, reward, trunc, final_obs, per_wave);
 }
 extern "C" void wg_launch_init(const WgParams* p, const WgPtrs* d, const uint8_t* mask, const uint64_t* seeds,
                                hipStream_t st) {
