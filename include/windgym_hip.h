@@ -184,8 +184,9 @@ int wg_destroy(wg_handle h);
 int wg_obs_dim(wg_handle h, int* obs_dim, int* obs_dim_multi);
 int wg_hist_max(wg_handle h, int* hist_max);
 
-/* Optional shared frozen-turbulence box (borrowed device memory; caller keeps it alive).
- * comps: 3 (u,v,w) planes of nx*ny*nz fp32, unit variance; spacing in metres.  Used when turb_mode==BOX. */
+/* Shared frozen-turbulence box for turb_mode BOX / BOX_SHIFT: 3 (u,v,w) planes of nx*ny*nz fp32 (z fastest),
+ * unit variance of u; spacing in metres.  The library makes its own interleaved copy (the caller's buffer may be
+ * released afterwards).  Must be called before wg_reset in the box modes.                               */
 int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, int ny, int nz,
                           double dx, double dy, double dz);
 

@@ -21,6 +21,7 @@ void wg_launch_create(const WgParams*, const WgPtrs*, hipStream_t);
 void wg_launch_obs_multi(const WgParams*, const WgPtrs*, float*, hipStream_t);
 void wg_launch_info(const WgParams*, const WgPtrs*, int, void*, hipStream_t);
 void wg_launch_metrics(const WgParams*, const WgPtrs*, float*, int, hipStream_t);
+void wg_launch_box_repack(const float*, void*, size_t, hipStream_t);
 }
 
 static thread_local std::string g_err;
@@ -46,6 +47,7 @@ struct wg_env_s {
     FlowP fp;
     FlowPtrs fd;
     unsigned long long flow_steps_mark = 0;
+    void* box4 = nullptr;            // interleaved copy of the caller's turbulence box (owned)
     int device;
     std::vector<Alloc> allocs;      // everything owned by the handle (state blob = allocs flagged `state`)
     std::vector<size_t> state_idx;  // indices into allocs that make up the serialisable state
@@ -323,6 +325,7 @@ extern "C" int wg_destroy(wg_handle h) {
     hipDeviceSynchronize();
     for (auto& e : h->ev) hipEventDestroy(e);
     for (auto& a : h->allocs) hipFree(a.ptr);
+    if (h->box4) hipFree(h->box4);
     delete h;
     return 0;
 }
@@ -344,10 +347,18 @@ extern "C" int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, 
     if (!h) return fail(WG_ERR_INVALID, "null handle");
     if (!box_dev || nx < 2 || ny < 2 || nz < 2 || !(dx > 0) || !(dy > 0) || !(dz > 0))
         return fail(WG_ERR_INVALID, "turbulence box: null pointer or bad dimensions");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    if (h->box4) { HIPCHK(hipFree(h->box4)); h->box4 = nullptr; }
+    const size_t n_cells = (size_t)nx * ny * nz;
+    HIPCHK(hipMalloc(&h->box4, n_cells * 16));
+    wg_launch_box_repack(box_dev, h->box4, n_cells, nullptr);
+    HIPCHK(hipDeviceSynchronize());
     h->d.box = box_dev;
     h->p.bnx = nx; h->p.bny = ny; h->p.bnz = nz; h->p.bdx = dx; h->p.bdy = dy; h->p.bdz = dz;
-    h->fd.box = box_dev;
+    h->fd.box4 = (const float4*)h->box4;
     h->fp.bnx = nx; h->fp.bny = ny; h->fp.bnz = nz;
+    h->fp.box_pow2 = ((nx & (nx - 1)) == 0) && ((ny & (ny - 1)) == 0) && ((nz & (nz - 1)) == 0);
     h->fp.inv_bdx = 1.0 / dx; h->fp.inv_bdy = 1.0 / dy; h->fp.inv_bdz = 1.0 / dz;
     return 0;
 }

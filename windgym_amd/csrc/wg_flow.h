@@ -21,14 +21,14 @@ struct FlowP {
     int ring_stride, fring_stride;
     float noise_sigma[WG_N_CH];
     // turbulent inflow (Random / frozen Mann box)
-    int turb_mode, bnx, bny, bnz;
+    int turb_mode, bnx, bny, bnz, box_pow2;
     double inv_bdx, inv_bdy, inv_bdz, fc_scale, D_d, hub_d;
     float inv_sqrt_S;
 };
 
 struct FlowPtrs {
     float *py, *ct_e, *k_e, *eps_e, *hv_e, *u_e, *pz, *vlp, *wlp;
-    const float* box;
+    const float4* box4;          // interleaved copy of the turbulence box: [Nx][Ny][Nz] x (u, v, w, 0)
     float *yaw, *u, *v, *w, *ti_loc, *power, *ct;
     WgSlot* slot;
     WgCtx* ctx;

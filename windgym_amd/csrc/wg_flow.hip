@@ -66,34 +66,43 @@ struct TurbCtx {
     double ws;
 };
 
-// trilinear, periodic lookup of NC consecutive components (from c0) of the frozen box at (x, y, z) metres.
-// Cell coordinates in double precision (x - U t reaches 1e5 m), weights in fp32 — as the oracle does.
-template <int NC>
-__device__ __forceinline__ void box_lookup(const float* __restrict__ box, const FlowP& p, int c0, double x, double y,
+// trilinear, periodic lookup of the frozen box at (x, y, z) metres.  The box is stored interleaved
+// ([Nx][Ny][Nz] cells of float4 = (u, v, w, 0), repacked once in wg_set_turbulence_box): the two z-neighbours
+// of a corner are 32 contiguous bytes and one 16-byte load brings all components, instead of 8 scattered 4-byte
+// loads per component.  Cell coordinates in double precision (x - U t reaches 1e5 m), weights in fp32 — as the
+// oracle does.  out[0..2] = (u, v, w).
+__device__ __forceinline__ void box_lookup(const float4* __restrict__ box, const FlowP& p, double x, double y,
                                            double z, float* __restrict__ out) {
     const double fx = x * p.inv_bdx, fy = y * p.inv_bdy, fz = z * p.inv_bdz;
     const double ix = floor(fx), iy = floor(fy), iz = floor(fz);
     const float tx = (float)(fx - ix), ty = (float)(fy - iy), tz = (float)(fz - iz);
-    long long i0 = (long long)ix % p.bnx; if (i0 < 0) i0 += p.bnx;
-    long long j0 = (long long)iy % p.bny; if (j0 < 0) j0 += p.bny;
-    long long k0 = (long long)iz % p.bnz; if (k0 < 0) k0 += p.bnz;
-    const int i1 = (int)((i0 + 1) % p.bnx), j1 = (int)((j0 + 1) % p.bny), k1 = (int)((k0 + 1) % p.bnz);
-    const size_t plane = (size_t)p.bnx * p.bny * p.bnz;
+    // |cell index| < 2^31 for any realistic episode (x - U t < 1e6 m); power-of-two boxes wrap with a mask
+    int i0, j0, k0, i1, j1, k1;
+    if (p.box_pow2) {
+        i0 = (int)ix & (p.bnx - 1); j0 = (int)iy & (p.bny - 1); k0 = (int)iz & (p.bnz - 1);
+        i1 = (i0 + 1) & (p.bnx - 1); j1 = (j0 + 1) & (p.bny - 1); k1 = (k0 + 1) & (p.bnz - 1);
+    } else {
+        i0 = (int)ix % p.bnx; if (i0 < 0) i0 += p.bnx;
+        j0 = (int)iy % p.bny; if (j0 < 0) j0 += p.bny;
+        k0 = (int)iz % p.bnz; if (k0 < 0) k0 += p.bnz;
+        i1 = i0 + 1 == p.bnx ? 0 : i0 + 1; j1 = j0 + 1 == p.bny ? 0 : j0 + 1; k1 = k0 + 1 == p.bnz ? 0 : k0 + 1;
+    }
     const size_t a00 = ((size_t)i0 * p.bny + j0) * p.bnz, a10 = ((size_t)i0 * p.bny + j1) * p.bnz;
     const size_t b00 = ((size_t)i1 * p.bny + j0) * p.bnz, b10 = ((size_t)i1 * p.bny + j1) * p.bnz;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const float* __restrict__ q = box + (size_t)(c0 + c) * plane;
-        const float v000 = q[a00 + k0], v100 = q[b00 + k0], v010 = q[a10 + k0], v110 = q[b10 + k0];
-        const float v001 = q[a00 + k1], v101 = q[b00 + k1], v011 = q[a10 + k1], v111 = q[b10 + k1];
-        const float c00 = v000 + tx * (v100 - v000);
-        const float c10 = v010 + tx * (v110 - v010);
-        const float c01 = v001 + tx * (v101 - v001);
-        const float c11 = v011 + tx * (v111 - v011);
-        const float d0 = c00 + ty * (c10 - c00);
-        const float d1 = c01 + ty * (c11 - c01);
-        out[c] = d0 + tz * (d1 - d0);
-    }
+    const float4 v000 = box[a00 + k0], v100 = box[b00 + k0], v010 = box[a10 + k0], v110 = box[b10 + k0];
+    const float4 v001 = box[a00 + k1], v101 = box[b00 + k1], v011 = box[a10 + k1], v111 = box[b10 + k1];
+#define WG_TRI(f)                                                         \
+    ([&]() {                                                              \
+        const float c00 = v000.f + tx * (v100.f - v000.f);                \
+        const float c10 = v010.f + tx * (v110.f - v010.f);                \
+        const float c01 = v001.f + tx * (v101.f - v001.f);                \
+        const float c11 = v011.f + tx * (v111.f - v011.f);                \
+        const float d0 = c00 + ty * (c10 - c00);                          \
+        const float d1 = c01 + ty * (c11 - c01);                          \
+        return d0 + tz * (d1 - d0);                                       \
+    }())
+    out[0] = WG_TRI(x); out[1] = WG_TRI(y); out[2] = WG_TRI(z);
+#undef WG_TRI
 }
 
 // barrier that orders LDS traffic only: does NOT wait for outstanding global stores (a plain
@@ -197,15 +206,15 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 if (j < n_valid) {
                     const float xrel = s_off_f + (float)j * p.dpart_f;
                     const float sp = kv[i] * (xrel * p.inv_D) + epv[i];
-                    float fvw[2];
+                    float f3[3];
                     if (TURB == WG_TURB_RANDOM) {
-                        fvw[0] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)(i4 + i), 1u, 0x50u);
-                        fvw[1] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)(i4 + i), 2u, 0x50u);
+                        f3[1] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)(i4 + i), 1u, 0x50u);
+                        f3[2] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)(i4 + i), 2u, 0x50u);
                     } else {
-                        box_lookup<2>(d.box, p, 1, tq.xr + (double)xrel + xshift, (double)pyv[i] + tc.oy, (double)pzv[i], fvw);
+                        box_lookup(d.box4, p, tq.xr + (double)xrel + xshift, (double)pyv[i] + tc.oy, (double)pzv[i], f3);
                     }
-                    vlv[i] += tc.alpha * (tc.sig * fvw[0] - vlv[i]);
-                    wlv[i] += tc.alpha * (tc.sig * fvw[1] - wlv[i]);
+                    vlv[i] += tc.alpha * (tc.sig * f3[1] - vlv[i]);
+                    wlv[i] += tc.alpha * (tc.sig * f3[2] - wlv[i]);
                     pyv[i] += (hvv[i] * m0_cfrac(ctv[i], sp) + vlv[i]) * p.dt;
                     pzv[i] += wlv[i] * p.dt;
                 }
@@ -400,8 +409,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 }
                 if (TURB == WG_TURB_BOX) {
                     // ambient fluctuation at this rotor point (8 corners x 3 components of the frozen box)
-                    box_lookup<3>(d.box, p, 0, T[t].xr - tc.ws * sr.time + tc.ox,
-                                  T[t].yr + (double)(rdy[s] * T[t].cg) + tc.oy, p.hub_d + (double)rdz[s], amb);
+                    box_lookup(d.box4, p, T[t].xr - tc.ws * sr.time + tc.ox,
+                               T[t].yr + (double)(rdy[s] * T[t].cg) + tc.oy, p.hub_d + (double)rdz[s], amb);
                 }
             }
             for (int o = p.S_pad >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);

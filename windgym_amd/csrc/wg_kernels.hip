@@ -634,6 +634,15 @@ __global__ void __launch_bounds__(WG_BLOCK) k_metrics(const WgParams p, const Wg
         for (int i = threadIdx.x; i < p.B * WG_N_METRICS; i += WG_BLOCK) d.metrics[i] = 0.f;
 }
 
+// planar [3][Nx][Ny][Nz] -> interleaved [Nx][Ny][Nz] x float4 (u, v, w, 0)
+__global__ void k_box_repack(const float* __restrict__ planar, float4* __restrict__ out, const size_t n_cells) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_cells) out[i] = make_float4(planar[i], planar[n_cells + i], planar[2 * n_cells + i], 0.f);
+}
+extern "C" void wg_launch_box_repack(const float* planar, void* out, size_t n_cells, hipStream_t st) {
+    hipLaunchKernelGGL(k_box_repack, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, st, planar, (float4*)out, n_cells);
+}
+
 // host-visible launch helpers (defined here so that the <<<>>> syntax stays in one translation unit)
 extern "C" void wg_launch_glue(const WgParams* p, const WgPtrs* d, int phase, const uint8_t* mask, float* obs,
                                float* reward, uint8_t* trunc, float* final_obs, hipStream_t st) {
