@@ -217,6 +217,10 @@ int wg_check(wg_handle h, void* stream);
 /* Per-agent observations of the PettingZoo facade for the current state: f32[B,N,obs_dim_multi].      */
 int wg_obs_multi(wg_handle h, float* obs_dev, void* stream);
 
+/* Unscaled, unclipped sensor values of the running episodes in the layout of the observation: f32[B,O]
+ * (farm_measurements.get_*_turb() / get_*_farm(), the "... measured" entries of _get_info :529-537).   */
+int wg_get_measurements(wg_handle h, float* out_dev, void* stream);
+
 /* Lazy info dict: copy one field to out_dev (dtype/shape per wg_info_field).                           */
 int wg_get_info(wg_handle h, wg_info_field field, void* out_dev, void* stream);
 

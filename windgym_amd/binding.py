@@ -21,7 +21,7 @@ UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 ABI_SYMBOLS = (
     "wg_last_error", "wg_abi_version", "wg_create", "wg_destroy", "wg_obs_dim", "wg_hist_max",
     "wg_set_turbulence_box", "wg_set_flow_script", "wg_reset", "wg_step", "wg_check", "wg_obs_multi",
-    "wg_get_info", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_algorithmic_bytes",
+    "wg_get_info", "wg_get_measurements", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_algorithmic_bytes",
 )
 
 _lib = None
@@ -54,6 +54,7 @@ def load_library():
     L.wg_check.argtypes = [C.c_void_p, C.c_void_p]
     L.wg_obs_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.wg_get_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.wg_get_measurements.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.wg_metrics.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.wg_get_state.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
     L.wg_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -147,6 +148,12 @@ class HipBatch:
     def obs_multi(self):
         out = self.torch.zeros((self.B, self.N, self.obs_dim_multi), dtype=self.torch.float32, device=self.device)
         _chk(self.L.wg_obs_multi(self._h, C.c_void_p(out.data_ptr()), self._stream()), "wg_obs_multi")
+        return out
+
+    def measurements(self):
+        """Unscaled sensor values in the layout of the observation, f32[B, O]."""
+        out = self.torch.zeros((self.B, self.obs_dim), dtype=self.torch.float32, device=self.device)
+        _chk(self.L.wg_get_measurements(self._h, C.c_void_p(out.data_ptr()), self._stream()), "wg_get_measurements")
         return out
 
     def info(self, name):

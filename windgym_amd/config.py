@@ -259,6 +259,21 @@ class EnvConfig:
     def _observed_variables(self):
         return self.turb_observed_variables() * self.n_turb + self.farm_observed_variables()
 
+    def obs_layout(self):
+        """Slices of the observation vector: {"turb": {channel: (offset in the turbine block, count)},
+        "turb_block": length, "farm": {channel: (absolute offset, count)}} (MesClass.py:328-351, 679-703)."""
+        m = self.mes_level
+        off, turb = 0, {}
+        for ch, name, on in ((0, "ws", m["turb_ws"]), (1, "wd", m["turb_wd"]), (2, "yaw", True)):
+            n = int(self._count(ch, on)); turb[name] = (off, n); off += n
+        n = int(bool(m["turb_TI"])); turb["TI"] = (off, n); off += n
+        n = int(self._count(3, m["turb_power"])); turb["power"] = (off, n); off += n
+        base, farm = off * self.n_turb, {}
+        for name, n in (("ws", self._count(0, m["farm_ws"])), ("wd", self._count(1, m["farm_wd"])),
+                        ("TI", bool(m["farm_TI"])), ("power", self._count(3, m["farm_power"]))):
+            farm[name] = (base, int(n)); base += int(n)
+        return dict(turb=turb, turb_block=off, farm=farm)
+
     def multi_declared_obs_var(self):
         """WindFarmEnvMulti.obs_var as *declared* (WindEnvMulti.py:65-69): counts farm yaw entries that
         are never produced."""

@@ -22,6 +22,7 @@ void wg_launch_obs_multi(const WgParams*, const WgPtrs*, float*, hipStream_t);
 void wg_launch_info(const WgParams*, const WgPtrs*, int, void*, hipStream_t);
 void wg_launch_metrics(const WgParams*, const WgPtrs*, float*, int, hipStream_t);
 void wg_launch_box_repack(const float*, void*, size_t, hipStream_t);
+void wg_launch_measurements(const WgParams*, const WgPtrs*, float*, hipStream_t);
 }
 
 static thread_local std::string g_err;
@@ -450,6 +451,12 @@ extern "C" int wg_check(wg_handle h, void* stream) {
 extern "C" int wg_obs_multi(wg_handle h, float* obs_dev, void* stream) {
     if (!h || !obs_dev) return fail(WG_ERR_INVALID, "null argument");
     wg_launch_obs_multi(&h->p, &h->d, obs_dev, (hipStream_t)stream);
+    return 0;
+}
+
+extern "C" int wg_get_measurements(wg_handle h, float* out_dev, void* stream) {
+    if (!h || !out_dev) return fail(WG_ERR_INVALID, "null argument");
+    wg_launch_measurements(&h->p, &h->d, out_dev, (hipStream_t)stream);
     return 0;
 }
 

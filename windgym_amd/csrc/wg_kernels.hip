@@ -98,8 +98,12 @@ __device__ inline void ctx_init(const WgParams& p, const WgPtrs& d, WgEnv& env, 
 // ===================================================================================================
 // observation (farm_mes.get_measurements(scaled=True) + clip, MesClass.py:679-703, Wind_Farm_Env.py:513-520)
 // ===================================================================================================
+// `raw`: unscaled, unclipped sensor values in the same layout (the "... measured" entries of the info dict,
+// farm_measurements.get_*_turb() / get_*_farm(), Wind_Farm_Env.py:529-537)
+#define WG_OBSV(v, mn, rng) (raw ? (v) : wg_clip1(wg_scale((v), (mn), (rng))))
 __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id, int lane, float* __restrict__ obs,
-                                 float* __restrict__ obs2, const float* rbase, const float* fbase) {
+                                 float* __restrict__ obs2, const float* rbase, const float* fbase,
+                                 const bool raw = false) {
     const int N = p.N;
     const int n_pushed = d.ctx[ctx_id].n_pushed;
     float ti_sum = 0.f;
@@ -113,7 +117,7 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
             if (ch == WG_CH_POWER && p.turb_ti) {
                 WgRing r(rbase + p.ring_off[WG_CH_WS] + (size_t)t * p.ch[WG_CH_WS].history_len, n_pushed,
                          p.ch[WG_CH_WS].history_len);
-                float v = wg_clip1(wg_scale(wg_calc_ti(r), p.ti_min_f, p.ti_rng_f));
+                float v = WG_OBSV(wg_calc_ti(r), p.ti_min_f, p.ti_rng_f);
                 o[n] = v; if (obs2) obs2[(size_t)t * p.turb_obs + n] = v;
                 ++n;
             }
@@ -124,7 +128,7 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
             const int avail = r.avail();
             if (avail == 0) continue;
             if (cur_on) {
-                float v = wg_clip1(wg_scale(r.at(avail - 1), p.sc_min[ch], p.sc_rng[ch]));
+                float v = WG_OBSV(r.at(avail - 1), p.sc_min[ch], p.sc_rng[ch]);
                 o[n] = v; if (obs2) obs2[(size_t)t * p.turb_obs + n] = v;
                 ++n;
             }
@@ -142,7 +146,7 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
                     }
                     float s = 0.f;
                     for (int q = lo; q < hi; ++q) s += r.at(q);
-                    float v = wg_clip1(wg_scale(s / (float)(hi - lo), p.sc_min[ch], p.sc_rng[ch]));
+                    float v = WG_OBSV(s / (float)(hi - lo), p.sc_min[ch], p.sc_rng[ch]);
                     o[n] = v; if (obs2) obs2[(size_t)t * p.turb_obs + n] = v;
                     ++n;
                 }
@@ -151,7 +155,7 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
         if (p.farm_ti) {   // farm TI = mean of the *scaled* turbine TIs (MesClass.py:670-673)
             WgRing r(rbase + p.ring_off[WG_CH_WS] + (size_t)t * p.ch[WG_CH_WS].history_len, n_pushed,
                      p.ch[WG_CH_WS].history_len);
-            ti_sum += wg_scale(wg_calc_ti(r), p.ti_min_f, p.ti_rng_f);
+            ti_sum += raw ? wg_calc_ti(r) : wg_scale(wg_calc_ti(r), p.ti_min_f, p.ti_rng_f);
         }
     }
     if (p.farm_ti) ti_sum = wg_wave_sum(ti_sum);
@@ -163,7 +167,7 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
         for (int ci = 0; ci < 3; ++ci) {
             const int ch = chs[ci];
             if (ch == WG_CH_POWER && p.farm_ti) {
-                float v = wg_clip1(ti_sum / (float)N);
+                float v = raw ? ti_sum / (float)N : wg_clip1(ti_sum / (float)N);
                 o[n] = v; if (o2) o2[n] = v;
                 ++n;
             }
@@ -172,13 +176,13 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
             const float rng = ch == WG_CH_POWER ? p.sc_rng_farm_power : p.sc_rng[ch];
             // farm windows are few: reuse the generic helper through a small buffer when it fits
             const int cnt = (p.ch[ch].current ? 1 : 0) + (p.ch[ch].rolling_mean ? p.ch[ch].history_n : 0);
-            if (cnt <= 8) {
+            if (cnt <= 8 && !raw) {
                 int m = wg_mes_get(p.ch[ch], p.ch[ch].current, p.ch[ch].rolling_mean, r, p.sc_min[ch], rng, buf);
                 for (int i = 0; i < m; ++i) { float v = wg_clip1(buf[i]); o[n] = v; if (o2) o2[n] = v; ++n; }
             } else {
                 const int avail = r.avail();
                 if (avail == 0) continue;
-                if (p.ch[ch].current) { float v = wg_clip1(wg_scale(r.at(avail - 1), p.sc_min[ch], rng)); o[n] = v; if (o2) o2[n] = v; ++n; }
+                if (p.ch[ch].current) { float v = WG_OBSV(r.at(avail - 1), p.sc_min[ch], rng); o[n] = v; if (o2) o2[n] = v; ++n; }
                 if (p.ch[ch].rolling_mean) {
                     const int W = p.ch[ch].window_len, HN = p.ch[ch].history_n;
                     for (int i = 0; i < HN; ++i) {
@@ -193,7 +197,7 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
                         }
                         float s = 0.f;
                         for (int q = lo; q < hi; ++q) s += r.at(q);
-                        float v = wg_clip1(wg_scale(s / (float)(hi - lo), p.sc_min[ch], rng));
+                        float v = WG_OBSV(s / (float)(hi - lo), p.sc_min[ch], rng);
                         o[n] = v; if (o2) o2[n] = v; ++n;
                     }
                 }
@@ -632,6 +636,19 @@ __global__ void __launch_bounds__(WG_BLOCK) k_metrics(const WgParams p, const Wg
     }
     if (reset_after)
         for (int i = threadIdx.x; i < p.B * WG_N_METRICS; i += WG_BLOCK) d.metrics[i] = 0.f;
+}
+
+// unscaled sensor values of the running episode, same layout as the observation: f32[B, obs_dim]
+__global__ void __launch_bounds__(WG_BLOCK) k_measurements(const WgParams p, const WgPtrs d, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * WG_NWAVES + (threadIdx.x >> 6);
+    if (e >= p.B) return;
+    const int ctx_id = e * 2 + d.env[e].live;
+    build_obs(p, d, ctx_id, lane, out + (size_t)e * p.obs_dim, nullptr, d.ring + (size_t)ctx_id * p.ring_stride,
+              d.fring + (size_t)ctx_id * p.fring_stride, true);
+}
+extern "C" void wg_launch_measurements(const WgParams* p, const WgPtrs* d, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_measurements, dim3((p->B + WG_NWAVES - 1) / WG_NWAVES), dim3(WG_BLOCK), 0, st, *p, *d, out);
 }
 
 // planar [3][Nx][Ny][Nz] -> interleaved [Nx][Ny][Nz] x float4 (u, v, w, 0)

@@ -383,25 +383,24 @@ class WindFarmEnv(_EnvBase):
         """Keys and shapes of WindFarmEnv._get_info (Wind_Farm_Env.py:522-555)."""
         b = self._batch
         g = lambda k: _np(b.info(k))[0].astype(np.float64)   # noqa: E731
-        obs_u = None
+        self._raw_cache = None
         d = {
             "yaw angles agent": g("yaw_agent"),
             "yaw angles measured": self._measured("yaw"),
             "Wind speed Global": float(g("ws_global")),
             "Wind speed at turbines": g("ws_turb"),
             "Wind speed at turbines measured": self._measured("ws"),
-            "Wind speed at farm measured": np.array([], dtype=np.float32),
+            "Wind speed at farm measured": self._measured("ws", farm=True),
             "Wind direction Global": float(g("wd_global")),
             "Wind direction at turbines": g("wd_turb"),
             "Wind direction at turbines measured": self._measured("wd"),
-            "Wind direction at farm measured": np.array([], dtype=np.float32),
+            "Wind direction at farm measured": self._measured("wd", farm=True),
             "Turbulence intensity": float(g("ti_global")),
             "Power agent": float(g("power_agent")),
             "Power pr turbine agent": g("power_turb_agent"),
             "Turbine x positions": g("turb_x"),
             "Turbine y positions": g("turb_y"),
         }
-        del obs_u
         if self.Baseline_comp:
             d["yaw angles base"] = g("yaw_base")
             d["Power baseline"] = float(g("power_base"))
@@ -409,11 +408,19 @@ class WindFarmEnv(_EnvBase):
             d["Wind speed at turbines baseline"] = g("ws_turb_base")
         return d
 
-    def _measured(self, which):
-        """Unscaled sensor values are not materialised by the kernels; the scaled ones are the observation.
-        The reference returns `farm_measurements.get_*_turb()` here (:529-537); callers in the reference tree
-        only read the keys, so an empty array keeps the key set identical without a second sensor pass."""
-        return np.array([], dtype=np.float32)
+    def _measured(self, which, farm=False):
+        """farm_measurements.get_{ws,wd,yaw}_turb() / get_{ws,wd}_farm() (Wind_Farm_Env.py:529-537): the unscaled
+        sensor windows, sliced out of wg_get_measurements' vector."""
+        raw = getattr(self, "_raw_cache", None)
+        if raw is None:
+            raw = self._raw_cache = _np(self._batch.measurements())[0]
+        lay = self.cfg.obs_layout()
+        if farm:
+            o, n = lay["farm"][which]
+            return raw[o:o + n].copy()
+        o, n = lay["turb"][which]
+        blk = lay["turb_block"]
+        return np.concatenate([raw[t * blk + o: t * blk + o + n] for t in range(self.n_turb)]) if n else np.array([], dtype=np.float32)
 
     # -- helpers callers use -----------------------------------------------------------------------------
     def _get_num_raw_features(self):
