@@ -182,8 +182,8 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     const size_t n_slots = (size_t)p.B * 2 * p.F, n_ctx = (size_t)p.B * 2;
     int rc = 0;
 #define A(field, n, st) if (!rc) rc = dev_alloc(h, &d.field, (n), (st))
-    A(py, n_slots * p.NP, true); A(ct_e, n_slots * p.NP, true); A(k_e, n_slots * p.NP, true);
-    A(eps_e, n_slots * p.NP, true); A(hv_e, n_slots * p.NP, true); A(u_e, n_slots * p.NP, true);
+    A(py, n_slots * p.NP, true); A(rec_a, n_slots * p.NP, true); A(rec_b, n_slots * p.NP, true);
+    A(u_e, n_slots * p.NP, true);
     if (p.turb_mode != WG_TURB_NONE) {
         A(pz, n_slots * p.NP, true); A(vlp, n_slots * p.NP, true); A(wlp, n_slots * p.NP, true);
     }
@@ -280,7 +280,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         f.inv_sqrt_S = 1.0f / std::sqrt((float)p.S);
         FlowPtrs& g = h->fd;
         memset(&g, 0, sizeof(g));
-        g.py = d.py; g.ct_e = d.ct_e; g.k_e = d.k_e; g.eps_e = d.eps_e; g.hv_e = d.hv_e; g.u_e = d.u_e;
+        g.py = d.py; g.rec_a = d.rec_a; g.rec_b = d.rec_b; g.u_e = d.u_e;
         g.pz = d.pz; g.vlp = d.vlp; g.wlp = d.wlp;
         g.yaw = d.yaw; g.u = d.u; g.v = d.v; g.w = d.w; g.ti_loc = d.ti_loc; g.power = d.power; g.ct = d.ct;
         g.slot = d.slot; g.ctx = d.ctx; g.env = d.env; g.xr = d.xr; g.yr = d.yr;
@@ -310,7 +310,8 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     // inflow None: py r/w + 4 record floats; turbulent: + pz, vlp, wlp r/w (24) and, for the box, 8 corners x
     // 2 components gathered per particle (64) and 8 x 3 per rotor point (96)
     const bool turb = p.turb_mode != WG_TURB_NONE, boxm = p.turb_mode >= WG_TURB_BOX;
-    const double per_farm_step = (double)p.NP * (4 + 4 + 16 + (turb ? 24 : 0) + (boxm ? 64 : 0)) +
+    // record: 2 x 32-bit packed words per particle (8 B)
+    const double per_farm_step = (double)p.NP * (4 + 4 + 8 + (turb ? 24 : 0) + (boxm ? 64 : 0)) +
                                  (double)p.N * (7 * 4 * 2 + 16) + (boxm ? (double)p.N * p.S * 96 : 0.0);
     h->alg_bytes = (double)p.B * ((double)p.K * p.F * per_farm_step + 20.0 * p.N + 12.0 * p.obs_dim + 20.0);
 

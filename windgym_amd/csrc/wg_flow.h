@@ -27,7 +27,8 @@ struct FlowP {
 };
 
 struct FlowPtrs {
-    float *py, *ct_e, *k_e, *eps_e, *hv_e, *u_e, *pz, *vlp, *wlp;
+    float *py, *u_e, *pz, *vlp, *wlp;
+    unsigned *rec_a, *rec_b;      // packed emission record (see wg_flow.hip)
     const float4* box4;          // interleaved copy of the turbulence box: [Nx][Ny][Nz] x (u, v, w, 0)
     float *yaw, *u, *v, *w, *ti_loc, *power, *ct;
     WgSlot* slot;

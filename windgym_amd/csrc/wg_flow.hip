@@ -36,6 +36,30 @@ __device__ __forceinline__ float m0_cfrac(float ct, float sp) {
     return 1.0f - __builtin_amdgcn_sqrtf(a);
 }
 
+// Frozen emission record of a wake particle, packed into two 32-bit words (16-bit fixed point):
+//   rec_a = ct (unorm16 over [0,1])   | k  (unorm16 over [0,0.25]) << 16
+//   rec_b = eps (unorm16 over [0,1])  | hv (snorm16 over [-16,16] m/s) << 16
+// Quantisation steps (1.5e-5, 3.8e-6, 1.5e-5, 4.9e-4 m/s) are an order of magnitude below the fp32 parity
+// tolerances; the streaming pass reads 8 instead of 16 record bytes per particle, and the
+// "does this particle move" test needs only rec_b.
+#define WG_K_MAX 0.25f
+#define WG_HV_MAX 16.0f
+__device__ __forceinline__ unsigned pack_a(float ct, float k) {
+    const unsigned qc = (unsigned)(fminf(fmaxf(ct, 0.f), 1.f) * 65535.0f + 0.5f);
+    const unsigned qk = (unsigned)(fminf(fmaxf(k, 0.f), WG_K_MAX) * (65535.0f / WG_K_MAX) + 0.5f);
+    return qc | (qk << 16);
+}
+__device__ __forceinline__ unsigned pack_b(float eps, float hv) {
+    const unsigned qe = (unsigned)(fminf(fmaxf(eps, 0.f), 1.f) * 65535.0f + 0.5f);
+    const int qh = (int)rintf(fminf(fmaxf(hv, -WG_HV_MAX), WG_HV_MAX) * (32767.0f / WG_HV_MAX));
+    return qe | ((unsigned)(qh & 0xffff) << 16);
+}
+__device__ __forceinline__ float rec_ct(unsigned a) { return (float)(a & 0xffffu) * (1.0f / 65535.0f); }
+__device__ __forceinline__ float rec_k(unsigned a) { return (float)(a >> 16) * (WG_K_MAX / 65535.0f); }
+__device__ __forceinline__ float rec_eps(unsigned b) { return (float)(b & 0xffffu) * (1.0f / 65535.0f); }
+__device__ __forceinline__ float rec_hv(unsigned b) { return (float)((int)b >> 16) * (WG_HV_MAX / 32767.0f); }
+__device__ __forceinline__ bool rec_moves(unsigned b) { return (b >> 16) != 0u; }
+
 // x^y for x >= 0 via v_log_f32 / v_exp_f32 (HIP's __powf expands to the full-precision routine)
 __device__ __forceinline__ float fast_pow(float x, float y) {
     return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
@@ -168,10 +192,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     const float s_off_f = (float)sr.s_off;
 
     float* __restrict__ gpy = d.py + pbase;
-    float* __restrict__ gct = d.ct_e + pbase;
-    float* __restrict__ gk = d.k_e + pbase;
-    float* __restrict__ geps = d.eps_e + pbase;
-    float* __restrict__ ghv = d.hv_e + pbase;
+    unsigned* __restrict__ gra = d.rec_a + pbase;
+    unsigned* __restrict__ grb = d.rec_b + pbase;
     float* __restrict__ gue = d.u_e + pbase;
     if (TURB != WG_TURB_NONE) {
         // turbulent inflow: every valid particle meanders -> all state arrays are streamed (py, pz, vlp, wlp r/w,
@@ -188,14 +210,11 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             float4 pz4 = *reinterpret_cast<const float4*>(gpz + i4);
             float4 vl4 = *reinterpret_cast<const float4*>(gvl + i4);
             float4 wl4 = *reinterpret_cast<const float4*>(gwl + i4);
-            float4 hv4 = *reinterpret_cast<const float4*>(ghv + i4);
-            float4 ct4 = *reinterpret_cast<const float4*>(gct + i4);
-            float4 k4 = *reinterpret_cast<const float4*>(gk + i4);
-            float4 ep4 = *reinterpret_cast<const float4*>(geps + i4);
+            const uint4 ra4 = *reinterpret_cast<const uint4*>(gra + i4);
+            const uint4 rb4 = *reinterpret_cast<const uint4*>(grb + i4);
+            unsigned rav[4] = {ra4.x, ra4.y, ra4.z, ra4.w}, rbv[4] = {rb4.x, rb4.y, rb4.z, rb4.w};
             float pyv[4] = {py4.x, py4.y, py4.z, py4.w}, pzv[4] = {pz4.x, pz4.y, pz4.z, pz4.w};
             float vlv[4] = {vl4.x, vl4.y, vl4.z, vl4.w}, wlv[4] = {wl4.x, wl4.y, wl4.z, wl4.w};
-            float hvv[4] = {hv4.x, hv4.y, hv4.z, hv4.w}, ctv[4] = {ct4.x, ct4.y, ct4.z, ct4.w};
-            float kv[4] = {k4.x, k4.y, k4.z, k4.w}, epv[4] = {ep4.x, ep4.y, ep4.z, ep4.w};
             int j0 = head - r0; if (j0 < 0) j0 += P;
             int e0 = r0 - head - 1; if (e0 < 0) e0 += P;
             const bool emits = (e0 < n_emit) || (n_emit > 0 && e0 + 3 >= P);
@@ -205,7 +224,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 int j = j0 - i; if (j < 0) j += P;
                 if (j < n_valid) {
                     const float xrel = s_off_f + (float)j * p.dpart_f;
-                    const float sp = kv[i] * (xrel * p.inv_D) + epv[i];
+                    const float sp = rec_k(rav[i]) * (xrel * p.inv_D) + rec_eps(rbv[i]);
                     float f3[3];
                     if (TURB == WG_TURB_RANDOM) {
                         f3[1] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)(i4 + i), 1u, 0x50u);
@@ -215,7 +234,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     }
                     vlv[i] += tc.alpha * (tc.sig * f3[1] - vlv[i]);
                     wlv[i] += tc.alpha * (tc.sig * f3[2] - wlv[i]);
-                    pyv[i] += (hvv[i] * m0_cfrac(ctv[i], sp) + vlv[i]) * p.dt;
+                    pyv[i] += (rec_hv(rbv[i]) * m0_cfrac(rec_ct(rav[i]), sp) + vlv[i]) * p.dt;
                     pzv[i] += wlv[i] * p.dt;
                 }
             }
@@ -226,14 +245,12 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     int ei = e0 + i; if (ei >= P) ei -= P;
                     if (ei < n_emit) {
                         pyv[i] = y0; pzv[i] = p.hub; vlv[i] = 0.f; wlv[i] = 0.f;
-                        ctv[i] = tq.rct; kv[i] = tq.rk; epv[i] = tq.reps; hvv[i] = tq.rhv;
+                        rav[i] = pack_a(tq.rct, tq.rk); rbv[i] = pack_b(tq.reps, tq.rhv);
                         gue[i4 + i] = tq.rue;
                     }
                 }
-                *reinterpret_cast<float4*>(gct + i4) = make_float4(ctv[0], ctv[1], ctv[2], ctv[3]);
-                *reinterpret_cast<float4*>(gk + i4) = make_float4(kv[0], kv[1], kv[2], kv[3]);
-                *reinterpret_cast<float4*>(geps + i4) = make_float4(epv[0], epv[1], epv[2], epv[3]);
-                *reinterpret_cast<float4*>(ghv + i4) = make_float4(hvv[0], hvv[1], hvv[2], hvv[3]);
+                *reinterpret_cast<uint4*>(gra + i4) = make_uint4(rav[0], rav[1], rav[2], rav[3]);
+                *reinterpret_cast<uint4*>(grb + i4) = make_uint4(rbv[0], rbv[1], rbv[2], rbv[3]);
             }
             *reinterpret_cast<float4*>(gpy + i4) = make_float4(pyv[0], pyv[1], pyv[2], pyv[3]);
             *reinterpret_cast<float4*>(gpz + i4) = make_float4(pzv[0], pzv[1], pzv[2], pzv[3]);
@@ -244,22 +261,22 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         // thread -> quads of 4 consecutive ring slots of one turbine (P % 4 == 0).  A thread owns QB quads per
         // batch, strided by NT*4 floats so that every load instruction of the wave is one contiguous 1 KiB.
         // Two stages keep many loads in flight per lane (the pass is latency-bound otherwise):
-        //   stage 1: hv of all QB quads            -> which quads move (any hv != 0) or receive a new particle
-        //   stage 2: py, ct, k, eps of those quads -> all issued before the first use
-        // A quad that neither moves nor emits costs only its hv read.
+        //   stage 1: rec_b (eps|hv) of all QB quads -> which quads move (any hv != 0) or receive a new particle
+        //   stage 2: py and rec_a (ct|k) of those quads -> all issued before the first use
+        // A quad that neither moves nor emits costs only its rec_b read (4 B per particle).
 #ifndef WG_QB
 #define WG_QB 2
 #endif
         constexpr int QB = WG_QB;
         const int stride = NT * 4;
         for (int b0 = tid * 4; b0 < p.NP; b0 += stride * QB) {
-            float4 hv[QB];
+            uint4 rb[QB];
             bool need[QB], emits[QB];
             int j0s[QB], e0s[QB], ts[QB];
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
                 const int i4 = b0 + q * stride;
-                hv[q] = (i4 < p.NP) ? *reinterpret_cast<const float4*>(ghv + i4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[q] = (i4 < p.NP) ? *reinterpret_cast<const uint4*>(grb + i4) : make_uint4(0u, 0u, 0u, 0u);
             }
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
@@ -269,18 +286,17 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 int j0 = head - r0; if (j0 < 0) j0 += P;           // age of ring slot r0 (slot r0+i: j0-i)
                 int e0 = r0 - head - 1; if (e0 < 0) e0 += P;       // emission index of slot r0 (r0+i: e0+i)
                 emits[q] = (i4 < p.NP) && ((e0 < n_emit) || (n_emit > 0 && e0 + 3 >= P));   // wraps past P-1 -> 0
-                need[q] = emits[q] || (hv[q].x != 0.f) | (hv[q].y != 0.f) | (hv[q].z != 0.f) | (hv[q].w != 0.f);
+                need[q] = emits[q] || rec_moves(rb[q].x) | rec_moves(rb[q].y) | rec_moves(rb[q].z) | rec_moves(rb[q].w);
                 j0s[q] = j0; e0s[q] = e0; ts[q] = t;
             }
-            float4 py[QB], ct[QB], kk[QB], ep[QB];
+            float4 py[QB];
+            uint4 ra[QB];
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
                 const int i4 = b0 + q * stride;
                 if (need[q]) {
                     py[q] = *reinterpret_cast<const float4*>(gpy + i4);
-                    ct[q] = *reinterpret_cast<const float4*>(gct + i4);
-                    kk[q] = *reinterpret_cast<const float4*>(gk + i4);
-                    ep[q] = *reinterpret_cast<const float4*>(geps + i4);
+                    ra[q] = *reinterpret_cast<const uint4*>(gra + i4);
                 }
             }
 #pragma unroll
@@ -288,17 +304,15 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 if (!need[q]) continue;
                 const int i4 = b0 + q * stride;
                 float pyv[4] = {py[q].x, py[q].y, py[q].z, py[q].w};
-                float hvv[4] = {hv[q].x, hv[q].y, hv[q].z, hv[q].w};
-                float ctv[4] = {ct[q].x, ct[q].y, ct[q].z, ct[q].w};
-                float kv[4] = {kk[q].x, kk[q].y, kk[q].z, kk[q].w};
-                float epv[4] = {ep[q].x, ep[q].y, ep[q].z, ep[q].w};
+                unsigned rav[4] = {ra[q].x, ra[q].y, ra[q].z, ra[q].w};
+                unsigned rbv[4] = {rb[q].x, rb[q].y, rb[q].z, rb[q].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     int j = j0s[q] - i; if (j < 0) j += P;
                     if (j < n_valid) {
                         const float xrel = s_off_f + (float)j * p.dpart_f;
-                        const float sp = kv[i] * (xrel * p.inv_D) + epv[i];
-                        pyv[i] += hvv[i] * m0_cfrac(ctv[i], sp) * p.dt;
+                        const float sp = rec_k(rav[i]) * (xrel * p.inv_D) + rec_eps(rbv[i]);
+                        pyv[i] += rec_hv(rbv[i]) * m0_cfrac(rec_ct(rav[i]), sp) * p.dt;
                     }
                 }
                 if (emits[q]) {
@@ -308,14 +322,12 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     for (int i = 0; i < 4; ++i) {
                         int ei = e0s[q] + i; if (ei >= P) ei -= P;
                         if (ei < n_emit) {
-                            pyv[i] = y0; ctv[i] = tq.rct; kv[i] = tq.rk; epv[i] = tq.reps; hvv[i] = tq.rhv;
+                            pyv[i] = y0; rav[i] = pack_a(tq.rct, tq.rk); rbv[i] = pack_b(tq.reps, tq.rhv);
                             gue[i4 + i] = tq.rue;
                         }
                     }
-                    *reinterpret_cast<float4*>(gct + i4) = make_float4(ctv[0], ctv[1], ctv[2], ctv[3]);
-                    *reinterpret_cast<float4*>(gk + i4) = make_float4(kv[0], kv[1], kv[2], kv[3]);
-                    *reinterpret_cast<float4*>(geps + i4) = make_float4(epv[0], epv[1], epv[2], epv[3]);
-                    *reinterpret_cast<float4*>(ghv + i4) = make_float4(hvv[0], hvv[1], hvv[2], hvv[3]);
+                    *reinterpret_cast<uint4*>(gra + i4) = make_uint4(rav[0], rav[1], rav[2], rav[3]);
+                    *reinterpret_cast<uint4*>(grb + i4) = make_uint4(rbv[0], rbv[1], rbv[2], rbv[3]);
                 }
                 *reinterpret_cast<float4*>(gpy + i4) = make_float4(pyv[0], pyv[1], pyv[2], pyv[3]);
             }
@@ -351,8 +363,10 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     int r1 = r0 - 1; if (r1 < 0) r1 += P;
                     const unsigned i0 = (unsigned)(s2 * P + r0), i1 = (unsigned)(s2 * P + r1);
                     // one round of gathers (L2 hits: this workgroup wrote these lines a moment ago)
-                    const float py0 = gpy[i0], py1 = gpy[i1], k0 = gk[i0], k1 = gk[i1], e0 = geps[i0], e1 = geps[i1];
-                    const float c0 = gct[i0], c1 = gct[i1], u0 = gue[i0], u1 = gue[i1];
+                    const float py0 = gpy[i0], py1 = gpy[i1], u0 = gue[i0], u1 = gue[i1];
+                    const unsigned a0 = gra[i0], a1 = gra[i1], b0_ = grb[i0], b1_ = grb[i1];
+                    const float k0 = rec_k(a0), k1 = rec_k(a1), e0 = rec_eps(b0_), e1 = rec_eps(b1_);
+                    const float c0 = rec_ct(a0), c1 = rec_ct(a1);
                     const float w0 = 1.0f - wgt, w1 = wgt;
                     const float yc = w0 * py0 + w1 * py1;
                     float zc = p.hub;

@@ -7,7 +7,7 @@
 //
 //   particle SoA, fp32, [n_slots][N*P] each, ring index fastest -> a workgroup streams contiguous memory:
 //       py                      transverse position of the wake particle (r/w every step)
-//       ct_e, k_e, eps_e, hv_e  frozen emission record (read every step by the advection pass)
+//       rec_a, rec_b            frozen emission record ct|k, eps|hv as 16-bit fixed point (read by the advection pass)
 //       u_e                     rotor wind speed at emission (gathered by the deficit pass only)
 //       pz, vlp, wlp            vertical position + low-pass filtered transverse turbulence (box inflow only)
 //   turbine SoA, fp32, [n_slots][N]: yaw, u, v, w, ti_loc, power, ct
@@ -109,7 +109,8 @@ struct WgEnv {
 
 struct WgPtrs {
     // particles
-    float *py, *ct_e, *k_e, *eps_e, *hv_e, *u_e, *pz, *vlp, *wlp;
+    float *py, *u_e, *pz, *vlp, *wlp;
+    unsigned *rec_a, *rec_b;   // packed emission record: ct|k and eps|hv as 16-bit fixed point
     // turbines [n_slots][N]
     float *yaw, *u, *v, *w, *ti_loc, *power, *ct;
     WgSlot* slot;
