@@ -189,6 +189,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     }
     A(yaw, n_slots * p.N, true); A(u, n_slots * p.N, true); A(v, n_slots * p.N, true); A(w, n_slots * p.N, true);
     A(ti_loc, n_slots * p.N, true); A(power, n_slots * p.N, true); A(ct, n_slots * p.N, true);
+    A(bnd, n_slots * p.N * 3, true);
     A(slot, n_slots, true); A(ctx, n_ctx, true); A(env, (size_t)p.B, true);
     A(xr, n_ctx * p.N, true); A(yr, n_ctx * p.N, true);
     A(ring, n_ctx * p.ring_stride, true); A(fring, n_ctx * p.fring_stride, true);
@@ -282,6 +283,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         memset(&g, 0, sizeof(g));
         g.py = d.py; g.rec_a = d.rec_a; g.rec_b = d.rec_b; g.u_e = d.u_e;
         g.pz = d.pz; g.vlp = d.vlp; g.wlp = d.wlp;
+        g.bnd = d.bnd;
         g.yaw = d.yaw; g.u = d.u; g.v = d.v; g.w = d.w; g.ti_loc = d.ti_loc; g.power = d.power; g.ct = d.ct;
         g.slot = d.slot; g.ctx = d.ctx; g.env = d.env; g.xr = d.xr; g.yr = d.yr;
         g.ring = d.ring; g.fring = d.fring; g.cur_ws = d.cur_ws; g.cur_wd = d.cur_wd;

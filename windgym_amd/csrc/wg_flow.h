@@ -31,6 +31,7 @@ struct FlowPtrs {
     unsigned *rec_a, *rec_b;      // packed emission record (see wg_flow.hip)
     const float4* box4;          // interleaved copy of the turbulence box: [Nx][Ny][Nz] x (u, v, w, 0)
     float *yaw, *u, *v, *w, *ti_loc, *power, *ct;
+    float* bnd;                   // [n_slots][N][3] conservative chain bounds (excursion, k, eps)
     WgSlot* slot;
     WgCtx* ctx;
     const WgEnv* env;
@@ -41,6 +42,6 @@ struct FlowPtrs {
 };
 
 // sizeof(TurbLds) in wg_flow.hip; kept here so the host can size the dynamic LDS
-#define WG_TURB_LDS_BYTES 88
+#define WG_TURB_LDS_BYTES 104
 // per-target bit mask of contributing sources: 32-bit words per target (N <= 32 * WG_MASK_WORDS)
 #define WG_MASK_WORDS 4

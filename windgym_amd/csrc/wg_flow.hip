@@ -26,7 +26,11 @@ struct __attribute__((aligned(8))) TurbLds {
     float yaw, u, v, w, ti, pow, ct, cg, sg;
     float rct, rk, reps, rhv, rue;
     float sws, swd, syaw, sp;
-};   // 22 dwords: lanes t = 0..15 of a column access hit 16 distinct banks
+    // conservative bounds over every particle this turbine has emitted in the episode (running maxima):
+    // lateral (and vertical) excursion from the turbine's (y, z_hub), wake-growth rate k, initial width eps.
+    // They let phase A discard a (target, source) pair BEFORE touching particle memory.
+    float bd, bk, be;
+};   // 25 dwords (odd stride): lanes t = 0..31 of a column access hit distinct banks
 static_assert(sizeof(TurbLds) == WG_TURB_LDS_BYTES, "keep WG_TURB_LDS_BYTES in sync");
 
 __device__ __forceinline__ float m0_cfrac(float ct, float sp) {
@@ -177,6 +181,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         q.rue = q.u;
         q.cg = cg;
         q.sg = sg;
+        q.bk = fmaxf(q.bk, q.rk + WG_K_MAX / 65535.0f);
+        q.be = fmaxf(q.be, q.reps + 1.0f / 65535.0f);
     }
     for (int i = tid; i < TC * WG_MASK_WORDS; i += NT) tmask[i] = 0u;
     lds_barrier<NT>();
@@ -251,6 +257,14 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 }
                 *reinterpret_cast<uint4*>(gra + i4) = make_uint4(rav[0], rav[1], rav[2], rav[3]);
                 *reinterpret_cast<uint4*>(grb + i4) = make_uint4(rbv[0], rbv[1], rbv[2], rbv[3]);
+            }
+            {
+                TurbLds& tw = T[t];
+                const float y0 = (float)tw.yr;
+                float ex = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ex = fmaxf(ex, fabsf(pyv[i] - y0) + fabsf(pzv[i] - p.hub));
+                if (ex > tw.bd) atomicMax(reinterpret_cast<int*>(&tw.bd), __float_as_int(ex));
             }
             *reinterpret_cast<float4*>(gpy + i4) = make_float4(pyv[0], pyv[1], pyv[2], pyv[3]);
             *reinterpret_cast<float4*>(gpz + i4) = make_float4(pzv[0], pzv[1], pzv[2], pzv[3]);
@@ -330,6 +344,12 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     *reinterpret_cast<uint4*>(grb + i4) = make_uint4(rbv[0], rbv[1], rbv[2], rbv[3]);
                 }
                 *reinterpret_cast<float4*>(gpy + i4) = make_float4(pyv[0], pyv[1], pyv[2], pyv[3]);
+                {
+                    TurbLds& tq = T[ts[q]];
+                    const float y0 = (float)tq.yr;
+                    const float ex = fmaxf(fmaxf(fabsf(pyv[0] - y0), fabsf(pyv[1] - y0)), fmaxf(fabsf(pyv[2] - y0), fabsf(pyv[3] - y0)));
+                    if (ex > tq.bd) atomicMax(reinterpret_cast<int*>(&tq.bd), __float_as_int(ex));   // ex >= 0: int order == float order
+                }
             }
         }
     }
@@ -352,7 +372,17 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             const int t = t0 + tl;
             float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
             const double dx = T[t].xr - T[s2].xr;
-            if (s2 != t && dx > 0.0) {
+            // conservative pre-check without touching particle memory: every particle of chain s2 is within
+            // bd of (y_s2, z_hub) and has sigma <= (bk x/D + be) D, so a pair farther apart than R + 5 sigma_max + bd
+            // cannot pass the exact cut-off below
+            bool cand = (s2 != t) && (dx > 0.0);
+            if (cand) {
+                const TurbLds& src = T[s2];
+                const float sig_max = (src.bk * ((float)dx * p.inv_D) + src.be) * p.D;
+                const float gap = fabsf((float)(T[t].yr - src.yr)) - (p.R_rot + 5.0f * sig_max + src.bd);
+                cand = gap <= 1.0e-3f * p.D;      // small margin for fp32 rounding of the bound itself
+            }
+            if (cand) {
                 const double xi = (dx - s_new) * p.inv_dpart;
                 const double jf = floor(xi);
                 float wgt = (float)(xi - jf);
@@ -522,12 +552,14 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     const uint8_t masked_out = (mode == WG_MODE_RESET && mask) ? (uint8_t)(mask[e] == 0) : (uint8_t)0;
     double l_xr = 0, l_yr = 0;
     float l_yaw = 0, l_u = 0, l_v = 0, l_w = 0, l_ti = 0, l_pow = 0, l_ct = 0, l_act = 0;
+    float l_bd = 0, l_bk = 0, l_be = 0;
     const int t_own = tid < N ? tid : 0;
     {
         l_xr = d.xr[(size_t)ctx_id * N + t_own];
         l_yr = d.yr[(size_t)ctx_id * N + t_own];
         l_yaw = d.yaw[tb + t_own]; l_u = d.u[tb + t_own]; l_v = d.v[tb + t_own]; l_w = d.w[tb + t_own];
         l_ti = d.ti_loc[tb + t_own]; l_pow = d.power[tb + t_own]; l_ct = d.ct[tb + t_own];
+        l_bd = d.bnd[(tb + t_own) * 3]; l_bk = d.bnd[(tb + t_own) * 3 + 1]; l_be = d.bnd[(tb + t_own) * 3 + 2];
         if (mode == WG_MODE_STEP && farm == 0) l_act = actions[(size_t)e * N + t_own];
     }
 
@@ -562,11 +594,13 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         TurbLds& q = T[t];
         if (t == tid && tid < N) {
             q.xr = l_xr; q.yr = l_yr; q.yaw = l_yaw; q.u = l_u; q.v = l_v; q.w = l_w; q.ti = l_ti; q.pow = l_pow; q.ct = l_ct;
+            q.bd = l_bd; q.bk = l_bk; q.be = l_be;
         }
         if (t >= NT) {   // N > 256 (not the common case): remaining turbines loaded the slow way
             q.xr = d.xr[(size_t)ctx_id * N + t]; q.yr = d.yr[(size_t)ctx_id * N + t];
             q.yaw = d.yaw[tb + t]; q.u = d.u[tb + t]; q.v = d.v[tb + t]; q.w = d.w[tb + t];
             q.ti = d.ti_loc[tb + t]; q.pow = d.power[tb + t]; q.ct = d.ct[tb + t];
+            q.bd = d.bnd[(tb + t) * 3]; q.bk = d.bnd[(tb + t) * 3 + 1]; q.be = d.bnd[(tb + t) * 3 + 2];
         }
         q.sws = 0.f; q.swd = 0.f; q.syaw = 0.f; q.sp = 0.f;
     }
@@ -712,6 +746,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         const TurbLds& q = T[t];
         d.yaw[tb + t] = q.yaw; d.u[tb + t] = q.u; d.v[tb + t] = q.v; d.w[tb + t] = q.w;
         d.ti_loc[tb + t] = q.ti; d.power[tb + t] = q.pow; d.ct[tb + t] = q.ct;
+        d.bnd[(tb + t) * 3] = q.bd; d.bnd[(tb + t) * 3 + 1] = q.bk; d.bnd[(tb + t) * 3 + 2] = q.be;
     }
     if (tid == 0) {
         slot.head = sr.head; slot.n_valid = sr.n_valid; slot.s_off = sr.s_off; slot.time = sr.time;

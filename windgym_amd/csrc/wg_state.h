@@ -113,6 +113,7 @@ struct WgPtrs {
     unsigned *rec_a, *rec_b;   // packed emission record: ct|k and eps|hv as 16-bit fixed point
     // turbines [n_slots][N]
     float *yaw, *u, *v, *w, *ti_loc, *power, *ct;
+    float* bnd;               // [n_slots][N][3]: running maxima over a chain: excursion, k, eps (pruning bounds)
     WgSlot* slot;
     WgCtx* ctx;
     WgEnv* env;
