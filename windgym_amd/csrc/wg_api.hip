@@ -284,6 +284,11 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         g.py = d.py; g.rec_a = d.rec_a; g.rec_b = d.rec_b; g.u_e = d.u_e;
         g.pz = d.pz; g.vlp = d.vlp; g.wlp = d.wlp;
         g.bnd = d.bnd;
+        g.dbg = nullptr;
+        if (getenv("WG_TIMELINE_OUT")) {
+            long long* dbgp = nullptr;
+            if (!dev_alloc(h, &dbgp, (size_t)p.B * 2 * p.F * 12, false)) g.dbg = dbgp;
+        }
         g.yaw = d.yaw; g.u = d.u; g.v = d.v; g.w = d.w; g.ti_loc = d.ti_loc; g.power = d.power; g.ct = d.ct;
         g.slot = d.slot; g.ctx = d.ctx; g.env = d.env; g.xr = d.xr; g.yr = d.yr;
         g.ring = d.ring; g.fring = d.fring; g.cur_ws = d.cur_ws; g.cur_wd = d.cur_wd;
@@ -327,6 +332,13 @@ extern "C" int wg_destroy(wg_handle h) {
     if (!h) return 0;
     hipSetDevice(h->device);
     hipDeviceSynchronize();
+    if (h->fd.dbg && getenv("WG_TIMELINE_OUT")) {      // -DWG_TIMELINE builds: dump the phase stamps of the last launch
+        const size_t n = (size_t)h->p.B * 2 * h->p.F * 12;
+        std::vector<long long> host(n);
+        if (hipMemcpy(host.data(), h->fd.dbg, n * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE* f = fopen(getenv("WG_TIMELINE_OUT"), "wb")) { fwrite(host.data(), sizeof(long long), n, f); fclose(f); }
+        }
+    }
     for (auto& e : h->ev) hipEventDestroy(e);
     for (auto& a : h->allocs) hipFree(a.ptr);
     if (h->box4) hipFree(h->box4);

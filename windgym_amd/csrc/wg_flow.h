@@ -3,7 +3,7 @@
 #include "wg_state.h"
 
 #ifndef WG_FLOW_WAVES
-#define WG_FLOW_WAVES 4   // min waves/SIMD the register allocator must leave room for (4 -> <= 128 VGPRs, no spills)
+#define WG_FLOW_WAVES 5   // min waves/SIMD the register allocator must leave room for (5 -> <= 96 VGPRs; measured best)
 #endif
 
 struct FlowP {
@@ -39,6 +39,7 @@ struct FlowPtrs {
     float *ring, *fring, *cur_ws, *cur_wd, *pend_farm, *pend_base, *old_yaw, *step_farm_pow, *step_base_pow;
     const float *rotor_dy, *rotor_dz, *tab_power, *tab_ct;   // tab_*: resampled on the uniform grid
     const float *script_uvw, *script_power;
+    long long* dbg;               // WG_TIMELINE debug builds: [n_blocks][12] phase stamps
 };
 
 // sizeof(TurbLds) in wg_flow.hip; kept here so the host can size the dynamic LDS

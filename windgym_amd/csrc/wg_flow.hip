@@ -79,6 +79,16 @@ __device__ __forceinline__ float tab_lookup(const float* __restrict__ ys, const 
     return ys[i] + f * (ys[i + 1] - ys[i]);
 }
 
+#ifdef WG_TIMELINE
+// debug build (-DWG_TIMELINE, env WG_TIMELINE_OUT=file): thread 0 of every workgroup records shader-clock stamps
+// at the phase boundaries of its step; wg_destroy dumps them.  This is how the per-workgroup latency budget in
+// DESIGN.md §4.1 was measured.
+__shared__ long long wg_stamps[12];
+#define WG_STAMP(k) do { if (threadIdx.x == 0) wg_stamps[k] = clock64(); } while (0)
+#else
+#define WG_STAMP(k) do { } while (0)
+#endif
+
 struct SlotRegs {
     double s_off, time;
     int head, n_valid;
@@ -186,6 +196,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     }
     for (int i = tid; i < TC * WG_MASK_WORDS; i += NT) tmask[i] = 0u;
     lds_barrier<NT>();
+    WG_STAMP(2);
 
     // (2) streaming pass over the particle SoA: advect over dt, release the new particles
     const int head = sr.head, n_valid = sr.n_valid;
@@ -354,7 +365,9 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         }
     }
     sr.head = new_head; sr.n_valid = new_valid; sr.s_off = s_new; sr.time += p.dt_d; sr.istep += 1u;
-    full_barrier<NT>();   // this workgroup's particle stores are visible to its own gathers below
+    WG_STAMP(3);
+    full_barrier<NT>();
+    WG_STAMP(4);   // this workgroup's particle stores are visible to its own gathers below
 
     // (3)+(4) rotor-averaged inflow
     const float ws_f = (float)ws;
@@ -427,6 +440,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             pair[i] = pp;
         }
         lds_barrier<NT>();
+        WG_STAMP(5);
         // phase B: one thread per (target, sample); S_pad = S rounded up to a power of two
         const int nitems = nt << p.S_shift;
         for (int it = tid; it < ((nitems + NT - 1) & ~(NT - 1)); it += NT) {
@@ -529,6 +543,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     const size_t tb = (size_t)slot_id * N;
     const size_t pbase = (size_t)slot_id * p.NP;
 
+    WG_STAMP(0);
     // ---- prologue: issue every independent global load up front (ONE exposed memory round trip) -------
     const WgEnv& env = d.env[e];
     const int env_live = env.live, env_done = env.done, env_shadow_iters = env.shadow_iters;
@@ -629,6 +644,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         }
     }
     lds_barrier<NT>();   // publishes T, the tables and the rotor offsets
+    WG_STAMP(1);
 
     // live:   one env step = K sub-steps with measurement (Wind_Farm_Env.py:932-979)
     // else:   background development of a not-yet-live episode: flow-development steps (fs.run), then
@@ -664,6 +680,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             ++n_flow;
         }
         --budget;
+        WG_STAMP(6);
         const bool measuring = !is_dev;
         const bool unit_end = measuring && (sub + 1 == p.K);
         // per-turbine tail (thread t owns turbine t): power / thrust with the current yaw (model M0 step 5),
@@ -741,6 +758,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         --fill_rem;
     }
 
+    WG_STAMP(7);
     // epilogue: write the slot back (thread t owns turbine t; no barrier needed for its own T[t])
     for (int t = tid; t < N; t += NT) {
         const TurbLds& q = T[t];
@@ -756,6 +774,12 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         if (farm == 0) { cx.n_pushed = n_pushed; cx.pend_farm_n = pend_farm_n; }
         else cx.pend_base_n = pend_base_n;
         slot.flow_count += (unsigned)n_flow;   // NOT a global atomic: one hot word serialises the whole grid
+#ifdef WG_TIMELINE
+        if (d.dbg && n_flow == 1) {
+            wg_stamps[8] = clock64();
+            for (int k = 0; k < 9; ++k) d.dbg[(size_t)blockIdx.x * 12 + k] = wg_stamps[k];
+        }
+#endif
     }
 }
 
