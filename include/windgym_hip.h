@@ -235,7 +235,8 @@ int wg_set_state(wg_handle h, const void* blob_host, size_t size);
 /* HIP-event timing of the step kernels on the stream they were launched on: average milliseconds per
  * launch of the dominant flow kernel and of the glue kernel since the last call, and the average number of
  * farm flow-steps one flow launch executed (live farms + background episode development) — the unit
- * count behind bench.py's roofline.                                                                    */
+ * count behind bench.py's roofline.  enable = 0 stops; enable = n >= 1 records events around every n-th
+ * wg_step (an event pair per launch costs a few percent of a ~200 us step).                            */
 int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, double* glue_ms_avg, int* n_launches,
                      double* flow_steps_per_launch);
 

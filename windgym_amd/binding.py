@@ -213,7 +213,8 @@ class HipBatch:
         _chk(self.L.wg_set_state(self._h, blob, len(blob)), "wg_set_state")
 
     def kernel_timing(self, enable=True):
-        """-> (flow kernel ms/launch, glue kernel ms/launch, launches timed, farm flow-steps per launch)"""
+        """-> (flow kernel ms/launch, glue kernel ms/launch, launches timed, farm flow-steps per launch).
+        enable: False/0 = stop, True/1 = time every step(), n > 1 = time every n-th step()."""
         f, g, n, fs = C.c_double(), C.c_double(), C.c_int(), C.c_double()
         _chk(self.L.wg_kernel_timing(self._h, int(enable), C.byref(f), C.byref(g), C.byref(n), C.byref(fs)),
              "wg_kernel_timing")

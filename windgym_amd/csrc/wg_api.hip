@@ -48,6 +48,7 @@ struct wg_env_s {
     FlowP fp;
     FlowPtrs fd;
     unsigned long long flow_steps_mark = 0;
+    long n_step_launches = 0;
     void* box4 = nullptr;            // interleaved copy of the caller's turbulence box (owned)
     int device;
     std::vector<Alloc> allocs;      // everything owned by the handle (state blob = allocs flagged `state`)
@@ -58,6 +59,7 @@ struct wg_env_s {
     int reset_chunk = 32;
     // timing
     bool timing = false;
+    int timing_period = 1, timing_phase = 0;   // record events around every `period`-th step() only
     std::vector<hipEvent_t> ev;     // pairs (start, stop) around flow launches, then glue launches
     std::vector<int> ev_kind;
     size_t ev_used = 0;
@@ -443,12 +445,13 @@ extern "C" int wg_step(wg_handle h, const float* actions_dev, float* obs_dev, fl
                        uint8_t* truncated_dev, float* final_obs_dev, void* stream) {
     if (!h || !actions_dev || !obs_dev) return fail(WG_ERR_INVALID, "null argument");
     hipStream_t st = (hipStream_t)stream;
-    time_begin(h, 0, st);
+    const bool sample = h->timing && (h->timing_phase++ % h->timing_period == 0);
+    h->n_step_launches++;
+    if (sample) time_begin(h, 0, st);
     wg_launch_flow(&h->fp, &h->fd, WG_MODE_STEP, actions_dev, nullptr, 0, st);
-    time_end(h, st);
-    time_begin(h, 1, st);
+    if (sample) { time_end(h, st); time_begin(h, 1, st); }
     wg_launch_glue(&h->p, &h->d, 0, nullptr, obs_dev, reward_dev, truncated_dev, final_obs_dev, st);
-    time_end(h, st);
+    if (sample) time_end(h, st);
     return 0;
 }
 
@@ -544,10 +547,14 @@ extern "C" int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, do
     if (flow_ms_avg) *flow_ms_avg = nf ? fsum / nf : 0.0;
     if (glue_ms_avg) *glue_ms_avg = ng ? gsum / ng : 0.0;
     if (n_launches) *n_launches = nf;
-    if (flow_steps_per_launch) *flow_steps_per_launch = nf ? (double)(fs_now - h->flow_steps_mark) / nf : 0.0;
+    // farm flow-steps per STEP-mode launch since the last call (all launches, sampled or not)
+    if (flow_steps_per_launch) *flow_steps_per_launch = h->n_step_launches ? (double)(fs_now - h->flow_steps_mark) / h->n_step_launches : 0.0;
+    h->n_step_launches = 0;
     h->flow_steps_mark = fs_now;
     h->ev_used = 0;
     h->timing = enable != 0;
+    h->timing_period = enable > 1 ? enable : 1;
+    h->timing_phase = 0;
     return 0;
 }
 
