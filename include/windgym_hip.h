@@ -190,6 +190,11 @@ int wg_hist_max(wg_handle h, int* hist_max);
 int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, int ny, int nz,
                           double dx, double dy, double dz);
 
+/* Evaluation sweeps (FarmEval.set_wind_vals for a whole batch, FarmEval.py:63-78): fix the wind conditions of
+ * env b to wind_host[b] = (ws, wd, ti) for every following episode; NaN entries keep the sampled value.  The env's
+ * generator still consumes its draws, so seeds stay aligned.  NULL removes the override.                  */
+int wg_set_wind(wg_handle h, const double* wind_host /*[B,3]*/);
+
 /* Test hook ("replay mode"): replace the flow physics of both farms by scripted tables so that the glue can
  * be checked against golden vectors recorded from the reference.  uvw_dev: f32[F,T,B,N,3], power_dev:
  * f32[F,T,B,N]; every flow sub-step of farm f in env b consumes row cursor[f,b]++ .  NULL disables.     */

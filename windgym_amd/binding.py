@@ -20,7 +20,7 @@ UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 # every symbol include/windgym_hip.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = (
     "wg_last_error", "wg_abi_version", "wg_create", "wg_destroy", "wg_obs_dim", "wg_hist_max",
-    "wg_set_turbulence_box", "wg_set_flow_script", "wg_reset", "wg_step", "wg_check", "wg_obs_multi",
+    "wg_set_turbulence_box", "wg_set_wind", "wg_set_flow_script", "wg_reset", "wg_step", "wg_check", "wg_obs_multi",
     "wg_get_info", "wg_get_measurements", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_algorithmic_bytes",
 )
 
@@ -49,6 +49,7 @@ def load_library():
     L.wg_set_turbulence_box.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
                                         C.c_double, C.c_double]
     L.wg_set_flow_script.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.wg_set_wind.argtypes = [C.c_void_p, C.c_void_p]
     L.wg_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.wg_step.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     L.wg_check.argtypes = [C.c_void_p, C.c_void_p]
@@ -178,6 +179,18 @@ class HipBatch:
         _chk(self.L.wg_metrics(self._h, C.c_void_p(self._metrics.data_ptr()), int(reset_after), self._stream()),
              "wg_metrics")
         return self._metrics
+
+    def set_wind(self, ws=None, wd=None, ti=None):
+        """Fix the wind conditions per env (arrays of length B or scalars; None keeps the sampled value)."""
+        if ws is None and wd is None and ti is None:
+            _chk(self.L.wg_set_wind(self._h, None), "wg_set_wind")
+            return
+        w = np.full((self.B, 3), np.nan)
+        for k, v in enumerate((ws, wd, ti)):
+            if v is not None:
+                w[:, k] = np.broadcast_to(np.asarray(v, dtype=np.float64), (self.B,))
+        w = np.ascontiguousarray(w)
+        _chk(self.L.wg_set_wind(self._h, w.ctypes.data_as(C.c_void_p)), "wg_set_wind")
 
     def set_flow_script(self, uvw, power):
         """Replay mode (test hook).  uvw [F,T,B,N,3], power [F,T,B,N] (array-likes)."""

@@ -50,6 +50,7 @@ struct wg_env_s {
     unsigned long long flow_steps_mark = 0;
     long n_step_launches = 0;
     void* box4 = nullptr;            // interleaved copy of the caller's turbulence box (owned)
+    double* wind_dev = nullptr;      // per-env wind override (wg_set_wind)
     int device;
     std::vector<Alloc> allocs;      // everything owned by the handle (state blob = allocs flagged `state`)
     std::vector<size_t> state_idx;  // indices into allocs that make up the serialisable state
@@ -378,6 +379,22 @@ extern "C" int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, 
     h->fp.bnx = nx; h->fp.bny = ny; h->fp.bnz = nz;
     h->fp.box_pow2 = ((nx & (nx - 1)) == 0) && ((ny & (ny - 1)) == 0) && ((nz & (nz - 1)) == 0);
     h->fp.inv_bdx = 1.0 / dx; h->fp.inv_bdy = 1.0 / dy; h->fp.inv_bdz = 1.0 / dz;
+    return 0;
+}
+
+extern "C" int wg_set_wind(wg_handle h, const double* wind_host) {
+    if (!h) return fail(WG_ERR_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    if (!wind_host) { h->d.wind_override = nullptr; return 0; }
+    if (!h->wind_dev) {
+        double* w = nullptr;
+        int rc = dev_alloc(h, &w, (size_t)h->p.B * 3, false);
+        if (rc) return rc;
+        h->wind_dev = w;
+    }
+    HIPCHK(hipMemcpy(h->wind_dev, wind_host, sizeof(double) * 3 * (size_t)h->p.B, hipMemcpyHostToDevice));
+    h->d.wind_override = h->wind_dev;
     return 0;
 }
 

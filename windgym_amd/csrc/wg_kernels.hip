@@ -23,6 +23,12 @@ __device__ inline void ctx_init(const WgParams& p, const WgPtrs& d, WgEnv& env, 
         ws = wg_pcg_uniform(env, p.ws_min, p.ws_max);     // _set_windconditions (:564-568)
         ti = wg_pcg_uniform(env, p.ti_min, p.ti_max);
         wd = wg_pcg_uniform(env, p.wd_min, p.wd_max);
+        if (d.wind_override) {                            // FarmEval.set_wind_vals, per env
+            const double *ov = d.wind_override + (size_t)e * 3;
+            if (ov[0] == ov[0]) ws = ov[0];
+            if (ov[1] == ov[1]) wd = ov[1];
+            if (ov[2] == ov[2]) ti = ov[2];
+        }
         uint32_t tseed = 0;
         if (p.turb_mode == WG_TURB_RANDOM || p.turb_mode == WG_TURB_BOX_SHIFT)
             tseed = wg_pcg_integers(env, 100000);                                  // _def_site (:623, :642)

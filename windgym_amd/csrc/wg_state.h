@@ -126,6 +126,7 @@ struct WgPtrs {
     float *step_farm_pow, *step_base_pow;   // [B] produced by the flow kernel, consumed by the glue kernel
     float* metrics;           // [B][WG_N_METRICS] running per-env sums
     int* status;              // sticky error word
+    const double* wind_override;   // [B][3] (ws, wd, ti) or null; NaN = keep the sampled value
     // config tables
     const double *x_pos, *y_pos, *yaw_defined;
     const float *rotor_dy, *rotor_dz;
