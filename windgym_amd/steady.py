@@ -1,0 +1,172 @@
+"""Steady-state limit of model M0 and the serial-refine yaw optimiser built on it.
+
+The reference's `PyWakeAgent` (WindGym/Agents/PyWakeAgent.py) optimises yaw set-points with the Serial-Refine
+Method over a py_wake steady-state Gaussian wake model (Blondel-Cathelain + Jimenez + Crespo-Hernandez).
+py_wake is not available; the build uses the steady state of its own flow model instead, which is what the
+dynamic env converges to for constant yaws: Gaussian wakes whose centre line is displaced by the
+integrated Hill-vortex deflection speed, wake-added turbulence as in §2.4, tabular P/Ct.  Everything is batched
+over arbitrary leading dimensions with torch (CPU or GPU), so all wind conditions and all candidate yaw offsets
+of a refine step are evaluated in one call.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .agents import BaseAgent
+from .config import rotor_points
+from .turbine import V80, as_tabular
+
+
+def _interp(x, xs, ys):
+    """Linear interpolation on a uniform or non-uniform ascending table, 0 outside (torch)."""
+    import torch
+    idx = torch.clamp(torch.searchsorted(xs, x.contiguous(), right=True) - 1, 0, len(xs) - 2)
+    f = (x - xs[idx]) / (xs[idx + 1] - xs[idx])
+    out = ys[idx] + f * (ys[idx + 1] - ys[idx])
+    return torch.where((x >= xs[0]) & (x <= xs[-1]), out, torch.zeros_like(out))
+
+
+def steady_state_power(x, y, ws, wd, ti, yaw, turbine=None, n_rotor_pts=16, n_quad=48, device="cpu"):
+    """Per-turbine power [..., N] of the steady state of model M0.
+
+    x, y [N] layout; ws, wd, ti broadcastable to the batch shape [...]; yaw [..., N] in degrees (flow frame)."""
+    import torch
+    tab = as_tabular(turbine if turbine is not None else V80())
+    dt = torch.float64
+    dev = torch.device(device)
+    T = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64), dtype=dt, device=dev)   # noqa: E731
+    x, y, yaw = T(x), T(y), (yaw.to(dev, dt) if isinstance(yaw, torch.Tensor) else T(yaw))
+    batch = yaw.shape[:-1]
+    N = yaw.shape[-1]
+    ws = T(ws).expand(batch) if not isinstance(ws, torch.Tensor) else ws.to(dev, dt).expand(batch)
+    wd = T(wd).expand(batch) if not isinstance(wd, torch.Tensor) else wd.to(dev, dt).expand(batch)
+    ti = T(ti).expand(batch) if not isinstance(ti, torch.Tensor) else ti.to(dev, dt).expand(batch)
+    D, hub = float(tab.diameter()), float(tab.hub_height())
+    tws, tp, tc = T(tab.ws_tab), T(tab.power_tab), T(tab.ct_tab)
+    ry, rz = (T(a) for a in rotor_points(n_rotor_pts, 0.5 * D))
+    th = torch.deg2rad(270.0 - wd)[..., None]
+    cx, cy = x.mean(), y.mean()
+    xr = cx + (x - cx) * torch.cos(th) + (y - cy) * torch.sin(th)          # [..., N]
+    yr = cy - (x - cx) * torch.sin(th) + (y - cy) * torch.cos(th)
+    order = torch.argsort(xr, dim=-1)
+    g = torch.deg2rad(yaw)
+    cg, sg = torch.cos(g), torch.sin(g)
+    u = ws[..., None].expand(batch + (N,)).clone()
+    til = ti[..., None].expand(batch + (N,)).clone()
+    ct = torch.zeros_like(u)
+    hv = torch.zeros_like(u)
+    s01 = torch.linspace(0.0, 1.0, n_quad, dtype=dt, device=dev)
+    R = 0.5 * D
+
+    def cfrac(ctv, sp):
+        m = torch.clamp(1.0 / (8.0 * sp * sp), max=1.0)
+        return 1.0 - torch.sqrt(torch.clamp(1.0 - ctv * m, min=0.0))
+
+    for pos in range(N):
+        t = order[..., pos:pos + 1]                                            # [..., 1] target index
+        xt, yt, cgt = (a.gather(-1, t) for a in (xr, yr, cg))
+        dx = xt - xr                                                            # [..., N] distance from every source
+        up = dx > 1e-9
+        k = 0.38 * til + 0.004
+        q = torch.sqrt(1.0 - ct)
+        eps = 0.2 * torch.sqrt(0.5 * (1.0 + q) / q)
+        xd = torch.clamp(dx, min=0.0) / D
+        sp = k * xd + eps
+        sig = sp * D
+        # wake-centre deflection: (hv / U) * integral_0^dx C(x') dx'  (trapezoid on n_quad points)
+        xq = torch.clamp(dx, min=0.0)[..., None] * s01                          # [..., N, Q]
+        cq = cfrac(ct[..., None], k[..., None] * (xq / D) + eps[..., None])
+        integ = torch.trapezoid(cq, xq, dim=-1)
+        yc = yr + hv / ws[..., None] * integ
+        amp = u * cfrac(ct, sp)
+        ys = yt[..., None] + ry * cgt[..., None]                                # [..., 1, S]
+        r2 = (ys - yc[..., None]) ** 2 + rz ** 2                                # [..., N, S]
+        rc2 = (yt - yc) ** 2
+        keep = up & (rc2 <= (R + 5.0 * sig) ** 2)
+        dfc = torch.where(keep[..., None], amp[..., None] * torch.exp(-r2 / (2.0 * sig[..., None] ** 2)), torch.zeros_like(r2))
+        ut = ws[..., None] - dfc.sum(dim=(-1, -2))[..., None] / n_rotor_pts
+        ind = 0.5 * (1.0 - torch.sqrt(1.0 - ct))
+        tia = 0.73 * ind ** 0.8325 * ti[..., None] ** 0.0325 * torch.clamp(xd, min=1.0) ** (-0.32) * torch.exp(-rc2 / (2 * sig ** 2))
+        tia = torch.where(keep, tia, torch.zeros_like(tia)).amax(dim=-1, keepdim=True)
+        tit = torch.sqrt(ti[..., None] ** 2 + tia ** 2)
+        wsn = torch.clamp(ut * cgt, min=0.0)
+        ctt = torch.clamp(_interp(wsn, tws, tc) * cgt ** 2, 0.0, 0.96)
+        u = u.scatter(-1, t, ut)
+        til = til.scatter(-1, t, tit)
+        ct = ct.scatter(-1, t, ctt)
+        hv = hv.scatter(-1, t, -0.4 * sg.gather(-1, t) * ut)
+    return _interp(torch.clamp(u * cg, min=0.0), tws, tp)
+
+
+def yaw_optimizer_srf(x, y, ws, wd, ti, turbine=None, refine_pass_n=8, yaw_n=9, yaw_max=30.0, device="cpu"):
+    """Serial-Refine yaw optimisation (PyWakeAgent.py:144-288) for a batch of wind conditions at once.
+    ws, wd, ti: arrays of the same length C.  Returns yaw [C, N] in degrees."""
+    import torch
+    ws, wd, ti = (np.atleast_1d(np.asarray(a, dtype=np.float64)) for a in (ws, wd, ti))
+    C, N = len(ws), len(x)
+    wd = wd + 1e-3                                   # break the two-maxima tie of perfectly aligned rows (:188-189)
+    yaw = torch.zeros((C, N), dtype=torch.float64)
+    power = steady_state_power(x, y, ws, wd, ti, yaw, turbine, device=device).sum(-1).cpu()
+    th = np.radians((270.0 - wd) % 360)
+    xrot = np.asarray(x)[None, :] * np.cos(th)[:, None] + np.asarray(y)[None, :] * np.sin(th)[:, None]
+    order = np.argsort(xrot, axis=1)                 # upstream -> downstream (:203-210)
+    rng = float(yaw_max)
+    ar = torch.arange(C)
+    for _ in range(refine_pass_n):
+        offs = torch.linspace(-rng, rng, yaw_n, dtype=torch.float64)
+        rng /= 2.0
+        for pos in range(N):
+            tidx = torch.as_tensor(order[:, pos])
+            cand = yaw[:, None, :].repeat(1, yaw_n, 1)                          # [C, yaw_n, N]
+            cand[ar[:, None], torch.arange(yaw_n)[None, :], tidx[:, None]] = yaw[ar, tidx][:, None] + offs[None, :]
+            p = steady_state_power(x, y, ws[:, None], wd[:, None], ti[:, None], cand, turbine, device=device).sum(-1).cpu()
+            best = p.argmax(dim=1)
+            bp = p[ar, best]
+            better = bp > power
+            yaw[ar[better], tidx[better]] = cand[ar[better], best[better], tidx[better]]
+            power[better] = bp[better]
+    return torch.clamp(yaw, -yaw_max, yaw_max).numpy()
+
+
+class SteadyStateYawAgent(BaseAgent):
+    """Drop-in for the reference's PyWakeAgent (same constructor, `update_wind`, `optimize`, `optimized_yaws`,
+    `predict`), with the steady state of model M0 as the wake model."""
+
+    def __init__(self, x_pos, y_pos, wind_speed=8, wind_dir=270, TI=0.07, yaw_max=45, yaw_min=-45, refine_pass_n=8,
+                 yaw_n=9, turbine=None, device="cpu"):
+        super().__init__(yaw_max, yaw_min)
+        self.pywakeagent = True
+        self.optimized = False
+        self.x_pos, self.y_pos = np.asarray(x_pos, dtype=float), np.asarray(y_pos, dtype=float)
+        if len(self.x_pos) != len(self.y_pos):
+            raise ValueError("x_pos and y_pos must have the same length.")
+        self.n_wt = len(self.x_pos)
+        self.wsp, self.wdir, self.TI = np.asarray([wind_speed], float), np.asarray([wind_dir], float), TI
+        self.refine_pass_n, self.yaw_n = refine_pass_n, yaw_n
+        self.turbine = turbine if turbine is not None else V80()
+        self.device = device
+
+    def update_wind(self, wind_speed, wind_direction, TI):
+        self.wsp, self.wdir, self.TI = np.asarray([wind_speed], float), np.asarray([wind_direction], float), TI
+        self.optimized = False
+
+    def reset(self):
+        self.optimized = False
+
+    def optimize(self):
+        self.optimized_yaws = yaw_optimizer_srf(self.x_pos, self.y_pos, self.wsp, self.wdir, [self.TI], self.turbine,
+                                                self.refine_pass_n, self.yaw_n, device=self.device)[0]
+        self.action = self.scale_yaw(self.optimized_yaws).astype(np.float32)
+        self.optimized = True
+
+    def power(self, yaws):
+        return float(steady_state_power(self.x_pos, self.y_pos, self.wsp[0], self.wdir[0], self.TI,
+                                        np.asarray(yaws, dtype=float), self.turbine, device=self.device).sum())
+
+    def predict(self, *args, **kwargs):
+        if not self.optimized:
+            self.optimize()
+        return self.action, None
+
+
+PyWakeAgent = SteadyStateYawAgent
