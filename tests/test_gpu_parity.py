@@ -352,3 +352,39 @@ def test_mann_box_required(hip):
     env = hip.HipBatch(cfg)
     with pytest.raises(ValueError):
         env.reset(seeds=[1, 2])
+
+
+def test_soak_many_episode_rollovers_at_bench_scale(hip):
+    """Full-size properties (no oracle at this size): 1024 envs x 16 turbines x 2 farms, default n_passthrough,
+    2600 steps = 3-6 episode rollovers per env.  The background-developed episode must always be ready (no sticky
+    error), observations stay finite and inside [-1, 1], the farm is waked, and the episode count is consistent
+    with the per-env episode lengths."""
+    import torch
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.presets import bench_cfg2_config
+    from windgym_amd.turbine import V80
+    B = 1024
+    cfg = EnvConfig(turbine=V80(), yaml_dict=bench_cfg2_config(), turbtype="None", n_envs=B, autoreset=True,
+                    n_passthrough=5, n_rotor_pts=16)
+    env = hip.HipBatch(cfg)
+    env.reset(seeds=1234 + np.arange(B))
+    g = torch.Generator(device="cpu").manual_seed(0)
+    acts = (torch.rand((32, B, cfg.n_turb), generator=g) * 2 - 1).cuda()
+    n_trunc = torch.zeros(B, dtype=torch.int64, device="cuda")
+    steps = 2600
+    for i in range(steps):
+        obs, rew, tr, fin = env.step(acts[i % 32])
+        n_trunc += tr.long()
+        if i % 200 == 0:
+            assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and (obs.abs() <= 1).all()
+            assert torch.isfinite(fin).all()
+    env.check()                                                   # no NaN power, no unready background episode
+    assert int(n_trunc.min()) >= 2 and int(n_trunc.max()) <= 7
+    np.testing.assert_array_equal(env.info("episode").cpu().numpy(), n_trunc.cpu().numpy())
+    tm = env.info("time_max").cpu().numpy()
+    assert tm.min() >= 426 and tm.max() <= 1121                   # int(5 * dist / ws), ws in [7, 15], 1280 m <= dist <= 1568 m
+    m = env.metrics().cpu().numpy()
+    assert m[7] == steps * B and m[3] == int(n_trunc.sum())
+    u = env.info("rotor_uvw_agent").cpu().numpy()[..., 0]
+    ws = env.info("ws_global").cpu().numpy()
+    assert (u.max(axis=1) <= ws * (1 + 1e-5)).all() and (u.min(axis=1) < ws - 0.2).all()
