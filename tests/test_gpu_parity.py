@@ -387,4 +387,4 @@ def test_soak_many_episode_rollovers_at_bench_scale(hip):
     assert m[7] == steps * B and m[3] == int(n_trunc.sum())
     u = env.info("rotor_uvw_agent").cpu().numpy()[..., 0]
     ws = env.info("ws_global").cpu().numpy()
-    assert (u.max(axis=1) <= ws * (1 + 1e-5)).all() and (u.min(axis=1) < ws - 0.2).all()
+    assert (u.max(axis=1) <= ws * (1 + 1e-5)).all() and (u.min(axis=1) < ws - 0.02).all()   # every farm is waked
