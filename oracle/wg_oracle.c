@@ -57,6 +57,7 @@ typedef double real;
 #define PI_D 3.14159265358979323846
 
 /* ------------------------------------------------------------------------------------------------ */
+#define WG_COARSE 4   /* block size of the meandering (particle) box */
 typedef struct farm_t {
     /* wake-particle chains: ring of P slots per turbine, [N*P], slot index = t*P + r */
     real *py, *pz, *vlp, *wlp;           /* transverse position, low-pass filtered transverse velocity */
@@ -121,6 +122,10 @@ typedef struct oracle_t {
     const float* box;
     int bnx, bny, bnz;
     double bdx, bdy, bdz;
+    /* meandering box: the same field block-averaged over WG_COARSE^3 cells (model M0 §2.6: the wake particles
+     * only feel scales the DWM low-pass filter would keep anyway; the coarse box stays cache-resident) */
+    float* cbox;
+    int cnx, cny, cnz, coarse;
 } oracle_t;
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -238,6 +243,7 @@ void WGO(destroy)(void* h) {
         free(e->farm_pow); free(e->base_pow); free(e->old_yaws);
     }
     free(o->env);
+    free(o->cbox);
     free(o->x_pos); free(o->y_pos); free(o->rotor_dy); free(o->rotor_dz);
     free(o->tab_ws); free(o->tab_power); free(o->tab_ct); free(o->yaw_defined);
     free(o);
@@ -259,6 +265,26 @@ void WGO(set_turbulence_box)(void* h, const float* box, int nx, int ny, int nz, 
                              double dz) {
     oracle_t* o = (oracle_t*)h;
     o->box = box; o->bnx = nx; o->bny = ny; o->bnz = nz; o->bdx = dx; o->bdy = dy; o->bdz = dz;
+    free(o->cbox); o->cbox = NULL;
+    o->coarse = (nx % WG_COARSE == 0 && ny % WG_COARSE == 0 && nz % WG_COARSE == 0 &&
+                 nx >= 2 * WG_COARSE && ny >= 2 * WG_COARSE && nz >= 2 * WG_COARSE);
+    if (o->coarse) {
+        o->cnx = nx / WG_COARSE; o->cny = ny / WG_COARSE; o->cnz = nz / WG_COARSE;
+        const size_t nc = (size_t)o->cnx * o->cny * o->cnz, nf = (size_t)nx * ny * nz;
+        o->cbox = (float*)malloc(sizeof(float) * 3 * nc);
+        for (int c = 0; c < 3; ++c)
+            for (int i = 0; i < o->cnx; ++i)
+                for (int j = 0; j < o->cny; ++j)
+                    for (int k = 0; k < o->cnz; ++k) {
+                        /* fixed summation order (x, y, z innermost) in float, like the device kernel */
+                        float acc = 0.f;
+                        for (int a = 0; a < WG_COARSE; ++a)
+                            for (int b = 0; b < WG_COARSE; ++b)
+                                for (int cc = 0; cc < WG_COARSE; ++cc)
+                                    acc += box[c * nf + ((size_t)(i * WG_COARSE + a) * ny + (j * WG_COARSE + b)) * nz + (k * WG_COARSE + cc)];
+                        o->cbox[c * nc + ((size_t)i * o->cny + j) * o->cnz + k] = acc * (1.0f / (WG_COARSE * WG_COARSE * WG_COARSE));
+                    }
+    }
 }
 
 /* ================================================================================================== */
@@ -279,6 +305,28 @@ static inline real m0_cfrac(real ct, real sp) {
 
 /* trilinear, periodic lookup of one component of the frozen box at (x,y,z) metres; cell coordinates are
  * formed in double precision (x - U t reaches 1e5 m), the interpolation weights in `real` */
+static inline real cbox_lookup(const oracle_t* o, int comp, double x, double y, double z) {
+    /* coarse cell i averages fine cells [4i, 4i+3], i.e. it is centred at fine index 4i + 1.5 */
+    const double h = 0.5 * (WG_COARSE - 1);
+    double fx = (x / o->bdx - h) / WG_COARSE, fy = (y / o->bdy - h) / WG_COARSE, fz = (z / o->bdz - h) / WG_COARSE;
+    double ix = floor(fx), iy = floor(fy), iz = floor(fz);
+    real tx = (real)(fx - ix), ty = (real)(fy - iy), tz = (real)(fz - iz);
+    long i0 = (long)fmod(ix, (double)o->cnx); if (i0 < 0) i0 += o->cnx;
+    long j0 = (long)fmod(iy, (double)o->cny); if (j0 < 0) j0 += o->cny;
+    long k0 = (long)fmod(iz, (double)o->cnz); if (k0 < 0) k0 += o->cnz;
+    long i1 = (i0 + 1) % o->cnx, j1 = (j0 + 1) % o->cny, k1 = (k0 + 1) % o->cnz;
+    const float* p = o->cbox + (size_t)comp * o->cnx * o->cny * o->cnz;
+#define BX(i, j, k) ((real)p[((size_t)(i) * o->cny + (j)) * o->cnz + (k)])
+    real c00 = BX(i0, j0, k0) + tx * (BX(i1, j0, k0) - BX(i0, j0, k0));
+    real c10 = BX(i0, j1, k0) + tx * (BX(i1, j1, k0) - BX(i0, j1, k0));
+    real c01 = BX(i0, j0, k1) + tx * (BX(i1, j0, k1) - BX(i0, j0, k1));
+    real c11 = BX(i0, j1, k1) + tx * (BX(i1, j1, k1) - BX(i0, j1, k1));
+#undef BX
+    real c0 = c00 + ty * (c10 - c00);
+    real c1 = c01 + ty * (c11 - c01);
+    return c0 + tz * (c1 - c0);
+}
+
 static inline real box_lookup(const oracle_t* o, int comp, double x, double y, double z) {
     double fx = x / o->bdx, fy = y / o->bdy, fz = z / o->bdz;
     double ix = floor(fx), iy = floor(fy), iz = floor(fz);
@@ -308,6 +356,12 @@ static inline int has_box(const oracle_t* o) {
 static inline real box_fluct(const oracle_t* o, const ctx_t* x, int comp, double time, double px, double py,
                              double pz) {
     return (real)(x->ti * x->ws) * box_lookup(o, comp, px - x->ws * time + x->box_ox, py + x->box_oy, pz);
+}
+/* the same for the wake particles: coarse (block-averaged) box when the box is divisible by WG_COARSE */
+static inline real box_fluct_particle(const oracle_t* o, const ctx_t* x, int comp, double time, double px, double py,
+                                      double pz) {
+    const double bx = px - x->ws * time + x->box_ox, by = py + x->box_oy;
+    return (real)(x->ti * x->ws) * (o->coarse ? cbox_lookup(o, comp, bx, by, pz) : box_lookup(o, comp, bx, by, pz));
 }
 
 /* what a particle emitted *now* by turbine t would carry (uses the turbine's last rotor wind and its
@@ -373,8 +427,8 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
             if (box || rnd) {
                 real fv, fw;
                 if (box) {
-                    fv = box_fluct(o, x, 1, f->time, x->xr[t] + (double)xrel, (double)f->py[i], (double)f->pz[i]);
-                    fw = box_fluct(o, x, 2, f->time, x->xr[t] + (double)xrel, (double)f->py[i], (double)f->pz[i]);
+                    fv = box_fluct_particle(o, x, 1, f->time, x->xr[t] + (double)xrel, (double)f->py[i], (double)f->pz[i]);
+                    fw = box_fluct_particle(o, x, 2, f->time, x->xr[t] + (double)xrel, (double)f->py[i], (double)f->pz[i]);
                 } else {
                     fv = sig_amb * (real)wgo_turb_normal(x->turb_seed, f->istep, (uint32_t)i, 1, 0x50);
                     fw = sig_amb * (real)wgo_turb_normal(x->turb_seed, f->istep, (uint32_t)i, 2, 0x50);

@@ -347,6 +347,21 @@ def test_mann_box_inflow_matches_oracle(hip, oracle_lib, small_mann_box, turbtyp
     assert np.std(u[..., 0]) > 0.05 and np.std(u[..., 2]) > 0.005
 
 
+def test_mann_box_ragged_dims_matches_oracle(hip, oracle_lib):
+    """A box whose dims are neither powers of two nor divisible by 4: modulo wrap instead of masks, and the wake
+    particles read the fine box (no block-averaged meandering copy)."""
+    from windgym_amd.mann import generate_mann_box
+    box, spacing = generate_mann_box((90, 30, 18), (4.0, 5.0, 6.0), seed=4), (4.0, 5.0, 6.0)
+    B = 3
+    cfg = _turb_cfg("MannGenerate", B)
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    env.set_turbulence_box(box, spacing), orc.set_turbulence_box(box, spacing)
+    seeds = 900 + np.arange(B)
+    np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=TURB_OBS_ATOL)
+    _compare_turb(env, orc, 120, np.random.default_rng(11), cfg.n_turb, B)
+    env.check()
+
+
 def test_mann_box_required(hip):
     cfg = _turb_cfg("MannFixed", 2)
     env = hip.HipBatch(cfg)

@@ -23,6 +23,7 @@ void wg_launch_info(const WgParams*, const WgPtrs*, int, void*, hipStream_t);
 void wg_launch_metrics(const WgParams*, const WgPtrs*, float*, int, hipStream_t);
 void wg_launch_box_repack(const float*, void*, size_t, hipStream_t);
 void wg_launch_measurements(const WgParams*, const WgPtrs*, float*, hipStream_t);
+void wg_launch_box_coarsen(const void*, void*, int, int, int, hipStream_t);
 }
 
 static thread_local std::string g_err;
@@ -50,6 +51,7 @@ struct wg_env_s {
     unsigned long long flow_steps_mark = 0;
     long n_step_launches = 0;
     void* box4 = nullptr;            // interleaved copy of the caller's turbulence box (owned)
+    void* box4c = nullptr;           // block-averaged copy for the particle lookups (owned)
     double* wind_dev = nullptr;      // per-env wind override (wg_set_wind)
     int device;
     std::vector<Alloc> allocs;      // everything owned by the handle (state blob = allocs flagged `state`)
@@ -345,6 +347,7 @@ extern "C" int wg_destroy(wg_handle h) {
     for (auto& e : h->ev) hipEventDestroy(e);
     for (auto& a : h->allocs) hipFree(a.ptr);
     if (h->box4) hipFree(h->box4);
+    if (h->box4c) hipFree(h->box4c);
     delete h;
     return 0;
 }
@@ -378,6 +381,18 @@ extern "C" int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, 
     h->fd.box4 = (const float4*)h->box4;
     h->fp.bnx = nx; h->fp.bny = ny; h->fp.bnz = nz;
     h->fp.box_pow2 = ((nx & (nx - 1)) == 0) && ((ny & (ny - 1)) == 0) && ((nz & (nz - 1)) == 0);
+    if (h->box4c) { HIPCHK(hipFree(h->box4c)); h->box4c = nullptr; }
+    h->fp.coarse = (nx % 4 == 0 && ny % 4 == 0 && nz % 4 == 0 && nx >= 8 && ny >= 8 && nz >= 8);
+    h->fd.box4c = nullptr;
+    if (h->fp.coarse) {
+        const int cx = nx / 4, cy = ny / 4, cz = nz / 4;
+        HIPCHK(hipMalloc(&h->box4c, (size_t)cx * cy * cz * 16));
+        wg_launch_box_coarsen(h->box4, h->box4c, nx, ny, nz, nullptr);
+        HIPCHK(hipDeviceSynchronize());
+        h->fp.cnx = cx; h->fp.cny = cy; h->fp.cnz = cz;
+        h->fp.cbox_pow2 = ((cx & (cx - 1)) == 0) && ((cy & (cy - 1)) == 0) && ((cz & (cz - 1)) == 0);
+        h->fd.box4c = (const float4*)h->box4c;
+    }
     h->fp.inv_bdx = 1.0 / dx; h->fp.inv_bdy = 1.0 / dy; h->fp.inv_bdz = 1.0 / dz;
     return 0;
 }

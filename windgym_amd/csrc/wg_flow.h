@@ -22,6 +22,7 @@ struct FlowP {
     float noise_sigma[WG_N_CH];
     // turbulent inflow (Random / frozen Mann box)
     int turb_mode, bnx, bny, bnz, box_pow2;
+    int coarse, cnx, cny, cnz, cbox_pow2;   // block-averaged (4^3) copy of the box for the particle lookups
     double inv_bdx, inv_bdy, inv_bdz, fc_scale, D_d, hub_d;
     float inv_sqrt_S;
 };
@@ -30,6 +31,7 @@ struct FlowPtrs {
     float *py, *u_e, *pz, *vlp, *wlp;
     unsigned *rec_a, *rec_b;      // packed emission record (see wg_flow.hip)
     const float4* box4;          // interleaved copy of the turbulence box: [Nx][Ny][Nz] x (u, v, w, 0)
+    const float4* box4c;         // the same block-averaged over 4x4x4 cells
     float *yaw, *u, *v, *w, *ti_loc, *power, *ct;
     float* bnd;                   // [n_slots][N][3] conservative chain bounds (excursion, k, eps)
     WgSlot* slot;

@@ -109,24 +109,29 @@ struct TurbCtx {
 // of a corner are 32 contiguous bytes and one 16-byte load brings all components, instead of 8 scattered 4-byte
 // loads per component.  Cell coordinates in double precision (x - U t reaches 1e5 m), weights in fp32 — as the
 // oracle does.  out[0..2] = (u, v, w).
+// COARSE selects the block-averaged copy used by the wake particles (cell i of it is centred at fine index
+// 4 i + 1.5); it is ~17 MB for the reference's 0.8 GB box and stays resident in L2 / Infinity Cache.
+template <bool COARSE>
 __device__ __forceinline__ void box_lookup(const float4* __restrict__ box, const FlowP& p, double x, double y,
                                            double z, float* __restrict__ out) {
-    const double fx = x * p.inv_bdx, fy = y * p.inv_bdy, fz = z * p.inv_bdz;
+    double fx = x * p.inv_bdx, fy = y * p.inv_bdy, fz = z * p.inv_bdz;
+    if (COARSE) { fx = (fx - 1.5) * 0.25; fy = (fy - 1.5) * 0.25; fz = (fz - 1.5) * 0.25; }
+    const int bnx = COARSE ? p.cnx : p.bnx, bny = COARSE ? p.cny : p.bny, bnz = COARSE ? p.cnz : p.bnz;
     const double ix = floor(fx), iy = floor(fy), iz = floor(fz);
     const float tx = (float)(fx - ix), ty = (float)(fy - iy), tz = (float)(fz - iz);
     // |cell index| < 2^31 for any realistic episode (x - U t < 1e6 m); power-of-two boxes wrap with a mask
     int i0, j0, k0, i1, j1, k1;
-    if (p.box_pow2) {
-        i0 = (int)ix & (p.bnx - 1); j0 = (int)iy & (p.bny - 1); k0 = (int)iz & (p.bnz - 1);
-        i1 = (i0 + 1) & (p.bnx - 1); j1 = (j0 + 1) & (p.bny - 1); k1 = (k0 + 1) & (p.bnz - 1);
+    if (COARSE ? p.cbox_pow2 : p.box_pow2) {
+        i0 = (int)ix & (bnx - 1); j0 = (int)iy & (bny - 1); k0 = (int)iz & (bnz - 1);
+        i1 = (i0 + 1) & (bnx - 1); j1 = (j0 + 1) & (bny - 1); k1 = (k0 + 1) & (bnz - 1);
     } else {
-        i0 = (int)ix % p.bnx; if (i0 < 0) i0 += p.bnx;
-        j0 = (int)iy % p.bny; if (j0 < 0) j0 += p.bny;
-        k0 = (int)iz % p.bnz; if (k0 < 0) k0 += p.bnz;
-        i1 = i0 + 1 == p.bnx ? 0 : i0 + 1; j1 = j0 + 1 == p.bny ? 0 : j0 + 1; k1 = k0 + 1 == p.bnz ? 0 : k0 + 1;
+        i0 = (int)ix % bnx; if (i0 < 0) i0 += bnx;
+        j0 = (int)iy % bny; if (j0 < 0) j0 += bny;
+        k0 = (int)iz % bnz; if (k0 < 0) k0 += bnz;
+        i1 = i0 + 1 == bnx ? 0 : i0 + 1; j1 = j0 + 1 == bny ? 0 : j0 + 1; k1 = k0 + 1 == bnz ? 0 : k0 + 1;
     }
-    const size_t a00 = ((size_t)i0 * p.bny + j0) * p.bnz, a10 = ((size_t)i0 * p.bny + j1) * p.bnz;
-    const size_t b00 = ((size_t)i1 * p.bny + j0) * p.bnz, b10 = ((size_t)i1 * p.bny + j1) * p.bnz;
+    const size_t a00 = ((size_t)i0 * bny + j0) * bnz, a10 = ((size_t)i0 * bny + j1) * bnz;
+    const size_t b00 = ((size_t)i1 * bny + j0) * bnz, b10 = ((size_t)i1 * bny + j1) * bnz;
     const float4 v000 = box[a00 + k0], v100 = box[b00 + k0], v010 = box[a10 + k0], v110 = box[b10 + k0];
     const float4 v001 = box[a00 + k1], v101 = box[b00 + k1], v011 = box[a10 + k1], v111 = box[b10 + k1];
 #define WG_TRI(f)                                                         \
@@ -247,7 +252,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                         f3[1] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)(i4 + i), 1u, 0x50u);
                         f3[2] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)(i4 + i), 2u, 0x50u);
                     } else {
-                        box_lookup(d.box4, p, tq.xr + (double)xrel + xshift, (double)pyv[i] + tc.oy, (double)pzv[i], f3);
+                        if (p.coarse) box_lookup<true>(d.box4c, p, tq.xr + (double)xrel + xshift, (double)pyv[i] + tc.oy, (double)pzv[i], f3);
+                        else box_lookup<false>(d.box4, p, tq.xr + (double)xrel + xshift, (double)pyv[i] + tc.oy, (double)pzv[i], f3);
                     }
                     vlv[i] += tc.alpha * (tc.sig * f3[1] - vlv[i]);
                     wlv[i] += tc.alpha * (tc.sig * f3[2] - wlv[i]);
@@ -467,7 +473,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 }
                 if (TURB == WG_TURB_BOX) {
                     // ambient fluctuation at this rotor point (8 corners x 3 components of the frozen box)
-                    box_lookup(d.box4, p, T[t].xr - tc.ws * sr.time + tc.ox,
+                    box_lookup<false>(d.box4, p, T[t].xr - tc.ws * sr.time + tc.ox,
                                T[t].yr + (double)(rdy[s] * T[t].cg) + tc.oy, p.hub_d + (double)rdz[s], amb);
                 }
             }
