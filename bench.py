@@ -168,9 +168,11 @@ def main():
         # algorithmic bytes of one k_flow launch = farm flow-steps it executed (live farms + background
         # development of the next episodes, counted on the device) x bytes per farm flow-step:
         # per particle: py read+write (8) + packed record ct|k, eps|hv read (8); per turbine: state r/w + positions
-        per_particle = 16.0 + (24.0 + 128.0 if args.workload == "cfg5" else 0.0)   # + pz,vlp,wlp r/w + 8 x 16-B corners
+        # box: + pz,vlp,wlp r/w (24) + 8 corners x (v, w) of the meandering box per particle (64), 8 corners x
+        # (u, v, w) of the fine box per rotor point (96)
+        per_particle = 16.0 + (24.0 + 64.0 if args.workload == "cfg5" else 0.0)
         bytes_per_flow_step = (cfg.n_turb * cfg.n_particles * per_particle + cfg.n_turb * 72.0
-                               + (cfg.n_turb * cfg.n_rotor_pts * 128.0 if args.workload == "cfg5" else 0.0))
+                               + (cfg.n_turb * cfg.n_rotor_pts * 96.0 if args.workload == "cfg5" else 0.0))
         alg_bytes_flow = flow_steps * bytes_per_flow_step
         achieved = alg_bytes_flow / (flow_ms * 1e-3) / 1e9 if flow_ms > 0 else 0.0
         # HBM bytes per k_flow launch from the rocprofv3 PMC passes of this same command (separate runs:

@@ -109,19 +109,15 @@ struct TurbCtx {
 // of a corner are 32 contiguous bytes and one 16-byte load brings all components, instead of 8 scattered 4-byte
 // loads per component.  Cell coordinates in double precision (x - U t reaches 1e5 m), weights in fp32 — as the
 // oracle does.  out[0..2] = (u, v, w).
-// COARSE selects the block-averaged copy used by the wake particles (cell i of it is centred at fine index
-// 4 i + 1.5); it is ~17 MB for the reference's 0.8 GB box and stays resident in L2 / Infinity Cache.
-template <bool COARSE>
 __device__ __forceinline__ void box_lookup(const float4* __restrict__ box, const FlowP& p, double x, double y,
                                            double z, float* __restrict__ out) {
-    double fx = x * p.inv_bdx, fy = y * p.inv_bdy, fz = z * p.inv_bdz;
-    if (COARSE) { fx = (fx - 1.5) * 0.25; fy = (fy - 1.5) * 0.25; fz = (fz - 1.5) * 0.25; }
-    const int bnx = COARSE ? p.cnx : p.bnx, bny = COARSE ? p.cny : p.bny, bnz = COARSE ? p.cnz : p.bnz;
+    const double fx = x * p.inv_bdx, fy = y * p.inv_bdy, fz = z * p.inv_bdz;
+    const int bnx = p.bnx, bny = p.bny, bnz = p.bnz;
     const double ix = floor(fx), iy = floor(fy), iz = floor(fz);
     const float tx = (float)(fx - ix), ty = (float)(fy - iy), tz = (float)(fz - iz);
     // |cell index| < 2^31 for any realistic episode (x - U t < 1e6 m); power-of-two boxes wrap with a mask
     int i0, j0, k0, i1, j1, k1;
-    if (COARSE ? p.cbox_pow2 : p.box_pow2) {
+    if (p.box_pow2) {
         i0 = (int)ix & (bnx - 1); j0 = (int)iy & (bny - 1); k0 = (int)iz & (bnz - 1);
         i1 = (i0 + 1) & (bnx - 1); j1 = (j0 + 1) & (bny - 1); k1 = (k0 + 1) & (bnz - 1);
     } else {
@@ -146,6 +142,43 @@ __device__ __forceinline__ void box_lookup(const float4* __restrict__ box, const
     }())
     out[0] = WG_TRI(x); out[1] = WG_TRI(y); out[2] = WG_TRI(z);
 #undef WG_TRI
+}
+
+// The wake particles read the transverse components from the meandering box: the field block-averaged over
+// 4x4x4 cells (coarse cell i is centred at fine index 4 i + 1.5), stored as cells of (v_k, w_k, v_k+1, w_k+1) so
+// that the two z-neighbours of a corner come with ONE 16-byte load: 4 gathers per particle instead of 8.  It is
+// ~17 MB for the reference's 0.8 GB box and stays resident in L2 / Infinity Cache.
+__device__ __forceinline__ void cbox_lookup_vw(const float4* __restrict__ box, const FlowP& p, double x, double y,
+                                               double z, float& fv, float& fw) {
+    const double fx = (x * p.inv_bdx - 1.5) * 0.25, fy = (y * p.inv_bdy - 1.5) * 0.25, fz = (z * p.inv_bdz - 1.5) * 0.25;
+    const int bnx = p.cnx, bny = p.cny, bnz = p.cnz;
+    const double ix = floor(fx), iy = floor(fy), iz = floor(fz);
+    const float tx = (float)(fx - ix), ty = (float)(fy - iy), tz = (float)(fz - iz);
+    int i0, j0, k0, i1, j1;
+    if (p.cbox_pow2) {
+        i0 = (int)ix & (bnx - 1); j0 = (int)iy & (bny - 1); k0 = (int)iz & (bnz - 1);
+        i1 = (i0 + 1) & (bnx - 1); j1 = (j0 + 1) & (bny - 1);
+    } else {
+        i0 = (int)ix % bnx; if (i0 < 0) i0 += bnx;
+        j0 = (int)iy % bny; if (j0 < 0) j0 += bny;
+        k0 = (int)iz % bnz; if (k0 < 0) k0 += bnz;
+        i1 = i0 + 1 == bnx ? 0 : i0 + 1; j1 = j0 + 1 == bny ? 0 : j0 + 1;
+    }
+    const float4 c00 = box[((size_t)i0 * bny + j0) * bnz + k0], c10 = box[((size_t)i1 * bny + j0) * bnz + k0];
+    const float4 c01 = box[((size_t)i0 * bny + j1) * bnz + k0], c11 = box[((size_t)i1 * bny + j1) * bnz + k0];
+    // same association as box_lookup / the oracle: x, then y, then z
+#define WG_TRI2(lo, hi)                                                   \
+    ([&]() {                                                              \
+        const float e00 = c00.lo + tx * (c10.lo - c00.lo);                \
+        const float e10 = c01.lo + tx * (c11.lo - c01.lo);                \
+        const float e01 = c00.hi + tx * (c10.hi - c00.hi);                \
+        const float e11 = c01.hi + tx * (c11.hi - c01.hi);                \
+        const float d0 = e00 + ty * (e10 - e00);                          \
+        const float d1 = e01 + ty * (e11 - e01);                          \
+        return d0 + tz * (d1 - d0);                                       \
+    }())
+    fv = WG_TRI2(x, z); fw = WG_TRI2(y, w);
+#undef WG_TRI2
 }
 
 // barrier that orders LDS traffic only: does NOT wait for outstanding global stores (a plain
@@ -252,8 +285,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                         f3[1] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)(i4 + i), 1u, 0x50u);
                         f3[2] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)(i4 + i), 2u, 0x50u);
                     } else {
-                        if (p.coarse) box_lookup<true>(d.box4c, p, tq.xr + (double)xrel + xshift, (double)pyv[i] + tc.oy, (double)pzv[i], f3);
-                        else box_lookup<false>(d.box4, p, tq.xr + (double)xrel + xshift, (double)pyv[i] + tc.oy, (double)pzv[i], f3);
+                        if (p.coarse) cbox_lookup_vw(d.box4c, p, tq.xr + (double)xrel + xshift, (double)pyv[i] + tc.oy, (double)pzv[i], f3[1], f3[2]);
+                        else box_lookup(d.box4, p, tq.xr + (double)xrel + xshift, (double)pyv[i] + tc.oy, (double)pzv[i], f3);
                     }
                     vlv[i] += tc.alpha * (tc.sig * f3[1] - vlv[i]);
                     wlv[i] += tc.alpha * (tc.sig * f3[2] - wlv[i]);
@@ -473,7 +506,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 }
                 if (TURB == WG_TURB_BOX) {
                     // ambient fluctuation at this rotor point (8 corners x 3 components of the frozen box)
-                    box_lookup<false>(d.box4, p, T[t].xr - tc.ws * sr.time + tc.ox,
+                    box_lookup(d.box4, p, T[t].xr - tc.ws * sr.time + tc.ox,
                                T[t].yr + (double)(rdy[s] * T[t].cg) + tc.oy, p.hub_d + (double)rdz[s], amb);
                 }
             }

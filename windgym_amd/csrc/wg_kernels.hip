@@ -667,20 +667,28 @@ extern "C" void wg_launch_box_repack(const float* planar, void* out, size_t n_ce
     hipLaunchKernelGGL(k_box_repack, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, st, planar, (float4*)out, n_cells);
 }
 
-// 4x4x4 block average of the interleaved box (summation order x, y, z innermost, float — as the oracle does)
+// 4x4x4 block average of the interleaved box (summation order x, y, z innermost, float — as the oracle does);
+// output cell (i, j, k) = (v_k, w_k, v_k+1, w_k+1), k+1 periodic: see cbox_lookup_vw
+__device__ __forceinline__ void coarse_cell(const float4* __restrict__ fine, int ny, int nz, int ii, int j, int k,
+                                            float& v, float& w) {
+    float ay = 0.f, az = 0.f;
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b)
+            for (int c = 0; c < 4; ++c) {
+                const float4 q = fine[((size_t)(ii * 4 + a) * ny + (j * 4 + b)) * nz + (k * 4 + c)];
+                ay += q.y; az += q.z;
+            }
+    v = ay * (1.0f / 64.0f); w = az * (1.0f / 64.0f);
+}
 __global__ void k_box_coarsen(const float4* __restrict__ fine, float4* __restrict__ out, int nx, int ny, int nz) {
     const int cnx = nx / 4, cny = ny / 4, cnz = nz / 4;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)cnx * cny * cnz) return;
     const int k = (int)(i % cnz), j = (int)((i / cnz) % cny), ii = (int)(i / ((size_t)cnz * cny));
-    float ax = 0.f, ay = 0.f, az = 0.f;
-    for (int a = 0; a < 4; ++a)
-        for (int b = 0; b < 4; ++b)
-            for (int c = 0; c < 4; ++c) {
-                const float4 v = fine[((size_t)(ii * 4 + a) * ny + (j * 4 + b)) * nz + (k * 4 + c)];
-                ax += v.x; ay += v.y; az += v.z;
-            }
-    out[i] = make_float4(ax * (1.0f / 64.0f), ay * (1.0f / 64.0f), az * (1.0f / 64.0f), 0.f);
+    float4 o;
+    coarse_cell(fine, ny, nz, ii, j, k, o.x, o.y);
+    coarse_cell(fine, ny, nz, ii, j, k + 1 == cnz ? 0 : k + 1, o.z, o.w);
+    out[i] = o;
 }
 extern "C" void wg_launch_box_coarsen(const void* fine, void* out, int nx, int ny, int nz, hipStream_t st) {
     const size_t n = (size_t)(nx / 4) * (ny / 4) * (nz / 4);
