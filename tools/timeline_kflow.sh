@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-WG_HIPCC_FLAGS="-DWG_TIMELINE" python windgym_amd/build.py > /dev/null 2>&1
+WG_HIPCC_FLAGS="-DWG_TIMELINE $XF" python windgym_amd/build.py > /dev/null 2>&1
 WG_TIMELINE_OUT=gpurun_out/timeline.bin python bench.py --workload ${WL:-cfg2} --steps 60 --warmup 10 --no-cpu 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['roofline']['kernel_ms'])"
 python - <<'PY'
 import numpy as np

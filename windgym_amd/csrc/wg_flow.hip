@@ -145,7 +145,7 @@ __device__ __forceinline__ void box_lookup(const float4* __restrict__ box, const
 }
 
 // The wake particles read the transverse components from the meandering box: the field block-averaged over
-// 4x4x4 cells (coarse cell i is centred at fine index 4 i + 1.5), stored as cells of (v_k, w_k, v_k+1, w_k+1) so
+// 4x4x4 cells (coarse cell i is centred at fine index 4 i + 1.5), stored [cny][cnz][cnx] as cells of (v_k, w_k, v_k+1, w_k+1) so
 // that the two z-neighbours of a corner come with ONE 16-byte load: 4 gathers per particle instead of 8.  It is
 // ~17 MB for the reference's 0.8 GB box and stays resident in L2 / Infinity Cache.
 __device__ __forceinline__ void cbox_lookup_vw(const float4* __restrict__ box, const FlowP& p, double x, double y,
@@ -164,8 +164,12 @@ __device__ __forceinline__ void cbox_lookup_vw(const float4* __restrict__ box, c
         k0 = (int)iz % bnz; if (k0 < 0) k0 += bnz;
         i1 = i0 + 1 == bnx ? 0 : i0 + 1; j1 = j0 + 1 == bny ? 0 : j0 + 1;
     }
-    const float4 c00 = box[((size_t)i0 * bny + j0) * bnz + k0], c10 = box[((size_t)i1 * bny + j0) * bnz + k0];
-    const float4 c01 = box[((size_t)i0 * bny + j1) * bnz + k0], c11 = box[((size_t)i1 * bny + j1) * bnz + k0];
+    // x is the FASTEST dimension of this copy: the particles of a chain are 0.2 D apart along x, so the lanes of a
+    // wave (consecutive ring slots) and the two x-corners of a lane fall into a few shared cache lines per
+    // (j, k) row instead of 64 different ones per gather
+    const size_t r0 = ((size_t)j0 * bnz + k0) * bnx, r1 = ((size_t)j1 * bnz + k0) * bnx;
+    const float4 c00 = box[r0 + i0], c10 = box[r0 + i1];
+    const float4 c01 = box[r1 + i0], c11 = box[r1 + i1];
     // same association as box_lookup / the oracle: x, then y, then z
 #define WG_TRI2(lo, hi)                                                   \
     ([&]() {                                                              \
@@ -195,6 +199,9 @@ __device__ __forceinline__ void full_barrier() {
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
+#ifndef WG_BOX_GROUP
+#define WG_BOX_GROUP 4   // box lookups of a quad the scheduler may interleave (register pressure vs gathers in flight)
+#endif
 #ifndef WG_ABLATE
 #define WG_ABLATE 0   // profiling only: 1 = no advection pass, 2 = no deficit phases
 #endif
@@ -258,15 +265,30 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         float* __restrict__ gvl = d.vlp + pbase;
         float* __restrict__ gwl = d.wlp + pbase;
         const double xshift = tc.ox - tc.ws * sr.time;
+        // software pipeline: the six streamed vectors of the NEXT quad are requested before the gathers of the
+        // current one are consumed, so each iteration exposes one memory round trip instead of two
+        float4 npy, npz, nvl, nwl; uint4 nra, nrb;
+        {
+            const int i4 = tid * 4;
+            if (i4 < p.NP) {
+                npy = *reinterpret_cast<const float4*>(gpy + i4); npz = *reinterpret_cast<const float4*>(gpz + i4);
+                nvl = *reinterpret_cast<const float4*>(gvl + i4); nwl = *reinterpret_cast<const float4*>(gwl + i4);
+                nra = *reinterpret_cast<const uint4*>(gra + i4); nrb = *reinterpret_cast<const uint4*>(grb + i4);
+            }
+        }
         for (int i4 = tid * 4; i4 < p.NP; i4 += NT * 4) {
             const int t = i4 / P;
             const int r0 = i4 - t * P;
-            float4 py4 = *reinterpret_cast<const float4*>(gpy + i4);
-            float4 pz4 = *reinterpret_cast<const float4*>(gpz + i4);
-            float4 vl4 = *reinterpret_cast<const float4*>(gvl + i4);
-            float4 wl4 = *reinterpret_cast<const float4*>(gwl + i4);
-            const uint4 ra4 = *reinterpret_cast<const uint4*>(gra + i4);
-            const uint4 rb4 = *reinterpret_cast<const uint4*>(grb + i4);
+            float4 py4 = npy, pz4 = npz, vl4 = nvl, wl4 = nwl;
+            const uint4 ra4 = nra, rb4 = nrb;
+            {
+                const int n4 = i4 + NT * 4;
+                if (n4 < p.NP) {
+                    npy = *reinterpret_cast<const float4*>(gpy + n4); npz = *reinterpret_cast<const float4*>(gpz + n4);
+                    nvl = *reinterpret_cast<const float4*>(gvl + n4); nwl = *reinterpret_cast<const float4*>(gwl + n4);
+                    nra = *reinterpret_cast<const uint4*>(gra + n4); nrb = *reinterpret_cast<const uint4*>(grb + n4);
+                }
+            }
             unsigned rav[4] = {ra4.x, ra4.y, ra4.z, ra4.w}, rbv[4] = {rb4.x, rb4.y, rb4.z, rb4.w};
             float pyv[4] = {py4.x, py4.y, py4.z, py4.w}, pzv[4] = {pz4.x, pz4.y, pz4.z, pz4.w};
             float vlv[4] = {vl4.x, vl4.y, vl4.z, vl4.w}, wlv[4] = {wl4.x, wl4.y, wl4.z, wl4.w};
@@ -293,6 +315,11 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     pyv[i] += (rec_hv(rbv[i]) * m0_cfrac(rec_ct(rav[i]), sp) + vlv[i]) * p.dt;
                     pzv[i] += wlv[i] * p.dt;
                 }
+#if WG_BOX_GROUP == 1
+                __builtin_amdgcn_sched_barrier(0);
+#elif WG_BOX_GROUP == 2
+                if (i == 1) __builtin_amdgcn_sched_barrier(0);
+#endif
             }
             if (emits) {
                 const float y0 = (float)tq.yr;
@@ -566,7 +593,7 @@ __device__ __forceinline__ void script_step(const FlowP& p, const FlowPtrs& d, T
     }())
 
 template <int NT, int TURB, bool REPLAY, bool NOISE>
-__global__ void __launch_bounds__(NT, WG_FLOW_WAVES)
+__global__ void __launch_bounds__(NT, TURB == WG_TURB_BOX ? WG_BOX_WAVES : WG_FLOW_WAVES)
 k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict__ actions,
        const uint8_t* __restrict__ mask, const int chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

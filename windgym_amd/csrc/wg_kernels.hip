@@ -684,7 +684,8 @@ __global__ void k_box_coarsen(const float4* __restrict__ fine, float4* __restric
     const int cnx = nx / 4, cny = ny / 4, cnz = nz / 4;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)cnx * cny * cnz) return;
-    const int k = (int)(i % cnz), j = (int)((i / cnz) % cny), ii = (int)(i / ((size_t)cnz * cny));
+    // output layout [cny][cnz][cnx]: x fastest (see cbox_lookup_vw)
+    const int ii = (int)(i % cnx), k = (int)((i / cnx) % cnz), j = (int)(i / ((size_t)cnx * cnz));
     float4 o;
     coarse_cell(fine, ny, nz, ii, j, k, o.x, o.y);
     coarse_cell(fine, ny, nz, ii, j, k + 1 == cnz ? 0 : k + 1, o.z, o.w);
