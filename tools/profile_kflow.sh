@@ -12,6 +12,8 @@ rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc3 -o p -- $BENCH > $OUT/bench_pmc3.log 2>&
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc4 -o p -- $BENCH > $OUT/bench_pmc4.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum -d $OUT/pmc5 -o p -- $BENCH > $OUT/bench_pmc5.log 2>&1
 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_32B_sum -d $OUT/pmc6 -o p -- $BENCH > $OUT/bench_pmc6.log 2>&1
+rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum TCC_REQ_sum -d $OUT/pmc7 -o p -- $BENCH > $OUT/bench_pmc7.log 2>&1
+rocprofv3 --pmc TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TCP_PENDING_STALL_CYCLES_sum SQ_INST_CYCLES_VMEM -d $OUT/pmc8 -o p -- $BENCH > $OUT/bench_pmc8.log 2>&1
 python - > $OUT/summary.txt <<PY
 import sqlite3, collections, glob
 out = "$OUT"

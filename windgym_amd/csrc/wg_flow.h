@@ -3,7 +3,7 @@
 #include "wg_state.h"
 
 #ifndef WG_BOX_WAVES
-#define WG_BOX_WAVES 2    // frozen-box variants: measured best with the full register budget (no spills, deeper gather ILP)
+#define WG_BOX_WAVES 2    // turbulent variants: measured best with the full register budget (no spills, deeper gather ILP)
 #endif
 #ifndef WG_FLOW_WAVES
 #define WG_FLOW_WAVES 5   // min waves/SIMD the register allocator must leave room for (5 -> <= 96 VGPRs; measured best)

@@ -20,6 +20,7 @@
 
 #include "wg_device.h"
 #include "wg_flow.h"
+#include <type_traits>
 
 struct __attribute__((aligned(8))) TurbLds {
     double xr, yr;
@@ -109,6 +110,7 @@ struct TurbCtx {
 // of a corner are 32 contiguous bytes and one 16-byte load brings all components, instead of 8 scattered 4-byte
 // loads per component.  Cell coordinates in double precision (x - U t reaches 1e5 m), weights in fp32 — as the
 // oracle does.  out[0..2] = (u, v, w).
+template <bool POW2>
 __device__ __forceinline__ void box_lookup(const float4* __restrict__ box, const FlowP& p, double x, double y,
                                            double z, float* __restrict__ out) {
     const double fx = x * p.inv_bdx, fy = y * p.inv_bdy, fz = z * p.inv_bdz;
@@ -117,7 +119,7 @@ __device__ __forceinline__ void box_lookup(const float4* __restrict__ box, const
     const float tx = (float)(fx - ix), ty = (float)(fy - iy), tz = (float)(fz - iz);
     // |cell index| < 2^31 for any realistic episode (x - U t < 1e6 m); power-of-two boxes wrap with a mask
     int i0, j0, k0, i1, j1, k1;
-    if (p.box_pow2) {
+    if (POW2) {
         i0 = (int)ix & (bnx - 1); j0 = (int)iy & (bny - 1); k0 = (int)iz & (bnz - 1);
         i1 = (i0 + 1) & (bnx - 1); j1 = (j0 + 1) & (bny - 1); k1 = (k0 + 1) & (bnz - 1);
     } else {
@@ -145,9 +147,13 @@ __device__ __forceinline__ void box_lookup(const float4* __restrict__ box, const
 }
 
 // The wake particles read the transverse components from the meandering box: the field block-averaged over
-// 4x4x4 cells (coarse cell i is centred at fine index 4 i + 1.5), stored [cny][cnz][cnx] as cells of (v_k, w_k, v_k+1, w_k+1) so
-// that the two z-neighbours of a corner come with ONE 16-byte load: 4 gathers per particle instead of 8.  It is
-// ~17 MB for the reference's 0.8 GB box and stays resident in L2 / Infinity Cache.
+// 4x4x4 cells (coarse cell i is centred at fine index 4 i + 1.5), stored [cny][cnz][cnx] with x FASTEST as cells of
+// (v_k, w_k, v_k+1, w_k+1): the two z-neighbours of a corner come with ONE aligned 16-byte load (4 gathers per
+// particle instead of 8), and because the particles of a chain are 0.2 D apart along x the lanes of a wave
+// (consecutive ring slots) share a few cache lines per row instead of touching 64.  17 MB for the reference's
+// 0.8 GB box: it lives in L2 / Infinity Cache.  (Measured alternatives: 8-byte cells with unaligned x-pair loads
+// halve the footprint but the compiler splits them into 8 gathers: -6 %.)
+template <bool POW2>
 __device__ __forceinline__ void cbox_lookup_vw(const float4* __restrict__ box, const FlowP& p, double x, double y,
                                                double z, float& fv, float& fw) {
     const double fx = (x * p.inv_bdx - 1.5) * 0.25, fy = (y * p.inv_bdy - 1.5) * 0.25, fz = (z * p.inv_bdz - 1.5) * 0.25;
@@ -155,7 +161,7 @@ __device__ __forceinline__ void cbox_lookup_vw(const float4* __restrict__ box, c
     const double ix = floor(fx), iy = floor(fy), iz = floor(fz);
     const float tx = (float)(fx - ix), ty = (float)(fy - iy), tz = (float)(fz - iz);
     int i0, j0, k0, i1, j1;
-    if (p.cbox_pow2) {
+    if (POW2) {
         i0 = (int)ix & (bnx - 1); j0 = (int)iy & (bny - 1); k0 = (int)iz & (bnz - 1);
         i1 = (i0 + 1) & (bnx - 1); j1 = (j0 + 1) & (bny - 1);
     } else {
@@ -164,9 +170,6 @@ __device__ __forceinline__ void cbox_lookup_vw(const float4* __restrict__ box, c
         k0 = (int)iz % bnz; if (k0 < 0) k0 += bnz;
         i1 = i0 + 1 == bnx ? 0 : i0 + 1; j1 = j0 + 1 == bny ? 0 : j0 + 1;
     }
-    // x is the FASTEST dimension of this copy: the particles of a chain are 0.2 D apart along x, so the lanes of a
-    // wave (consecutive ring slots) and the two x-corners of a lane fall into a few shared cache lines per
-    // (j, k) row instead of 64 different ones per gather
     const size_t r0 = ((size_t)j0 * bnz + k0) * bnx, r1 = ((size_t)j1 * bnz + k0) * bnx;
     const float4 c00 = box[r0 + i0], c10 = box[r0 + i1];
     const float4 c01 = box[r1 + i0], c11 = box[r1 + i1];
@@ -199,8 +202,14 @@ __device__ __forceinline__ void full_barrier() {
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-#ifndef WG_BOX_GROUP
-#define WG_BOX_GROUP 4   // box lookups of a quad the scheduler may interleave (register pressure vs gathers in flight)
+// streamed particle state of the turbulent pass: touched once per launch -> non-temporal, so that it does not evict
+// the meandering box from L2
+#ifdef WG_NO_NT
+#define WG_LDS(p) (*(p))
+#define WG_STS(p, v) (*(p) = (v))
+#else
+#define WG_LDS(p) __builtin_nontemporal_load(p)
+#define WG_STS(p, v) __builtin_nontemporal_store((v), (p))
 #endif
 #ifndef WG_ABLATE
 #define WG_ABLATE 0   // profiling only: 1 = no advection pass, 2 = no deficit phases
@@ -265,89 +274,95 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         float* __restrict__ gvl = d.vlp + pbase;
         float* __restrict__ gwl = d.wlp + pbase;
         const double xshift = tc.ox - tc.ws * sr.time;
-        // software pipeline: the six streamed vectors of the NEXT quad are requested before the gathers of the
-        // current one are consumed, so each iteration exposes one memory round trip instead of two
-        float4 npy, npz, nvl, nwl; uint4 nra, nrb;
-        {
-            const int i4 = tid * 4;
-            if (i4 < p.NP) {
-                npy = *reinterpret_cast<const float4*>(gpy + i4); npz = *reinterpret_cast<const float4*>(gpz + i4);
-                nvl = *reinterpret_cast<const float4*>(gvl + i4); nwl = *reinterpret_cast<const float4*>(gwl + i4);
-                nra = *reinterpret_cast<const uint4*>(gra + i4); nrb = *reinterpret_cast<const uint4*>(grb + i4);
+        // lane -> ONE ring slot per sub-iteration, U slots NT apart per iteration: consecutive lanes hold consecutive
+        // particles of a chain (0.2 D apart along x), so one gather instruction of the wave touches ~11 cache lines
+        // of an x-fastest box row instead of 64 — the gathers are bound by L2->L1 line transfers, not by HBM.
+        // Software pipeline: the streamed words of the NEXT iteration are requested before the gathers of the
+        // current one are consumed, so an iteration exposes one memory round trip instead of two.
+        // (the box variant and the wrap rule are uniform: hoisted out of the loop as compile-time tags, so the
+        // lookups of an iteration stay in one basic block)
+        auto turbulent_pass = [&](auto coarse_tag, auto pow2_tag) {
+        constexpr bool COARSE = decltype(coarse_tag)::value;
+        constexpr bool POW2 = decltype(pow2_tag)::value;
+        constexpr int U = 4;
+        float npy[U], npz[U], nvl[U], nwl[U]; unsigned nra[U], nrb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ix = tid + u * NT;
+            if (ix < p.NP) {
+                npy[u] = WG_LDS(gpy + ix); npz[u] = WG_LDS(gpz + ix); nvl[u] = WG_LDS(gvl + ix); nwl[u] = WG_LDS(gwl + ix);
+                nra[u] = WG_LDS(gra + ix); nrb[u] = WG_LDS(grb + ix);
             }
         }
-        for (int i4 = tid * 4; i4 < p.NP; i4 += NT * 4) {
-            const int t = i4 / P;
-            const int r0 = i4 - t * P;
-            float4 py4 = npy, pz4 = npz, vl4 = nvl, wl4 = nwl;
-            const uint4 ra4 = nra, rb4 = nrb;
-            {
-                const int n4 = i4 + NT * 4;
-                if (n4 < p.NP) {
-                    npy = *reinterpret_cast<const float4*>(gpy + n4); npz = *reinterpret_cast<const float4*>(gpz + n4);
-                    nvl = *reinterpret_cast<const float4*>(gvl + n4); nwl = *reinterpret_cast<const float4*>(gwl + n4);
-                    nra = *reinterpret_cast<const uint4*>(gra + n4); nrb = *reinterpret_cast<const uint4*>(grb + n4);
+        for (int b0 = tid; b0 < p.NP; b0 += NT * U) {
+            float pyv[U], pzv[U], vlv[U], wlv[U], fv[U], fw[U]; unsigned rav[U], rbv[U];
+            int jv[U], tv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                pyv[u] = npy[u]; pzv[u] = npz[u]; vlv[u] = nvl[u]; wlv[u] = nwl[u]; rav[u] = nra[u]; rbv[u] = nrb[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ix = b0 + (U + u) * NT;
+                if (ix < p.NP) {
+                    npy[u] = WG_LDS(gpy + ix); npz[u] = WG_LDS(gpz + ix); nvl[u] = WG_LDS(gvl + ix); nwl[u] = WG_LDS(gwl + ix);
+                    nra[u] = WG_LDS(gra + ix); nrb[u] = WG_LDS(grb + ix);
                 }
             }
-            unsigned rav[4] = {ra4.x, ra4.y, ra4.z, ra4.w}, rbv[4] = {rb4.x, rb4.y, rb4.z, rb4.w};
-            float pyv[4] = {py4.x, py4.y, py4.z, py4.w}, pzv[4] = {pz4.x, pz4.y, pz4.z, pz4.w};
-            float vlv[4] = {vl4.x, vl4.y, vl4.z, vl4.w}, wlv[4] = {wl4.x, wl4.y, wl4.z, wl4.w};
-            int j0 = head - r0; if (j0 < 0) j0 += P;
-            int e0 = r0 - head - 1; if (e0 < 0) e0 += P;
-            const bool emits = (e0 < n_emit) || (n_emit > 0 && e0 + 3 >= P);
-            const TurbLds& tq = T[t];
+            // the inflow is looked up unconditionally (slots that hold no particle yet wrap into the box like any
+            // other position, their result is discarded): no divergent branch between the lookups, so all gathers
+            // of the iteration are in flight together
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int j = j0 - i; if (j < 0) j += P;
+            for (int u = 0; u < U; ++u) {
+                const int ix = b0 + u * NT;
+                const int t = min(ix / P, N - 1);
+                const int r = ix - t * P;
+                int j = head - r; if (j < 0) j += P;
+                jv[u] = j; tv[u] = t;
+                if (TURB != WG_TURB_RANDOM) {
+                    const float xrel = s_off_f + (float)j * p.dpart_f;
+                    const double bx = T[t].xr + (double)xrel + xshift, by = (double)pyv[u] + tc.oy, bz = (double)pzv[u];
+                    if (WG_ABLATE & 4) { fv[u] = (float)bx * 1e-6f; fw[u] = (float)(by + bz) * 1e-6f; }
+                    else if (COARSE) cbox_lookup_vw<POW2>(d.box4c, p, bx, by, bz, fv[u], fw[u]);
+                    else { float f3[3]; box_lookup<POW2>(d.box4, p, bx, by, bz, f3); fv[u] = f3[1]; fw[u] = f3[2]; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ix = b0 + u * NT;
+                if (ix >= p.NP) continue;
+                const int j = jv[u], t = tv[u];
+                TurbLds& tq = T[t];
                 if (j < n_valid) {
                     const float xrel = s_off_f + (float)j * p.dpart_f;
-                    const float sp = rec_k(rav[i]) * (xrel * p.inv_D) + rec_eps(rbv[i]);
-                    float f3[3];
+                    const float sp = rec_k(rav[u]) * (xrel * p.inv_D) + rec_eps(rbv[u]);
                     if (TURB == WG_TURB_RANDOM) {
-                        f3[1] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)(i4 + i), 1u, 0x50u);
-                        f3[2] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)(i4 + i), 2u, 0x50u);
-                    } else {
-                        if (p.coarse) cbox_lookup_vw(d.box4c, p, tq.xr + (double)xrel + xshift, (double)pyv[i] + tc.oy, (double)pzv[i], f3[1], f3[2]);
-                        else box_lookup(d.box4, p, tq.xr + (double)xrel + xshift, (double)pyv[i] + tc.oy, (double)pzv[i], f3);
+                        fv[u] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)ix, 1u, 0x50u);
+                        fw[u] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)ix, 2u, 0x50u);
                     }
-                    vlv[i] += tc.alpha * (tc.sig * f3[1] - vlv[i]);
-                    wlv[i] += tc.alpha * (tc.sig * f3[2] - wlv[i]);
-                    pyv[i] += (rec_hv(rbv[i]) * m0_cfrac(rec_ct(rav[i]), sp) + vlv[i]) * p.dt;
-                    pzv[i] += wlv[i] * p.dt;
+                    vlv[u] += tc.alpha * (tc.sig * fv[u] - vlv[u]);
+                    wlv[u] += tc.alpha * (tc.sig * fw[u] - wlv[u]);
+                    pyv[u] += (rec_hv(rbv[u]) * m0_cfrac(rec_ct(rav[u]), sp) + vlv[u]) * p.dt;
+                    pzv[u] += wlv[u] * p.dt;
                 }
-#if WG_BOX_GROUP == 1
-                __builtin_amdgcn_sched_barrier(0);
-#elif WG_BOX_GROUP == 2
-                if (i == 1) __builtin_amdgcn_sched_barrier(0);
-#endif
-            }
-            if (emits) {
+                int e = P - 1 - j; // = (r - head - 1) mod P: emission index of this slot
                 const float y0 = (float)tq.yr;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int ei = e0 + i; if (ei >= P) ei -= P;
-                    if (ei < n_emit) {
-                        pyv[i] = y0; pzv[i] = p.hub; vlv[i] = 0.f; wlv[i] = 0.f;
-                        rav[i] = pack_a(tq.rct, tq.rk); rbv[i] = pack_b(tq.reps, tq.rhv);
-                        gue[i4 + i] = tq.rue;
-                    }
+                if (e < n_emit) {
+                    pyv[u] = y0; pzv[u] = p.hub; vlv[u] = 0.f; wlv[u] = 0.f;
+                    gra[ix] = pack_a(tq.rct, tq.rk); grb[ix] = pack_b(tq.reps, tq.rhv);
+                    gue[ix] = tq.rue;
                 }
-                *reinterpret_cast<uint4*>(gra + i4) = make_uint4(rav[0], rav[1], rav[2], rav[3]);
-                *reinterpret_cast<uint4*>(grb + i4) = make_uint4(rbv[0], rbv[1], rbv[2], rbv[3]);
+                const float ex = fabsf(pyv[u] - y0) + fabsf(pzv[u] - p.hub);
+                if (ex > tq.bd) atomicMax(reinterpret_cast<int*>(&tq.bd), __float_as_int(ex));
+                WG_STS(gpy + ix, pyv[u]); WG_STS(gpz + ix, pzv[u]); WG_STS(gvl + ix, vlv[u]); WG_STS(gwl + ix, wlv[u]);
             }
-            {
-                TurbLds& tw = T[t];
-                const float y0 = (float)tw.yr;
-                float ex = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) ex = fmaxf(ex, fabsf(pyv[i] - y0) + fabsf(pzv[i] - p.hub));
-                if (ex > tw.bd) atomicMax(reinterpret_cast<int*>(&tw.bd), __float_as_int(ex));
-            }
-            *reinterpret_cast<float4*>(gpy + i4) = make_float4(pyv[0], pyv[1], pyv[2], pyv[3]);
-            *reinterpret_cast<float4*>(gpz + i4) = make_float4(pzv[0], pzv[1], pzv[2], pzv[3]);
-            *reinterpret_cast<float4*>(gvl + i4) = make_float4(vlv[0], vlv[1], vlv[2], vlv[3]);
-            *reinterpret_cast<float4*>(gwl + i4) = make_float4(wlv[0], wlv[1], wlv[2], wlv[3]);
         }
+        };
+        if (TURB == WG_TURB_BOX && p.coarse) {
+            if (p.cbox_pow2) turbulent_pass(std::true_type{}, std::true_type{});
+            else turbulent_pass(std::true_type{}, std::false_type{});
+        } else if (TURB == WG_TURB_BOX && p.box_pow2) turbulent_pass(std::false_type{}, std::true_type{});
+        else turbulent_pass(std::false_type{}, std::false_type{});
     } else if (!(WG_ABLATE & 1)) {
         // thread -> quads of 4 consecutive ring slots of one turbine (P % 4 == 0).  A thread owns QB quads per
         // batch, strided by NT*4 floats so that every load instruction of the wave is one contiguous 1 KiB.
@@ -520,6 +535,14 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 const float4* __restrict__ pr = pair + tl * N;
                 const float ys = (float)T[t].yr + rdy[s] * T[t].cg;
                 const float zs = p.hub + rdz[s];
+                if (TURB == WG_TURB_BOX) {
+                    // ambient fluctuation at this rotor point (8 corners x 3 components of the frozen box): requested
+                    // first, the scattered HBM reads overlap the wake sum below
+                    const double bx = T[t].xr - tc.ws * sr.time + tc.ox;
+                    const double by = T[t].yr + (double)(rdy[s] * T[t].cg) + tc.oy, bz = p.hub_d + (double)rdz[s];
+                    if (p.box_pow2) box_lookup<true>(d.box4, p, bx, by, bz, amb);
+                    else box_lookup<false>(d.box4, p, bx, by, bz, amb);
+                }
                 for (int wd = 0; wd * 32 < N; ++wd) {
                     unsigned m = tmask[tl * WG_MASK_WORDS + wd];
                     while (m) {                       // ascending source order -> deterministic sum
@@ -530,11 +553,6 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                         const float dy = ys - pp.x, dz = zs - pp.y;
                         acc += pp.w * __expf(-(dy * dy + dz * dz) * pp.z);
                     }
-                }
-                if (TURB == WG_TURB_BOX) {
-                    // ambient fluctuation at this rotor point (8 corners x 3 components of the frozen box)
-                    box_lookup(d.box4, p, T[t].xr - tc.ws * sr.time + tc.ox,
-                               T[t].yr + (double)(rdy[s] * T[t].cg) + tc.oy, p.hub_d + (double)rdz[s], amb);
                 }
             }
             for (int o = p.S_pad >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
@@ -593,7 +611,7 @@ __device__ __forceinline__ void script_step(const FlowP& p, const FlowPtrs& d, T
     }())
 
 template <int NT, int TURB, bool REPLAY, bool NOISE>
-__global__ void __launch_bounds__(NT, TURB == WG_TURB_BOX ? WG_BOX_WAVES : WG_FLOW_WAVES)
+__global__ void __launch_bounds__(NT, TURB != WG_TURB_NONE ? WG_BOX_WAVES : WG_FLOW_WAVES)
 k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict__ actions,
        const uint8_t* __restrict__ mask, const int chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
