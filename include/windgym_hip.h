@@ -226,6 +226,13 @@ int wg_obs_multi(wg_handle h, float* obs_dev, void* stream);
  * (farm_measurements.get_*_turb() / get_*_farm(), the "... measured" entries of _get_info :529-537).   */
 int wg_get_measurements(wg_handle h, float* out_dev, void* stream);
 
+/* Flow-field view of ONE farm (0 = agent, 1 = baseline) of ONE env: (u, v, w) at the nx x ny points
+ * (x_dev[i], y_dev[j], z) of the flow frame -> uvw_dev f32[3, nx, ny].  Replaces
+ * fs.get_windspeed(XYView(z=hub_height, x=a, y=b), include_wakes=True) behind WindFarmEnv._render_frame /
+ * init_render (Wind_Farm_Env.py:1040-1083, :464-476; AgentEval.py:220-228).                               */
+int wg_get_windspeed(wg_handle h, int env, int farm, const float* x_dev, int nx, const float* y_dev, int ny,
+                     float z, int include_wakes, float* uvw_dev, void* stream);
+
 /* Lazy info dict: copy one field to out_dev (dtype/shape per wg_info_field).                           */
 int wg_get_info(wg_handle h, wg_info_field field, void* out_dev, void* stream);
 

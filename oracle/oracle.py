@@ -52,7 +52,8 @@ class Oracle:
         pre = "wgo_" if precision == "f64" else "wgof_"
         self._f = {n: getattr(L, pre + n) for n in (
             "create", "destroy", "obs_dim", "hist_max", "set_flow_script", "set_turbulence_box", "reset",
-            "step", "obs_multi", "get_obs", "get_info", "metrics", "get_chain", "set_threads", "max_threads")}
+            "step", "obs_multi", "get_obs", "get_info", "metrics", "get_chain", "set_threads", "max_threads",
+            "get_windspeed")}
         self._f["create"].restype = C.c_void_p
         self._f["create"].argtypes = [C.c_void_p]
         self._h = C.c_void_p(self._f["create"](C.byref(self._c)))
@@ -100,6 +101,18 @@ class Oracle:
         self._f["set_turbulence_box"](self._h, box.ctypes.data_as(C.c_void_p), C.c_int(box.shape[1]),
                                       C.c_int(box.shape[2]), C.c_int(box.shape[3]), C.c_double(spacing[0]),
                                       C.c_double(spacing[1]), C.c_double(spacing[2]))
+
+    def windspeed(self, env, x, y, z=None, farm=0, include_wakes=True):
+        """(u, v, w)[3, nx, ny] of one farm of one env on an XY grid at height z (flow frame)."""
+        xs = np.ascontiguousarray(x, dtype=np.float64)
+        ys = np.ascontiguousarray(y, dtype=np.float64)
+        out = np.zeros((3, xs.size, ys.size))
+        zz = float(self.cfg.tab.hub_height() if z is None else z)
+        rc = self._f["get_windspeed"](self._h, C.c_int(int(env)), C.c_int(int(farm)), _d(xs), C.c_int(xs.size), _d(ys),
+                                      C.c_int(ys.size), C.c_double(zz), C.c_int(1 if include_wakes else 0), _d(out))
+        if rc != 0:
+            raise RuntimeError("get_windspeed failed")
+        return out
 
     def reset(self, seeds=None, mask=None):
         obs = np.zeros((self.B, self.obs_dim))

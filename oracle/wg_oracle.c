@@ -1129,6 +1129,62 @@ int WGO(get_info)(void* h, int field, double* out) {
     return 0;
 }
 
+/* Flow-field view: (u, v, w) on an XY grid at height z in the flow frame — fs.get_windspeed(XYView(z, x, y),
+ * include_wakes) behind WindFarmEnv._render_frame / init_render (Wind_Farm_Env.py:1040-1083, :464-476).  Model M0
+ * at a point: ambient (+ frozen-box fluctuation; the "Random" inflow has no spatial field, so it adds nothing here)
+ * minus the Gaussian deficits of all chains passing upstream of the point, wake centre / record interpolated between
+ * the two bracketing particles exactly like the rotor inflow (no lateral cut-off).  out[3][nx][ny]. */
+int WGO(get_windspeed)(void* h, int b, int fi, const double* xs, int nx, const double* ys, int ny, double z,
+                       int include_wakes, double* out) {
+    oracle_t* o = (oracle_t*)h;
+    if (b < 0 || b >= o->B || fi < 0 || fi >= o->F) return WG_ERR_INVALID;
+    const wg_config* c = &o->cfg;
+    const ctx_t* x = &o->env[b].ctx;
+    const farm_t* f = &x->farm[fi];
+    const int N = o->N, P = o->P;
+    const real D = (real)c->rotor_diameter, inv_D = (real)1 / D;
+    const double dpart = c->d_particle * c->rotor_diameter, inv_dpart = 1.0 / dpart;
+    const int box = has_box(o) && (c->turb_mode == WG_TURB_BOX || c->turb_mode == WG_TURB_BOX_SHIFT);
+    const size_t plane = (size_t)nx * ny;
+    for (int ix = 0; ix < nx; ++ix)
+        for (int iy = 0; iy < ny; ++iy) {
+            const double px = xs[ix], py = ys[iy];
+            real amb[3] = {0, 0, 0};
+            if (box)
+                for (int cc = 0; cc < 3; ++cc) amb[cc] = box_fluct(o, x, cc, f->time, px, py, z);
+            real dsum = 0;
+            for (int s2 = 0; include_wakes && s2 < N; ++s2) {
+                double dx = px - x->xr[s2];
+                if (!(dx > 0.0)) continue;
+                double xi = (dx - f->s_off) * inv_dpart;
+                double jf = floor(xi);
+                real wgt = (real)(xi - jf);
+                long j = (long)jf;
+                if (j < 0) { j = 0; wgt = 0; }
+                if (j + 1 > f->n_valid - 1) continue;
+                int r0 = f->head - (int)j; r0 %= P; if (r0 < 0) r0 += P;
+                int r1 = r0 - 1; if (r1 < 0) r1 += P;
+                size_t i0 = (size_t)s2 * P + r0, i1 = (size_t)s2 * P + r1;
+                real w0 = (real)1 - wgt, w1 = wgt;
+                real yc = w0 * f->py[i0] + w1 * f->py[i1];
+                real zc = w0 * f->pz[i0] + w1 * f->pz[i1];
+                real ctv = w0 * f->ct_e[i0] + w1 * f->ct_e[i1];
+                real kv = w0 * f->k_e[i0] + w1 * f->k_e[i1];
+                real epv = w0 * f->eps_e[i0] + w1 * f->eps_e[i1];
+                real uev = w0 * f->u_e[i0] + w1 * f->u_e[i1];
+                real sp = m0_sigma_over_d(kv, epv, (real)dx * inv_D);
+                real sig = sp * D;
+                real inv2s2 = (real)1 / ((real)2 * sig * sig);
+                real r2 = ((real)py - yc) * ((real)py - yc) + ((real)z - zc) * ((real)z - zc);
+                dsum += uev * m0_cfrac(ctv, sp) * R_EXP(-r2 * inv2s2);
+            }
+            out[0 * plane + (size_t)ix * ny + iy] = (real)x->ws + amb[0] - dsum;
+            out[1 * plane + (size_t)ix * ny + iy] = amb[1];
+            out[2 * plane + (size_t)ix * ny + iy] = amb[2];
+        }
+    return 0;
+}
+
 /* debug access to the particle chains of one farm: py, u_e, ct_e by age index (0 = newest) */
 int WGO(get_chain)(void* h, int b, int fi, int t, double* py, double* ue, double* ct, double* s_off) {
     oracle_t* o = (oracle_t*)h;

@@ -281,3 +281,30 @@ def test_greedy_agent_reproduces_the_baseline_controller(wg, tmp_path):
     assert np.abs(ya - yb).max() < 0.3           # both follow the local wind direction, 1 deg/step limited
     assert np.abs(rew).max() < 0.02
     venv.close()
+
+
+def test_render_and_flow_field_view(wg, tmp_path):
+    """render_mode="rgb_array" / plot_frame / fs.get_windspeed (Wind_Farm_Env.py:464-476, :1036-1103)."""
+    from windgym_amd import presets
+    env = wg.WindFarmEnv(turbine=wg.V80(), n_passthrough=2, yaml_path=_yaml(tmp_path, presets.env1_config()),
+                         turbtype="None", seed=5, render_mode="rgb_array", Baseline_comp=True)
+    env.reset(seed=5)
+    for _ in range(5):
+        env.step(env.action_space.sample())
+    env.init_render()
+    assert env.a.shape == (250,) and env.b.shape == (250,)
+    uvw = env.fs.get_windspeed(env.view, include_wakes=True)
+    assert uvw.shape == (3, 250, 250) and np.isfinite(uvw).all()
+    ws = float(env.ws)
+    assert uvw[0].max() <= ws + 1e-3 and uvw[0].min() < ws - 1.0          # wakes, no speed-up in model M0
+    # the field at a turbine's hub is consistent with what the turbine sees (rotor average of the same field)
+    x_t, y_t = env.fs.windTurbines.positions_xyz[:2]
+    t_last = int(np.argmax(x_t))
+    u_hub = env.get_windspeed(x=[x_t[t_last] - 1.0], y=[y_t[t_last]])[0, 0, 0]      # just upstream of its own wake
+    u_rot = env.fs.windTurbines.rotor_avg_windspeed[t_last, 0]
+    assert abs(u_hub - u_rot) < 0.35 * max(ws - u_rot, 0.5) + 0.05
+    img = env.render()
+    assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3 and img.std() > 5
+    img_b = env.plot_frame(baseline=True)
+    assert img_b.shape == img.shape
+    env.close()

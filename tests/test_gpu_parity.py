@@ -362,6 +362,47 @@ def test_mann_box_ragged_dims_matches_oracle(hip, oracle_lib):
     env.check()
 
 
+@pytest.mark.parametrize("turbtype", ["None", "MannGenerate"])
+def test_flow_field_view_matches_oracle(hip, oracle_lib, small_mann_box, turbtype):
+    """wg_get_windspeed (fs.get_windspeed(XYView(...)), Wind_Farm_Env.py:1040-1083): the (u, v, w) field on an XY
+    grid, agent and baseline farm, with and without wakes, after the farms were yawed for a while."""
+    import torch
+    B = 3
+    cfg = _turb_cfg(turbtype, B)
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    if turbtype != "None":
+        box, spacing = small_mann_box
+        env.set_turbulence_box(box, spacing), orc.set_turbulence_box(box, spacing)
+    seeds = 40 + np.arange(B)
+    env.reset(seeds=seeds), orc.reset(seeds=seeds)
+    rng = np.random.default_rng(12)
+    for _ in range(40):
+        a = rng.uniform(-1, 1, size=(B, cfg.n_turb)).astype(np.float32)
+        env.step(torch.as_tensor(a, device="cuda")), orc.step(a)
+    tx = orc.info("turb_x")
+    ty = orc.info("turb_y")
+    for b in (0, 2):
+        xs = np.linspace(tx[b].min() - 200.0, tx[b].max() + 1000.0, 97).astype(np.float32)
+        ys = np.linspace(ty[b].min() - 200.0, ty[b].max() + 200.0, 61).astype(np.float32)
+        for farm in (0, 1):
+            for wakes in (True, False):
+                got = env.windspeed(b, xs, ys, farm=farm, include_wakes=wakes).cpu().numpy()
+                ref = orc.windspeed(b, xs, ys, farm=farm, include_wakes=wakes)
+                assert got.shape == (3, 97, 61)
+                np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-3, err_msg=f"env {b} farm {farm} wakes {wakes}")
+        # the wakes are there: behind the first row the field drops well below the free stream
+        u = env.windspeed(b, xs, ys, farm=0).cpu().numpy()[0]
+        u0 = env.windspeed(b, xs, ys, farm=0, include_wakes=False).cpu().numpy()[0]
+        assert (u0 - u).max() > 1.0 and (u0 - u).min() > -1e-3
+    # a different height: above the rotors the deficit is much weaker than at the hub
+    hub_def = (env.windspeed(0, xs, ys, include_wakes=False) - env.windspeed(0, xs, ys))[0].max().item()
+    top_def = (env.windspeed(0, xs, ys, z=cfg.tab.hub_height() + 120.0, include_wakes=False)
+               - env.windspeed(0, xs, ys, z=cfg.tab.hub_height() + 120.0))[0].max().item()
+    assert top_def < 0.5 * hub_def
+    with pytest.raises(Exception):
+        env.windspeed(B, xs, ys)
+
+
 def test_mann_box_required(hip):
     cfg = _turb_cfg("MannFixed", 2)
     env = hip.HipBatch(cfg)

@@ -21,7 +21,7 @@ UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 ABI_SYMBOLS = (
     "wg_last_error", "wg_abi_version", "wg_create", "wg_destroy", "wg_obs_dim", "wg_hist_max",
     "wg_set_turbulence_box", "wg_set_wind", "wg_set_flow_script", "wg_reset", "wg_step", "wg_check", "wg_obs_multi",
-    "wg_get_info", "wg_get_measurements", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_algorithmic_bytes",
+    "wg_get_info", "wg_get_measurements", "wg_get_windspeed", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_algorithmic_bytes",
 )
 
 _lib = None
@@ -56,6 +56,8 @@ def load_library():
     L.wg_obs_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.wg_get_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.wg_get_measurements.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.wg_get_windspeed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float,
+                                   C.c_int, C.c_void_p, C.c_void_p]
     L.wg_metrics.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.wg_get_state.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
     L.wg_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -155,6 +157,20 @@ class HipBatch:
         """Unscaled sensor values in the layout of the observation, f32[B, O]."""
         out = self.torch.zeros((self.B, self.obs_dim), dtype=self.torch.float32, device=self.device)
         _chk(self.L.wg_get_measurements(self._h, C.c_void_p(out.data_ptr()), self._stream()), "wg_get_measurements")
+        return out
+
+    def windspeed(self, env, x, y, z=None, farm=0, include_wakes=True):
+        """(u, v, w) of one farm of one env on the grid x[nx] x y[ny] at height z (default: hub height), flow frame:
+        f32[3, nx, ny] — fs.get_windspeed(XYView(...)) of the reference (Wind_Farm_Env.py:1040-1083)."""
+        t = self.torch
+        xs = t.as_tensor(x, dtype=t.float32, device=self.device).contiguous()
+        ys = t.as_tensor(y, dtype=t.float32, device=self.device).contiguous()
+        out = t.empty((3, xs.numel(), ys.numel()), dtype=t.float32, device=self.device)
+        zz = float(self.cfg.tab.hub_height() if z is None else z)
+        _chk(self.L.wg_get_windspeed(self._h, C.c_int(int(env)), C.c_int(int(farm)), C.c_void_p(xs.data_ptr()),
+                                     C.c_int(xs.numel()), C.c_void_p(ys.data_ptr()), C.c_int(ys.numel()),
+                                     C.c_float(zz), C.c_int(1 if include_wakes else 0), C.c_void_p(out.data_ptr()),
+                                     self._stream()), "wg_get_windspeed")
         return out
 
     def info(self, name):

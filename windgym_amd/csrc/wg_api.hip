@@ -24,6 +24,7 @@ void wg_launch_metrics(const WgParams*, const WgPtrs*, float*, int, hipStream_t)
 void wg_launch_box_repack(const float*, void*, size_t, hipStream_t);
 void wg_launch_measurements(const WgParams*, const WgPtrs*, float*, hipStream_t);
 void wg_launch_box_coarsen(const void*, void*, int, int, int, hipStream_t);
+void wg_launch_windspeed(const FlowP*, const FlowPtrs*, int, int, const float*, int, const float*, int, float, int, float*, hipStream_t);
 }
 
 static thread_local std::string g_err;
@@ -507,6 +508,16 @@ extern "C" int wg_obs_multi(wg_handle h, float* obs_dev, void* stream) {
 extern "C" int wg_get_measurements(wg_handle h, float* out_dev, void* stream) {
     if (!h || !out_dev) return fail(WG_ERR_INVALID, "null argument");
     wg_launch_measurements(&h->p, &h->d, out_dev, (hipStream_t)stream);
+    return 0;
+}
+
+extern "C" int wg_get_windspeed(wg_handle h, int env, int farm, const float* x_dev, int nx, const float* y_dev, int ny,
+                                float z, int include_wakes, float* uvw_dev, void* stream) {
+    if (!h || !x_dev || !y_dev || !uvw_dev) return fail(WG_ERR_INVALID, "null argument");
+    if (env < 0 || env >= h->p.B || farm < 0 || farm >= h->p.F) return fail(WG_ERR_INVALID, "env / farm index out of range");
+    if (nx <= 0 || ny <= 0 || (long long)nx * ny > (1ll << 30)) return fail(WG_ERR_INVALID, "bad grid size");
+    if (h->fp.script_rows > 0) return fail(WG_ERR_UNSUPPORTED, "no flow field in flow-script replay mode");
+    wg_launch_windspeed(&h->fp, &h->fd, env, farm, x_dev, nx, y_dev, ny, z, include_wakes, uvw_dev, (hipStream_t)stream);
     return 0;
 }
 

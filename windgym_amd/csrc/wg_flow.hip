@@ -895,3 +895,76 @@ extern "C" void wg_launch_flow(const FlowP* p, const FlowPtrs* d, int mode, cons
     else if (p->block == 128) launch_nt<128>(p, d, mode, actions, mask, chunk, st);
     else launch_nt<256>(p, d, mode, actions, mask, chunk, st);
 }
+
+// ===================================================================================================
+// k_windspeed: flow-field view — (u, v, w) on an XY grid at height z of ONE farm of ONE env, in the flow frame:
+// fs.get_windspeed(XYView(z, x, y), include_wakes) behind WindFarmEnv._render_frame / init_render
+// (Wind_Farm_Env.py:1040-1083, :464-476).  One thread per grid point; the same bracketed-chain evaluation as phase A
+// of k_flow, without the lateral cut-off.  "Random" inflow has no spatial field and adds nothing here.
+// ===================================================================================================
+__global__ void __launch_bounds__(256)
+k_windspeed(const FlowP p, const FlowPtrs d, const int e, const int farm, const float* __restrict__ xs, const int nx,
+            const float* __restrict__ ys, const int ny, const float z, const int include_wakes,
+            float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nx * ny) return;
+    const int ix = idx / ny, iy = idx - ix * ny;
+    const double px = (double)xs[ix], pyd = (double)ys[iy];
+    const int N = p.N, P = p.P;
+    const int ctx_id = e * 2 + d.env[e].live;
+    const int slot_id = ctx_id * p.F + farm;
+    const size_t pbase = (size_t)slot_id * p.NP;
+    const WgSlot& slot = d.slot[slot_id];
+    const WgCtx& cx = d.ctx[ctx_id];
+    const double s_off = slot.s_off;
+    const int head = slot.head, n_valid = slot.n_valid;
+    float amb[3] = {0.f, 0.f, 0.f};
+    const bool boxm = (p.turb_mode == WG_TURB_BOX || p.turb_mode == WG_TURB_BOX_SHIFT) && d.box4 != nullptr;
+    if (boxm) {
+        const double bx = px - cx.ws * slot.time + cx.box_ox, by = pyd + cx.box_oy;
+        if (p.box_pow2) box_lookup<true>(d.box4, p, bx, by, (double)z, amb);
+        else box_lookup<false>(d.box4, p, bx, by, (double)z, amb);
+        const float sig = (float)(cx.ti * cx.ws);
+        amb[0] *= sig; amb[1] *= sig; amb[2] *= sig;
+    }
+    float dsum = 0.f;
+    const float yp = (float)pyd;
+    for (int s2 = 0; include_wakes && s2 < N; ++s2) {
+        const double dx = px - d.xr[(size_t)ctx_id * N + s2];
+        if (!(dx > 0.0)) continue;
+        const double xi = (dx - s_off) * p.inv_dpart;
+        const double jf = floor(xi);
+        float wgt = (float)(xi - jf);
+        long long j = (long long)jf;
+        if (j < 0) { j = 0; wgt = 0.f; }
+        if (j + 1 > n_valid - 1) continue;
+        int r0 = head - (int)j; if (r0 < 0) r0 += P;
+        int r1 = r0 - 1; if (r1 < 0) r1 += P;
+        const size_t i0 = pbase + (size_t)s2 * P + r0, i1 = pbase + (size_t)s2 * P + r1;
+        const unsigned a0 = d.rec_a[i0], a1 = d.rec_a[i1], b0 = d.rec_b[i0], b1 = d.rec_b[i1];
+        const float w0 = 1.0f - wgt, w1 = wgt;
+        const float yc = w0 * d.py[i0] + w1 * d.py[i1];
+        float zc = p.hub;
+        if (p.turb_mode != WG_TURB_NONE) zc = w0 * d.pz[i0] + w1 * d.pz[i1];
+        const float ctv = w0 * rec_ct(a0) + w1 * rec_ct(a1);
+        const float kv = w0 * rec_k(a0) + w1 * rec_k(a1);
+        const float epv = w0 * rec_eps(b0) + w1 * rec_eps(b1);
+        const float uev = w0 * d.u_e[i0] + w1 * d.u_e[i1];
+        const float sp = kv * ((float)dx * p.inv_D) + epv;
+        const float sig = sp * p.D;
+        const float inv2s2 = 1.0f / (2.0f * sig * sig);
+        const float r2 = (yp - yc) * (yp - yc) + (z - zc) * (z - zc);
+        dsum += uev * m0_cfrac(ctv, sp) * __expf(-r2 * inv2s2);
+    }
+    const size_t plane = (size_t)nx * ny;
+    out[idx] = (float)cx.ws + amb[0] - dsum;
+    out[plane + idx] = amb[1];
+    out[2 * plane + idx] = amb[2];
+}
+
+extern "C" void wg_launch_windspeed(const FlowP* p, const FlowPtrs* d, int e, int farm, const float* xs, int nx,
+                                    const float* ys, int ny, float z, int include_wakes, float* out, hipStream_t st) {
+    const int n = nx * ny;
+    hipLaunchKernelGGL(k_windspeed, dim3((n + 255) / 256), dim3(256), 0, st, *p, *d, e, farm, xs, nx, ys, ny, z,
+                       include_wakes, out);
+}

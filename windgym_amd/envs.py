@@ -79,6 +79,9 @@ class _TurbinesProxy:
 
     rotor_positions_xyz = positions_xyz
 
+    def yaw_tilt(self):
+        return self.yaw, np.zeros(len(self.yaw))
+
 
 class _FlowProxy:
     """Duck type of the DYNAMIKS flow-simulation object (`env.fs`, `env.fs_baseline`)."""
@@ -94,6 +97,13 @@ class _FlowProxy:
     @property
     def wind_direction(self):
         return float(_np(self._b.info("wd_global"))[self._i])
+
+    def get_windspeed(self, view, include_wakes=True, xarray=False):
+        """fs.get_windspeed(XYView(z=, x=, y=), include_wakes=) (Wind_Farm_Env.py:1056; AgentEval.py:220-228):
+        np.float32 [3, nx, ny]; ``view`` is anything with x, y, z attributes or keys."""
+        g = (lambda k: view[k]) if isinstance(view, dict) else (lambda k: getattr(view, k))
+        farm = 1 if self.windTurbines._farm == "base" else 0
+        return _np(self._b.windspeed(self._i, g("x"), g("y"), z=g("z"), farm=farm, include_wakes=include_wakes))
 
 
 # ======================================================================================================
@@ -261,8 +271,8 @@ class WindFarmEnv(_EnvBase):
     """Single farm with the reference's API (WindGym/Wind_Farm_Env.py:47-1034), backed by a batch of 1.
 
     Differences, all documented in DESIGN.md §3: the flow physics is model M0 (DYNAMIKS is not available);
-    ``HTC_path`` (HAWC2 turbines), ``sample_site`` and rendering are not part of the step() path and raise
-    ``NotImplementedError``.
+    ``HTC_path`` (HAWC2 turbines) and ``sample_site`` are not part of the step() path and raise
+    ``NotImplementedError``.  Rendering draws the flow field evaluated on the device (k_windspeed) off-screen.
     """
 
     metadata = {"render_modes": ["human", "rgb_array"]}
@@ -279,8 +289,6 @@ class WindFarmEnv(_EnvBase):
         if sample_site is not None:
             raise NotImplementedError("site-based wind sampling (sample_site) is not implemented in this build")
         assert render_mode is None or render_mode in self.metadata["render_modes"]
-        if render_mode is not None:
-            raise NotImplementedError("rendering is not part of the MI355X step() path")
         self.render_mode = render_mode
         self.turbine = turbine
         self.seed = seed
@@ -440,8 +448,62 @@ class WindFarmEnv(_EnvBase):
             pen_val = np.mean(np.abs(yaw)) / self.yaw_max
         return self.action_penalty * pen_val
 
+    # -- flow-field view / rendering (Wind_Farm_Env.py:464-476, :1036-1083) --------------------------------
+    def init_render(self):
+        """The reference's view: x from 200 m upstream of the first to 1000 m behind the last turbine, y +-200 m
+        around the farm, 250 x 250 points at hub height (:464-476); flow-frame coordinates."""
+        x_turb, y_turb = self.fs.windTurbines.positions_xyz[:2]
+        self.a = np.linspace(-200 + min(x_turb), 1000 + max(x_turb), 250)
+        self.b = np.linspace(-200 + min(y_turb), 200 + max(y_turb), 250)
+        self.view = dict(z=self.turbine.hub_height(), x=self.a, y=self.b)
+
+    def get_windspeed(self, x=None, y=None, z=None, baseline=False, include_wakes=True):
+        """fs.get_windspeed(XYView(z, x, y), include_wakes) -> np.float32 [3, nx, ny] (u, v, w), evaluated by
+        k_windspeed on the device from the env's current particle state."""
+        if x is None or y is None:
+            if not hasattr(self, "view"):
+                self.init_render()
+            x = self.view["x"] if x is None else x
+            y = self.view["y"] if y is None else y
+        if baseline and not self.Baseline_comp:
+            raise ValueError("no baseline farm in this env (Baseline_comp is off)")
+        return _np(self._batch.windspeed(0, x, y, z=z, farm=1 if baseline else 0, include_wakes=include_wakes))
+
+    def _render_frame(self, baseline=False):
+        """Flow field (u component) + turbines, like the reference's _render_frame (:1040-1083); returns the frame as
+        uint8 [H, W, 3] (off-screen Agg canvas — no display / IPython on a GPU box)."""
+        from matplotlib.backends.backend_agg import FigureCanvasAgg
+        from matplotlib.figure import Figure
+        if not hasattr(self, "view"):
+            self.init_render()
+        uvw = self.get_windspeed(baseline=baseline)
+        fs_use = self.fs_baseline if baseline else self.fs
+        wt = fs_use.windTurbines
+        x_turb, y_turb = wt.positions_xyz[:2]
+        fig = Figure(figsize=(10, 4), dpi=100)
+        canvas = FigureCanvasAgg(fig)
+        ax = fig.add_subplot(111)
+        pc = ax.pcolormesh(self.view["x"], self.view["y"], uvw[0].T, shading="nearest")
+        fig.colorbar(pc, ax=ax, label="u [m/s]")
+        R = 0.5 * self.turbine.diameter()
+        for xt, yt, g in zip(x_turb, y_turb, np.deg2rad(np.asarray(wt.yaw, dtype=float))):
+            # rotor disc seen from above: a line normal to the (yawed) rotor axis
+            ax.plot([xt + R * np.sin(g), xt - R * np.sin(g)], [yt - R * np.cos(g), yt + R * np.cos(g)], "k-", lw=2)
+        ax.set_aspect("equal")
+        ax.set_xlabel("x [m]"), ax.set_ylabel("y [m]")
+        ax.set_title("Flow field at {} s".format(fs_use.time))
+        canvas.draw()
+        return np.asarray(canvas.buffer_rgba())[..., :3].copy()
+
     def render(self):
-        raise NotImplementedError("rendering is not part of the MI355X step() path")
+        if self.render_mode == "rgb_array":
+            return self._render_frame()
+        return None
+
+    def plot_frame(self, baseline=False):
+        """Plots a single frame of the flow field and the wind turbines (:1098-1103); returns the image."""
+        self.init_render()
+        return self._render_frame(baseline=baseline)
 
     def close(self):
         b = getattr(self, "_batch", None)
