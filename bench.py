@@ -103,13 +103,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # under torch.distributed.run (RANK / MASTER_PORT in the env) the RCCL group is always created — also for one
+    # rank, so that the single-GPU box exercises exactly the collectives the 8-GPU run uses
+    dist_on = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if dist_on else 0)
 
     from windgym_amd import binding
     from windgym_amd.parallel import ShardedMetrics
@@ -130,7 +133,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -157,7 +160,7 @@ def main():
     m = metrics.all_reduce()            # the only collective on the path: 8 floats
 
     t = torch.tensor([el], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el_max = float(t.item())
     total_envs = B * world
@@ -206,7 +209,7 @@ def main():
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

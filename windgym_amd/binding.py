@@ -40,6 +40,10 @@ def load_library():
         raise WindGymHipError(
             f"{LIB_PATH} is missing: build it with `python -m windgym_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the step() path.")
+    # torch first: its bundled HIP runtime must be the one the process initialises — loading ours against the
+    # system libamdhip64 before `import torch` leaves two runtimes in the process and hipSetDevice then fails with
+    # "no ROCm-capable device is detected"
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.wg_last_error.restype = C.c_char_p
     L.wg_create.argtypes = [C.POINTER(CConfig), C.c_int, C.POINTER(C.c_void_p)]

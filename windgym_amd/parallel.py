@@ -27,7 +27,7 @@ def global_seeds(base_seed: int, n_envs_total: int, rank: int, world: int):
 def reduce_metric_vector(vec):
     """all-reduce(sum) of the 8-float partial-sum vector (in place) when a process group exists."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
     return vec
 
