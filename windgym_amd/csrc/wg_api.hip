@@ -189,7 +189,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     int rc = 0;
 #define A(field, n, st) if (!rc) rc = dev_alloc(h, &d.field, (n), (st))
     A(py, n_slots * p.NP, true); A(rec_a, n_slots * p.NP, true); A(rec_b, n_slots * p.NP, true);
-    A(u_e, n_slots * p.NP, true);
+
     if (p.turb_mode != WG_TURB_NONE) {
         A(pz, n_slots * p.NP, true); A(vlp, n_slots * p.NP, true); A(wlp, n_slots * p.NP, true);
     }
@@ -267,6 +267,10 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         // workgroups per CU (a single-wave workgroup needs no barriers at all); big farms want more lanes
         f.block = p.NP <= 1024 ? 64 : (p.NP <= 8192 ? 128 : 256);   // measured on cfg2 (NP = 2048): 128 best
         if (const char* ev = getenv("WG_FLOW_BLOCK")) { int b = atoi(ev); if (b == 64 || b == 128 || b == 256) f.block = b; }
+        // frozen-record layout for the deficit gathers follows the workgroup size (k_flow<256> reads rec4)
+        if (f.block == 256) { if (!rc) rc = dev_alloc(h, &d.rec4, n_slots * p.NP, true); }
+        else { if (!rc) rc = dev_alloc(h, &d.u_e, n_slots * p.NP, true); }
+        if (rc) { wg_destroy(h); return rc; }
         size_t off = sizeof(float) * 4 * (size_t)tc * p.N;
         f.lds_off_turb = (int)off; off += (size_t)WG_TURB_LDS_BYTES * p.N;
         off = (off + 15) & ~(size_t)15;
@@ -287,7 +291,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         f.inv_sqrt_S = 1.0f / std::sqrt((float)p.S);
         FlowPtrs& g = h->fd;
         memset(&g, 0, sizeof(g));
-        g.py = d.py; g.rec_a = d.rec_a; g.rec_b = d.rec_b; g.u_e = d.u_e;
+        g.py = d.py; g.rec_a = d.rec_a; g.rec_b = d.rec_b; g.u_e = d.u_e; g.rec4 = d.rec4;
         g.pz = d.pz; g.vlp = d.vlp; g.wlp = d.wlp;
         g.bnd = d.bnd;
         g.dbg = nullptr;

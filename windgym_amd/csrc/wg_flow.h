@@ -32,6 +32,7 @@ struct FlowP {
 
 struct FlowPtrs {
     float *py, *u_e, *pz, *vlp, *wlp;
+    uint4* rec4;                  // gather copy of the frozen record per particle: (rec_a, rec_b, bits of u_e, 0); used instead of u_e when block == 256
     unsigned *rec_a, *rec_b;      // packed emission record (see wg_flow.hip)
     const float4* box4;          // interleaved copy of the turbulence box: [Nx][Ny][Nz] x (u, v, w, 0)
     const float4* box4c;         // the same block-averaged over 4x4x4 cells

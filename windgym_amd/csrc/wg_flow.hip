@@ -265,6 +265,9 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     float* __restrict__ gpy = d.py + pbase;
     unsigned* __restrict__ gra = d.rec_a + pbase;
     unsigned* __restrict__ grb = d.rec_b + pbase;
+    // large farms (256-thread workgroups): the frozen record is gathered from a 16-byte AoS copy, see phase A
+    constexpr bool AOS = (NT == 256);
+    uint4* __restrict__ gr4 = d.rec4 + pbase;
     float* __restrict__ gue = d.u_e + pbase;
     if (TURB != WG_TURB_NONE) {
         // turbulent inflow: every valid particle meanders -> all state arrays are streamed (py, pz, vlp, wlp r/w,
@@ -349,8 +352,10 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 const float y0 = (float)tq.yr;
                 if (e < n_emit) {
                     pyv[u] = y0; pzv[u] = p.hub; vlv[u] = 0.f; wlv[u] = 0.f;
-                    gra[ix] = pack_a(tq.rct, tq.rk); grb[ix] = pack_b(tq.reps, tq.rhv);
-                    gue[ix] = tq.rue;
+                    const unsigned na = pack_a(tq.rct, tq.rk), nb = pack_b(tq.reps, tq.rhv);
+                    gra[ix] = na; grb[ix] = nb;
+                    if (AOS) gr4[ix] = make_uint4(na, nb, __float_as_uint(tq.rue), 0u);
+                    else gue[ix] = tq.rue;
                 }
                 const float ex = fabsf(pyv[u] - y0) + fabsf(pzv[u] - p.hub);
                 if (ex > tq.bd) atomicMax(reinterpret_cast<int*>(&tq.bd), __float_as_int(ex));
@@ -429,7 +434,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                         int ei = e0s[q] + i; if (ei >= P) ei -= P;
                         if (ei < n_emit) {
                             pyv[i] = y0; rav[i] = pack_a(tq.rct, tq.rk); rbv[i] = pack_b(tq.reps, tq.rhv);
-                            gue[i4 + i] = tq.rue;
+                            if (AOS) gr4[i4 + i] = make_uint4(rav[i], rbv[i], __float_as_uint(tq.rue), 0u);
+                            else gue[i4 + i] = tq.rue;
                         }
                     }
                     *reinterpret_cast<uint4*>(gra + i4) = make_uint4(rav[0], rav[1], rav[2], rav[3]);
@@ -486,9 +492,22 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     int r0 = new_head - j; if (r0 < 0) r0 += P;
                     int r1 = r0 - 1; if (r1 < 0) r1 += P;
                     const unsigned i0 = (unsigned)(s2 * P + r0), i1 = (unsigned)(s2 * P + r1);
-                    // one round of gathers (L2 hits: this workgroup wrote these lines a moment ago)
-                    const float py0 = gpy[i0], py1 = gpy[i1], u0 = gue[i0], u1 = gue[i1];
-                    const unsigned a0 = gra[i0], a1 = gra[i1], b0_ = grb[i0], b1_ = grb[i1];
+                    // one round of gathers.  Small farms: the lines were streamed by this workgroup a moment ago (L2
+                    // hits).  Large farms (AOS): the particle state of the resident workgroups exceeds L2, every gather
+                    // line comes from HBM and these gathers were half of the kernel's traffic -> the frozen record is
+                    // read from its 16-byte copy (written once, at emission): the two bracketing particles are 32
+                    // contiguous bytes, a pair touches two lines (record, py) instead of four (py, u_e, rec_a, rec_b)
+                    const float py0 = gpy[i0], py1 = gpy[i1];
+                    float u0, u1;
+                    unsigned a0, a1, b0_, b1_;
+                    if (AOS) {
+                        const uint4 q0 = gr4[i0], q1 = gr4[i1];
+                        u0 = __uint_as_float(q0.z); u1 = __uint_as_float(q1.z);
+                        a0 = q0.x; a1 = q1.x; b0_ = q0.y; b1_ = q1.y;
+                    } else {
+                        u0 = gue[i0]; u1 = gue[i1];
+                        a0 = gra[i0]; a1 = gra[i1]; b0_ = grb[i0]; b1_ = grb[i1];
+                    }
                     const float k0 = rec_k(a0), k1 = rec_k(a1), e0 = rec_eps(b0_), e1 = rec_eps(b1_);
                     const float c0 = rec_ct(a0), c1 = rec_ct(a1);
                     const float w0 = 1.0f - wgt, w1 = wgt;
@@ -941,7 +960,14 @@ k_windspeed(const FlowP p, const FlowPtrs d, const int e, const int farm, const 
         int r0 = head - (int)j; if (r0 < 0) r0 += P;
         int r1 = r0 - 1; if (r1 < 0) r1 += P;
         const size_t i0 = pbase + (size_t)s2 * P + r0, i1 = pbase + (size_t)s2 * P + r1;
-        const unsigned a0 = d.rec_a[i0], a1 = d.rec_a[i1], b0 = d.rec_b[i0], b1 = d.rec_b[i1];
+        unsigned a0, a1, b0, b1;
+        float ue0, ue1;
+        if (d.rec4) {
+            const uint4 q0 = d.rec4[i0], q1 = d.rec4[i1];
+            a0 = q0.x; a1 = q1.x; b0 = q0.y; b1 = q1.y; ue0 = __uint_as_float(q0.z); ue1 = __uint_as_float(q1.z);
+        } else {
+            a0 = d.rec_a[i0]; a1 = d.rec_a[i1]; b0 = d.rec_b[i0]; b1 = d.rec_b[i1]; ue0 = d.u_e[i0]; ue1 = d.u_e[i1];
+        }
         const float w0 = 1.0f - wgt, w1 = wgt;
         const float yc = w0 * d.py[i0] + w1 * d.py[i1];
         float zc = p.hub;
@@ -949,7 +975,7 @@ k_windspeed(const FlowP p, const FlowPtrs d, const int e, const int farm, const 
         const float ctv = w0 * rec_ct(a0) + w1 * rec_ct(a1);
         const float kv = w0 * rec_k(a0) + w1 * rec_k(a1);
         const float epv = w0 * rec_eps(b0) + w1 * rec_eps(b1);
-        const float uev = w0 * d.u_e[i0] + w1 * d.u_e[i1];
+        const float uev = w0 * ue0 + w1 * ue1;
         const float sp = kv * ((float)dx * p.inv_D) + epv;
         const float sig = sp * p.D;
         const float inv2s2 = 1.0f / (2.0f * sig * sig);

@@ -8,7 +8,8 @@
 //   particle SoA, fp32, [n_slots][N*P] each, ring index fastest -> a workgroup streams contiguous memory:
 //       py                      transverse position of the wake particle (r/w every step)
 //       rec_a, rec_b            frozen emission record ct|k, eps|hv as 16-bit fixed point (read by the advection pass)
-//       u_e                     rotor wind speed at emission (gathered by the deficit pass only)
+//       u_e | rec4              rotor wind speed at emission (small farms) | 16-byte gather copy of the frozen record incl.
+//                               u_e (farms whose workgroups have 256 threads: their deficit gathers miss L2)
 //       pz, vlp, wlp            vertical position + low-pass filtered transverse turbulence (box inflow only)
 //   turbine SoA, fp32, [n_slots][N]: yaw, u, v, w, ti_loc, power, ct
 //   sensors, fp32, per ctx: ring[ch][N][H_ch], farm ring[ch][H_ch]   (MesClass deques)
@@ -109,7 +110,8 @@ struct WgEnv {
 
 struct WgPtrs {
     // particles
-    float *py, *u_e, *pz, *vlp, *wlp;
+    float *py, *u_e, *pz, *vlp, *wlp;   // u_e: rotor wind speed at emission (small farms; NULL when rec4 is used)
+    uint4* rec4;               // gather copy of the frozen emission record: (rec_a, rec_b, bits of u_e, 0), written at emission
     unsigned *rec_a, *rec_b;   // packed emission record: ct|k and eps|hv as 16-bit fixed point
     // turbines [n_slots][N]
     float *yaw, *u, *v, *w, *ti_loc, *power, *ct;
