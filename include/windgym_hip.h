@@ -195,6 +195,13 @@ int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, int ny, int
  * generator still consumes its draws, so seeds stay aligned.  NULL removes the override.                  */
 int wg_set_wind(wg_handle h, const double* wind_host /*[B,3]*/);
 
+/* The same with a caller-owned DEVICE buffer f64[B,3] that is read (stream-ordered) whenever an episode of env b is
+ * initialised — the caller may rewrite it between steps.  This is how site-based sampling (`sample_site`,
+ * WindFarmEnv._set_windconditions / _sample_site, Wind_Farm_Env.py:569-594: wd from the sector frequencies, ws from
+ * the sector's Weibull, both clipped to the env's ranges; TI stays uniform = NaN here) is fed to a running batch
+ * without host synchronisation.  NULL removes the override.                                                 */
+int wg_set_wind_device(wg_handle h, const double* wind_dev /*[B,3]*/);
+
 /* Test hook ("replay mode"): replace the flow physics of both farms by scripted tables so that the glue can
  * be checked against golden vectors recorded from the reference.  uvw_dev: f32[F,T,B,N,3], power_dev:
  * f32[F,T,B,N]; every flow sub-step of farm f in env b consumes row cursor[f,b]++ .  NULL disables.     */

@@ -308,3 +308,51 @@ def test_render_and_flow_field_view(wg, tmp_path):
     img_b = env.plot_frame(baseline=True)
     assert img_b.shape == img.shape
     env.close()
+
+
+def test_set_windconditions_with_site(wg, tmp_path):      # tests/test_basics.py:369-407
+    """sample_site: wd / ws from the site's wind rose, clipped to the env's ranges; TI stays uniform."""
+    from windgym_amd import presets
+    from windgym_amd.site import hornsrev1_site
+    env = wg.WindFarmEnv(turbine=wg.V80(), n_passthrough=1, yaml_path=_yaml(tmp_path, presets.env1_config()),
+                         turbtype="None", seed=7, sample_site=hornsrev1_site())
+    samples = []
+    for _ in range(10):
+        env._set_windconditions()
+        samples.append((env.ws, env.wd, env.ti))
+    for ws, wd, ti in samples:
+        assert env.ws_min <= ws <= env.ws_max and env.wd_min <= wd <= env.wd_max and env.TI_min <= ti <= env.TI_max
+    assert len({s[0] for s in samples}) > 1 and len({s[2] for s in samples}) > 1
+    # the episodes themselves use the site's draw: integer directions (1-degree wind rose), clipped speeds
+    seen = []
+    for i in range(6):
+        env.reset(seed=100 + i)
+        assert env.ws_min <= env.ws <= env.ws_max and env.wd_min <= env.wd <= env.wd_max
+        assert float(env.wd).is_integer()
+        assert env.TI_min <= env.ti <= env.TI_max
+        seen.append((env.ws, env.wd, env.ti))
+    assert len({s[0] for s in seen}) > 1 and len({s[2] for s in seen}) > 1
+    env.reset(seed=100)                                   # reproducible per seed
+    assert (env.ws, env.wd, env.ti) == seen[0]
+    env.close()
+
+    # batched: every new episode of every env gets a fresh draw from the device-resident table
+    d = presets.two_turb_config()
+    d["wind"].update(ws_min=6, ws_max=14, wd_min=250, wd_max=290)
+    venv = wg.WindFarmVecEnv(wg.V80(), 64, yaml_path=_yaml(tmp_path, d, "v.yaml"), turbtype="None", seed=1,
+                             n_passthrough=1, sample_site=hornsrev1_site())
+    venv.reset(seed=1)
+    first = np.stack([venv.infos()["Wind speed Global"], venv.infos()["Wind direction Global"]], axis=1).copy()
+    assert (first[:, 0] >= 6).all() and (first[:, 0] <= 14).all() and (first[:, 1] >= 250).all() and (first[:, 1] <= 290).all()
+    assert np.allclose(first[:, 1], np.round(first[:, 1])) and len(np.unique(first[:, 0])) > 20
+    n_tr = 0
+    for _ in range(400):
+        _, _, _, tr, _ = venv.step(np.zeros((64, venv.n_turb), dtype=np.float32))
+        n_tr += int(np.sum(tr))
+    assert n_tr >= 64
+    later = np.stack([venv.infos()["Wind speed Global"], venv.infos()["Wind direction Global"]], axis=1)
+    assert (later[:, 0] >= 6).all() and (later[:, 0] <= 14).all() and (later[:, 1] >= 250).all() and (later[:, 1] <= 290).all()
+    assert np.allclose(later[:, 1], np.round(later[:, 1]))
+    assert (np.abs(later[:, 0] - first[:, 0]) > 1e-6).mean() > 0.8     # new episodes, new draws
+    venv.batch.check()
+    venv.close()

@@ -1,0 +1,31 @@
+"""Site-based wind sampling (sample_site, Wind_Farm_Env.py:569-594) — host side, no GPU."""
+import numpy as np
+
+from windgym_amd.site import WeibullSite, hornsrev1_site, sample_site, site_tables
+
+
+def test_site_tables_follow_the_reference_call():
+    dirs, freqs, As, ks = site_tables(hornsrev1_site())
+    assert dirs.shape == freqs.shape == As.shape == ks.shape == (360,)
+    assert abs(freqs.sum() - 1.0) < 1e-12 and (freqs > 0).all()
+    # sector centres reproduce the table, in between it is interpolated linearly
+    s = hornsrev1_site()
+    assert abs(As[30] - s.A[1]) < 1e-12 and abs(ks[270] - s.k[9]) < 1e-12
+    assert abs(As[15] - 0.5 * (s.A[0] + s.A[1])) < 1e-12
+    # westerly winds dominate at Horns Rev
+    assert freqs[240:300].sum() > 2.0 * freqs[0:60].sum()
+
+
+def test_sampling_statistics_and_clipping():
+    rng = np.random.default_rng(3)
+    site = WeibullSite(f=[1, 0, 0, 3], A=[8, 8, 8, 12], k=[2, 2, 2, 2.5])
+    wd, ws = sample_site(site, 40000, rng)
+    # directions: the wind rose is interpolated between the 4 sector centres, most mass around 270 deg
+    assert ((wd >= 225) & (wd < 315)).mean() > 0.45
+    sel = wd == 270
+    # Weibull mean A * Gamma(1 + 1/k) for the 270-degree bin (A = 12, k = 2.5)
+    from math import gamma
+    assert abs(ws[sel].mean() - 12 * gamma(1 + 1 / 2.5)) < 0.35
+    wd_c, ws_c = sample_site(site, 2000, rng, wd_range=(260, 280), ws_range=(6, 10))
+    assert wd_c.min() >= 260 and wd_c.max() <= 280 and ws_c.min() >= 6 and ws_c.max() <= 10
+    assert len(set(ws_c.tolist())) > 10

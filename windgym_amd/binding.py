@@ -20,7 +20,7 @@ UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 # every symbol include/windgym_hip.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = (
     "wg_last_error", "wg_abi_version", "wg_create", "wg_destroy", "wg_obs_dim", "wg_hist_max",
-    "wg_set_turbulence_box", "wg_set_wind", "wg_set_flow_script", "wg_reset", "wg_step", "wg_check", "wg_obs_multi",
+    "wg_set_turbulence_box", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_check", "wg_obs_multi",
     "wg_get_info", "wg_get_measurements", "wg_get_windspeed", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_algorithmic_bytes",
 )
 
@@ -54,6 +54,7 @@ def load_library():
                                         C.c_double, C.c_double]
     L.wg_set_flow_script.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.wg_set_wind.argtypes = [C.c_void_p, C.c_void_p]
+    L.wg_set_wind_device.argtypes = [C.c_void_p, C.c_void_p]
     L.wg_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.wg_step.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     L.wg_check.argtypes = [C.c_void_p, C.c_void_p]
@@ -211,6 +212,18 @@ class HipBatch:
                 w[:, k] = np.broadcast_to(np.asarray(v, dtype=np.float64), (self.B,))
         w = np.ascontiguousarray(w)
         _chk(self.L.wg_set_wind(self._h, w.ctypes.data_as(C.c_void_p)), "wg_set_wind")
+
+    def set_wind_device(self, wind):
+        """Borrow a CUDA float64 tensor [B, 3] = (ws, wd, ti; NaN = keep the sampled value) as the per-env wind
+        override; the caller may rewrite it between steps (stream-ordered).  None removes it."""
+        if wind is None:
+            self._wind_dev = None
+            _chk(self.L.wg_set_wind_device(self._h, None), "wg_set_wind_device")
+            return
+        t = self.torch
+        assert wind.is_cuda and wind.dtype == t.float64 and wind.is_contiguous() and tuple(wind.shape) == (self.B, 3)
+        self._wind_dev = wind                                   # keep it alive
+        _chk(self.L.wg_set_wind_device(self._h, C.c_void_p(wind.data_ptr())), "wg_set_wind_device")
 
     def set_flow_script(self, uvw, power):
         """Replay mode (test hook).  uvw [F,T,B,N,3], power [F,T,B,N] (array-likes)."""

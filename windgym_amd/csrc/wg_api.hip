@@ -418,6 +418,12 @@ extern "C" int wg_set_wind(wg_handle h, const double* wind_host) {
     return 0;
 }
 
+extern "C" int wg_set_wind_device(wg_handle h, const double* wind_dev) {
+    if (!h) return fail(WG_ERR_INVALID, "null handle");
+    h->d.wind_override = wind_dev;      // borrowed; read by ctx_init (k_init / k_glue) in stream order
+    return 0;
+}
+
 extern "C" int wg_set_flow_script(wg_handle h, const float* uvw_dev, const float* power_dev, int n_rows) {
     if (!h) return fail(WG_ERR_INVALID, "null handle");
     h->d.script_uvw = uvw_dev;

@@ -117,11 +117,19 @@ class WindFarmVecEnv:
     """
 
     def __init__(self, turbine, n_envs: int, yaml_path=None, *, seed: Optional[int] = 0, device: Optional[int] = None,
-                 as_torch: bool = False, autoreset: bool = True, turbulence_box=None, **kwargs):
+                 as_torch: bool = False, autoreset: bool = True, turbulence_box=None, sample_site=None, **kwargs):
         self.cfg = EnvConfig(turbine=turbine, yaml_path=yaml_path, n_envs=int(n_envs), autoreset=autoreset,
                              seed=seed, **kwargs)
         self.batch = HipBatch(self.cfg, device=device)
         _attach_box(self.batch, self.cfg, turbulence_box)
+        # site-based wind sampling (Wind_Farm_Env.py:569-594) for the whole batch: a device-resident override table
+        # refreshed with torch ops before every step, so every episode initialisation sees an independent draw
+        self._site = None
+        if sample_site is not None:
+            from .site import DeviceSiteSampler
+            c = self.cfg
+            self._site = DeviceSiteSampler(sample_site, self.batch, (c.wd_min, c.wd_max), (c.ws_min, c.ws_max),
+                                           seed=0 if seed is None else seed)
         self.num_envs = self.n_envs = int(n_envs)
         self.n_turb = self.cfg.n_turb
         self.as_torch = as_torch
@@ -169,6 +177,8 @@ class WindFarmVecEnv:
         elif not (actions.is_cuda and actions.dtype == t.float32 and actions.is_contiguous()):
             self._actions.copy_(actions.reshape(self.num_envs, self.n_turb))
             actions = self._actions
+        if self._site is not None:
+            self._site.refresh()
         obs, rew, trunc, fin = self.batch.step(actions)
         term = t.zeros_like(trunc, dtype=t.bool)                         # terminated is always False (:1029)
         infos = self.infos()
@@ -271,8 +281,8 @@ class WindFarmEnv(_EnvBase):
     """Single farm with the reference's API (WindGym/Wind_Farm_Env.py:47-1034), backed by a batch of 1.
 
     Differences, all documented in DESIGN.md §3: the flow physics is model M0 (DYNAMIKS is not available);
-    ``HTC_path`` (HAWC2 turbines) and ``sample_site`` are not part of the step() path and raise
-    ``NotImplementedError``.  Rendering draws the flow field evaluated on the device (k_windspeed) off-screen.
+    ``HTC_path`` (HAWC2 turbines) is not part of the step() path and raises ``NotImplementedError``.
+    ``sample_site`` takes any object with py_wake's ``Site.local_wind`` duck type (windgym_amd.site.WeibullSite).  Rendering draws the flow field evaluated on the device (k_windspeed) off-screen.
     """
 
     metadata = {"render_modes": ["human", "rgb_array"]}
@@ -286,8 +296,8 @@ class WindFarmEnv(_EnvBase):
                  n_rotor_pts=16, x_pos=None, y_pos=None, turbulence_box=None):
         if HTC_path is not None:
             raise NotImplementedError("HAWC2 turbines (HTC_path) are outside the MI355X step() path")
-        if sample_site is not None:
-            raise NotImplementedError("site-based wind sampling (sample_site) is not implemented in this build")
+        self.sample_site = sample_site
+        self._site_rng = np.random.default_rng(seed)     # the reference draws from numpy's global, unseeded state
         assert render_mode is None or render_mode in self.metadata["render_modes"]
         self.render_mode = render_mode
         self.turbine = turbine
@@ -356,12 +366,36 @@ class WindFarmEnv(_EnvBase):
         if self._dirty:
             self._build()
         seeds = None if seed is None else np.array([seed], dtype=np.uint64)
+        if self.sample_site is not None:                 # _set_windconditions with a site (:569-584)
+            if seed is not None:
+                self._site_rng = np.random.default_rng(seed)
+            from .site import sample_site
+            wd, ws = sample_site(self.sample_site, 1, self._site_rng, (self.wd_min, self.wd_max), (self.ws_min, self.ws_max))
+            self._batch.set_wind(ws=ws, wd=wd, ti=None)  # TI stays uniform, drawn on the device
+            self._site_active = True
+        elif getattr(self, "_site_active", False):
+            self._batch.set_wind()
+            self._site_active = False
         obs = self._batch.reset(seeds=seeds)
         self._batch.check()
         self._torn_down = False
         self.timestep = 0
         self._refresh_episode_attrs()
         return _np(obs)[0].copy(), self._get_info()
+
+    def _set_windconditions(self):
+        """Host-side restatement of Wind_Farm_Env.py:557-584 for callers that probe it (the episode's own draw is
+        made inside reset(): on the device without a site, from the site's wind rose with one)."""
+        rng = self._site_rng
+        if self.sample_site is None:
+            self.ws = float(rng.uniform(self.ws_min, self.ws_max))
+            self.ti = float(rng.uniform(self.TI_min, self.TI_max))
+            self.wd = float(rng.uniform(self.wd_min, self.wd_max))
+        else:
+            from .site import sample_site
+            wd, ws = sample_site(self.sample_site, 1, rng, (self.wd_min, self.wd_max), (self.ws_min, self.ws_max))
+            self.wd, self.ws = float(wd[0]), float(ws[0])
+            self.ti = float(rng.uniform(self.TI_min, self.TI_max))
 
     def _refresh_episode_attrs(self):
         b = self._batch
