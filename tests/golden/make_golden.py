@@ -409,6 +409,61 @@ def run_case(mods, name, cfg, kwargs, n_steps, seed, script_seed, multi=False, n
           f" ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def fuzz_cfg(rng):
+    """A random but valid YAML document + constructor kwargs: every switch of the glue gets exercised in
+    combinations the hand-written scenarios do not cover."""
+    def mes(prefix):
+        hlen = int(rng.integers(1, 40))
+        win = int(rng.integers(1, hlen + 1))
+        cur, rol = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        if not cur and not rol:
+            rol = True
+        return {f"{prefix}_current": cur, f"{prefix}_rolling_mean": rol,
+                f"{prefix}_history_N": int(rng.integers(1, 6)), f"{prefix}_history_length": hlen,
+                f"{prefix}_window_length": win}
+    flags = {k: bool(rng.integers(0, 2)) for k in ("turb_ws", "turb_wd", "turb_TI", "turb_power", "farm_ws",
+                                                   "farm_wd", "farm_TI", "farm_power")}
+    if not any(flags.values()):
+        flags["turb_ws"] = True
+    reward = str(rng.choice(["Baseline", "Power_avg", "None", "Power_diff"]))
+    pavg = int(rng.integers(40, 70)) if reward == "Power_diff" else int(rng.integers(1, 30))
+    ymin = -float(rng.choice([10, 25, 45]))
+    cfg = base_cfg(
+        yaw_init=str(rng.choice(["Zeros", "Random"])), BaseController=str(rng.choice(["Local", "Global"])),
+        ActionMethod=str(rng.choice(["yaw", "wind"])),
+        farm=dict(yaw_min=ymin, yaw_max=float(rng.choice([15, 30, 45])), xDist=float(rng.choice([3, 4, 6.5])),
+                  yDist=float(rng.choice([3, 4, 5])), nx=int(rng.integers(1, 4)), ny=int(rng.integers(1, 3))),
+        wind=dict(ws_min=float(rng.uniform(5, 9)), ws_max=float(rng.uniform(9, 16)), TI_min=0.02, TI_max=0.15,
+                  wd_min=float(rng.uniform(240, 268)), wd_max=float(rng.uniform(272, 300))),
+        act_pen=dict(action_penalty=float(rng.choice([0.0, 0.0005, 0.05, 0.4])),
+                     action_penalty_type=str(rng.choice(["Change", "Total"]))),
+        power_def=dict(Power_reward=reward, Power_avg=pavg, Power_scaling=float(rng.choice([1.0, 0.5, 3.0]))),
+        mes_level=flags, ws_mes=mes("ws"), wd_mes=mes("wd"), yaw_mes=mes("yaw"), power_mes=mes("power"),
+    )
+    fill = [True, False, int(rng.integers(2, 9))][int(rng.integers(0, 3))]
+    kwargs = dict(n_passthrough=int(rng.integers(1, 3)), fill_window=fill, dt_sim=1, dt_env=int(rng.choice([1, 1, 2])),
+                  yaw_step=float(rng.choice([0.5, 1, 2.5])), Baseline_comp=bool(rng.integers(0, 2)),
+                  TI_min_mes=float(rng.choice([0.0, 0.01])), TI_max_mes=float(rng.choice([0.5, 0.3])))
+    return cfg, kwargs
+
+
+def fuzz_cases(mods, n=16):
+    rng = np.random.default_rng(20260929)
+    made = 0
+    tries = 0
+    while made < n and tries < 200:
+        tries += 1
+        cfg, kwargs = fuzz_cfg(rng)
+        try:
+            run_case(mods, f"fuzz{made:02d}", cfg, kwargs, int(rng.integers(30, 90)), seed=int(rng.integers(1, 10**6)),
+                     script_seed=500 + tries, n_episodes=int(rng.choice([1, 1, 2])),
+                     action_kind=str(rng.choice(["uniform", "uniform", "const"])))
+            made += 1
+        except (ValueError, NotImplementedError, ZeroDivisionError) as e:      # combination the reference rejects
+            print(f"fuzz try {tries}: reference raised {type(e).__name__}: {e}")
+    assert made == n
+
+
 def mes_unit_cases(mods):
     """Known answers of the bare `Mes` window logic for a sweep of (history_N, window, length, count)."""
     Mes = mods["MesClass"].Mes
@@ -469,6 +524,8 @@ def main():
              dict(n_passthrough=2), 300, seed=51, script_seed=110, multi=True)
     run_case(mods, "multi_env1", cfg_env1(), dict(n_passthrough=2), 200, seed=52, script_seed=111,
              multi=True)
+    # randomised combinations of every switch of the glue
+    fuzz_cases(mods)
 
 
 if __name__ == "__main__":
