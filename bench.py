@@ -90,6 +90,8 @@ def main():
                     help="cfg2 is the headline metric; the others are BASELINE.json's remaining GPU configs")
     ap.add_argument("--one-farm", action="store_true", help="F=1 (no baseline farm)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-autoreset", action="store_true",
+                    help="diagnostic only: no background episodes (the run must stay shorter than the shortest episode)")
     ap.add_argument("--cpu-envs", type=int, default=64)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-max-steps", type=int, default=400)
@@ -117,7 +119,7 @@ def main():
     from windgym_amd import binding
     from windgym_amd.parallel import ShardedMetrics
     B = args.envs if args.envs else WORKLOADS[args.workload][0]
-    cfg = make_cfg(B, autoreset=True, farms2=not args.one_farm, workload=args.workload)
+    cfg = make_cfg(B, autoreset=not args.no_autoreset, farms2=not args.one_farm, workload=args.workload)
     env = binding.HipBatch(cfg, device=dev.index)
     if args.workload == "cfg5":
         from windgym_amd.mann import generate_mann_box_torch, reference_box_spec

@@ -636,10 +636,16 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int F = p.F, N = p.N;
     const int bid = blockIdx.x;
-    const int farm = bid % F;
     const int ec = bid / F;
-    const int c = ec & 1;
     const int e = ec >> 1;
+    // Which of the env's two contexts this workgroup serves is a pseudo-random function of the env index.  The
+    // dispatcher hands workgroups to XCDs / shader engines / CUs in fixed round-robin patterns of blockIdx; with the
+    // context bit taken straight from the index, "all live farms" (after a synchronised start every env has
+    // live == 0) and "background work only" land on disjoint halves of the chip: measured 4.3 resident workgroups
+    // per CU instead of 9 and a launch that lasts as long as the loaded half.  Hashing the bit spreads both kinds of
+    // work over every XCD, SE and CU whatever the pattern is.
+    const int c = (ec & 1) ^ (int)((((uint32_t)e * 2654435761u) >> 13) & 1u);
+    const int farm = bid % F;      // (hashing the farm index as well was measured neutral)
     const int tid = threadIdx.x;
     const int ctx_id = e * 2 + c;
     const int slot_id = ctx_id * F + farm;

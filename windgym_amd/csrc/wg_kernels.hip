@@ -251,6 +251,21 @@ __device__ inline float deque_at(const float* dq, int n_total, int maxlen, int q
     return dq[(n_total - n + q) % maxlen];
 }
 
+// Share of the background episode's remaining work (flow sub-steps) to run during the next step(), `left` steps
+// before the running episode truncates.  work/left per step on average, spread EVENLY: floor(work/left + phi) with a
+// low-discrepancy dither phi (golden-ratio sequence over the step index, de-phased per env).  The ratio is recomputed
+// from the remaining quantities every step, so the schedule is self-correcting, and at left == 1 it returns all that
+// remains: the episode is ready exactly at truncation.  (ceil(work/left) — the first version — front-loads: a
+// background episode needing 280 steps during a 600-step episode ran on each of the first 280 launches, so after a
+// synchronised start every launch carried twice the flow work of the steady state.)
+__device__ inline int shadow_share(const int work, long left, const int steps_done, const int e) {
+    if (work <= 0) return 0;
+    if (left < 1) left = 1;
+    const uint32_t phi24 = ((uint32_t)steps_done * 2654435769u + (uint32_t)e * 0x9E3779B1u) >> 8;   // [0, 2^24)
+    const unsigned long long num = ((unsigned long long)work << 24) + (unsigned long long)phi24 * (unsigned long long)left;
+    return (int)(num / ((unsigned long long)left << 24));
+}
+
 // plan how many flow sub-steps the background episode must advance during the next step() so that it is
 // ready exactly when the running episode truncates
 __device__ inline int plan_shadow(const WgParams& p, const WgPtrs& d, const WgEnv& env, int e) {
@@ -265,9 +280,7 @@ __device__ inline int plan_shadow(const WgParams& p, const WgPtrs& d, const WgEn
     const int inc = 1 + (p.extra_inc ? 1 : 0);
     const int tm = d.ctx[e * 2 + live].time_max;
     const long total = (long)((tm + inc - 1) / inc) + 1;
-    long left = total - env.steps_done;
-    if (left < 1) left = 1;
-    return (int)((work + left - 1) / left);
+    return shadow_share(work, total - env.steps_done, env.steps_done, e);
 }
 
 // ===================================================================================================
@@ -501,9 +514,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         else {
             const int inc = 1 + (p.extra_inc ? 1 : 0);
             const long total = (long)((time_max + inc - 1) / inc) + 1;
-            long left = total - ev.steps_done;
-            if (left < 1) left = 1;
-            ev.shadow_iters = (int)((work + left - 1) / left);
+            ev.shadow_iters = shadow_share(work, total - ev.steps_done, ev.steps_done, e);
         }
     }
     if (lane == 0) env = ev;
