@@ -90,6 +90,7 @@ def main():
                     help="cfg2 is the headline metric; the others are BASELINE.json's remaining GPU configs")
     ap.add_argument("--one-farm", action="store_true", help="F=1 (no baseline farm)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--full-chains", action="store_true", help="no chain pruning: advect all P slots of every chain")
     ap.add_argument("--no-autoreset", action="store_true",
                     help="diagnostic only: no background episodes (the run must stay shorter than the shortest episode)")
     ap.add_argument("--cpu-envs", type=int, default=64)
@@ -120,6 +121,7 @@ def main():
     from windgym_amd.parallel import ShardedMetrics
     B = args.envs if args.envs else WORKLOADS[args.workload][0]
     cfg = make_cfg(B, autoreset=not args.no_autoreset, farms2=not args.one_farm, workload=args.workload)
+    cfg.advect_full_chains = bool(args.full_chains)
     env = binding.HipBatch(cfg, device=dev.index)
     if args.workload == "cfg5":
         from windgym_amd.mann import generate_mann_box_torch, reference_box_spec
@@ -157,7 +159,7 @@ def main():
         one_step(i)
     barrier()
     el = time.perf_counter() - t0
-    flow_ms, glue_ms, n_launch, flow_steps = env.kernel_timing(False)
+    flow_ms, glue_ms, n_launch, flow_steps, particles = env.kernel_timing(False)
     env.check()
     m = metrics.all_reduce()            # the only collective on the path: 8 floats
 
@@ -170,15 +172,16 @@ def main():
 
     if rank == 0:
         F = cfg.to_c().n_farms
-        # algorithmic bytes of one k_flow launch = farm flow-steps it executed (live farms + background
-        # development of the next episodes, counted on the device) x bytes per farm flow-step:
-        # per particle: py read+write (8) + packed record ct|k, eps|hv read (8); per turbine: state r/w + positions
+        # algorithmic bytes of one k_flow launch, from two counts made on the device: the wake
+        # particles the advection passes streamed (chain pruning: a particle behind the last turbine is not touched)
+        # and the farm flow-steps executed (live farms + background development of the next episodes).
+        # per particle: py read+write (8) + packed record ct|k, eps|hv read (8); per turbine: state r/w + positions;
         # box: + pz,vlp,wlp r/w (24) + 8 corners x (v, w) of the meandering box per particle (64), 8 corners x
         # (u, v, w) of the fine box per rotor point (96)
         per_particle = 16.0 + (24.0 + 64.0 if args.workload == "cfg5" else 0.0)
-        bytes_per_flow_step = (cfg.n_turb * cfg.n_particles * per_particle + cfg.n_turb * 72.0
-                               + (cfg.n_turb * cfg.n_rotor_pts * 96.0 if args.workload == "cfg5" else 0.0))
-        alg_bytes_flow = flow_steps * bytes_per_flow_step
+        per_farm_step = cfg.n_turb * 72.0 + (cfg.n_turb * cfg.n_rotor_pts * 96.0 if args.workload == "cfg5" else 0.0)
+        alg_bytes_flow = particles * per_particle + flow_steps * per_farm_step
+        bytes_per_flow_step = alg_bytes_flow / flow_steps if flow_steps > 0 else 0.0
         achieved = alg_bytes_flow / (flow_ms * 1e-3) / 1e9 if flow_ms > 0 else 0.0
         # HBM bytes per k_flow launch from the rocprofv3 PMC passes of this same command (separate runs:
         # tools/profile_kflow.sh -> profiles/r01_kflow_traffic.json); only quoted for the profiled workload
@@ -205,6 +208,8 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic, "kernel": "k_flow",
                          "kernel_ms": flow_ms, "glue_kernel_ms": glue_ms, "launches_timed": n_launch,
                          "algorithmic_bytes_per_launch": alg_bytes_flow, "farm_flow_steps_per_launch": flow_steps,
+                         "particles_streamed_per_launch": particles,
+                         "particle_slots_per_launch": flow_steps * cfg.n_turb * cfg.n_particles,
                          "bytes_per_farm_flow_step": bytes_per_flow_step},
             "episode_metrics": {k: float(v) for k, v in m.items()},
         }

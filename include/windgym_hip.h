@@ -133,6 +133,11 @@ typedef struct wg_config {
     double m0_hill;            /* Hill-vortex deflection speed factor (0.4)                           */
     double m0_ti_a, m0_ti_b, m0_ti_c, m0_ti_d; /* Crespo-Hernandez added TI: a*ind^b*TI^c*(x/D)^d     */
     double m0_fc_scale;        /* meandering low-pass cut-off f_c = U/(fc_scale*D)   (2.0)            */
+    /* ---- chain pruning -------------------------------------------------------------------------- */
+    int32_t full_chains;       /* 0: a wake particle that has passed the most downstream turbine of the farm is no
+                                * longer advected — it cannot reach a rotor any more, every output of step() is
+                                * unchanged; 1: advect all P slots of every chain (needed only if wg_get_windspeed
+                                * must be exact behind the last turbine row)                               */
 } wg_config;
 
 typedef struct wg_env_s* wg_handle;
@@ -254,10 +259,11 @@ int wg_set_state(wg_handle h, const void* blob_host, size_t size);
 /* HIP-event timing of the step kernels on the stream they were launched on: average milliseconds per
  * launch of the dominant flow kernel and of the glue kernel since the last call, and the average number of
  * farm flow-steps one flow launch executed (live farms + background episode development) — the unit
- * count behind bench.py's roofline.  enable = 0 stops; enable = n >= 1 records events around every n-th
+ * count behind bench.py's roofline; particles_per_launch = wake particles the advection passes actually streamed
+ * (chain pruning: particles behind the last turbine are not touched).  enable = 0 stops; enable = n >= 1 records events around every n-th
  * wg_step (an event pair per launch costs a few percent of a ~200 us step).                            */
 int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, double* glue_ms_avg, int* n_launches,
-                     double* flow_steps_per_launch);
+                     double* flow_steps_per_launch, double* particles_per_launch);
 
 /* Algorithmic HBM bytes one wg_step() moves (the figure bench.py's roofline uses).       */
 int wg_algorithmic_bytes(wg_handle h, double* bytes_per_step);

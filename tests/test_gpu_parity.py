@@ -369,6 +369,7 @@ def test_flow_field_view_matches_oracle(hip, oracle_lib, small_mann_box, turbtyp
     import torch
     B = 3
     cfg = _turb_cfg(turbtype, B)
+    cfg.advect_full_chains = True          # the view reaches 1000 m behind the last row: no chain pruning
     env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
     if turbtype != "None":
         box, spacing = small_mann_box
@@ -401,6 +402,42 @@ def test_flow_field_view_matches_oracle(hip, oracle_lib, small_mann_box, turbtyp
     assert top_def < 0.5 * hub_def
     with pytest.raises(Exception):
         env.windspeed(B, xs, ys)
+
+
+def test_chain_pruning_changes_no_output_and_streams_fewer_particles(hip):
+    """wg_config.full_chains = 0 (default for batches): particles behind the most downstream turbine are not advected
+    (compiled into the 256-thread, large-farm variant of k_flow — selected here with WG_FLOW_BLOCK).  Every output of
+    step() must be bit-identical to the run that advects all P slots."""
+    import os
+    import torch
+    B = 8
+    outs = []
+    streamed = []
+    for full in (False, True):
+        cfg = _turb_cfg("None", B)
+        cfg.advect_full_chains = full
+        os.environ["WG_FLOW_BLOCK"] = "256"
+        try:
+            env = hip.HipBatch(cfg)
+        finally:
+            del os.environ["WG_FLOW_BLOCK"]
+        env.reset(seeds=60 + np.arange(B))
+        env.kernel_timing(1)
+        rng = np.random.default_rng(13)
+        rec = []
+        for _ in range(150):
+            a = rng.uniform(-1, 1, size=(B, cfg.n_turb)).astype(np.float32)
+            obs, rew, tr, fin = env.step(torch.as_tensor(a, device="cuda"))
+            rec.append((obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), tr.cpu().numpy().copy()))
+        rec.append((env.info("rotor_uvw_agent").cpu().numpy(), env.info("power_turb_base").cpu().numpy(),
+                    env.info("yaw_base").cpu().numpy()))
+        _, _, _, fsteps, parts = env.kernel_timing(False)
+        streamed.append(parts / (fsteps * cfg.n_turb * cfg.n_particles))
+        outs.append(rec)
+        env.check()
+    for (a0, a1, a2), (b0, b1, b2) in zip(*outs):
+        np.testing.assert_array_equal(a0, b0), np.testing.assert_array_equal(a1, b1), np.testing.assert_array_equal(a2, b2)
+    assert streamed[0] < 0.75 * streamed[1] and streamed[1] > 0.3, streamed
 
 
 def test_mann_box_required(hip):

@@ -67,7 +67,7 @@ def load_library():
     L.wg_get_state.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
     L.wg_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.wg_kernel_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
-                                   C.POINTER(C.c_int), C.POINTER(C.c_double)]
+                                   C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.wg_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     _lib = L
     return L
@@ -259,12 +259,12 @@ class HipBatch:
         _chk(self.L.wg_set_state(self._h, blob, len(blob)), "wg_set_state")
 
     def kernel_timing(self, enable=True):
-        """-> (flow kernel ms/launch, glue kernel ms/launch, launches timed, farm flow-steps per launch).
-        enable: False/0 = stop, True/1 = time every step(), n > 1 = time every n-th step()."""
-        f, g, n, fs = C.c_double(), C.c_double(), C.c_int(), C.c_double()
-        _chk(self.L.wg_kernel_timing(self._h, int(enable), C.byref(f), C.byref(g), C.byref(n), C.byref(fs)),
-             "wg_kernel_timing")
-        return f.value, g.value, n.value, fs.value
+        """-> (flow kernel ms/launch, glue kernel ms/launch, launches timed, farm flow-steps per launch, wake particles
+        streamed per launch).  enable: False/0 = stop, True/1 = time every step(), n > 1 = time every n-th step()."""
+        f, g, n, fs, pt = C.c_double(), C.c_double(), C.c_int(), C.c_double(), C.c_double()
+        _chk(self.L.wg_kernel_timing(self._h, int(enable), C.byref(f), C.byref(g), C.byref(n), C.byref(fs),
+                                     C.byref(pt)), "wg_kernel_timing")
+        return f.value, g.value, n.value, fs.value, pt.value
 
     def algorithmic_bytes(self):
         v = C.c_double()

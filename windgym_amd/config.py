@@ -82,6 +82,7 @@ class CConfig(C.Structure):
         ("m0_ka", C.c_double), ("m0_kb", C.c_double), ("m0_eps", C.c_double), ("m0_hill", C.c_double),
         ("m0_ti_a", C.c_double), ("m0_ti_b", C.c_double), ("m0_ti_c", C.c_double), ("m0_ti_d", C.c_double),
         ("m0_fc_scale", C.c_double),
+        ("full_chains", C.c_int32),
     ]
 
 
@@ -146,6 +147,7 @@ class EnvConfig:
     yaml_dict: Optional[dict] = None             # alternative to yaml_path
     never_truncate: bool = False
     extra_timestep_inc: bool = False
+    advect_full_chains: bool = False             # True: no chain pruning (exact flow-field view behind the last row)
     yaw_defined: Optional[Sequence[float]] = None
     _keep: list = field(default_factory=list, repr=False)
 
@@ -347,4 +349,5 @@ class EnvConfig:
         c.autoreset = int(bool(self.autoreset))
         c.extra_timestep_inc = int(bool(self.extra_timestep_inc))
         c.turb_mode = TURB[self.turbtype]
+        c.full_chains = int(bool(self.advect_full_chains))
         return c

@@ -49,7 +49,7 @@ struct wg_env_s {
     WgPtrs d;
     FlowP fp;
     FlowPtrs fd;
-    unsigned long long flow_steps_mark = 0;
+    unsigned long long flow_steps_mark = 0, particles_mark = 0;
     long n_step_launches = 0;
     void* box4 = nullptr;            // interleaved copy of the caller's turbulence box (owned)
     void* box4c = nullptr;           // block-averaged copy for the particle lookups (owned)
@@ -146,6 +146,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     p.ws_min = c->ws_min; p.ws_max = c->ws_max; p.ti_min = c->ti_min; p.ti_max = c->ti_max;
     p.wd_min = c->wd_min; p.wd_max = c->wd_max; p.n_passthrough = c->n_passthrough;
     p.never_truncate = c->never_truncate;
+    p.full_chains = c->full_chains;
     for (int i = 0; i < WG_N_CH; ++i) p.ch[i] = c->ch[i];
     p.turb_on[WG_CH_WS] = c->turb_ws; p.turb_on[WG_CH_WD] = c->turb_wd; p.turb_on[WG_CH_YAW] = 1;
     p.turb_on[WG_CH_POWER] = c->turb_power;
@@ -197,7 +198,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     A(ti_loc, n_slots * p.N, true); A(power, n_slots * p.N, true); A(ct, n_slots * p.N, true);
     A(bnd, n_slots * p.N * 3, true);
     A(slot, n_slots, true); A(ctx, n_ctx, true); A(env, (size_t)p.B, true);
-    A(xr, n_ctx * p.N, true); A(yr, n_ctx * p.N, true);
+    A(xr, n_ctx * p.N, true); A(yr, n_ctx * p.N, true); A(jneed, n_ctx * p.N, true);
     A(ring, n_ctx * p.ring_stride, true); A(fring, n_ctx * p.fring_stride, true);
     A(cur_ws, n_ctx * p.N, true); A(cur_wd, n_ctx * p.N, true);
     A(pend_farm, n_ctx * p.power_avg, true); A(pend_base, n_ctx * p.power_avg, true);
@@ -275,6 +276,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         f.lds_off_turb = (int)off; off += (size_t)WG_TURB_LDS_BYTES * p.N;
         off = (off + 15) & ~(size_t)15;
         f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S) + sizeof(unsigned) * WG_MASK_WORDS * (size_t)tc + sizeof(float) * (size_t)tc * p.N;
+        off += sizeof(int) * ((size_t)p.N + 1);      // chain-pruning ages + the particle counter
         f.lds_bytes = (int)((off + 15) & ~(size_t)15);
         f.dt = p.dt; f.D = p.D; f.inv_D = p.inv_D; f.hub = p.hub; f.dpart_f = (float)p.dpart; f.R_rot = 0.5f * p.D;
         f.inv_N = 1.0f / (float)p.N; f.inv_S = 1.0f / (float)p.S;
@@ -300,7 +302,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             if (!dev_alloc(h, &dbgp, (size_t)p.B * 2 * p.F * 12, false)) g.dbg = dbgp;
         }
         g.yaw = d.yaw; g.u = d.u; g.v = d.v; g.w = d.w; g.ti_loc = d.ti_loc; g.power = d.power; g.ct = d.ct;
-        g.slot = d.slot; g.ctx = d.ctx; g.env = d.env; g.xr = d.xr; g.yr = d.yr;
+        g.slot = d.slot; g.ctx = d.ctx; g.env = d.env; g.xr = d.xr; g.yr = d.yr; g.jneed = d.jneed;
         g.ring = d.ring; g.fring = d.fring; g.cur_ws = d.cur_ws; g.cur_wd = d.cur_wd;
         g.pend_farm = d.pend_farm; g.pend_base = d.pend_base; g.old_yaw = d.old_yaw;
         g.step_farm_pow = d.step_farm_pow; g.step_base_pow = d.step_base_pow;
@@ -577,15 +579,15 @@ extern "C" int wg_set_state(wg_handle h, const void* blob_host, size_t size) {
 }
 
 extern "C" int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, double* glue_ms_avg, int* n_launches,
-                                double* flow_steps_per_launch) {
+                                double* flow_steps_per_launch, double* particles_per_launch) {
     if (!h) return fail(WG_ERR_INVALID, "null handle");
     HIPCHK(hipDeviceSynchronize());
-    unsigned long long fs_now = 0;
+    unsigned long long fs_now = 0, pt_now = 0;
     {
         const size_t n_slots = (size_t)h->p.B * 2 * h->p.F;
         std::vector<WgSlot> slots(n_slots);
         HIPCHK(hipMemcpy(slots.data(), h->d.slot, sizeof(WgSlot) * n_slots, hipMemcpyDeviceToHost));
-        for (const WgSlot& s : slots) fs_now += s.flow_count;
+        for (const WgSlot& s : slots) { fs_now += s.flow_count; pt_now += s.part_count; }
     }
     double fsum = 0, gsum = 0;
     int nf = 0, ng = 0;
@@ -602,8 +604,17 @@ extern "C" int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, do
     if (n_launches) *n_launches = nf;
     // farm flow-steps per STEP-mode launch since the last call (all launches, sampled or not)
     if (flow_steps_per_launch) *flow_steps_per_launch = h->n_step_launches ? (double)(fs_now - h->flow_steps_mark) / h->n_step_launches : 0.0;
+    // particles streamed by the advection passes per launch (chain pruning makes this < farm steps x N x P);
+    // the per-slot counters are 32-bit: differences stay exact as long as a slot streams < 2^32 particles per window
+    // (counted on the device by the pruning-capable 256-thread variant; the others stream all N x P slots per farm step)
+    if (particles_per_launch) {
+        const double per_launch = h->n_step_launches ? 1.0 / h->n_step_launches : 0.0;
+        *particles_per_launch = h->fp.block == 256 ? (double)(pt_now - h->particles_mark) * per_launch
+                                                   : (double)(fs_now - h->flow_steps_mark) * per_launch * h->p.N * h->p.P;
+    }
     h->n_step_launches = 0;
     h->flow_steps_mark = fs_now;
+    h->particles_mark = pt_now;
     h->ev_used = 0;
     h->timing = enable != 0;
     h->timing_period = enable > 1 ? enable : 1;

@@ -42,6 +42,7 @@ struct FlowPtrs {
     WgCtx* ctx;
     const WgEnv* env;
     const double *xr, *yr;
+    const int* jneed;             // [B*2][N] chain pruning: ages above this are not advected (see ctx_init)
     float *ring, *fring, *cur_ws, *cur_wd, *pend_farm, *pend_base, *old_yaw, *step_farm_pow, *step_base_pow;
     const float *rotor_dy, *rotor_dz, *tab_power, *tab_ct;   // tab_*: resampled on the uniform grid
     const float *script_uvw, *script_power;

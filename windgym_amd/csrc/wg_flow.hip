@@ -222,7 +222,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                                           const float* __restrict__ tabct,
                                           const float* __restrict__ rdy, const float* __restrict__ rdz,
                                           float4* __restrict__ pair, float* __restrict__ tiap,
-                                          unsigned* __restrict__ tmask,
+                                          unsigned* __restrict__ tmask, const int* __restrict__ jnl,
                                           const size_t pbase, const double ws,
                                           const float ti_f, const float ti_pow, const TurbCtx& tc, SlotRegs& sr) {
     const int tid = threadIdx.x;
@@ -267,6 +267,10 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     unsigned* __restrict__ grb = d.rec_b + pbase;
     // large farms (256-thread workgroups): the frozen record is gathered from a 16-byte AoS copy, see phase A
     constexpr bool AOS = (NT == 256);
+    // chain pruning is compiled into the large-farm variant only: there the advection pass is traffic-bound and a
+    // skipped quad saves real time; in the small-farm variants the extra predicate cost registers (spills at the 96
+    // VGPR budget: +26 % on cfg2) and was measured slower even with two thirds of the particles skipped
+    constexpr bool PRUNE = (NT == 256);
     uint4* __restrict__ gr4 = d.rec4 + pbase;
     float* __restrict__ gue = d.u_e + pbase;
     if (TURB != WG_TURB_NONE) {
@@ -289,10 +293,21 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         constexpr bool POW2 = decltype(pow2_tag)::value;
         constexpr int U = 4;
         float npy[U], npz[U], nvl[U], nwl[U]; unsigned nra[U], nrb[U];
+        // chain pruning: a slot is streamed only if its particle can still reach a rotor (age <= jnl[t]) or is
+        // being emitted in this step
+        auto slot_live = [&](const int ix) -> bool {
+            if (ix >= p.NP) return false;
+            if (!PRUNE) return true;
+            const int t = ix / P;
+            int j = head - (ix - t * P); if (j < 0) j += P;
+            return (j <= jnl[t] && j < n_valid) || (P - 1 - j < n_emit);
+        };
+        bool nlive[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ix = tid + u * NT;
-            if (ix < p.NP) {
+            nlive[u] = slot_live(ix);
+            if (nlive[u]) {
                 npy[u] = WG_LDS(gpy + ix); npz[u] = WG_LDS(gpz + ix); nvl[u] = WG_LDS(gvl + ix); nwl[u] = WG_LDS(gwl + ix);
                 nra[u] = WG_LDS(gra + ix); nrb[u] = WG_LDS(grb + ix);
             }
@@ -300,14 +315,17 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         for (int b0 = tid; b0 < p.NP; b0 += NT * U) {
             float pyv[U], pzv[U], vlv[U], wlv[U], fv[U], fw[U]; unsigned rav[U], rbv[U];
             int jv[U], tv[U];
+            bool live[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 pyv[u] = npy[u]; pzv[u] = npz[u]; vlv[u] = nvl[u]; wlv[u] = nwl[u]; rav[u] = nra[u]; rbv[u] = nrb[u];
+                live[u] = nlive[u];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int ix = b0 + (U + u) * NT;
-                if (ix < p.NP) {
+                nlive[u] = slot_live(ix);
+                if (nlive[u]) {
                     npy[u] = WG_LDS(gpy + ix); npz[u] = WG_LDS(gpz + ix); nvl[u] = WG_LDS(gvl + ix); nwl[u] = WG_LDS(gwl + ix);
                     nra[u] = WG_LDS(gra + ix); nrb[u] = WG_LDS(grb + ix);
                 }
@@ -322,7 +340,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 const int r = ix - t * P;
                 int j = head - r; if (j < 0) j += P;
                 jv[u] = j; tv[u] = t;
-                if (TURB != WG_TURB_RANDOM) {
+                if (TURB != WG_TURB_RANDOM && (!PRUNE || live[u])) {     // (unconditional in the small-farm variants)
                     const float xrel = s_off_f + (float)j * p.dpart_f;
                     const double bx = T[t].xr + (double)xrel + xshift, by = (double)pyv[u] + tc.oy, bz = (double)pzv[u];
                     if (WG_ABLATE & 4) { fv[u] = (float)bx * 1e-6f; fw[u] = (float)(by + bz) * 1e-6f; }
@@ -333,7 +351,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int ix = b0 + u * NT;
-                if (ix >= p.NP) continue;
+                if (!live[u]) continue;
                 const int j = jv[u], t = tv[u];
                 TurbLds& tq = T[t];
                 if (j < n_valid) {
@@ -387,19 +405,21 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
                 const int i4 = b0 + q * stride;
-                rb[q] = (i4 < p.NP) ? *reinterpret_cast<const uint4*>(grb + i4) : make_uint4(0u, 0u, 0u, 0u);
-            }
-#pragma unroll
-            for (int q = 0; q < QB; ++q) {
-                const int i4 = b0 + q * stride;
-                const int t = i4 / P;                              // P is a multiple of 4: the quad has one owner
+                const int t = PRUNE ? min(i4 / P, N - 1) : i4 / P;   // P is a multiple of 4: the quad has one owner
                 const int r0 = i4 - t * P;
                 int j0 = head - r0; if (j0 < 0) j0 += P;           // age of ring slot r0 (slot r0+i: j0-i)
                 int e0 = r0 - head - 1; if (e0 < 0) e0 += P;       // emission index of slot r0 (r0+i: e0+i)
                 emits[q] = (i4 < p.NP) && ((e0 < n_emit) || (n_emit > 0 && e0 + 3 >= P));   // wraps past P-1 -> 0
-                need[q] = emits[q] || rec_moves(rb[q].x) | rec_moves(rb[q].y) | rec_moves(rb[q].z) | rec_moves(rb[q].w);
+                // chain pruning (large farms): all four particles (ages j0-3 .. j0, no wrap) are older than anything
+                // a rotor can still see, or none has been emitted yet -> the quad is not streamed at all
+                const bool live = PRUNE ? (i4 < p.NP) && (emits[q] || j0 < 3 || (j0 - 3 <= jnl[t] && j0 - 3 < n_valid))
+                                        : (i4 < p.NP);
                 j0s[q] = j0; e0s[q] = e0; ts[q] = t;
+                rb[q] = live ? *reinterpret_cast<const uint4*>(grb + i4) : make_uint4(0u, 0u, 0u, 0u);
             }
+#pragma unroll
+            for (int q = 0; q < QB; ++q)
+                need[q] = emits[q] || rec_moves(rb[q].x) | rec_moves(rb[q].y) | rec_moves(rb[q].z) | rec_moves(rb[q].w);
             float4 py[QB];
             uint4 ra[QB];
 #pragma unroll
@@ -677,6 +697,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     double l_xr = 0, l_yr = 0;
     float l_yaw = 0, l_u = 0, l_v = 0, l_w = 0, l_ti = 0, l_pow = 0, l_ct = 0, l_act = 0;
     float l_bd = 0, l_bk = 0, l_be = 0;
+    int l_jn = 0;
     const int t_own = tid < N ? tid : 0;
     {
         l_xr = d.xr[(size_t)ctx_id * N + t_own];
@@ -684,6 +705,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         l_yaw = d.yaw[tb + t_own]; l_u = d.u[tb + t_own]; l_v = d.v[tb + t_own]; l_w = d.w[tb + t_own];
         l_ti = d.ti_loc[tb + t_own]; l_pow = d.power[tb + t_own]; l_ct = d.ct[tb + t_own];
         l_bd = d.bnd[(tb + t_own) * 3]; l_bk = d.bnd[(tb + t_own) * 3 + 1]; l_be = d.bnd[(tb + t_own) * 3 + 2];
+        if (NT == 256) l_jn = d.jneed[(size_t)ctx_id * N + t_own];      // chain pruning: large-farm variant only
         if (mode == WG_MODE_STEP && farm == 0) l_act = actions[(size_t)e * N + t_own];
     }
 
@@ -713,21 +735,25 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     float* rdz = rdy + p.S;
     unsigned* tmask = reinterpret_cast<unsigned*>(rdz + p.S);
     float* tiap = reinterpret_cast<float*>(tmask + p.target_chunk * WG_MASK_WORDS);
+    int* jnl = reinterpret_cast<int*>(tiap + p.target_chunk * N);          // [N] chain pruning ages
 
     for (int t = tid; t < N; t += NT) {
         TurbLds& q = T[t];
         if (t == tid && tid < N) {
             q.xr = l_xr; q.yr = l_yr; q.yaw = l_yaw; q.u = l_u; q.v = l_v; q.w = l_w; q.ti = l_ti; q.pow = l_pow; q.ct = l_ct;
             q.bd = l_bd; q.bk = l_bk; q.be = l_be;
+            if (NT == 256) jnl[t] = l_jn;
         }
         if (t >= NT) {   // N > 256 (not the common case): remaining turbines loaded the slow way
             q.xr = d.xr[(size_t)ctx_id * N + t]; q.yr = d.yr[(size_t)ctx_id * N + t];
             q.yaw = d.yaw[tb + t]; q.u = d.u[tb + t]; q.v = d.v[tb + t]; q.w = d.w[tb + t];
             q.ti = d.ti_loc[tb + t]; q.pow = d.power[tb + t]; q.ct = d.ct[tb + t];
             q.bd = d.bnd[(tb + t) * 3]; q.bk = d.bnd[(tb + t) * 3 + 1]; q.be = d.bnd[(tb + t) * 3 + 2];
+            if (NT == 256) jnl[t] = d.jneed[(size_t)ctx_id * N + t];
         }
         q.sws = 0.f; q.swd = 0.f; q.syaw = 0.f; q.sp = 0.f;
     }
+    if (NT == 256 && tid == 0) jnl[N] = 0;
     for (int i = tid; i < p.n_tab; i += NT) { tabp[i] = d.tab_power[i]; tabct[i] = d.tab_ct[i]; }
     for (int i = tid; i < p.S; i += NT) { rdy[i] = d.rotor_dy[i]; rdz[i] = d.rotor_dz[i]; }
 
@@ -785,7 +811,13 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             // sin/cos are not needed in replay mode: power comes from the script
             script_step<NT>(p, d, T, e, farm, cursor, sr.time);
         } else {
-            flow_step<NT, TURB>(p, d, T, tabct, rdy, rdz, pair, tiap, tmask, pbase, ws, ti_f, ti_pow, tc, sr);
+            flow_step<NT, TURB>(p, d, T, tabct, rdy, rdz, pair, tiap, tmask, jnl, pbase, ws, ti_f, ti_pow, tc, sr);
+            if (NT == 256 && tid < WG_WAVE) {   // roofline accounting: particles that can still reach a rotor
+                int cnt = 0;
+                for (int t = tid; t < N; t += WG_WAVE) cnt += min(sr.n_valid, jnl[t] + 1);
+                cnt = wg_wave_sum_i(cnt);
+                if (tid == 0) jnl[N] += cnt;          // only thread 0 ever touches this word
+            }
             ++n_flow;
         }
         --budget;
@@ -876,6 +908,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         d.bnd[(tb + t) * 3] = q.bd; d.bnd[(tb + t) * 3 + 1] = q.bk; d.bnd[(tb + t) * 3 + 2] = q.be;
     }
     if (tid == 0) {
+        if (NT == 256) slot.part_count += (unsigned)jnl[N];
         slot.head = sr.head; slot.n_valid = sr.n_valid; slot.s_off = sr.s_off; slot.time = sr.time;
         slot.istep = sr.istep;
         slot.cursor = cursor;

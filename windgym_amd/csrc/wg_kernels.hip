@@ -66,6 +66,13 @@ __device__ inline void ctx_init(const WgParams& p, const WgPtrs& d, WgEnv& env, 
         xmin = fmin(xmin, xr); xmax = fmax(xmax, xr);
     }
     xmin = wg_wave_min_d(xmin); xmax = wg_wave_max_d(xmax);
+    // chain pruning: a particle of turbine t that is older than jneed[t] has passed the most downstream turbine of
+    // the farm (the bracket of the farthest target uses ages floor(dx / dpart) and + 1) and can never reach a rotor
+    // again -> the advection pass stops streaming it.  Every output of step() is unchanged.
+    for (int t = lane; t < N; t += WG_WAVE) {
+        const double dxm = xmax - d.xr[(size_t)ctx_id * N + t];
+        d.jneed[(size_t)ctx_id * N + t] = p.full_chains ? p.P : (int)(dxm / p.dpart) + 2;
+    }
     int n_dev = 0;
     if (lane == 0) {
         cx.dist = xmax - xmin;                                                     // :723-724

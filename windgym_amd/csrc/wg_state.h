@@ -35,6 +35,7 @@ struct WgParams {
     int action_method, base_controller, yaw_init, has_yaw_defined;
     double ws_min, ws_max, ti_min, ti_max, wd_min, wd_max, n_passthrough;
     int never_truncate;
+    int full_chains;     // 1: no chain pruning (wg_config.full_chains)
     wg_channel ch[WG_N_CH];
     int turb_on[WG_N_CH];   // level flags per channel for the turbine block (yaw always on)
     int farm_on[WG_N_CH];   // level flags for the farm block (yaw never)
@@ -74,7 +75,7 @@ struct WgSlot {
     int cursor;         // replay mode row
     unsigned flow_count; // flow_step() executions of this slot (roofline accounting; summed on the host)
     unsigned istep;      // flow steps since the farm was built (counter of the inflow random stream)
-    int pad;
+    unsigned part_count; // particles the advection passes streamed (roofline accounting, like flow_count)
 };
 
 // per episode context
@@ -120,6 +121,7 @@ struct WgPtrs {
     WgCtx* ctx;
     WgEnv* env;
     double *xr, *yr;          // [B*2][N] flow-frame positions
+    int* jneed;               // [B*2][N] oldest particle age of a chain that can still reach a rotor (chain pruning)
     float *ring, *fring;      // [B*2][ring_stride], [B*2][fring_stride]
     float *cur_ws, *cur_wd;   // [B*2][N] last sub-step measurement (info dict)
     float *pend_farm, *pend_base;   // [B*2][power_avg]

@@ -308,6 +308,7 @@ class WindFarmEnv(_EnvBase):
                         yaw_init=yaw_init, seed=seed, dt_sim=dt_sim, dt_env=dt_env, yaw_step=yaw_step,
                         fill_window=fill_window, yaml_dict=yaml_dict, n_particles=n_particles,
                         n_rotor_pts=n_rotor_pts, x_pos=x_pos, y_pos=y_pos, n_envs=1, autoreset=False,
+                        advect_full_chains=True,     # single envs render: keep the far wake exact (no chain pruning)
                         never_truncate=self._never_truncate, extra_timestep_inc=self._extra_timestep_inc)
         self.yaw_initial = [0]
         self._overrides = {}
