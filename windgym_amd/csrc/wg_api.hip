@@ -113,6 +113,8 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     if (c->n_particles < 8 || c->n_particles % 4) return fail(WG_ERR_INVALID, "n_particles must be a multiple of 4 (>= 8)");
     if (c->n_rotor_pts < 1 || c->n_rotor_pts > 64) return fail(WG_ERR_INVALID, "n_rotor_pts must be in [1, 64]");
     if (c->n_turb > 32 * WG_MASK_WORDS) return fail(WG_ERR_UNSUPPORTED, "n_turb > 128 is not supported by this build");
+    if ((long long)c->n_turb * c->n_particles >= (1ll << 22) || c->n_particles > 16384)
+        return fail(WG_ERR_UNSUPPORTED, "n_turb * n_particles must stay below 2^22 (and n_particles <= 16384)");
     if (!c->x_pos || !c->y_pos || !c->rotor_dy || !c->rotor_dz || !c->tab_ws || !c->tab_power || !c->tab_ct || c->n_tab < 2)
         return fail(WG_ERR_INVALID, "layout / rotor points / turbine table missing");
     if (c->action_method != WG_ACT_YAW && c->action_method != WG_ACT_WIND)
@@ -279,13 +281,15 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         off += sizeof(int) * ((size_t)p.N + 1);      // chain-pruning ages + the particle counter
         f.lds_bytes = (int)((off + 15) & ~(size_t)15);
         f.dt = p.dt; f.D = p.D; f.inv_D = p.inv_D; f.hub = p.hub; f.dpart_f = (float)p.dpart; f.R_rot = 0.5f * p.D;
-        f.inv_N = 1.0f / (float)p.N; f.inv_S = 1.0f / (float)p.S;
+        f.inv_N = 1.0f / (float)p.N; f.inv_S = 1.0f / (float)p.S; f.inv_P = 1.0f / (float)p.P;
+        f.inv_power_avg = 1.0f / (float)(p.power_avg > 0 ? p.power_avg : 1);
         f.dt_d = p.dt_d; f.dpart = p.dpart; f.inv_dpart = 1.0 / p.dpart;
         f.yaw_min = p.yaw_min; f.yaw_max = p.yaw_max; f.yaw_step = p.yaw_step;
         f.ka = p.ka; f.kb = p.kb; f.eps0 = p.eps0; f.hill = p.hill; f.tia = p.tia; f.tib = p.tib; f.tic = p.tic; f.tid = p.tid;
         f.tab_x0 = (float)x0; f.tab_inv_dx = (float)(1.0 / dxu);
         for (int i = 0; i < WG_N_CH; ++i) {
             f.hlen[i] = p.ch[i].history_len; f.ring_off[i] = p.ring_off[i]; f.fring_off[i] = p.fring_off[i];
+            f.inv_hlen[i] = 1.0f / (float)(p.ch[i].history_len > 0 ? p.ch[i].history_len : 1);
             f.noise_sigma[i] = p.noise_sigma[i];
         }
         f.ring_stride = p.ring_stride; f.fring_stride = p.fring_stride;

@@ -15,12 +15,13 @@ struct FlowP {
     int block;                    // threads per workgroup: 64, 128 or 256
     int target_chunk;             // targets whose pair parameters are staged in LDS at once
     int lds_off_turb, lds_off_tab, lds_bytes;
-    float dt, D, inv_D, hub, dpart_f, R_rot, inv_N, inv_S;
+    float dt, D, inv_D, hub, dpart_f, R_rot, inv_N, inv_S, inv_P;
     double dt_d, dpart, inv_dpart;
     float yaw_min, yaw_max, yaw_step;
     float ka, kb, eps0, hill, tia, tib, tic, tid;
     float tab_x0, tab_inv_dx;     // uniform-grid turbine table
     int hlen[WG_N_CH], ring_off[WG_N_CH], fring_off[WG_N_CH];
+    float inv_hlen[WG_N_CH], inv_power_avg;   // reciprocals for the division-free ring positions (fast_mod)
     int ring_stride, fring_stride;
     float noise_sigma[WG_N_CH];
     // turbulent inflow (Random / frozen Mann box)

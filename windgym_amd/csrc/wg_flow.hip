@@ -70,6 +70,15 @@ __device__ __forceinline__ float fast_pow(float x, float y) {
     return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
 }
 
+// n % H for 0 <= n < 2^24, H >= 1, without the ~25-instruction integer division: quotient estimate from the float
+// reciprocal (off by at most one), then one correction step each way
+__device__ __forceinline__ int fast_mod(int n, int H, float invH) {
+    int r = n - (int)((float)n * invH) * H;
+    if (r < 0) r += H;
+    if (r >= H) r -= H;
+    return r;
+}
+
 // uniform-grid table lookup (linear interpolation, 0 outside)
 __device__ __forceinline__ float tab_lookup(const float* __restrict__ ys, const FlowP& p, float x) {
     const float fx = (x - p.tab_x0) * p.tab_inv_dx;
@@ -298,7 +307,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         auto slot_live = [&](const int ix) -> bool {
             if (ix >= p.NP) return false;
             if (!PRUNE) return true;
-            const int t = ix / P;
+            const int t = (int)(((float)ix + 0.5f) * p.inv_P);
             int j = head - (ix - t * P); if (j < 0) j += P;
             return (j <= jnl[t] && j < n_valid) || (P - 1 - j < n_emit);
         };
@@ -336,7 +345,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int ix = b0 + u * NT;
-                const int t = min(ix / P, N - 1);
+                const int t = min((int)(((float)ix + 0.5f) * p.inv_P), N - 1);
                 const int r = ix - t * P;
                 int j = head - r; if (j < 0) j += P;
                 jv[u] = j; tv[u] = t;
@@ -405,7 +414,10 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
                 const int i4 = b0 + q * stride;
-                const int t = PRUNE ? min(i4 / P, N - 1) : i4 / P;   // P is a multiple of 4: the quad has one owner
+                // owner of the quad (P is a multiple of 4: a quad has one owner); i4 / P without the ~20-instruction
+                // integer division: exact for i4 + 0.5 < 2^23 (the host enforces N * P < 2^23)
+                const int tq_ = (int)(((float)i4 + 0.5f) * p.inv_P);
+                const int t = PRUNE ? min(tq_, N - 1) : tq_;
                 const int r0 = i4 - t * P;
                 int j0 = head - r0; if (j0 < 0) j0 += P;           // age of ring slot r0 (slot r0+i: j0-i)
                 int e0 = r0 - head - 1; if (e0 < 0) e0 += P;       // emission index of slot r0 (r0+i: e0+i)
@@ -656,7 +668,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int F = p.F, N = p.N;
     const int bid = blockIdx.x;
-    const int ec = bid / F;
+    const int ec = F == 2 ? (bid >> 1) : bid / F;
     const int e = ec >> 1;
     // Which of the env's two contexts this workgroup serves is a pseudo-random function of the env index.  The
     // dispatcher hands workgroups to XCDs / shader engines / CUs in fixed round-robin patterns of blockIdx; with the
@@ -665,7 +677,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     // per CU instead of 9 and a launch that lasts as long as the loaded half.  Hashing the bit spreads both kinds of
     // work over every XCD, SE and CU whatever the pattern is.
     const int c = (ec & 1) ^ (int)((((uint32_t)e * 2654435761u) >> 13) & 1u);
-    const int farm = bid % F;      // (hashing the farm index as well was measured neutral)
+    const int farm = F == 2 ? (bid & 1) : bid % F;      // (hashing the farm index as well was measured neutral)
     const int tid = threadIdx.x;
     const int ctx_id = e * 2 + c;
     const int slot_id = ctx_id * F + farm;
@@ -856,7 +868,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
 #pragma unroll
                     for (int ch = 0; ch < WG_N_CH; ++ch) {
                         const int H = p.hlen[ch];
-                        rbase[p.ring_off[ch] + t * H + (n_pushed % H)] = val[ch];
+                        rbase[p.ring_off[ch] + t * H + fast_mod(n_pushed, H, p.inv_hlen[ch])] = val[ch];
                     }
                     // stage the pushed values for the farm-level mean / mean / sum
                     q.sws = val[0]; q.swd = val[1]; q.sp = val[3];
@@ -875,11 +887,11 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
                 const float sws = WG_TURB_SUM(sws), swd = WG_TURB_SUM(swd), tot = WG_TURB_SUM(sp);
                 if (tid == 0) {
                     float* fbase = d.fring + (size_t)ctx_id * p.fring_stride;
-                    fbase[p.fring_off[WG_CH_WS] + n_pushed % p.hlen[WG_CH_WS]] = sws * p.inv_N;
-                    fbase[p.fring_off[WG_CH_WD] + n_pushed % p.hlen[WG_CH_WD]] = swd * p.inv_N;
-                    fbase[p.fring_off[WG_CH_POWER] + n_pushed % p.hlen[WG_CH_POWER]] = tot;
+                    fbase[p.fring_off[WG_CH_WS] + fast_mod(n_pushed, p.hlen[WG_CH_WS], p.inv_hlen[WG_CH_WS])] = sws * p.inv_N;
+                    fbase[p.fring_off[WG_CH_WD] + fast_mod(n_pushed, p.hlen[WG_CH_WD], p.inv_hlen[WG_CH_WD])] = swd * p.inv_N;
+                    fbase[p.fring_off[WG_CH_POWER] + fast_mod(n_pushed, p.hlen[WG_CH_POWER], p.inv_hlen[WG_CH_POWER])] = tot;
                     if (live_step) d.step_farm_pow[e] = tot;
-                    else d.pend_farm[(size_t)ctx_id * p.power_avg + pend_farm_n % p.power_avg] = tot;
+                    else d.pend_farm[(size_t)ctx_id * p.power_avg + fast_mod(pend_farm_n, p.power_avg, p.inv_power_avg)] = tot;
                 }
             }
             ++n_pushed;
@@ -890,7 +902,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             if (tid == 0) {
                 const float bp = p.K == 1 ? base_acc : base_acc * inv_k;
                 if (live_step) d.step_base_pow[e] = bp;
-                else d.pend_base[(size_t)ctx_id * p.power_avg + pend_base_n % p.power_avg] = bp;
+                else d.pend_base[(size_t)ctx_id * p.power_avg + fast_mod(pend_base_n, p.power_avg, p.inv_power_avg)] = bp;
             }
             if (!live_step) ++pend_base_n;
             base_acc = 0.f;
