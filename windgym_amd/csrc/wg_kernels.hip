@@ -269,8 +269,13 @@ __device__ inline int shadow_share(const int work, long left, const int steps_do
     if (work <= 0) return 0;
     if (left < 1) left = 1;
     const uint32_t phi24 = ((uint32_t)steps_done * 2654435769u + (uint32_t)e * 0x9E3779B1u) >> 8;   // [0, 2^24)
-    const unsigned long long num = ((unsigned long long)work << 24) + (unsigned long long)phi24 * (unsigned long long)left;
-    return (int)(num / ((unsigned long long)left << 24));
+    // float arithmetic (a 64-bit integer division costs ~150 instructions on this kernel's latency chain): rcp(1) is
+    // exact, so left == 1 still returns exactly `work`; elsewhere an off-by-one in the floor is absorbed by the
+    // next step's recomputed ratio
+    const float share = (float)work * __builtin_amdgcn_rcpf((float)left) + (float)phi24 * (1.0f / 16777216.0f);
+    int it = (int)share;
+    if (left == 1) it = work;
+    return it > work ? work : it;
 }
 
 // plan how many flow sub-steps the background episode must advance during the next step() so that it is
@@ -376,7 +381,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     }
 
     // power deques (:975-981): one lane per deque element, the new value patched in registers
-    const int fslot = ev.farm_pow_n % p.power_avg, bslot = ev.base_pow_n % p.power_avg;
+    const int fslot = ev.farm_pow_n % p.power_avg, bslot = ev.base_pow_n % p.power_avg;   // (counts run over all episodes)
     ev.farm_pow_n++;
     if (p.F == 2) ev.base_pow_n++;
     double fsum = 0.0, bsum = 0.0, fl = 0.0, fo = 0.0;
