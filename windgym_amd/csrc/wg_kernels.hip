@@ -295,6 +295,33 @@ __device__ inline int plan_shadow(const WgParams& p, const WgPtrs& d, const WgEn
     return shadow_share(work, total - env.steps_done, env.steps_done, e);
 }
 
+// Write the env header back from the wave's register copy.  `env = ev` by lane 0 compiled into ~26 dependent
+// single-lane stores and cost 6 us of the kernel's 28; the 11 scalar fields the step path changes are contiguous, so
+// lane i stores field i: ONE coalesced store.  The generator state only changes when an episode was initialised.
+__device__ inline void env_writeback(WgEnv& env, const WgEnv& ev, const int lane, const bool rng_too) {
+    static_assert(offsetof(WgEnv, timestep) == offsetof(WgEnv, live) + 4 && offsetof(WgEnv, episode) == offsetof(WgEnv, live) + 8 &&
+                  offsetof(WgEnv, done) == offsetof(WgEnv, live) + 12 && offsetof(WgEnv, shadow_iters) == offsetof(WgEnv, live) + 16 &&
+                  offsetof(WgEnv, farm_pow_n) == offsetof(WgEnv, live) + 20 && offsetof(WgEnv, base_pow_n) == offsetof(WgEnv, live) + 24 &&
+                  offsetof(WgEnv, steps_done) == offsetof(WgEnv, live) + 28 && offsetof(WgEnv, ep_return) == offsetof(WgEnv, live) + 32 &&
+                  offsetof(WgEnv, ep_power_sum) == offsetof(WgEnv, live) + 36 && offsetof(WgEnv, ep_len) == offsetof(WgEnv, live) + 40,
+                  "env_writeback relies on the field order of WgEnv");
+    int v = ev.live;
+    v = lane == 1 ? ev.timestep : v;
+    v = lane == 2 ? ev.episode : v;
+    v = lane == 3 ? ev.done : v;
+    v = lane == 4 ? ev.shadow_iters : v;
+    v = lane == 5 ? ev.farm_pow_n : v;
+    v = lane == 6 ? ev.base_pow_n : v;
+    v = lane == 7 ? ev.steps_done : v;
+    v = lane == 8 ? __float_as_int(ev.ep_return) : v;
+    v = lane == 9 ? __float_as_int(ev.ep_power_sum) : v;
+    v = lane == 10 ? ev.ep_len : v;
+    if (lane < 11) (&env.live)[lane] = v;
+    if (rng_too && lane == 0) {
+        env.rng_state = ev.rng_state; env.rng_inc = ev.rng_inc; env.rng_has32 = ev.rng_has32; env.rng_u32 = ev.rng_u32;
+    }
+}
+
 // ===================================================================================================
 // k_glue: one wave per env.  phase 0 = after a flow step (step()); phase 1 = end of reset().
 // ===================================================================================================
@@ -461,6 +488,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         if (reward_out) reward_out[e] = reward;
         if (trunc_out) trunc_out[e] = (uint8_t)truncated;
     }
+    if (WG_GLUE_ABLATE == 5) return;
     if (lane < WG_N_METRICS) {            // lane m owns metric m
         float add = 0.f;
         switch (lane) {
@@ -475,12 +503,13 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         }
         met[lane] = l_met + add;
     }
+    if (WG_GLUE_ABLATE == 6) return;
     if (truncated) {
         ev.ep_return = 0.f; ev.ep_power_sum = 0.f; ev.ep_len = 0;
         ev.episode += 1;
         if (!p.autoreset) {
             ev.done = 1;
-            if (lane == 0) env = ev;
+            env_writeback(env, ev, lane, false);
             return;
         }
         // same-step autoreset: the next episode was developed in the background; make it live
@@ -514,6 +543,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         ctx_init(p, d, ev, e, live, lane, ev.episode + 1);
         __threadfence_block();
     }
+    if (WG_GLUE_ABLATE == 7) return;
     if (!p.autoreset) {
         ev.shadow_iters = 0;
     } else if (truncated) {
@@ -529,7 +559,8 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
             ev.shadow_iters = shadow_share(work, total - ev.steps_done, ev.steps_done, e);
         }
     }
-    if (lane == 0) env = ev;
+    if (WG_GLUE_ABLATE == 8) return;
+    env_writeback(env, ev, lane, truncated != 0);
 }
 
 // ===================================================================================================
