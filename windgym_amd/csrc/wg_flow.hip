@@ -668,7 +668,19 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int F = p.F, N = p.N;
     const int bid = blockIdx.x;
-    const int ec = F == 2 ? (bid >> 1) : bid / F;
+    // Block order.  Inflow "None" / "Random": farm-major — all agent farms first; the lighter baseline farms (un-yawed
+    // chains do not move) form the tail of the launch, where CUs drain (+1.6 % on cfg2).  Frozen box: env-major — the
+    // two farms of an env gather the same region of the box and share its lines in L2 when they run side by side
+    // (farm-major: -4 % on cfg5).
+    int farm, ec;
+    if (TURB == WG_TURB_BOX) {
+        ec = F == 2 ? (bid >> 1) : bid / F;
+        farm = F == 2 ? (bid & 1) : bid - ec * F;
+    } else {
+        const int nec = p.B * 2;
+        farm = bid < nec ? 0 : bid / nec;
+        ec = bid - farm * nec;
+    }
     const int e = ec >> 1;
     // Which of the env's two contexts this workgroup serves is a pseudo-random function of the env index.  The
     // dispatcher hands workgroups to XCDs / shader engines / CUs in fixed round-robin patterns of blockIdx; with the
@@ -677,7 +689,6 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     // per CU instead of 9 and a launch that lasts as long as the loaded half.  Hashing the bit spreads both kinds of
     // work over every XCD, SE and CU whatever the pattern is.
     const int c = (ec & 1) ^ (int)((((uint32_t)e * 2654435761u) >> 13) & 1u);
-    const int farm = F == 2 ? (bid & 1) : bid % F;      // (hashing the farm index as well was measured neutral)
     const int tid = threadIdx.x;
     const int ctx_id = e * 2 + c;
     const int slot_id = ctx_id * F + farm;
