@@ -5,6 +5,9 @@
 #ifndef WG_BOX_WAVES
 #define WG_BOX_WAVES 2    // turbulent variants: measured best with the full register budget (no spills, deeper gather ILP)
 #endif
+#ifndef WG_FLOW_WAVES_128
+#define WG_FLOW_WAVES_128 6   // 128-thread variants stream one quad per lane at a time (QB = 1): 80 VGPRs, 6 waves/SIMD
+#endif
 #ifndef WG_FLOW_WAVES
 #define WG_FLOW_WAVES 5   // min waves/SIMD the register allocator must leave room for (5 -> <= 96 VGPRs; measured best)
 #endif

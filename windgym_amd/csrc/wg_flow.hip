@@ -402,10 +402,14 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         //   stage 1: rec_b (eps|hv) of all QB quads -> which quads move (any hv != 0) or receive a new particle
         //   stage 2: py and rec_a (ct|k) of those quads -> all issued before the first use
         // A quad that neither moves nor emits costs only its rec_b read (4 B per particle).
-#ifndef WG_QB
-#define WG_QB 2
-#endif
+        // quads in flight per lane and occupancy are tuned together per workgroup size (measured, cfg2 / cfg3 / cfg4):
+        // 128 threads: QB = 1 at 6 waves/SIMD (80 VGPRs) beats QB = 2 at 5 waves (96 VGPRs) by 6 %; 256 threads (large
+        // farms, long streaming loops): QB = 2 at 5 waves is 8 % better; 64 threads: no difference
+#ifdef WG_QB
         constexpr int QB = WG_QB;
+#else
+        constexpr int QB = (NT == 128) ? 1 : 2;
+#endif
         const int stride = NT * 4;
         for (int b0 = tid * 4; b0 < p.NP; b0 += stride * QB) {
             uint4 rb[QB];
@@ -662,7 +666,7 @@ __device__ __forceinline__ void script_step(const FlowP& p, const FlowPtrs& d, T
     }())
 
 template <int NT, int TURB, bool REPLAY, bool NOISE>
-__global__ void __launch_bounds__(NT, TURB != WG_TURB_NONE ? WG_BOX_WAVES : WG_FLOW_WAVES)
+__global__ void __launch_bounds__(NT, TURB != WG_TURB_NONE ? WG_BOX_WAVES : (NT == 128 ? WG_FLOW_WAVES_128 : WG_FLOW_WAVES))
 k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict__ actions,
        const uint8_t* __restrict__ mask, const int chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
