@@ -234,6 +234,11 @@ int wg_check(wg_handle h, void* stream);
 /* Per-agent observations of the PettingZoo facade for the current state: f32[B,N,obs_dim_multi].      */
 int wg_obs_multi(wg_handle h, float* obs_dev, void* stream);
 
+/* The same, fused into the step: once a caller-owned buffer f32[B,N,obs_dim_multi] is registered, every following
+ * wg_step / wg_reset also writes the per-agent observations there (the values wg_obs_multi would return right
+ * after the call) — WindFarmEnvMulti.step calls _get_obs_multi every step (WindEnvMulti.py:188-227).  NULL stops. */
+int wg_set_obs_multi_buffer(wg_handle h, float* obs_multi_dev);
+
 /* Unscaled, unclipped sensor values of the running episodes in the layout of the observation: f32[B,O]
  * (farm_measurements.get_*_turb() / get_*_farm(), the "... measured" entries of _get_info :529-537).   */
 int wg_get_measurements(wg_handle h, float* out_dev, void* stream);

@@ -313,6 +313,40 @@ def test_multi_agent_3x3_batched_matches_oracle(hip, oracle_lib):
     env.check()
 
 
+def test_fused_per_agent_observations_equal_the_explicit_packing(hip, oracle_lib):
+    """wg_set_obs_multi_buffer: the per-agent observations written by the step's own glue kernel are bit-identical to
+    what wg_obs_multi returns after the step (and to the oracle's packing), across resets and episode rollovers."""
+    import torch
+    from windgym_amd import presets
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.turbine import V80
+    B = 6
+    cfg = EnvConfig(turbine=V80(), yaml_dict=presets.multi_3x3_config(), turbtype="None", n_envs=B, autoreset=True,
+                    n_passthrough=1, extra_timestep_inc=True)
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    buf = env.fuse_obs_multi()
+    seeds = 31 + np.arange(B)
+    env.reset(seeds=seeds), orc.reset(seeds=seeds)
+    assert torch.equal(buf, env.obs_multi())
+    np.testing.assert_allclose(buf.cpu().numpy(), orc.obs_multi(), rtol=0, atol=OBS_ATOL)
+    rng = np.random.default_rng(2)
+    n_tr = 0
+    for step in range(260):
+        a = rng.uniform(-1, 1, size=(B, cfg.n_turb)).astype(np.float32)
+        _, _, tr, _ = env.step(torch.as_tensor(a, device="cuda"))
+        orc.step(a)
+        assert torch.equal(buf, env.obs_multi()), step
+        if step % 13 == 0:
+            np.testing.assert_allclose(buf.cpu().numpy(), orc.obs_multi(), rtol=0, atol=OBS_ATOL, err_msg=f"step {step}")
+        n_tr += int(tr.sum().item())
+    assert n_tr >= B
+    env.fuse_obs_multi(False)
+    before = buf.clone()
+    env.step(torch.zeros((B, cfg.n_turb), device="cuda"))
+    assert torch.equal(buf, before)                     # unregistered: no longer written
+    env.check()
+
+
 def test_noise_normal_matches_oracle_stream(hip, oracle_lib):
     """noise: "Normal" (2turb.yaml / 4turb.yaml): the Philox/Box-Muller stream is the same on both sides; the
     kernel evaluates log/cos in fast fp32 -> tolerance 2e-3 deg on the 2-deg wd noise (1e-4 of the wd scale)."""

@@ -20,7 +20,7 @@ UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 # every symbol include/windgym_hip.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = (
     "wg_last_error", "wg_abi_version", "wg_create", "wg_destroy", "wg_obs_dim", "wg_hist_max",
-    "wg_set_turbulence_box", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_check", "wg_obs_multi",
+    "wg_set_turbulence_box", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_check", "wg_obs_multi", "wg_set_obs_multi_buffer",
     "wg_get_info", "wg_get_measurements", "wg_get_windspeed", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_algorithmic_bytes",
 )
 
@@ -59,6 +59,7 @@ def load_library():
     L.wg_step.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     L.wg_check.argtypes = [C.c_void_p, C.c_void_p]
     L.wg_obs_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.wg_set_obs_multi_buffer.argtypes = [C.c_void_p, C.c_void_p]
     L.wg_get_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.wg_get_measurements.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.wg_get_windspeed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float,
@@ -157,6 +158,19 @@ class HipBatch:
         out = self.torch.zeros((self.B, self.N, self.obs_dim_multi), dtype=self.torch.float32, device=self.device)
         _chk(self.L.wg_obs_multi(self._h, C.c_void_p(out.data_ptr()), self._stream()), "wg_obs_multi")
         return out
+
+    def fuse_obs_multi(self, enable=True):
+        """Let every following step() / reset() also write the per-agent observations (PettingZoo facade) into a
+        persistent tensor [B, N, obs_dim_multi] — returned here, updated in place — instead of a separate
+        obs_multi() launch per step."""
+        if not enable:
+            _chk(self.L.wg_set_obs_multi_buffer(self._h, None), "wg_set_obs_multi_buffer")
+            self._multi_buf = None
+            return None
+        t = self.torch
+        self._multi_buf = t.zeros((self.B, self.N, self.obs_dim_multi), dtype=t.float32, device=self.device)
+        _chk(self.L.wg_set_obs_multi_buffer(self._h, C.c_void_p(self._multi_buf.data_ptr())), "wg_set_obs_multi_buffer")
+        return self._multi_buf
 
     def measurements(self):
         """Unscaled sensor values in the layout of the observation, f32[B, O]."""

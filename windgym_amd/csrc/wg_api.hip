@@ -515,6 +515,12 @@ extern "C" int wg_check(wg_handle h, void* stream) {
     return status;
 }
 
+extern "C" int wg_set_obs_multi_buffer(wg_handle h, float* obs_multi_dev) {
+    if (!h) return fail(WG_ERR_INVALID, "null handle");
+    h->d.multi_out = obs_multi_dev;     // borrowed; written by k_glue in every following wg_step / wg_reset
+    return 0;
+}
+
 extern "C" int wg_obs_multi(wg_handle h, float* obs_dev, void* stream) {
     if (!h || !obs_dev) return fail(WG_ERR_INVALID, "null argument");
     wg_launch_obs_multi(&h->p, &h->d, obs_dev, (hipStream_t)stream);

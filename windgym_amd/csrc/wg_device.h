@@ -270,11 +270,10 @@ __device__ inline float wg_clip1(float v) { return fminf(fmaxf(v, -1.0f), 1.0f);
 
 // one turb_mes.get_measurements(scaled=True) block (MesClass.py:328-340).  farm_level selects the
 // farm_mes.farm_mes object used by the PettingZoo facade (WindEnvMulti.py:90-92).
-__device__ inline int wg_turb_block(const WgParams& p, const WgPtrs& d, int ctx_id, int n_pushed, int t,
-                                    bool farm_level, float* out) {
+// (rbase / fbase: the context's turbine / farm rings — global memory or a staged LDS copy)
+__device__ inline int wg_turb_block_b(const WgParams& p, const float* rbase, const float* fbase, int n_pushed, int t,
+                                      bool farm_level, float* out) {
     int n = 0;
-    const float* rbase = d.ring + (size_t)ctx_id * p.ring_stride;
-    const float* fbase = d.fring + (size_t)ctx_id * p.fring_stride;
     for (int ch = 0; ch < WG_N_CH; ++ch) {
         if (ch == WG_CH_POWER) {
             bool ti_on = farm_level ? p.farm_ti : p.turb_ti;
@@ -300,4 +299,9 @@ __device__ inline int wg_turb_block(const WgParams& p, const WgPtrs& d, int ctx_
                         out + n);
     }
     return n;
+}
+__device__ inline int wg_turb_block(const WgParams& p, const WgPtrs& d, int ctx_id, int n_pushed, int t,
+                                    bool farm_level, float* out) {
+    return wg_turb_block_b(p, d.ring + (size_t)ctx_id * p.ring_stride, d.fring + (size_t)ctx_id * p.fring_stride,
+                           n_pushed, t, farm_level, out);
 }

@@ -115,9 +115,12 @@ __device__ inline void ctx_init(const WgParams& p, const WgPtrs& d, WgEnv& env, 
 // `raw`: unscaled, unclipped sensor values in the same layout (the "... measured" entries of the info dict,
 // farm_measurements.get_*_turb() / get_*_farm(), Wind_Farm_Env.py:529-537)
 #define WG_OBSV(v, mn, rng) (raw ? (v) : wg_clip1(wg_scale((v), (mn), (rng))))
+// `obs_m` (optional): this env's slice of the per-agent observation buffer [N][obs_dim_multi] of the PettingZoo facade
+// (WindEnvMulti._get_obs_multi, WindEnvMulti.py:79-103): agent t = its own turbine block (the values just computed) ++
+// the farm_mes.farm_mes block, which differs from the single-agent farm block in its TI entry
 __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id, int lane, float* __restrict__ obs,
                                  float* __restrict__ obs2, const float* rbase, const float* fbase,
-                                 const bool raw = false) {
+                                 const bool raw = false, float* __restrict__ obs_m = nullptr) {
     const int N = p.N;
     const int n_pushed = d.ctx[ctx_id].n_pushed;
     float ti_sum = 0.f;
@@ -133,6 +136,7 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
                          p.ch[WG_CH_WS].history_len);
                 float v = WG_OBSV(wg_calc_ti(r), p.ti_min_f, p.ti_rng_f);
                 o[n] = v; if (obs2) obs2[(size_t)t * p.turb_obs + n] = v;
+                if (obs_m) obs_m[(size_t)t * p.obs_dim_multi + n] = v;
                 ++n;
             }
             WgRing r(rbase + p.ring_off[ch] + (size_t)t * H, n_pushed, H);
@@ -144,6 +148,7 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
             if (cur_on) {
                 float v = WG_OBSV(r.at(avail - 1), p.sc_min[ch], p.sc_rng[ch]);
                 o[n] = v; if (obs2) obs2[(size_t)t * p.turb_obs + n] = v;
+                if (obs_m) obs_m[(size_t)t * p.obs_dim_multi + n] = v;
                 ++n;
             }
             if (rol_on) {
@@ -162,9 +167,16 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
                     for (int q = lo; q < hi; ++q) s += r.at(q);
                     float v = WG_OBSV(s / (float)(hi - lo), p.sc_min[ch], p.sc_rng[ch]);
                     o[n] = v; if (obs2) obs2[(size_t)t * p.turb_obs + n] = v;
+                    if (obs_m) obs_m[(size_t)t * p.obs_dim_multi + n] = v;
                     ++n;
                 }
             }
+        }
+        if (obs_m) {
+            // written in place, then clipped in place (no private staging array: it would put the kernel on scratch)
+            float* om = obs_m + (size_t)t * p.obs_dim_multi + n;
+            const int m = wg_turb_block_b(p, rbase, fbase, n_pushed, 0, true, om);
+            for (int k = 0; k < m; ++k) om[k] = wg_clip1(om[k]);
         }
         if (p.farm_ti) {   // farm TI = mean of the *scaled* turbine TIs (MesClass.py:670-673)
             WgRing r(rbase + p.ring_off[WG_CH_WS] + (size_t)t * p.ch[WG_CH_WS].history_len, n_pushed,
@@ -364,7 +376,8 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         }
         if (obs) {
             stage_rings(p, d, ctx_id, lane, my_lds, rbase, fbase);
-            build_obs(p, d, ctx_id, lane, obs, nullptr, rbase, fbase);
+            build_obs(p, d, ctx_id, lane, obs, nullptr, rbase, fbase, false,
+                      d.multi_out ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr);
         }
         return;
     }
@@ -449,7 +462,8 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     if (WG_GLUE_ABLATE == 2) return;
     stage_rings(p, d, ctx_id, lane, my_lds, rbase, fbase);
     if (WG_GLUE_ABLATE == 3) return;
-    build_obs(p, d, ctx_id, lane, obs, fin, rbase, fbase);
+    build_obs(p, d, ctx_id, lane, obs, fin, rbase, fbase, false,
+              d.multi_out ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr);
     if (WG_GLUE_ABLATE == 4) return;
 
     // action penalty sums (:804-820) and current farm powers ("Power agent", :539)
@@ -537,7 +551,8 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         __threadfence_block();
         if (obs) {
             stage_rings(p, d, nctx, lane, my_lds, rbase, fbase);
-            build_obs(p, d, nctx, lane, obs, nullptr, rbase, fbase);
+            build_obs(p, d, nctx, lane, obs, nullptr, rbase, fbase, false,
+                      d.multi_out ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr);
         }
         // the retired context starts developing the episode after the next one (lane 0 draws from ev's PCG64)
         ctx_init(p, d, ev, e, live, lane, ev.episode + 1);

@@ -121,6 +121,7 @@ struct WgPtrs {
     WgCtx* ctx;
     WgEnv* env;
     double *xr, *yr;          // [B*2][N] flow-frame positions
+    float* multi_out;         // optional [B][N][obs_dim_multi]: per-agent observations written by the glue every step
     int* jneed;               // [B*2][N] oldest particle age of a chain that can still reach a rotor (chain pruning)
     float *ring, *fring;      // [B*2][ring_stride], [B*2][fring_stride]
     float *cur_ws, *cur_wd;   // [B*2][N] last sub-step measurement (info dict)
