@@ -292,8 +292,8 @@ __device__ inline int shadow_share(const int work, long left, const int steps_do
 
 // plan how many flow sub-steps the background episode must advance during the next step() so that it is
 // ready exactly when the running episode truncates
-__device__ inline int plan_shadow(const WgParams& p, const WgPtrs& d, const WgEnv& env, int e) {
-    const int live = env.live, sh = live ^ 1;
+__device__ inline int plan_shadow(const WgParams& p, const WgPtrs& d, const int live, const int steps_done, int e) {
+    const int sh = live ^ 1;
     int work = 0;
     for (int f = 0; f < p.F; ++f) {
         const WgSlot& s = d.slot[(e * 2 + sh) * p.F + f];
@@ -304,13 +304,28 @@ __device__ inline int plan_shadow(const WgParams& p, const WgPtrs& d, const WgEn
     const int inc = 1 + (p.extra_inc ? 1 : 0);
     const int tm = d.ctx[e * 2 + live].time_max;
     const long total = (long)((tm + inc - 1) / inc) + 1;
-    return shadow_share(work, total - env.steps_done, env.steps_done, e);
+    return shadow_share(work, total - steps_done, steps_done, e);
 }
 
 // Write the env header back from the wave's register copy.  `env = ev` by lane 0 compiled into ~26 dependent
 // single-lane stores and cost 6 us of the kernel's 28; the 11 scalar fields the step path changes are contiguous, so
 // lane i stores field i: ONE coalesced store.  The generator state only changes when an episode was initialised.
-__device__ inline void env_writeback(WgEnv& env, const WgEnv& ev, const int lane, const bool rng_too) {
+// (the register copy holds ONLY these scalars: a full `WgEnv ev = env` copy has its address taken by ctx_init /
+// the PCG64 helpers and therefore lived in scratch memory — every field access of the hot path was a private-memory
+// round trip)
+struct EnvHot {
+    int live, timestep, episode, done, shadow_iters, farm_pow_n, base_pow_n, steps_done;
+    float ep_return, ep_power_sum;
+    int ep_len;
+};
+__device__ inline EnvHot env_load(const WgEnv& env) {
+    EnvHot h;
+    h.live = env.live; h.timestep = env.timestep; h.episode = env.episode; h.done = env.done;
+    h.shadow_iters = env.shadow_iters; h.farm_pow_n = env.farm_pow_n; h.base_pow_n = env.base_pow_n;
+    h.steps_done = env.steps_done; h.ep_return = env.ep_return; h.ep_power_sum = env.ep_power_sum; h.ep_len = env.ep_len;
+    return h;
+}
+__device__ inline void env_writeback(WgEnv& env, const EnvHot& ev, const int lane) {
     static_assert(offsetof(WgEnv, timestep) == offsetof(WgEnv, live) + 4 && offsetof(WgEnv, episode) == offsetof(WgEnv, live) + 8 &&
                   offsetof(WgEnv, done) == offsetof(WgEnv, live) + 12 && offsetof(WgEnv, shadow_iters) == offsetof(WgEnv, live) + 16 &&
                   offsetof(WgEnv, farm_pow_n) == offsetof(WgEnv, live) + 20 && offsetof(WgEnv, base_pow_n) == offsetof(WgEnv, live) + 24 &&
@@ -329,9 +344,6 @@ __device__ inline void env_writeback(WgEnv& env, const WgEnv& ev, const int lane
     v = lane == 9 ? __float_as_int(ev.ep_power_sum) : v;
     v = lane == 10 ? ev.ep_len : v;
     if (lane < 11) (&env.live)[lane] = v;
-    if (rng_too && lane == 0) {
-        env.rng_state = ev.rng_state; env.rng_inc = ev.rng_inc; env.rng_has32 = ev.rng_has32; env.rng_u32 = ev.rng_u32;
-    }
 }
 
 // ===================================================================================================
@@ -372,7 +384,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
             cx.pend_farm_n = 0; cx.pend_base_n = 0;
             env.timestep = 0; env.done = 0; env.steps_done = 0;
             env.ep_return = 0.f; env.ep_power_sum = 0.f; env.ep_len = 0;
-            env.shadow_iters = p.autoreset ? plan_shadow(p, d, env, e) : 0;
+            env.shadow_iters = p.autoreset ? plan_shadow(p, d, env.live, env.steps_done, e) : 0;
         }
         if (obs) {
             stage_rings(p, d, ctx_id, lane, my_lds, rbase, fbase);
@@ -393,7 +405,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
 #define WG_GLUE_ABLATE 0
 #endif
     if (WG_GLUE_ABLATE == 1) return;
-    WgEnv ev = env;
+    EnvHot ev = env_load(env);
     const int live = ev.live;
     const int ctx_id = e * 2 + live;
     WgCtx& cx = d.ctx[ctx_id];
@@ -523,7 +535,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         ev.episode += 1;
         if (!p.autoreset) {
             ev.done = 1;
-            env_writeback(env, ev, lane, false);
+            env_writeback(env, ev, lane);
             return;
         }
         // same-step autoreset: the next episode was developed in the background; make it live
@@ -554,15 +566,16 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
             build_obs(p, d, nctx, lane, obs, nullptr, rbase, fbase, false,
                       d.multi_out ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr);
         }
-        // the retired context starts developing the episode after the next one (lane 0 draws from ev's PCG64)
-        ctx_init(p, d, ev, e, live, lane, ev.episode + 1);
+        // the retired context starts developing the episode after the next one (lane 0 draws from the env's PCG64,
+        // in place in global memory: rare path)
+        ctx_init(p, d, env, e, live, lane, ev.episode + 1);
         __threadfence_block();
     }
     if (WG_GLUE_ABLATE == 7) return;
     if (!p.autoreset) {
         ev.shadow_iters = 0;
     } else if (truncated) {
-        ev.shadow_iters = plan_shadow(p, d, ev, e);               // contexts were swapped / re-initialised
+        ev.shadow_iters = plan_shadow(p, d, ev.live, ev.steps_done, e);   // contexts were swapped / re-initialised
     } else {
         int work = l_work;                                        // max over the farms of the background ctx
         for (int o = 1; o < 4; o <<= 1) work = max(work, __shfl_xor(work, o, 64));
@@ -575,7 +588,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         }
     }
     if (WG_GLUE_ABLATE == 8) return;
-    env_writeback(env, ev, lane, truncated != 0);
+    env_writeback(env, ev, lane);
 }
 
 // ===================================================================================================
