@@ -326,24 +326,20 @@ __device__ inline EnvHot env_load(const WgEnv& env) {
     return h;
 }
 __device__ inline void env_writeback(WgEnv& env, const EnvHot& ev, const int lane) {
-    static_assert(offsetof(WgEnv, timestep) == offsetof(WgEnv, live) + 4 && offsetof(WgEnv, episode) == offsetof(WgEnv, live) + 8 &&
-                  offsetof(WgEnv, done) == offsetof(WgEnv, live) + 12 && offsetof(WgEnv, shadow_iters) == offsetof(WgEnv, live) + 16 &&
-                  offsetof(WgEnv, farm_pow_n) == offsetof(WgEnv, live) + 20 && offsetof(WgEnv, base_pow_n) == offsetof(WgEnv, live) + 24 &&
-                  offsetof(WgEnv, steps_done) == offsetof(WgEnv, live) + 28 && offsetof(WgEnv, ep_return) == offsetof(WgEnv, live) + 32 &&
-                  offsetof(WgEnv, ep_power_sum) == offsetof(WgEnv, live) + 36 && offsetof(WgEnv, ep_len) == offsetof(WgEnv, live) + 40,
-                  "env_writeback relies on the field order of WgEnv");
-    int v = ev.live;
-    v = lane == 1 ? ev.timestep : v;
-    v = lane == 2 ? ev.episode : v;
-    v = lane == 3 ? ev.done : v;
-    v = lane == 4 ? ev.shadow_iters : v;
-    v = lane == 5 ? ev.farm_pow_n : v;
-    v = lane == 6 ? ev.base_pow_n : v;
-    v = lane == 7 ? ev.steps_done : v;
-    v = lane == 8 ? __float_as_int(ev.ep_return) : v;
-    v = lane == 9 ? __float_as_int(ev.ep_power_sum) : v;
-    v = lane == 10 ? ev.ep_len : v;
-    if (lane < 11) (&env.live)[lane] = v;
+    // one field per lane: independent fire-and-forget stores.  (A select chain "lane i stores field i" is turned by the
+    // compiler into an indexed load from a scratch copy of the struct — a private-memory round trip at the very end
+    // of the kernel's latency chain.)
+    if (lane == 0) env.live = ev.live;
+    if (lane == 1) env.timestep = ev.timestep;
+    if (lane == 2) env.episode = ev.episode;
+    if (lane == 3) env.done = ev.done;
+    if (lane == 4) env.shadow_iters = ev.shadow_iters;
+    if (lane == 5) env.farm_pow_n = ev.farm_pow_n;
+    if (lane == 6) env.base_pow_n = ev.base_pow_n;
+    if (lane == 7) env.steps_done = ev.steps_done;
+    if (lane == 8) env.ep_return = ev.ep_return;
+    if (lane == 9) env.ep_power_sum = ev.ep_power_sum;
+    if (lane == 10) env.ep_len = ev.ep_len;
 }
 
 // ===================================================================================================
@@ -515,18 +511,17 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         if (trunc_out) trunc_out[e] = (uint8_t)truncated;
     }
     if (WG_GLUE_ABLATE == 5) return;
-    if (lane < WG_N_METRICS) {            // lane m owns metric m
+    if (lane < WG_N_METRICS) {            // lane m owns metric m (select chain: a switch became a scratch table)
+        const float trf = truncated ? 1.f : 0.f;
         float add = 0.f;
-        switch (lane) {
-        case WG_MET_STEP_REWARD_SUM: add = reward; break;
-        case WG_MET_FARM_POWER_SUM: add = pnow; break;
-        case WG_MET_BASE_POWER_SUM: add = pbase; break;
-        case WG_MET_N_STEPS: add = 1.f; break;
-        case WG_MET_EP_RETURN_SUM: add = truncated ? ev.ep_return : 0.f; break;
-        case WG_MET_EP_LENGTH_SUM: add = truncated ? (float)ev.ep_len : 0.f; break;
-        case WG_MET_EP_MEAN_POWER_SUM: add = truncated ? ev.ep_power_sum / (float)ev.ep_len : 0.f; break;
-        case WG_MET_N_EPISODES: add = truncated ? 1.f : 0.f; break;
-        }
+        add = lane == WG_MET_STEP_REWARD_SUM ? reward : add;
+        add = lane == WG_MET_FARM_POWER_SUM ? pnow : add;
+        add = lane == WG_MET_BASE_POWER_SUM ? pbase : add;
+        add = lane == WG_MET_N_STEPS ? 1.f : add;
+        add = lane == WG_MET_EP_RETURN_SUM ? trf * ev.ep_return : add;
+        add = lane == WG_MET_EP_LENGTH_SUM ? trf * (float)ev.ep_len : add;
+        add = lane == WG_MET_EP_MEAN_POWER_SUM ? (truncated ? ev.ep_power_sum / (float)ev.ep_len : 0.f) : add;
+        add = lane == WG_MET_N_EPISODES ? trf : add;
         met[lane] = l_met + add;
     }
     if (WG_GLUE_ABLATE == 6) return;
