@@ -120,9 +120,11 @@ __device__ inline void ctx_init(const WgParams& p, const WgPtrs& d, WgEnv& env, 
 // the farm_mes.farm_mes block, which differs from the single-agent farm block in its TI entry
 __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id, int lane, float* __restrict__ obs,
                                  float* __restrict__ obs2, const float* rbase, const float* fbase,
-                                 const bool raw = false, float* __restrict__ obs_m = nullptr) {
+                                 const bool raw = false, float* __restrict__ obs_m = nullptr,
+                                 const int n_pushed_known = -1) {
     const int N = p.N;
-    const int n_pushed = d.ctx[ctx_id].n_pushed;
+    // (callers that already hold the context header pass it: one dependent load less on the kernel's latency chain)
+    const int n_pushed = n_pushed_known >= 0 ? n_pushed_known : d.ctx[ctx_id].n_pushed;
     float ti_sum = 0.f;
     float buf[8];
     for (int t = lane; t < N; t += WG_WAVE) {
@@ -407,6 +409,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     WgCtx& cx = d.ctx[ctx_id];
     const int time_max = cx.time_max;
     const float rated_power = cx.rated_power;
+    const int n_pushed_live = cx.n_pushed;
     const size_t tb_a = (size_t)(ctx_id * p.F) * N;
     const float fp = d.step_farm_pow[e];
     const float bp = p.F == 2 ? d.step_base_pow[e] : 0.f;
@@ -471,7 +474,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     stage_rings(p, d, ctx_id, lane, my_lds, rbase, fbase);
     if (WG_GLUE_ABLATE == 3) return;
     build_obs(p, d, ctx_id, lane, obs, fin, rbase, fbase, false,
-              d.multi_out ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr);
+              d.multi_out ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr, n_pushed_live);
     if (WG_GLUE_ABLATE == 4) return;
 
     // action penalty sums (:804-820) and current farm powers ("Power agent", :539)
