@@ -356,3 +356,32 @@ def test_set_windconditions_with_site(wg, tmp_path):      # tests/test_basics.py
     assert (np.abs(later[:, 0] - first[:, 0]) > 1e-6).mean() > 0.8     # new episodes, new draws
     venv.batch.check()
     venv.close()
+
+
+def test_mannload_reads_the_turbbox_file_or_falls_back(wg, tmp_path, capsys):
+    """turbtype "MannLoad": TurbBox = a box file / a directory of TF_* files (Wind_Farm_Env.py:197-213, :611-618);
+    without files the reference switches to generated turbulence."""
+    from windgym_amd import presets
+    from windgym_amd.mann import generate_mann_box, save_box
+    d = tmp_path / "boxes"
+    d.mkdir()
+    box = generate_mann_box((128, 32, 16), (3.0, 3.0, 3.0), seed=11)
+    save_box(str(d / "TF_test.npz"), box, (3.0, 3.0, 3.0))
+    y = _yaml(tmp_path, presets.env1_config())
+    env = wg.WindFarmEnv(turbine=wg.V80(), n_passthrough=1, yaml_path=y, turbtype="MannLoad", TurbBox=str(d), seed=2)
+    ref = wg.WindFarmEnv(turbine=wg.V80(), n_passthrough=1, yaml_path=y, turbtype="MannLoad", seed=2,
+                         turbulence_box=(box, (3.0, 3.0, 3.0)))
+    for _ in range(25):
+        a = env.action_space.sample()
+        o1, r1, *_ = env.step(a)
+        o2, r2, *_ = ref.step(a)
+        np.testing.assert_array_equal(o1, o2)                 # the file round-trips to the same field
+    v = env.fs.windTurbines.rotor_avg_windspeed[:, 1]
+    assert np.abs(v).max() > 1e-3                             # turbulent inflow is on
+    env.close(), ref.close()
+    capsys.readouterr()
+    env = wg.WindFarmEnv(turbine=wg.V80(), n_passthrough=1, yaml_path=y, turbtype="MannLoad",
+                         TurbBox=str(tmp_path / "nowhere"), seed=2)
+    assert "switch to generated turbulence" in capsys.readouterr().out
+    env.step(env.action_space.sample())
+    env.close()

@@ -29,3 +29,25 @@ def test_sampling_statistics_and_clipping():
     wd_c, ws_c = sample_site(site, 2000, rng, wd_range=(260, 280), ws_range=(6, 10))
     assert wd_c.min() >= 260 and wd_c.max() <= 280 and ws_c.min() >= 6 and ws_c.max() <= 10
     assert len(set(ws_c.tolist())) > 10
+
+
+def test_turbulence_box_files_round_trip(tmp_path):
+    """On-disk boxes for turbtype "MannLoad" (TurbBox = file or directory of TF_* files, Wind_Farm_Env.py:197-213)."""
+    from windgym_amd.mann import find_box_files, generate_mann_box, load_box, save_box
+    box = generate_mann_box((32, 16, 8), (3.0, 4.0, 5.0), seed=3)
+    d = tmp_path / "boxes"
+    d.mkdir()
+    save_box(str(d / "TF_a.npz"), box * 2.5, (3.0, 4.0, 5.0))            # amplitude is normalised away on load
+    (box * 1.0).astype(np.float32).tofile(str(d / "TF_mann_32x16x8_3.000x4.00x5.00_s0001.bin"))
+    np.save(str(d / "other_32x16x8_3.0x4.0x5.0.npy"), box)
+    files = find_box_files(str(d))
+    assert [f.split("/")[-1] for f in files] == ["TF_a.npz", "TF_mann_32x16x8_3.000x4.00x5.00_s0001.bin"]
+    assert find_box_files(str(d / "TF_a.npz")) == [str(d / "TF_a.npz")] and find_box_files(str(d / "missing")) == []
+    for f in files + [str(d / "other_32x16x8_3.0x4.0x5.0.npy")]:
+        b, dx = load_box(f)
+        assert dx == (3.0, 4.0, 5.0) and b.shape == (3, 32, 16, 8) and b.dtype == np.float32
+        np.testing.assert_allclose(b, box / box[0].std(), rtol=1e-5, atol=1e-6)
+    (d / "TF_hdf5.nc").write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)      # a NetCDF4/HDF5 container: cannot be read here
+    import pytest
+    with pytest.raises(NotImplementedError):
+        load_box(str(d / "TF_hdf5.nc"), dxyz=(3, 3, 3))

@@ -44,6 +44,16 @@ def _attach_box(batch: HipBatch, cfg: EnvConfig, turbulence_box=None):
     reference's box for this turbtype on the GPU (hipFFT)."""
     if cfg.turbtype not in ("MannFixed", "MannGenerate", "MannLoad"):
         return
+    if turbulence_box is None and cfg.turbtype == "MannLoad":
+        # TurbBox = a box file or a directory of TF_* files (:197-213).  ONE box is shared by all envs of the handle
+        # (episodes differ by their random offset into it), so the first readable file is loaded; without files the
+        # reference falls back to generated turbulence, and so does this build.
+        from .mann import find_box_files, load_box
+        for f in find_box_files(getattr(cfg, "TurbBox", None)):
+            turbulence_box = load_box(f)
+            break
+        else:
+            print("Coudnt find the turbulence box file(s), so we switch to generated turbulence")
     if turbulence_box is None:
         from .mann import generate_mann_box_torch, reference_box_spec
         spec = reference_box_spec(cfg.turbtype, cfg.D)
@@ -332,6 +342,13 @@ class WindFarmEnv(_EnvBase):
             old.close()
         self.cfg = cfg
         self._batch = HipBatch(cfg, device=self._device)
+        if self._turbulence_box is None and cfg.turbtype == "MannLoad":
+            from .mann import find_box_files, load_box                         # TurbBox file / directory (:197-213)
+            files = find_box_files(getattr(cfg, "TurbBox", None))
+            if files:
+                self._turbulence_box = load_box(files[0])
+            else:
+                print("Coudnt find the turbulence box file(s), so we switch to generated turbulence")
         if self._turbulence_box is None and cfg.turbtype in ("MannFixed", "MannGenerate", "MannLoad"):
             from .mann import generate_mann_box_torch, reference_box_spec      # generated once, reused on rebuilds
             spec = reference_box_spec(cfg.turbtype, cfg.D)

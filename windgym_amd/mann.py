@@ -134,3 +134,90 @@ def reference_box_spec(turbtype: str, D: float):
     if turbtype == "MannFixed":
         return dict(Nxyz=(2048, 512, 64), dxyz=(3.0, 3.0, 3.0), seed=1234)
     return dict(Nxyz=(4096, 512, 64), dxyz=(D / 20, D / 10, D / 10), seed=1234)
+
+
+# ---------------------------------------------------------------------------------------------------
+# on-disk boxes (row f2): what `TurbBox=` may point to for turbtype "MannLoad" (Wind_Farm_Env.py:197-213, :611-618)
+# ---------------------------------------------------------------------------------------------------
+def save_box(path, box, dxyz):
+    """Write a box [3, Nx, Ny, Nz] with its spacing as .npz (keys uvw, dxyz)."""
+    np.savez_compressed(path, uvw=np.asarray(box, dtype=np.float32), dxyz=np.asarray(dxyz, dtype=np.float64))
+
+
+def _dims_from_name(name):
+    """hipersim-style file names carry the grid: ..._128x128x128_3.000x3.00x3.00_s0001.nc"""
+    import re
+    m = re.search(r"_(\d+)x(\d+)x(\d+)_(\d+(?:\.\d+)?)x(\d+(?:\.\d+)?)x(\d+(?:\.\d+)?)", name)
+    if not m:
+        return None, None
+    return tuple(int(m.group(i)) for i in (1, 2, 3)), tuple(float(m.group(i)) for i in (4, 5, 6))
+
+
+def load_box(path, dxyz=None, Nxyz=None):
+    """Read a turbulence box from disk -> (float32 [3, Nx, Ny, Nz] normalised to unit std of u, (dx, dy, dz)).
+
+    * ``.npz`` written by :func:`save_box` (or with keys u, v, w + dxyz);
+    * ``.npy`` [3, Nx, Ny, Nz] (spacing from ``dxyz`` or from a hipersim-style file name);
+    * raw float32 binaries (HAWC2 / Mann-generator convention): one file holding u, v, w one after the other, or the
+      ``*_u.bin`` of a ``_u / _v / _w`` triplet; grid from ``Nxyz`` / ``dxyz`` or from the file name;
+    * netCDF: only the classic (NetCDF3) container can be read here (``scipy.io.netcdf_file``); hipersim's NetCDF4/HDF5
+      files need netCDF4 or h5py, which this image does not have — convert them once with :func:`save_box`.
+    """
+    import os
+    name = os.path.basename(path)
+    ext = os.path.splitext(name)[1].lower()
+    n_name, d_name = _dims_from_name(name)
+    Nxyz = Nxyz or n_name
+    dxyz = dxyz or d_name
+    if ext == ".npz":
+        z = np.load(path)
+        box = z["uvw"] if "uvw" in z else np.stack([z["u"], z["v"], z["w"]])
+        dxyz = tuple(float(v) for v in z["dxyz"]) if "dxyz" in z else dxyz
+    elif ext == ".npy":
+        box = np.load(path)
+    elif ext in (".bin", ".dat", ".raw"):
+        if Nxyz is None:
+            raise ValueError("raw box: pass Nxyz (and dxyz) or use a file name that carries NxXNyXNz_dxXdyXdz")
+        n = int(np.prod(Nxyz))
+        if name.endswith("_u" + ext):
+            box = np.stack([np.fromfile(path[: -len("_u" + ext)] + f"_{c}{ext}", dtype=np.float32, count=n).reshape(Nxyz)
+                            for c in "uvw"])
+        else:
+            box = np.fromfile(path, dtype=np.float32, count=3 * n).reshape((3,) + tuple(Nxyz))
+    elif ext in (".nc", ".cdf"):
+        try:
+            from scipy.io import netcdf_file
+            f = netcdf_file(path, "r", mmap=False)
+        except Exception as e:                      # NetCDF4 / HDF5 container
+            raise NotImplementedError(
+                f"{name}: not a classic NetCDF3 file ({e}); NetCDF4/HDF5 needs netCDF4 or h5py, which are not installed "
+                "here — convert the box once with windgym_amd.mann.save_box") from e
+        keys = [k for k in ("uvw", "turb", "u") if k in f.variables]
+        if "uvw" in f.variables or "turb" in f.variables:
+            box = np.array(f.variables[keys[0]][:], dtype=np.float32)
+        else:
+            box = np.stack([np.array(f.variables[c][:], dtype=np.float32) for c in "uvw"])
+        if dxyz is None and all(c in f.variables for c in "xyz"):
+            dxyz = tuple(float(f.variables[c][1] - f.variables[c][0]) for c in "xyz")
+        f.close()
+    else:
+        raise ValueError(f"unknown turbulence box format: {name}")
+    box = np.ascontiguousarray(box, dtype=np.float32)
+    if box.ndim != 4 or box.shape[0] != 3:
+        raise ValueError(f"{name}: expected [3, Nx, Ny, Nz], got {box.shape}")
+    if dxyz is None:
+        raise ValueError(f"{name}: grid spacing unknown (pass dxyz)")
+    box = box / float(box[0].std())
+    return box, tuple(float(v) for v in dxyz)
+
+
+def find_box_files(turb_box):
+    """The reference's TurbBox rule (:197-213): a file is used as it is, a directory contributes its ``TF_*`` files."""
+    import os
+    if turb_box is None or not isinstance(turb_box, (str, os.PathLike)):
+        return []
+    if os.path.isfile(turb_box):
+        return [str(turb_box)]
+    if os.path.isdir(turb_box):
+        return sorted(os.path.join(turb_box, f) for f in os.listdir(turb_box) if f.split("_")[0] == "TF")
+    return []
