@@ -118,3 +118,59 @@ def test_fp32_oracle_tracks_fp64_within_the_stated_tolerance(oracle_lib):
     assert worst < 2e-4
     np.testing.assert_allclose(o32.info("rotor_uvw_agent"), o64.info("rotor_uvw_agent"), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(o32.info("yaw_agent"), o64.info("yaw_agent"), atol=1e-4)
+
+
+# Weak external anchors: the only flow numbers the reference publishes — the info dict printed in
+# examples/"Example 1 Make environment.ipynb" (cell 4; a DYNAMIKS run of Env1.yaml: 2 x 2 V80, 8 D pitch, inflow
+# "Random").  Not parity (20 random steps after reset, turbulent), but they pin the frame convention exactly and the
+# wake depth loosely.
+NOTEBOOK = dict(
+    ws=9.30284324942623, wd=266.83258489660614, ti=0.026745343387242243,
+    turb_x=[-17.19232582, 621.82997765, 18.17002235, 657.19232582],
+    turb_y=[218.17002235, 182.80767418, 857.19232582, 821.82997765],
+    ws_turb=[9.03923718, 8.65581559, 9.545715, 4.6348599], ws_turb_base=[9.13321536, 8.67363838, 9.46790185, 4.68019019],
+    yaw=[-0.92572613, -12.55765152, 5.95814133, 4.09113768],
+)
+
+
+def test_flow_frame_matches_the_positions_the_reference_prints(oracle_lib):
+    d = env1_config()
+    d["wind"].update(ws_min=NOTEBOOK["ws"], ws_max=NOTEBOOK["ws"], TI_min=NOTEBOOK["ti"], TI_max=NOTEBOOK["ti"],
+                     wd_min=NOTEBOOK["wd"], wd_max=NOTEBOOK["wd"])
+    cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_passthrough=1)
+    o = oracle_lib.Oracle(cfg)
+    o.reset(seeds=[0])
+    np.testing.assert_allclose(o.info("turb_x")[0], NOTEBOOK["turb_x"], rtol=0, atol=1e-6)
+    # same rotation about the farm centre; the reference's y carries a constant +200 m offset of its flow domain
+    np.testing.assert_allclose(o.info("turb_y")[0] + 200.0, NOTEBOOK["turb_y"], rtol=0, atol=1e-6)
+
+
+def _converged_ratio(oracle_lib, wd):
+    d = env1_config()
+    d["yaw_init"] = "Zeros"
+    d["ActionMethod"] = "yaw"
+    d["wind"].update(ws_min=NOTEBOOK["ws"], ws_max=NOTEBOOK["ws"], TI_min=NOTEBOOK["ti"], TI_max=NOTEBOOK["ti"],
+                     wd_min=wd, wd_max=wd)
+    cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_passthrough=5, n_rotor_pts=16)
+    o = oracle_lib.Oracle(cfg)
+    o.reset(seeds=[0])
+    for _ in range(200):
+        o.step(np.zeros((1, 4)))
+    return o.info("rotor_uvw_agent")[0][:, 0] / NOTEBOOK["ws"]
+
+
+def test_wake_depth_against_the_reference_notebook(oracle_lib):
+    """The turbine 8 D behind another one saw 4.63 of 9.30 m/s (0.50) in the reference's DYNAMIKS run (TI 2.7 %, wake
+    centre 0.44 D off the rotor axis, upstream rotor yawed 6 deg, 20 steps into a turbulent episode).  Model M0 — the
+    Gaussian profile north_star asks for, with the literature constants k* = 0.38 TI + 0.004, eps = 0.2 sqrt(beta) — has
+    a 48 % centre-line deficit there but is narrower than DWM's Ainslie profile at this low TI: rotor-averaged 0.68 on
+    the wake axis and 0.80 at the same lateral offset.  This is the documented physics gap ("parity unpinned",
+    DESIGN.md §2): the test pins M0's own values next to the reference's number instead of pretending agreement."""
+    ref = NOTEBOOK["ws_turb"][3] / NOTEBOOK["ws"]                                  # 0.498
+    assert 0.49 < ref < 0.51
+    r = _converged_ratio(oracle_lib, NOTEBOOK["wd"])
+    assert abs(r[0] - 1.0) < 1e-9 and abs(r[2] - 1.0) < 1e-9                      # front row: free stream
+    assert abs(r[1] - r[3]) < 1e-6                                                 # the two rows are symmetric in M0
+    assert 0.77 < r[3] < 0.82                                                      # M0 at 0.44 D offset (reference: 0.50)
+    r0 = _converged_ratio(oracle_lib, 270.0)                                       # wake axis through the rotor centre
+    assert 0.66 < r0[3] < 0.71                                                     # rotor-averaged, aligned
