@@ -385,3 +385,23 @@ def test_mannload_reads_the_turbbox_file_or_falls_back(wg, tmp_path, capsys):
     assert "switch to generated turbulence" in capsys.readouterr().out
     env.step(env.action_space.sample())
     env.close()
+
+
+def test_agent_eval_facade(wg, tmp_path):
+    """AgentEval(env, model, name, t_sim).set_conditions / eval_multiple / save_performance / load_performance
+    (AgentEval.py:478-715; tests/test_basics.py:327-365 drives it this way)."""
+    from windgym_amd import presets
+    env = wg.FarmEval(turbine=wg.V80(), yaml_path=_yaml(tmp_path, presets.env1_config()), turbtype="None",
+                      yaw_init="Zeros", seed=1)
+    tester = wg.AgentEval(env=env, model=wg.ConstantAgent(yaw_angles=[0, 0, 0, 0]), name=str(tmp_path / "const"), t_sim=12)
+    tester.set_conditions(winddirs=[260, 270], windspeeds=[10], turbintensities=[0.07], turbboxes=["Default"])
+    ds = tester.eval_multiple(save_figs=False, debug=False)
+    data = ds["data"] if isinstance(ds, dict) else {k: ds[k].values for k in ds.data_vars}
+    assert data["powerF_a"].shape == (12, 1, 2, 1, 1, 1) and data["powerT_a"].shape == (12, 4, 1, 2, 1, 1, 1)
+    assert (data["powerF_a"] > 0).all() and "pct_inc" in data
+    path = tester.save_performance()
+    other = wg.AgentEval(env=env, model=None, name="x")
+    ds2 = other.load_performance(path)
+    np.testing.assert_array_equal(ds2["data"]["powerF_a"], data["powerF_a"])
+    assert list(ds2["coords"]["wd"]) == [260.0, 270.0]
+    env.close()

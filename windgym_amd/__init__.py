@@ -14,4 +14,13 @@ def __getattr__(name):   # lazy: importing the env classes pulls in torch
     if name == "HipBatch":
         from .binding import HipBatch
         return HipBatch
+    if name in ("AgentEval", "eval_sweep"):
+        from . import evaluate
+        return getattr(evaluate, name)
+    if name in ("ConstantAgent", "RandomAgent", "GreedyAgent", "BaseAgent"):
+        from . import agents
+        return getattr(agents, name)
+    if name in ("PyWakeAgent", "SteadyStateYawAgent"):
+        from . import steady
+        return getattr(steady, name)
     raise AttributeError(name)

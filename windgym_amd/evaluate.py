@@ -79,3 +79,76 @@ def eval_sweep(turbine, yaml_path=None, model=None, *, winddirs=(270.0,), windsp
         return xr.Dataset({k: (dims5 if v.ndim == 7 else dims4, v) for k, v in data.items()}, coords=coords)
     except Exception:
         return dict(coords=coords, dims={k: (dims5 if v.ndim == 7 else dims4) for k, v in data.items()}, data=data)
+
+
+class AgentEval:
+    """The reference's evaluation driver (AgentEval.py:478-715) on top of :func:`eval_sweep`: ``set_conditions`` collects
+    the grid, ``eval_multiple`` runs ALL combinations in one batched rollout (the reference loops over them, :579-617)
+    and keeps the result in ``multiple_eval_ds`` with the reference's dims / variable names; ``save_performance`` /
+    ``load_performance`` persist it (``.npz`` — xarray / netCDF are not available here).  Plotting is out of scope.
+
+    ``env`` may be a :class:`FarmEval` / :class:`WindFarmEnv` (its turbine, YAML and constructor kwargs are reused) or
+    None with ``turbine`` / ``yaml_path`` given explicitly."""
+
+    def __init__(self, env=None, model=None, name="NoName", t_sim=1000, *, turbine=None, yaml_path=None, **env_kwargs):
+        self.ws, self.ti, self.wd, self.yaw, self.turbbox = 10.0, 0.05, 270, 0.0, "Default"
+        self.t_sim = t_sim
+        self.winddirs, self.windspeeds, self.turbintensities, self.turbboxes = [270], [10], [0.05], ["Default"]
+        self.multiple_eval, self.multiple_eval_ds = False, None
+        self.env, self.model, self.name = env, model, name
+        kw = dict(getattr(env, "_kw", {}))
+        self._turbine = turbine if turbine is not None else kw.get("turbine")
+        self._yaml = yaml_path if yaml_path is not None else kw.get("yaml_path")
+        self._env_kwargs = dict(turbtype=kw.get("turbtype", "None"), yaml_dict=kw.get("yaml_dict"),
+                                n_passthrough=kw.get("n_passthrough", 5))
+        self._env_kwargs.update(env_kwargs)
+        if self._turbine is None:
+            raise ValueError("AgentEval needs an env (FarmEval / WindFarmEnv) or turbine= and yaml_path=")
+
+    def set_conditions(self, winddirs: list = [], windspeeds: list = [], turbintensities: list = [],
+                       turbboxes: list = ["Default"]):
+        if winddirs:
+            self.winddirs = list(winddirs)
+        if windspeeds:
+            self.windspeeds = list(windspeeds)
+        if turbintensities:
+            self.turbintensities = list(turbintensities)
+        if turbboxes:
+            self.turbboxes = list(turbboxes)
+
+    def eval_multiple(self, save_figs=False, scale_obs=None, debug=False):
+        n = len(self.winddirs) * len(self.windspeeds) * len(self.turbintensities) * len(self.turbboxes)
+        print("Running for a total of ", n, "simulations.")
+        if save_figs or debug:
+            raise NotImplementedError("figures / debug plots of AgentEval are not part of this build")
+        kw = {k: v for k, v in self._env_kwargs.items() if v is not None}
+        self.multiple_eval_ds = eval_sweep(self._turbine, self._yaml, self.model, winddirs=self.winddirs,
+                                           windspeeds=self.windspeeds, turbintensities=self.turbintensities,
+                                           t_sim=self.t_sim, turbbox=self.turbboxes[0], **kw)
+        self.multiple_eval = True
+        return self.multiple_eval_ds
+
+    def save_performance(self, path=None):
+        if not self.multiple_eval:
+            print("It doenst look like you have any data to save my guy")
+            return None
+        ds = self.multiple_eval_ds
+        path = path or (str(self.name) + "_eval.npz")
+        if isinstance(ds, dict):
+            flat = {f"data__{k}": v for k, v in ds["data"].items()}
+            flat.update({f"coord__{k}": np.asarray(v) for k, v in ds["coords"].items()})
+            np.savez_compressed(path, **flat)
+        else:                                           # an xarray.Dataset when xarray is installed
+            ds.to_netcdf(path if path.endswith(".nc") else path + ".nc")
+        return path
+
+    def load_performance(self, path):
+        z = np.load(path, allow_pickle=False)
+        data = {k[6:]: z[k] for k in z.files if k.startswith("data__")}
+        coords = {k[7:]: z[k] for k in z.files if k.startswith("coord__")}
+        dims4 = ("time", "ws", "wd", "TI", "turbbox", "model_step")
+        dims5 = ("time", "turb", "ws", "wd", "TI", "turbbox", "model_step")
+        self.multiple_eval_ds = dict(coords=coords, dims={k: (dims5 if v.ndim == 7 else dims4) for k, v in data.items()},
+                                     data=data)
+        self.multiple_eval = True
+        return self.multiple_eval_ds
