@@ -220,6 +220,25 @@ def test_hip_autoreset_pipeline_matches_oracle(hip, oracle_lib):
     np.testing.assert_allclose(m_gpu, m_cpu, rtol=2e-3, atol=1e-2)
 
 
+def test_large_odd_batch_with_rollovers_matches_oracle(hip, oracle_lib):
+    """B = 389 envs (not a multiple of anything), cfg2-shaped farm, two farms, same-step autoreset with several episode
+    rollovers: every batch-size dependent path (block order, context hashing, background scheduling) against the
+    oracle, which knows none of them."""
+    B = 389
+    cfg = _physics_cfg(B, autoreset=True, n_passthrough=1)
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    seeds = 5000 + np.arange(B)
+    np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=OBS_ATOL)
+    rng = np.random.default_rng(8)
+    n_tr = 0
+    for step in range(260):
+        a = rng.uniform(-1, 1, size=(B, cfg.n_turb)).astype(np.float32)
+        _compare_step(env, orc, a, step, check_flow=(step % 40 == 0))
+        n_tr += int((orc.info("timestep") == 0).sum())
+    env.check()
+    assert n_tr >= B
+
+
 def test_partial_reset_and_state_roundtrip(hip, oracle_lib):
     B = 4
     cfg = _physics_cfg(B, autoreset=False, n_passthrough=2, nx=2, ny=2)
