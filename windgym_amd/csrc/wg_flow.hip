@@ -1,6 +1,9 @@
 // wg_flow.hip — k_flow, the dominant kernel of libwindgym_hip.so (gfx950, wave64).
 //
-// One 256-thread workgroup per farm slot (env x ctx x farm).  Per flow step it
+// One workgroup per farm slot (env x ctx x farm); 64 / 128 / 256 threads chosen on the host from N x P (k_flow<NT,...>:
+// each size has its own tuning — quads in flight per lane, occupancy target, record layout for the deficit gathers,
+// chain pruning).  Which slot a workgroup serves is a hashed / reordered function of blockIdx (see k_flow) so that
+// live farms and background episodes are spread over all XCDs, shader engines and CUs.  Per flow step it
 //   (1) computes the emission record of every turbine (N threads),
 //   (2) streams the slot's wake-particle SoA through HBM with 16-byte coalesced accesses: advection by the
 //       Hill-vortex deflection speed + release of the new particles                        [HBM-bound part]
