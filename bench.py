@@ -1,22 +1,40 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/sec of the batched WindGym step() on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = one batched step() over all envs of this rank (actions already resident in HBM).  Prints ONE
-JSON line on rank 0 with `value` = whole-job env-steps/s, `roofline` for the dominant kernel (k_flow) and
-`cpu_baseline` (the oracle's C port timed on the host cores, rank 0, N=1 only).
+One "step" = one batched step() over all envs of a rank (actions already resident in HBM).  Rank 0 prints ONE JSON
+line: `value` = whole-job env-steps/s, `roofline` for the dominant kernel (k_flow), `cpu_baseline` (the oracle's C
+port timed on the host cores; rank 0, N = 1 only).
+
+Launch: for N > 1 the driver starts this file under `python -m torch.distributed.run --nproc-per-node N`; when it is
+started directly with --gpus N > 1 it re-executes itself that way.  A world size that differs from --gpus, or fewer
+visible GPUs than ranks, is an error — the line never reports a GPU count it did not run on.
+
+Timed region: after `--preroll` untimed steps (the batch leaves its synchronised start: episodes truncate and reset at
+their own times, background episodes are in their steady-state schedule) and W warm-up steps, EXACTLY K steps are timed
+between barrier + synchronize; that is repeated `--reps` times and the MEDIAN repetition is reported (all of them are
+listed in `ms_per_step_reps`), so that one descheduled host thread does not decide the number.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# host threads must not spin: idle OpenMP workers (torch's pool, the oracle's) busy-waiting inside a CPU-quota'd
+# container starve the one thread that launches kernels
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+os.environ.setdefault("KMP_BLOCKTIME", "0")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 WORKLOADS = {
@@ -50,18 +68,43 @@ def make_cfg(n_envs, autoreset=True, farms2=True, workload="cfg2"):
                      n_passthrough=5, n_rotor_pts=16, **kw)
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(args):
-    """The oracle's C port (OpenMP over envs) on a bounded sample of the same workload."""
+    """The oracle's C port (OpenMP over envs, one thread per usable core, passive waits) on a bounded sample of
+    the same workload: >= 2 envs per thread, ~10-15 s of CPU work."""
     import numpy as np
     from oracle import oracle as om
     om.build()
-    n = args.cpu_envs
+    cores = min(host_cores(), 64)
+    n = args.cpu_envs if args.cpu_envs else max(64, 2 * cores)
     cfg = make_cfg(n, autoreset=True, farms2=not args.one_farm, workload=args.workload)
     orc = om.Oracle(cfg, "f32" if args.cpu_f32 else "f64")
+    orc.set_threads(cores)
     if args.workload == "cfg5":
         from windgym_amd.mann import generate_mann_box
         orc.set_turbulence_box(generate_mann_box((512, 128, 32), (3.0, 3.0, 3.0), seed=1234), (3.0, 3.0, 3.0))
-    cores = orc.max_threads()
     orc.reset(seeds=1234 + np.arange(n))
     rng = np.random.default_rng(0)
     acts = rng.uniform(-1, 1, size=(8, n, cfg.n_turb)).astype(np.float32)
@@ -77,45 +120,88 @@ def cpu_baseline(args):
             break
     return {"value": n * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{n} envs x {steps} steps of the same {args.workload} workload (oracle C port, "
-                      f"{'fp32' if args.cpu_f32 else 'fp64'}, OpenMP over envs, after reset)"}
+                      f"{'fp32' if args.cpu_f32 else 'fp64'}, OpenMP over envs on {cores} threads = usable cores "
+                      f"(affinity mask capped by the cgroup quota), passive waits, after reset)"}
 
 
-def main():
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step timed region; the median is reported")
+    ap.add_argument("--preroll", type=int, default=None,
+                    help="untimed steps before the warm-up that take the batch out of its synchronised start "
+                         "(default: 600 for cfg2/cfg4/cfg5, 100 for cfg3)")
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (weak scaling); default per workload")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
                     help="cfg2 is the headline metric; the others are BASELINE.json's remaining GPU configs")
     ap.add_argument("--one-farm", action="store_true", help="F=1 (no baseline farm)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--graph", type=int, default=None, help="1: step() as one hipGraphLaunch, 0: direct launches "
+                                                             "(default: the library's default)")
     ap.add_argument("--full-chains", action="store_true", help="no chain pruning: advect all P slots of every chain")
     ap.add_argument("--no-autoreset", action="store_true",
                     help="diagnostic only: no background episodes (the run must stay shorter than the shortest episode)")
-    ap.add_argument("--cpu-envs", type=int, default=64)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-envs", type=int, default=0, help="envs of the CPU sample (default: max(64, 2 x cores))")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-max-steps", type=int, default=400)
     ap.add_argument("--cpu-f32", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    # stdout carries exactly ONE line (the JSON): everything a library prints there (RCCL's version banner, ...) is
+    # sent to stderr instead; the line itself is written to the saved descriptor at the very end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    if args.gpus < 1 or args.steps < 1 or args.reps < 1:
+        sys.exit("bench.py: --gpus, --steps and --reps must be >= 1")
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    import torch
+    n_vis = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_vis < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, found {n_vis}")
+    if args.gpus > 1 and not launched:
+        # started directly: become the N-rank job the flag asks for (one process per GPU over RCCL)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, stdout=json_fd))
 
     import numpy as np
-    import torch
     import torch.distributed as dist
+    torch.set_num_threads(1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # under torch.distributed.run (RANK / MASTER_PORT in the env) the RCCL group is always created — also for one
-    # rank, so that the single-GPU box exercises exactly the collectives the 8-GPU run uses
-    dist_on = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
-    if dist_on:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if dist_on else 0)
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a GPU count that did not run")
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    # The RCCL group exists for every N — also N = 1, so that the single-GPU run exercises exactly the collective
+    # the 8-GPU run uses (ShardedMetrics.all_reduce over "nccl").
+    if not launched:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(free_port())
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    rccl = True
+    try:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    except Exception as ex:          # pragma: no cover — only tolerated for a single rank
+        if world > 1:
+            raise
+        print(f"bench.py: RCCL process group unavailable for the single rank ({ex}); metrics stay local", file=sys.stderr)
+        rccl = False
 
     from windgym_amd import binding
     from windgym_amd.parallel import ShardedMetrics
@@ -123,6 +209,8 @@ def main():
     cfg = make_cfg(B, autoreset=not args.no_autoreset, farms2=not args.one_farm, workload=args.workload)
     cfg.advect_full_chains = bool(args.full_chains)
     env = binding.HipBatch(cfg, device=dev.index)
+    if args.graph is not None:
+        env.set_step_graph(bool(args.graph))
     if args.workload == "cfg5":
         from windgym_amd.mann import generate_mann_box_torch, reference_box_spec
         spec = reference_box_spec("MannFixed", cfg.D)
@@ -133,11 +221,12 @@ def main():
     gen = torch.Generator(device="cpu").manual_seed(0 + rank)
     n_act = 16
     actions = (torch.rand((n_act, B, cfg.n_turb), generator=gen) * 2 - 1).to(dev).contiguous()
+    acts = [actions[i] for i in range(n_act)]
     metrics = ShardedMetrics(env)
 
     def barrier():
         torch.cuda.synchronize()
-        if dist_on:
+        if rccl:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -145,31 +234,49 @@ def main():
     # step's own glue kernel into a registered buffer (no separate packing launch)
     multi_out = env.fuse_obs_multi() if args.workload == "cfg4" else None
 
-    def one_step(i):
-        env.step(actions[i % n_act])
-
-    for i in range(args.warmup):
-        one_step(i)
+    step = env.step
+    it = 0
+    preroll = args.preroll if args.preroll is not None else (0 if args.no_autoreset else
+                                                             (100 if args.workload == "cfg3" else 600))
+    for _ in range(preroll):
+        step(acts[it % n_act]); it += 1
     env.check()
-    env.kernel_timing(4)          # HIP events around every 4th step() of the timed region
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(i)
-    barrier()
-    el = time.perf_counter() - t0
-    flow_ms, glue_ms, n_launch, flow_steps, particles = env.kernel_timing(False)
+    metrics.all_reduce()                 # RCCL warm-up of the one collective + reset of the episode-metric sums
+    env.kernel_timing(4)                 # creates the event pool (outside every timed region)
+    env.kernel_timing(0)
+    rep_s = []
+    flow_ms = glue_ms = 0.0
+    n_launch = 0
+    flow_steps = particles = 0.0
+    for _ in range(args.warmup):
+        step(acts[it % n_act]); it += 1
     env.check()
+    for rep in range(args.reps):
+        env.kernel_timing(4)             # HIP events around every 4th step() of the timed region
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(acts[it % n_act]); it += 1
+        barrier()
+        el = time.perf_counter() - t0
+        f, g, n, fs, pt = env.kernel_timing(0)
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        if rccl:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)        # slowest rank
+        rep_s.append(float(t.item()))
+        flow_ms += f * n; glue_ms += g * n; n_launch += n
+        flow_steps += fs; particles += pt
+    env.check()
+    if n_launch:
+        flow_ms /= n_launch; glue_ms /= n_launch
+    flow_steps /= args.reps; particles /= args.reps
     if multi_out is not None:          # the fused buffer holds what an explicit wg_obs_multi returns
         assert torch.equal(multi_out, env.obs_multi())
     m = metrics.all_reduce()            # the only collective on the path: 8 floats
 
-    t = torch.tensor([el], dtype=torch.float64, device=dev)
-    if dist_on:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el_max = float(t.item())
+    el_med = sorted(rep_s)[len(rep_s) // 2]
     total_envs = B * world
-    value = total_envs * args.steps / el_max
+    value = total_envs * args.steps / el_med
 
     if rank == 0:
         F = cfg.to_c().n_farms
@@ -182,13 +289,14 @@ def main():
         per_particle = 16.0 + (24.0 + 64.0 if args.workload == "cfg5" else 0.0)
         per_farm_step = cfg.n_turb * 72.0 + (cfg.n_turb * cfg.n_rotor_pts * 96.0 if args.workload == "cfg5" else 0.0)
         alg_bytes_flow = particles * per_particle + flow_steps * per_farm_step
+        slot_bytes_flow = flow_steps * (cfg.n_turb * cfg.n_particles * per_particle + per_farm_step)
         bytes_per_flow_step = alg_bytes_flow / flow_steps if flow_steps > 0 else 0.0
         achieved = alg_bytes_flow / (flow_ms * 1e-3) / 1e9 if flow_ms > 0 else 0.0
         # HBM bytes per k_flow launch from the rocprofv3 PMC passes of this same command (separate runs:
-        # tools/profile_kflow.sh -> profiles/r01_kflow_traffic.json); only quoted for the profiled workload
+        # tools/profile_kflow.sh -> profiles/r02_kflow_traffic.json); only quoted for the profiled workload
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_kflow_traffic.json")
-        if os.path.exists(tf) and B == 4096 and F == 2 and world == 1 and args.workload == "cfg2":
+        tf = os.path.join(ROOT, "profiles", "r02_kflow_traffic.json")
+        if os.path.exists(tf) and B == 4096 and F == 2 and args.workload == "cfg2":
             try:
                 traffic = json.load(open(tf))["hbm_bytes_per_launch"]
             except Exception:
@@ -197,7 +305,7 @@ def main():
             "metric": "env-steps/sec (whole node), 16-turbine farm x 4096 envs" if args.workload == "cfg2"
                       else f"env-steps/sec (whole node), {args.workload}",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": el_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": el_med / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload][1]} "
                                    f"(O={env.obs_dim}), {B} envs/GPU, F={F} farms/env "
@@ -205,20 +313,31 @@ def main():
                                    f"S={cfg.n_rotor_pts}, same-step autoreset on",
                        "envs_per_gpu": B, "n_turb": cfg.n_turb, "farms_per_env": F,
                        "parallelism": f"env-axis shard x{world}"},
+            "reps": args.reps, "preroll": preroll,
+            "ms_per_step_reps": [r / args.steps * 1e3 for r in rep_s],
+            "gpu_ms_per_step": flow_ms + glue_ms,
+            "rccl": rccl,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "kernel": "k_flow",
                          "kernel_ms": flow_ms, "glue_kernel_ms": glue_ms, "launches_timed": n_launch,
                          "algorithmic_bytes_per_launch": alg_bytes_flow, "farm_flow_steps_per_launch": flow_steps,
-                         "particles_streamed_per_launch": particles,
+                         "particles_needed_per_launch": particles,
                          "particle_slots_per_launch": flow_steps * cfg.n_turb * cfg.n_particles,
-                         "bytes_per_farm_flow_step": bytes_per_flow_step},
+                         "bytes_per_farm_flow_step": bytes_per_flow_step,
+                         "frac_all_slots": (slot_bytes_flow / (flow_ms * 1e-3) / 1e9 / 8000.0) if flow_ms > 0 else 0.0},
             "episode_metrics": {k: float(v) for k, v in m.items()},
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out))
-    if dist_on:
+        line = json.dumps(out)
+    else:
+        line = None
+    if rccl:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if line is not None:
+        os.write(json_fd, (line + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

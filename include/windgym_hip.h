@@ -226,9 +226,17 @@ int wg_reset(wg_handle h, const uint8_t* env_mask_host, const uint64_t* seeds_ho
 int wg_step(wg_handle h, const float* actions_dev, float* obs_dev, float* reward_dev,
             uint8_t* truncated_dev, float* final_obs_dev, void* stream);
 
+/* step() as ONE graph launch: with enable != 0 the kernels of a step are captured once per
+ * distinct set of I/O pointers into a HIP graph (at most 32 sets are cached, least recently used evicted) and every
+ * following wg_step is a single hipGraphLaunch on the caller's stream.  Results are identical to the direct launches.
+ * Setters that change kernel arguments (turbulence box, wind override, flow script, obs-multi buffer) drop the cached
+ * graphs.  Default: off (two direct launches; measured faster on the host for a two-kernel step — DESIGN.md §4.4);
+ * the environment variable WG_STEP_GRAPH=1 switches it on at wg_create.                                   */
+int wg_set_step_graph(wg_handle h, int enable);
+
 /* step() is asynchronous, so the errors the reference raises inside step() (Exception("NaN Power"), stepping
  * a torn-down env) are latched in a sticky device word.  wg_check synchronises `stream` and returns it
- * (0, WG_ERR_NAN_POWER or WG_ERR_STATE); wg_reset clears it.                                           */
+ * (0, WG_ERR_NAN_POWER or WG_ERR_STATE); a wg_reset of the whole batch clears it.                                           */
 int wg_check(wg_handle h, void* stream);
 
 /* Per-agent observations of the PettingZoo facade for the current state: f32[B,N,obs_dim_multi].      */
@@ -257,7 +265,9 @@ int wg_get_info(wg_handle h, wg_info_field field, void* out_dev, void* stream);
  * in device memory (ready for one RCCL all-reduce(sum)).                                              */
 int wg_metrics(wg_handle h, float* out_dev, int reset_after, void* stream);
 
-/* Checkpoint / golden replay: serialise the full device state.  Call with blob_host == NULL to get size. */
+/* Checkpoint / golden replay: serialise the full device state.  Call with blob_host == NULL to get size.  The blob
+ * carries a header (magic, ABI version, batch geometry); wg_set_state rejects a blob taken from a differently
+ * configured handle.  The wind override of wg_set_wind is configuration, not state (re-apply it after a restore). */
 int wg_get_state(wg_handle h, void* blob_host, size_t* size);
 int wg_set_state(wg_handle h, const void* blob_host, size_t size);
 

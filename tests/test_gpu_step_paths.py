@@ -1,0 +1,137 @@
+"""GPU tests of the step() plumbing around the kernels: graph launch vs direct launches, the RCCL metric
+all-reduce at world size 1, resets under a wind override below the config's range, the state-blob header."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import OBS_ATOL, _physics_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    from windgym_amd import binding
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    binding.load_library()
+    return binding
+
+
+def test_graph_step_is_bit_identical_to_direct_launches(hip):
+    """wg_set_step_graph: the captured step (one hipGraphLaunch) and the two direct launches produce the same bits,
+    for several action buffers (one cached graph each), across an eviction of the graph cache and across an
+    autoreset."""
+    import torch
+    B = 9
+    cfg = _physics_cfg(B, autoreset=True, n_passthrough=0.3)
+    a_env, g_env = hip.HipBatch(cfg), hip.HipBatch(cfg)
+    g_env.set_step_graph(True)
+    seeds = 77 + np.arange(B)
+    o_a = a_env.reset(seeds=seeds).clone()
+    o_g = g_env.reset(seeds=seeds).clone()
+    assert torch.equal(o_a, o_g)
+    gen = torch.Generator().manual_seed(3)
+    bufs = [(torch.rand((B, cfg.n_turb), generator=gen) * 2 - 1).cuda() for _ in range(40)]   # > 32: forces eviction
+    n_trunc = 0
+    for i in range(160):
+        a = bufs[(i * 7) % len(bufs)]
+        ra = [t.clone() for t in a_env.step(a)]
+        rg = [t.clone() for t in g_env.step(a)]
+        for x, y in zip(ra, rg):
+            assert torch.equal(x, y), i
+        n_trunc += int(ra[2].sum())
+    assert n_trunc >= B            # every env rolled over at least once inside the graph path
+    a_env.check(); g_env.check()
+    for k in ("rotor_uvw_agent", "power_turb_base", "yaw_base"):
+        assert torch.equal(a_env.info(k), g_env.info(k))
+    # a setter that changes kernel arguments invalidates the cached graphs
+    buf = g_env.fuse_obs_multi()
+    g_env.step(bufs[0]); a_env.step(bufs[0])
+    assert torch.equal(buf, a_env.obs_multi())
+    a_env.close(); g_env.close()
+
+
+def test_sharded_metrics_over_rccl_world_size_one(hip):
+    """The one collective of the path (8-float all-reduce) through backend "nccl" (= RCCL) with a single rank."""
+    import torch
+    import torch.distributed as dist
+    from windgym_amd.parallel import METRIC_NAMES, ShardedMetrics
+    B = 16
+    cfg = _physics_cfg(B, autoreset=True, n_passthrough=0.3)
+    env = hip.HipBatch(cfg)
+    env.reset(seeds=np.arange(B))
+    gen = torch.Generator().manual_seed(0)
+    for _ in range(60):
+        env.step((torch.rand((B, cfg.n_turb), generator=gen) * 2 - 1).cuda())
+    local = env.metrics(reset_after=False).clone().cpu()
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        m = ShardedMetrics(env).all_reduce(reset_after=True)
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+    for i, k in enumerate(METRIC_NAMES):
+        assert m[k] == pytest.approx(float(local[i]), rel=1e-6), k
+    assert m["n_steps"] == 60 * B and m["n_episodes"] >= 1
+    assert float(env.metrics().sum()) == 0.0          # reset_after cleared the device sums
+    env.close()
+
+
+def test_reset_with_wind_override_below_the_sampling_range(hip, oracle_lib):
+    """FarmEval.set_wind_vals may ask for a slower wind than the YAML's ws_min (FarmEval.py:63-78): the episode then
+    needs more development steps than wg_reset's planned launches cover.  The reset must still return a fully developed
+    wake and filled sensor windows (parity with the synchronous oracle reset), on the host table and the device table."""
+    import torch
+    B = 4
+    cfg = _physics_cfg(B, autoreset=False, n_passthrough=1.0, nx=3, ny=1)
+    assert cfg.to_c().ws_min >= 7.0
+    ws = np.array([4.0, 4.5, 9.0, 3.6])
+    orc = oracle_lib.Oracle(cfg)
+    orc_env = None
+    for mode in ("host", "device"):
+        env = hip.HipBatch(cfg)
+        if mode == "host":
+            env.set_wind(ws=ws)
+        else:
+            w = torch.full((B, 3), float("nan"), dtype=torch.float64, device="cuda")
+            w[:, 0] = torch.as_tensor(ws)
+            env.set_wind_device(w)
+        obs = env.reset(seeds=5 + np.arange(B)).cpu().numpy()
+        env.check()
+        np.testing.assert_allclose(env.info("ws_global").cpu().numpy(), ws, rtol=1e-6)
+        if orc_env is None:
+            # the oracle has no override hook: pin against an oracle whose sampling range is the override itself
+            ref = []
+            for b in range(B):
+                c1 = _physics_cfg(1, autoreset=False, n_passthrough=1.0, nx=3, ny=1,
+                                  wind=dict(ws_min=float(ws[b]), ws_max=float(ws[b])))
+                o1 = oracle_lib.Oracle(c1)
+                ref.append((o1, o1.reset(seeds=[5 + b])[0]))
+            orc_env = ref
+        for b in range(B):
+            # same ws; wd / ti come from the same generator stream position (the override keeps the draws aligned)
+            np.testing.assert_allclose(env.info("wd_global").cpu().numpy()[b], orc_env[b][0].info("wd_global")[0], rtol=1e-6)
+            np.testing.assert_allclose(obs[b], orc_env[b][1], rtol=0, atol=OBS_ATOL)
+            np.testing.assert_allclose(env.info("rotor_uvw_agent").cpu().numpy()[b], orc_env[b][0].info("rotor_uvw_agent")[0],
+                                       rtol=1e-4, atol=1e-4)
+        env.close()
+
+
+def test_state_blob_is_rejected_by_a_differently_configured_handle(hip):
+    cfg_a = _physics_cfg(4, autoreset=True, n_passthrough=1.0, nx=2, ny=2)
+    cfg_b = _physics_cfg(4, autoreset=True, n_passthrough=1.0, nx=2, ny=2, power_def=dict(Power_avg=11))
+    a, b = hip.HipBatch(cfg_a), hip.HipBatch(cfg_b)
+    a.reset(seeds=np.arange(4))
+    blob = a.get_state()
+    a.set_state(blob)                         # round trip on the same geometry
+    with pytest.raises(ValueError):
+        b.set_state(blob)
+    with pytest.raises(ValueError):
+        a.set_state(b"\0" * len(blob))
+    a.close(); b.close()

@@ -20,7 +20,7 @@ UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 # every symbol include/windgym_hip.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = (
     "wg_last_error", "wg_abi_version", "wg_create", "wg_destroy", "wg_obs_dim", "wg_hist_max",
-    "wg_set_turbulence_box", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_check", "wg_obs_multi", "wg_set_obs_multi_buffer",
+    "wg_set_turbulence_box", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_set_step_graph", "wg_check", "wg_obs_multi", "wg_set_obs_multi_buffer",
     "wg_get_info", "wg_get_measurements", "wg_get_windspeed", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_algorithmic_bytes",
 )
 
@@ -57,6 +57,7 @@ def load_library():
     L.wg_set_wind_device.argtypes = [C.c_void_p, C.c_void_p]
     L.wg_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.wg_step.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    L.wg_set_step_graph.argtypes = [C.c_void_p, C.c_int]
     L.wg_check.argtypes = [C.c_void_p, C.c_void_p]
     L.wg_obs_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.wg_set_obs_multi_buffer.argtypes = [C.c_void_p, C.c_void_p]
@@ -113,6 +114,11 @@ class HipBatch:
         self.reward = torch.zeros(self.B, **f32)
         self.truncated = torch.zeros(self.B, dtype=torch.uint8, device=self.device)
         self._metrics = torch.zeros(WG_N_METRICS, **f32)
+        # step() hot path: the persistent output pointers and the bound C function, prepared once
+        self._out_ptrs = (self.obs.data_ptr(), self.reward.data_ptr(), self.truncated.data_ptr(),
+                          self.final_obs.data_ptr())
+        self._wg_step = self.L.wg_step
+        self._cur_stream = torch.cuda.current_stream
         self._script = None
         self._box = None
 
@@ -145,11 +151,18 @@ class HipBatch:
 
     def step(self, actions):
         """actions: float32 CUDA tensor [B, N].  Returns views of the persistent output tensors."""
-        assert actions.is_cuda and actions.dtype == self.torch.float32 and actions.is_contiguous()
-        _chk(self.L.wg_step(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(self.obs.data_ptr()),
-                            C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.truncated.data_ptr()),
-                            C.c_void_p(self.final_obs.data_ptr()), self._stream()), "wg_step")
+        if not (actions.is_cuda and actions.dtype == self.torch.float32 and actions.is_contiguous()
+                and actions.numel() == self.B * self.N):
+            raise ValueError("step(): actions must be a contiguous float32 CUDA tensor [B, N]")
+        o, r, t, f = self._out_ptrs
+        rc = self._wg_step(self._h, actions.data_ptr(), o, r, t, f, self._cur_stream(self.device).cuda_stream)
+        if rc:
+            _chk(rc, "wg_step")
         return self.obs, self.reward, self.truncated, self.final_obs
+
+    def set_step_graph(self, enable=True):
+        """step() as one hipGraphLaunch (captured per distinct set of I/O pointers) instead of direct launches."""
+        _chk(self.L.wg_set_step_graph(self._h, int(bool(enable))), "wg_set_step_graph")
 
     def check(self):
         _chk(self.L.wg_check(self._h, self._stream()), "wg_check")

@@ -25,6 +25,7 @@ void wg_launch_box_repack(const float*, void*, size_t, hipStream_t);
 void wg_launch_measurements(const WgParams*, const WgPtrs*, float*, hipStream_t);
 void wg_launch_box_coarsen(const void*, void*, int, int, int, hipStream_t);
 void wg_launch_windspeed(const FlowP*, const FlowPtrs*, int, int, const float*, int, const float*, int, float, int, float*, hipStream_t);
+void wg_launch_unready(const WgParams*, const WgPtrs*, const uint8_t*, int*, hipStream_t);
 }
 
 static thread_local std::string g_err;
@@ -68,7 +69,40 @@ struct wg_env_s {
     std::vector<int> ev_kind;
     size_t ev_used = 0;
     double alg_bytes = 0;
+    // step() as ONE graph launch: the launches of a step are captured once per distinct set of I/O pointers on an
+    // internal stream and replayed on the caller's stream (wg_set_step_graph)
+    struct StepGraph {
+        const void* key[5];
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        unsigned long long last_use;
+    };
+    std::vector<StepGraph> graphs;
+    hipStream_t cap_stream = nullptr;
+    int graph_mode = 0;
+    unsigned long long graph_clock = 0;
+    int* unready_dev = nullptr;     // wg_reset: live slots of the masked envs that are not developed yet
 };
+
+static const size_t WG_MAX_STEP_GRAPHS = 32;   // distinct (actions, obs, reward, truncated, final_obs) pointer sets cached
+static const size_t WG_MAX_TIMING_EVENTS = 4096;
+
+static void drop_step_graphs(wg_env_s* h) {
+    for (auto& g : h->graphs) {
+        hipGraphExecDestroy(g.exec);
+        hipGraphDestroy(g.graph);
+    }
+    h->graphs.clear();
+}
+
+static int use_device(wg_env_s* h) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) {
+        hipError_t e = hipSetDevice(h->device);
+        if (e != hipSuccess) return fail(WG_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    }
+    return 0;
+}
 
 template <typename T>
 static int dev_alloc(wg_env_s* h, T** out, size_t n, bool state, bool zero = true) {
@@ -212,6 +246,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
 #undef A
     if (!rc) rc = dev_alloc(h, &h->mask_dev, (size_t)p.B, false);
     if (!rc) rc = dev_alloc(h, &h->seeds_dev, (size_t)p.B, false);
+    if (!rc) rc = dev_alloc(h, &h->unready_dev, 1, false);
     if (!rc) rc = dev_upload<double>(h, &d.x_pos, c->x_pos, p.N);
     if (!rc) rc = dev_upload<double>(h, &d.y_pos, c->y_pos, p.N);
     if (!rc && c->yaw_defined) rc = dev_upload<double>(h, &d.yaw_defined, c->yaw_defined, p.N);
@@ -339,7 +374,15 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     h->alg_bytes = (double)p.B * ((double)p.K * p.F * per_farm_step + 20.0 * p.N + 12.0 * p.obs_dim + 20.0);
 
     wg_launch_create(&p, &d, nullptr);
-    HIPCHK(hipDeviceSynchronize());
+    {
+        hipError_t e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            wg_destroy(h);
+            return fail(WG_ERR_HIP, std::string("wg_create: ") + hipGetErrorString(e));
+        }
+    }
+    if (const char* ev = getenv("WG_STEP_GRAPH")) h->graph_mode = atoi(ev) != 0;
     *out = h;
     return 0;
 }
@@ -355,6 +398,8 @@ extern "C" int wg_destroy(wg_handle h) {
             if (FILE* f = fopen(getenv("WG_TIMELINE_OUT"), "wb")) { fwrite(host.data(), sizeof(long long), n, f); fclose(f); }
         }
     }
+    drop_step_graphs(h);
+    if (h->cap_stream) hipStreamDestroy(h->cap_stream);
     for (auto& e : h->ev) hipEventDestroy(e);
     for (auto& a : h->allocs) hipFree(a.ptr);
     if (h->box4) hipFree(h->box4);
@@ -382,7 +427,11 @@ extern "C" int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, 
         return fail(WG_ERR_INVALID, "turbulence box: null pointer or bad dimensions");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
-    if (h->box4) { HIPCHK(hipFree(h->box4)); h->box4 = nullptr; }
+    drop_step_graphs(h);           // the kernel arguments captured in them are about to change
+    // the kernel-side pointers are cleared first: a failure below must not leave them dangling
+    h->d.box = nullptr; h->fd.box4 = nullptr; h->fd.box4c = nullptr; h->fp.coarse = 0;
+    if (h->box4) { void* q = h->box4; h->box4 = nullptr; HIPCHK(hipFree(q)); }
+    if (h->box4c) { void* q = h->box4c; h->box4c = nullptr; HIPCHK(hipFree(q)); }
     const size_t n_cells = (size_t)nx * ny * nz;
     HIPCHK(hipMalloc(&h->box4, n_cells * 16));
     wg_launch_box_repack(box_dev, h->box4, n_cells, nullptr);
@@ -392,7 +441,6 @@ extern "C" int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, 
     h->fd.box4 = (const float4*)h->box4;
     h->fp.bnx = nx; h->fp.bny = ny; h->fp.bnz = nz;
     h->fp.box_pow2 = ((nx & (nx - 1)) == 0) && ((ny & (ny - 1)) == 0) && ((nz & (nz - 1)) == 0);
-    if (h->box4c) { HIPCHK(hipFree(h->box4c)); h->box4c = nullptr; }
     h->fp.coarse = (nx % 4 == 0 && ny % 4 == 0 && nz % 4 == 0 && nx >= 8 && ny >= 8 && nz >= 8);
     h->fd.box4c = nullptr;
     if (h->fp.coarse) {
@@ -412,6 +460,7 @@ extern "C" int wg_set_wind(wg_handle h, const double* wind_host) {
     if (!h) return fail(WG_ERR_INVALID, "null handle");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
+    drop_step_graphs(h);
     if (!wind_host) { h->d.wind_override = nullptr; return 0; }
     if (!h->wind_dev) {
         double* w = nullptr;
@@ -426,12 +475,14 @@ extern "C" int wg_set_wind(wg_handle h, const double* wind_host) {
 
 extern "C" int wg_set_wind_device(wg_handle h, const double* wind_dev) {
     if (!h) return fail(WG_ERR_INVALID, "null handle");
+    if (h->d.wind_override != wind_dev) drop_step_graphs(h);
     h->d.wind_override = wind_dev;      // borrowed; read by ctx_init (k_init / k_glue) in stream order
     return 0;
 }
 
 extern "C" int wg_set_flow_script(wg_handle h, const float* uvw_dev, const float* power_dev, int n_rows) {
     if (!h) return fail(WG_ERR_INVALID, "null handle");
+    drop_step_graphs(h);
     h->d.script_uvw = uvw_dev;
     h->d.script_power = power_dev;
     h->p.script_rows = n_rows;
@@ -441,22 +492,15 @@ extern "C" int wg_set_flow_script(wg_handle h, const float* uvw_dev, const float
     return 0;
 }
 
-static void time_begin(wg_env_s* h, int kind, hipStream_t st) {
-    if (!h->timing) return;
-    if (h->ev_used + 2 > h->ev.size()) {
-        for (int i = 0; i < 2; ++i) {
-            hipEvent_t e;
-            hipEventCreate(&e);
-            h->ev.push_back(e);
-        }
-        h->ev_kind.push_back(kind);
-    } else {
-        h->ev_kind[h->ev_used / 2] = kind;
-    }
+// The event pool is created by wg_kernel_timing(enable), i.e. outside any timed region, and is bounded: when it is
+// exhausted the remaining steps of the window simply go unsampled.
+static bool time_begin(wg_env_s* h, int kind, hipStream_t st) {
+    if (!h->timing || h->ev_used + 2 > h->ev.size()) return false;
+    h->ev_kind[h->ev_used / 2] = kind;
     hipEventRecord(h->ev[h->ev_used], st);
+    return true;
 }
 static void time_end(wg_env_s* h, hipStream_t st) {
-    if (!h->timing) return;
     hipEventRecord(h->ev[h->ev_used + 1], st);
     h->ev_used += 2;
 }
@@ -470,7 +514,9 @@ extern "C" int wg_reset(wg_handle h, const uint8_t* env_mask_host, const uint64_
         return fail(WG_ERR_INVALID, "turbtype Mann*: call wg_set_turbulence_box before wg_reset");
     const uint8_t* mask = nullptr;
     const uint64_t* seeds = nullptr;
+    bool all = true;
     if (env_mask_host) {
+        for (int b = 0; b < h->p.B; ++b) all = all && env_mask_host[b] != 0;
         HIPCHK(hipMemcpyAsync(h->mask_dev, env_mask_host, (size_t)h->p.B, hipMemcpyHostToDevice, st));
         mask = h->mask_dev;
     }
@@ -478,34 +524,101 @@ extern "C" int wg_reset(wg_handle h, const uint8_t* env_mask_host, const uint64_
         HIPCHK(hipMemcpyAsync(h->seeds_dev, seeds_host, sizeof(uint64_t) * (size_t)h->p.B, hipMemcpyHostToDevice, st));
         seeds = h->seeds_dev;
     }
-    HIPCHK(hipMemsetAsync(h->d.status, 0, sizeof(int), st));
+    // the sticky error word is cleared only by a reset of the whole batch: a masked reset must not drop an error
+    // another env latched
+    if (all) HIPCHK(hipMemsetAsync(h->d.status, 0, sizeof(int), st));
     wg_launch_init(&h->p, &h->d, mask, seeds, st);
-    const int n_launch = h->d.script_uvw ? ((h->p.K * (std::max(h->p.fill_a, h->p.fill_b) + 1)) / h->reset_chunk + 2)
-                                         : h->reset_launches;
-    for (int i = 0; i < n_launch; ++i) wg_launch_flow(&h->fp, &h->fd, WG_MODE_RESET, nullptr, mask, h->reset_chunk, st);
+    // RESET-mode launches develop the masked envs' episodes (fs.run(t_developed) + window fill).  The planned count
+    // covers every episode the config's wind range can produce; a wind override (wg_set_wind / wg_set_wind_device,
+    // FarmEval.set_wind_vals) may ask for a slower wind than ws_min, so the device reports how many live slots are
+    // still developing and the loop goes on until none is.
+    const int n_plan = h->d.script_uvw ? ((h->p.K * (std::max(h->p.fill_a, h->p.fill_b) + 1)) / h->reset_chunk + 2)
+                                       : h->reset_launches;
+    long launched = 0;
+    int batch = n_plan;
+    for (;;) {
+        for (int i = 0; i < batch; ++i) wg_launch_flow(&h->fp, &h->fd, WG_MODE_RESET, nullptr, mask, h->reset_chunk, st);
+        launched += batch;
+        int unready = 0;
+        HIPCHK(hipMemsetAsync(h->unready_dev, 0, sizeof(int), st));
+        wg_launch_unready(&h->p, &h->d, mask, h->unready_dev, st);
+        HIPCHK(hipMemcpyAsync(&unready, h->unready_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (unready == 0) break;
+        if (launched > 4000000L / h->reset_chunk)
+            return fail(WG_ERR_STATE, "wg_reset: episode development does not terminate (wind speed override ~ 0?)");
+        batch = std::max(8, n_plan / 4);
+    }
     wg_launch_glue(&h->p, &h->d, 1, mask, obs_dev, nullptr, nullptr, nullptr, st);
     HIPCHK(hipGetLastError());
-    // the host staging buffers must not be reused before the copies above are done
-    if (env_mask_host || seeds_host) HIPCHK(hipStreamSynchronize(st));
     return 0;
+}
+
+// the launches of one step(); `sample`: bracket the two kernels with timing events
+static void launch_step(wg_env_s* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* truncated_dev,
+                        float* final_obs_dev, hipStream_t st, bool sample) {
+    if (sample) sample = time_begin(h, 0, st);
+    wg_launch_flow(&h->fp, &h->fd, WG_MODE_STEP, actions_dev, nullptr, 0, st);
+    if (sample) { time_end(h, st); sample = time_begin(h, 1, st); }
+    wg_launch_glue(&h->p, &h->d, 0, nullptr, obs_dev, reward_dev, truncated_dev, final_obs_dev, st);
+    if (sample) time_end(h, st);
 }
 
 extern "C" int wg_step(wg_handle h, const float* actions_dev, float* obs_dev, float* reward_dev,
                        uint8_t* truncated_dev, float* final_obs_dev, void* stream) {
     if (!h || !actions_dev || !obs_dev) return fail(WG_ERR_INVALID, "null argument");
+    if (int rc = use_device(h)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const bool sample = h->timing && (h->timing_phase++ % h->timing_period == 0);
     h->n_step_launches++;
-    if (sample) time_begin(h, 0, st);
-    wg_launch_flow(&h->fp, &h->fd, WG_MODE_STEP, actions_dev, nullptr, 0, st);
-    if (sample) { time_end(h, st); time_begin(h, 1, st); }
-    wg_launch_glue(&h->p, &h->d, 0, nullptr, obs_dev, reward_dev, truncated_dev, final_obs_dev, st);
-    if (sample) time_end(h, st);
+    if (!h->graph_mode || sample) {
+        launch_step(h, actions_dev, obs_dev, reward_dev, truncated_dev, final_obs_dev, st, sample);
+        return 0;
+    }
+    // graph mode: one hipGraphLaunch per step.  A graph is captured once per distinct set of I/O pointers (a training
+    // loop recycles a handful of action / observation buffers) on the handle's own stream — the caller's stream may be
+    // the null stream, which cannot be captured — and replayed on the caller's stream.
+    const void* key[5] = {actions_dev, obs_dev, reward_dev, truncated_dev, final_obs_dev};
+    wg_env_s::StepGraph* g = nullptr;
+    for (auto& c : h->graphs)
+        if (!memcmp(c.key, key, sizeof(key))) { g = &c; break; }
+    if (!g) {
+        if (h->graphs.size() >= WG_MAX_STEP_GRAPHS) {      // evict the least recently used entry
+            size_t lru = 0;
+            for (size_t i = 1; i < h->graphs.size(); ++i)
+                if (h->graphs[i].last_use < h->graphs[lru].last_use) lru = i;
+            hipGraphExecDestroy(h->graphs[lru].exec);
+            hipGraphDestroy(h->graphs[lru].graph);
+            h->graphs.erase(h->graphs.begin() + lru);
+        }
+        wg_env_s::StepGraph ng;
+        memcpy(ng.key, key, sizeof(key));
+        HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+        launch_step(h, actions_dev, obs_dev, reward_dev, truncated_dev, final_obs_dev, h->cap_stream, false);
+        HIPCHK(hipStreamEndCapture(h->cap_stream, &ng.graph));
+        hipError_t e = hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) {
+            hipGraphDestroy(ng.graph);
+            return fail(WG_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        }
+        h->graphs.push_back(ng);
+        g = &h->graphs.back();
+    }
+    g->last_use = ++h->graph_clock;
+    HIPCHK(hipGraphLaunch(g->exec, st));
+    return 0;
+}
+
+extern "C" int wg_set_step_graph(wg_handle h, int enable) {
+    if (!h) return fail(WG_ERR_INVALID, "null handle");
+    h->graph_mode = enable != 0;
+    if (!h->graph_mode) drop_step_graphs(h);
     return 0;
 }
 
 extern "C" int wg_check(wg_handle h, void* stream) {
     if (!h) return fail(WG_ERR_INVALID, "null handle");
+    if (int rc = use_device(h)) return rc;
     int status = 0;
     HIPCHK(hipMemcpyAsync(&status, h->d.status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
@@ -517,18 +630,21 @@ extern "C" int wg_check(wg_handle h, void* stream) {
 
 extern "C" int wg_set_obs_multi_buffer(wg_handle h, float* obs_multi_dev) {
     if (!h) return fail(WG_ERR_INVALID, "null handle");
+    if (h->d.multi_out != obs_multi_dev) drop_step_graphs(h);
     h->d.multi_out = obs_multi_dev;     // borrowed; written by k_glue in every following wg_step / wg_reset
     return 0;
 }
 
 extern "C" int wg_obs_multi(wg_handle h, float* obs_dev, void* stream) {
     if (!h || !obs_dev) return fail(WG_ERR_INVALID, "null argument");
+    if (int rc = use_device(h)) return rc;
     wg_launch_obs_multi(&h->p, &h->d, obs_dev, (hipStream_t)stream);
     return 0;
 }
 
 extern "C" int wg_get_measurements(wg_handle h, float* out_dev, void* stream) {
     if (!h || !out_dev) return fail(WG_ERR_INVALID, "null argument");
+    if (int rc = use_device(h)) return rc;
     wg_launch_measurements(&h->p, &h->d, out_dev, (hipStream_t)stream);
     return 0;
 }
@@ -536,6 +652,7 @@ extern "C" int wg_get_measurements(wg_handle h, float* out_dev, void* stream) {
 extern "C" int wg_get_windspeed(wg_handle h, int env, int farm, const float* x_dev, int nx, const float* y_dev, int ny,
                                 float z, int include_wakes, float* uvw_dev, void* stream) {
     if (!h || !x_dev || !y_dev || !uvw_dev) return fail(WG_ERR_INVALID, "null argument");
+    if (int rc = use_device(h)) return rc;
     if (env < 0 || env >= h->p.B || farm < 0 || farm >= h->p.F) return fail(WG_ERR_INVALID, "env / farm index out of range");
     if (nx <= 0 || ny <= 0 || (long long)nx * ny > (1ll << 30)) return fail(WG_ERR_INVALID, "bad grid size");
     if (h->fp.script_rows > 0) return fail(WG_ERR_UNSUPPORTED, "no flow field in flow-script replay mode");
@@ -545,6 +662,7 @@ extern "C" int wg_get_windspeed(wg_handle h, int env, int farm, const float* x_d
 
 extern "C" int wg_get_info(wg_handle h, wg_info_field field, void* out_dev, void* stream) {
     if (!h || !out_dev) return fail(WG_ERR_INVALID, "null argument");
+    if (int rc = use_device(h)) return rc;
     if ((int)field < 0 || (int)field > WG_INFO_WIND_F64) return fail(WG_ERR_INVALID, "unknown info field");
     wg_launch_info(&h->p, &h->d, (int)field, out_dev, (hipStream_t)stream);
     return 0;
@@ -552,21 +670,45 @@ extern "C" int wg_get_info(wg_handle h, wg_info_field field, void* out_dev, void
 
 extern "C" int wg_metrics(wg_handle h, float* out_dev, int reset_after, void* stream) {
     if (!h || !out_dev) return fail(WG_ERR_INVALID, "null argument");
+    if (int rc = use_device(h)) return rc;
     wg_launch_metrics(&h->p, &h->d, out_dev, reset_after, (hipStream_t)stream);
     return 0;
 }
 
+// The state blob starts with a header that identifies the handle geometry it was taken from; the payload is the
+// concatenation of the handle's state allocations (a blob only makes sense for an identically configured handle).
+// The host-owned wind override table (wg_set_wind) is configuration, not state: re-apply it after wg_set_state.
+struct StateHeader {
+    uint32_t magic;
+    int32_t abi, B, N, F, P, S, K, turb_mode, block, ring_stride, fring_stride, power_avg, n_allocs;
+    uint64_t payload;
+};
+static const uint32_t WG_STATE_MAGIC = 0x53474757u;   // "WGGS"
+static StateHeader state_header(const wg_env_s* h) {
+    StateHeader sh;
+    memset(&sh, 0, sizeof(sh));
+    sh.magic = WG_STATE_MAGIC; sh.abi = WG_ABI_VERSION;
+    sh.B = h->p.B; sh.N = h->p.N; sh.F = h->p.F; sh.P = h->p.P; sh.S = h->p.S; sh.K = h->p.K;
+    sh.turb_mode = h->p.turb_mode; sh.block = h->fp.block; sh.ring_stride = h->p.ring_stride;
+    sh.fring_stride = h->p.fring_stride; sh.power_avg = h->p.power_avg; sh.n_allocs = (int32_t)h->state_idx.size();
+    for (size_t i : h->state_idx) sh.payload += h->allocs[i].bytes;
+    return sh;
+}
+
 extern "C" int wg_get_state(wg_handle h, void* blob_host, size_t* size) {
     if (!h || !size) return fail(WG_ERR_INVALID, "null argument");
-    size_t total = 0;
-    for (size_t i : h->state_idx) total += h->allocs[i].bytes;
+    const StateHeader sh = state_header(h);
+    const size_t total = sizeof(StateHeader) + sh.payload;
     if (!blob_host) {
         *size = total;
         return 0;
     }
     if (*size < total) return fail(WG_ERR_INVALID, "state buffer too small");
+    if (int rc = use_device(h)) return rc;
     HIPCHK(hipDeviceSynchronize());
     char* o = (char*)blob_host;
+    memcpy(o, &sh, sizeof(sh));
+    o += sizeof(sh);
     for (size_t i : h->state_idx) {
         HIPCHK(hipMemcpy(o, h->allocs[i].ptr, h->allocs[i].bytes, hipMemcpyDeviceToHost));
         o += h->allocs[i].bytes;
@@ -576,11 +718,16 @@ extern "C" int wg_get_state(wg_handle h, void* blob_host, size_t* size) {
 }
 extern "C" int wg_set_state(wg_handle h, const void* blob_host, size_t size) {
     if (!h || !blob_host) return fail(WG_ERR_INVALID, "null argument");
-    size_t total = 0;
-    for (size_t i : h->state_idx) total += h->allocs[i].bytes;
-    if (size != total) return fail(WG_ERR_INVALID, "state size mismatch");
+    const StateHeader want = state_header(h);
+    if (size < sizeof(StateHeader)) return fail(WG_ERR_INVALID, "state blob too small");
+    StateHeader got;
+    memcpy(&got, blob_host, sizeof(got));
+    if (got.magic != WG_STATE_MAGIC) return fail(WG_ERR_INVALID, "not a windgym state blob");
+    if (memcmp(&got, &want, sizeof(got)) || size != sizeof(StateHeader) + want.payload)
+        return fail(WG_ERR_INVALID, "state blob was taken from a differently configured handle (or another ABI version)");
+    if (int rc = use_device(h)) return rc;
     HIPCHK(hipDeviceSynchronize());
-    const char* o = (const char*)blob_host;
+    const char* o = (const char*)blob_host + sizeof(StateHeader);
     for (size_t i : h->state_idx) {
         HIPCHK(hipMemcpy(h->allocs[i].ptr, o, h->allocs[i].bytes, hipMemcpyHostToDevice));
         o += h->allocs[i].bytes;
@@ -629,6 +776,14 @@ extern "C" int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, do
     h->timing = enable != 0;
     h->timing_period = enable > 1 ? enable : 1;
     h->timing_phase = 0;
+    if (h->timing && h->ev.empty()) {          // the event pool, created here so that no timed region ever pays for it
+        for (size_t i = 0; i < WG_MAX_TIMING_EVENTS; ++i) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            h->ev.push_back(e);
+        }
+        h->ev_kind.assign(WG_MAX_TIMING_EVENTS / 2, 0);
+    }
     return 0;
 }
 

@@ -366,6 +366,10 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         // the freshly developed episode goes live: flush its deferred power-deque pushes (:766, :796)
         const int ctx_id = e * 2 + env.live;
         WgCtx& cx = d.ctx[ctx_id];
+        if (lane < p.F) {     // wg_reset develops until every slot is ready; anything else is a bug
+            const WgSlot& sl = d.slot[ctx_id * p.F + lane];
+            if (sl.dev_remaining != 0 || sl.fill_remaining != 0) atomicMin(d.status, (int)WG_ERR_STATE);
+        }
         if (lane == 0) {
             const int nf = cx.pend_farm_n < p.power_avg ? cx.pend_farm_n : p.power_avg;
             for (int q = 0; q < nf; ++q) {
@@ -610,6 +614,20 @@ k_init(const WgParams p, const WgPtrs d, const uint8_t* __restrict__ mask, const
     const int live = env.live;
     ctx_init(p, d, env, e, live, lane, env.episode);
     if (p.autoreset) ctx_init(p, d, env, e, live ^ 1, lane, env.episode + 1);
+}
+
+// wg_reset: number of live farm slots of the masked envs whose episode is not fully developed yet
+__global__ void k_unready(const WgParams p, const WgPtrs d, const uint8_t* __restrict__ mask, int* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.B * p.F) return;
+    const int e = i / p.F, f = i - e * p.F;
+    if (mask && !mask[e]) return;
+    const WgSlot& sl = d.slot[(e * 2 + d.env[e].live) * p.F + f];
+    if (sl.dev_remaining != 0 || sl.fill_remaining != 0) atomicAdd(out, 1);
+}
+extern "C" void wg_launch_unready(const WgParams* p, const WgPtrs* d, const uint8_t* mask, int* out, hipStream_t st) {
+    const int n = p->B * p->F;
+    hipLaunchKernelGGL(k_unready, dim3((n + 255) / 256), dim3(256), 0, st, *p, *d, mask, out);
 }
 
 // fresh-handle initialisation: generator state of np.random.default_rng(b)
