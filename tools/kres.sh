@@ -5,13 +5,13 @@ f=$1; shift
 import sys, re
 cur = {}
 for ln in sys.stdin:
-    m = re.search(r"remark: +([A-Za-z ]+): (.+?) \[-Rpass", ln)
+    m = re.search(r"remark: +([A-Za-z \[\]/]+): (.+?) \[-Rpass", ln)
     if not m: continue
     k, v = m.group(1).strip(), m.group(2).strip()
     if k == "Function Name":
         if cur: print(cur)
         cur = {"fn": v[:70]}
-    elif k in ("VGPRs", "AGPRs", "TotalSGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "LDS Size [bytes/block]", "VGPR Spill", "SGPR Spill"):
-        cur[k.split(" ")[0]] = v
+    elif k in ("VGPRs", "AGPRs", "TotalSGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "LDS Size [bytes/block]", "VGPRs Spill", "SGPRs Spill"):
+        cur[k.replace(" [bytes/lane]","").replace(" [waves/SIMD]","").replace(" [bytes/block]","")] = v
 if cur: print(cur)
 '

@@ -14,7 +14,8 @@ import numpy as np
 from .config import INFO, INFO_INT, WG_N_METRICS, CConfig, EnvConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwindgym_hip.so")
+# WG_LIB: alternative build of the same library (same-box A/B measurements of kernel variants, tools/ab.sh)
+LIB_PATH = os.environ.get("WG_LIB") or os.path.join(_HERE, "libwindgym_hip.so")
 UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 
 # every symbol include/windgym_hip.h declares (tests check the built library exports all of them)

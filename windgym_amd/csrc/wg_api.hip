@@ -82,6 +82,8 @@ struct wg_env_s {
     int graph_mode = 0;
     unsigned long long graph_clock = 0;
     int* unready_dev = nullptr;     // wg_reset: live slots of the masked envs that are not developed yet
+    WgParams* p_dev = nullptr;      // device copies of p / d, read by the episode-initialisation path at the head of k_flow
+    WgPtrs* d_dev = nullptr;
 };
 
 static const size_t WG_MAX_STEP_GRAPHS = 32;   // distinct (actions, obs, reward, truncated, final_obs) pointer sets cached
@@ -93,6 +95,14 @@ static void drop_step_graphs(wg_env_s* h) {
         hipGraphDestroy(g.graph);
     }
     h->graphs.clear();
+}
+
+// the device copies of the parameter blocks follow every host-side change (setters are rare, synchronous calls)
+static int sync_dev_params(wg_env_s* h) {
+    hipError_t e = hipMemcpy(h->p_dev, &h->p, sizeof(WgParams), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->d_dev, &h->d, sizeof(WgPtrs), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail(WG_ERR_HIP, std::string("hipMemcpy(params): ") + hipGetErrorString(e));
+    return 0;
 }
 
 static int use_device(wg_env_s* h) {
@@ -219,6 +229,18 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         p.fring_off[i] = foff; foff += c->ch[i].history_len;
     }
     p.ring_stride = off; p.fring_stride = foff;
+    // what k_glue stages of the turbine rings (the farm rings are tiny and always staged): a channel read through
+    // windows (rolling means) or through the TI of its whole deque needs the whole ring, a channel read through its
+    // `current` value only needs the newest sample, anything else is not part of the observation.  The per-agent
+    // observation (PettingZoo facade) reads the same turbine-level channels.
+    for (int i = 0; i < WG_N_CH; ++i) {
+        const bool on = p.turb_on[i] != 0;
+        int st = 0;
+        if (on && c->ch[i].current) st = 1;
+        if (on && c->ch[i].rolling_mean) st = 2;
+        if (i == WG_CH_WS && (c->turb_ti || c->farm_ti)) st = 2;
+        p.stage_ch[i] = st;
+    }
 
     WgPtrs& d = h->d;
     memset(&d, 0, sizeof(d));
@@ -247,6 +269,13 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     if (!rc) rc = dev_alloc(h, &h->mask_dev, (size_t)p.B, false);
     if (!rc) rc = dev_alloc(h, &h->seeds_dev, (size_t)p.B, false);
     if (!rc) rc = dev_alloc(h, &h->unready_dev, 1, false);
+    if (!rc) rc = dev_alloc(h, &h->p_dev, 1, false);
+    if (!rc) rc = dev_alloc(h, &h->d_dev, 1, false);
+    {
+        double sx = 0, sy = 0;          // farm centre, summed in layout order like the oracle does
+        for (int t = 0; t < p.N; ++t) { sx += c->x_pos[t]; sy += c->y_pos[t]; }
+        p.cx0 = sx / p.N; p.cy0 = sy / p.N;
+    }
     if (!rc) rc = dev_upload<double>(h, &d.x_pos, c->x_pos, p.N);
     if (!rc) rc = dev_upload<double>(h, &d.y_pos, c->y_pos, p.N);
     if (!rc && c->yaw_defined) rc = dev_upload<double>(h, &d.yaw_defined, c->yaw_defined, p.N);
@@ -346,6 +375,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         g.pend_farm = d.pend_farm; g.pend_base = d.pend_base; g.old_yaw = d.old_yaw;
         g.step_farm_pow = d.step_farm_pow; g.step_base_pow = d.step_base_pow;
         g.rotor_dy = d.rotor_dy; g.rotor_dz = d.rotor_dz; g.tab_power = tpu; g.tab_ct = tcu;
+        g.gp = h->p_dev; g.gd = h->d_dev; g.env_rw = d.env;
     }
 
     // how many RESET-mode launches develop the slowest possible episode: the chain needs
@@ -374,6 +404,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     h->alg_bytes = (double)p.B * ((double)p.K * p.F * per_farm_step + 20.0 * p.N + 12.0 * p.obs_dim + 20.0);
 
     wg_launch_create(&p, &d, nullptr);
+    if (sync_dev_params(h)) { wg_destroy(h); return WG_ERR_HIP; }
     {
         hipError_t e = hipDeviceSynchronize();
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking);
@@ -453,7 +484,7 @@ extern "C" int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, 
         h->fd.box4c = (const float4*)h->box4c;
     }
     h->fp.inv_bdx = 1.0 / dx; h->fp.inv_bdy = 1.0 / dy; h->fp.inv_bdz = 1.0 / dz;
-    return 0;
+    return sync_dev_params(h);
 }
 
 extern "C" int wg_set_wind(wg_handle h, const double* wind_host) {
@@ -461,7 +492,7 @@ extern "C" int wg_set_wind(wg_handle h, const double* wind_host) {
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
     drop_step_graphs(h);
-    if (!wind_host) { h->d.wind_override = nullptr; return 0; }
+    if (!wind_host) { h->d.wind_override = nullptr; return sync_dev_params(h); }
     if (!h->wind_dev) {
         double* w = nullptr;
         int rc = dev_alloc(h, &w, (size_t)h->p.B * 3, false);
@@ -470,14 +501,15 @@ extern "C" int wg_set_wind(wg_handle h, const double* wind_host) {
     }
     HIPCHK(hipMemcpy(h->wind_dev, wind_host, sizeof(double) * 3 * (size_t)h->p.B, hipMemcpyHostToDevice));
     h->d.wind_override = h->wind_dev;
-    return 0;
+    return sync_dev_params(h);
 }
 
 extern "C" int wg_set_wind_device(wg_handle h, const double* wind_dev) {
     if (!h) return fail(WG_ERR_INVALID, "null handle");
     if (h->d.wind_override != wind_dev) drop_step_graphs(h);
-    h->d.wind_override = wind_dev;      // borrowed; read by ctx_init (k_init / k_glue) in stream order
-    return 0;
+    h->d.wind_override = wind_dev;      // borrowed; read by wg_ctx_init (k_init / head of k_flow) in stream order
+    if (int rc = use_device(h)) return rc;
+    return sync_dev_params(h);
 }
 
 extern "C" int wg_set_flow_script(wg_handle h, const float* uvw_dev, const float* power_dev, int n_rows) {
@@ -489,7 +521,8 @@ extern "C" int wg_set_flow_script(wg_handle h, const float* uvw_dev, const float
     h->fd.script_uvw = uvw_dev;
     h->fd.script_power = power_dev;
     h->fp.script_rows = n_rows;
-    return 0;
+    if (int rc = use_device(h)) return rc;
+    return sync_dev_params(h);
 }
 
 // The event pool is created by wg_kernel_timing(enable), i.e. outside any timed region, and is bounded: when it is
@@ -632,7 +665,8 @@ extern "C" int wg_set_obs_multi_buffer(wg_handle h, float* obs_multi_dev) {
     if (!h) return fail(WG_ERR_INVALID, "null handle");
     if (h->d.multi_out != obs_multi_dev) drop_step_graphs(h);
     h->d.multi_out = obs_multi_dev;     // borrowed; written by k_glue in every following wg_step / wg_reset
-    return 0;
+    if (int rc = use_device(h)) return rc;
+    return sync_dev_params(h);
 }
 
 extern "C" int wg_obs_multi(wg_handle h, float* obs_dev, void* stream) {

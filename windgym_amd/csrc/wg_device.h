@@ -27,7 +27,8 @@ __device__ inline uint32_t wg_ss_mix(uint32_t x, uint32_t y) {
     return r;
 }
 // np.random.default_rng(seed): SeedSequence(seed).generate_state(4, uint64) -> PCG64 srandom
-__device__ inline void wg_pcg_seed(WgEnv& e, uint64_t seed) {
+template <class R>
+__device__ inline void wg_pcg_seed(R& e, uint64_t seed) {
     uint32_t ent[2] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
     int n_ent = ent[1] != 0 ? 2 : 1;
     uint32_t pool[4];
@@ -59,14 +60,16 @@ __device__ inline void wg_pcg_seed(WgEnv& e, uint64_t seed) {
     e.rng_has32 = 0;
     e.rng_u32 = 0;
 }
-__device__ inline uint64_t wg_pcg_next64(WgEnv& e) {
+template <class R>
+__device__ inline uint64_t wg_pcg_next64(R& e) {
     e.rng_state = e.rng_state * WG_PCG_MULT + e.rng_inc;
     uint64_t hi = (uint64_t)(e.rng_state >> 64), lo = (uint64_t)e.rng_state;
     uint64_t x = hi ^ lo;
     unsigned rot = (unsigned)(e.rng_state >> 122);
     return (x >> rot) | (x << ((-rot) & 63));
 }
-__device__ inline uint32_t wg_pcg_next32(WgEnv& e) {
+template <class R>
+__device__ inline uint32_t wg_pcg_next32(R& e) {
     if (e.rng_has32) {
         e.rng_has32 = 0;
         return e.rng_u32;
@@ -76,11 +79,13 @@ __device__ inline uint32_t wg_pcg_next32(WgEnv& e) {
     e.rng_u32 = (uint32_t)(n >> 32);
     return (uint32_t)(n & 0xffffffffu);
 }
-__device__ inline double wg_pcg_uniform(WgEnv& e, double low, double high) {
+template <class R>
+__device__ inline double wg_pcg_uniform(R& e, double low, double high) {
     double u = (double)(wg_pcg_next64(e) >> 11) * (1.0 / 9007199254740992.0);
     return low + (high - low) * u;
 }
-__device__ inline uint32_t wg_pcg_integers(WgEnv& e, uint32_t high) {
+template <class R>
+__device__ inline uint32_t wg_pcg_integers(R& e, uint32_t high) {
     uint32_t rng = high - 1;
     if (rng == 0) return 0;
     uint32_t rng_excl = rng + 1;
@@ -190,6 +195,132 @@ __device__ inline double wg_wave_max_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// episode context initialisation (wave-cooperative): WindFarmEnv.reset up to fs.run (Wind_Farm_Env.py:689-732)
+//   rng        the env's PCG64 (any struct with rng_state / rng_inc / rng_has32 / rng_u32): lane 0 draws from it
+//   f_lo..f_hi farms whose slot + turbine arrays this call initialises (k_init: all; k_flow: the workgroup's own farm —
+//              the two farm workgroups of a context run this redundantly from the same generator snapshot and write
+//              IDENTICAL context-level values, see WgCtx::init_pending)
+// ---------------------------------------------------------------------------------------------------
+struct WgRng {
+    wg_u128 rng_state, rng_inc;
+    uint32_t rng_has32, rng_u32;
+};
+
+// Share of the background episode's remaining work (flow sub-steps) to run during the next step(), `left` steps
+// before the running episode truncates.  work/left per step on average, spread EVENLY: floor(work/left + phi) with a
+// low-discrepancy dither phi (golden-ratio sequence over the step index, de-phased per env).  The ratio is recomputed
+// from the remaining quantities every step, so the schedule is self-correcting, and at left == 1 it returns all that
+// remains: the episode is ready exactly at truncation.  (ceil(work/left) — the first version — front-loads: a
+// background episode needing 280 steps during a 600-step episode ran on each of the first 280 launches, so after a
+// synchronised start every launch carried twice the flow work of the steady state.)
+__device__ inline int wg_shadow_share(const int work, long left, const int steps_done, const int e) {
+    if (work <= 0) return 0;
+    if (left < 1) left = 1;
+    const uint32_t phi24 = ((uint32_t)steps_done * 2654435769u + (uint32_t)e * 0x9E3779B1u) >> 8;   // [0, 2^24)
+    // float arithmetic (a 64-bit integer division costs ~150 instructions on this kernel's latency chain): rcp(1) is
+    // exact, so left == 1 still returns exactly `work`; elsewhere an off-by-one in the floor is absorbed by the
+    // next step's recomputed ratio
+    const float share = (float)work * __builtin_amdgcn_rcpf((float)left) + (float)phi24 * (1.0f / 16777216.0f);
+    int it = (int)share;
+    if (left == 1) it = work;
+    return it > work ? work : it;
+}
+
+template <class R>
+__device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, const int e, const int c, const int lane,
+                                   const int episode_tag, const int f_lo, const int f_hi) {
+    const int N = p.N, F = p.F;
+    const int ctx_id = e * 2 + c;
+    WgCtx& cx = d.ctx[ctx_id];
+    double ws = 0, ti = 0, wd = 0;
+    if (lane == 0) {
+        ws = wg_pcg_uniform(rng, p.ws_min, p.ws_max);     // _set_windconditions (:564-568)
+        ti = wg_pcg_uniform(rng, p.ti_min, p.ti_max);
+        wd = wg_pcg_uniform(rng, p.wd_min, p.wd_max);
+        if (d.wind_override) {                            // FarmEval.set_wind_vals, per env
+            const double *ov = d.wind_override + (size_t)e * 3;
+            if (ov[0] == ov[0]) ws = ov[0];
+            if (ov[1] == ov[1]) wd = ov[1];
+            if (ov[2] == ov[2]) ti = ov[2];
+        }
+        uint32_t tseed = 0;
+        if (p.turb_mode == WG_TURB_RANDOM || p.turb_mode == WG_TURB_BOX_SHIFT)
+            tseed = wg_pcg_integers(rng, 100000);                                  // _def_site (:623, :642)
+        cx.box_ox = 0.0; cx.box_oy = 0.0;
+        if (p.turb_mode == WG_TURB_BOX_SHIFT && p.bnx > 0) {
+            uint32_t a, b;
+            wg_philox_turb(tseed, 0u, 0u, 0u, 0x4fu, a, b);
+            cx.box_ox = (double)a * (1.0 / 4294967296.0) * p.bnx * p.bdx;
+            cx.box_oy = (double)b * (1.0 / 4294967296.0) * p.bny * p.bdy;
+        }
+        for (int t = 0; t < N; ++t) {                     // yaw init (:715-720); the baseline farm starts from the
+            float y0 = 0.f;                               // agent's yaws (:781)
+            if (p.yaw_init == WG_YAWINIT_RANDOM) y0 = (float)wg_pcg_uniform(rng, -p.yaw_start, p.yaw_start);
+            else if (p.yaw_init == WG_YAWINIT_DEFINED && p.has_yaw_defined) y0 = (float)d.yaw_defined[t];
+            for (int f = f_lo; f < f_hi; ++f) d.yaw[(size_t)(ctx_id * F + f) * N + t] = y0;
+        }
+        cx.ws = ws; cx.ti = ti; cx.wd = wd; cx.turb_seed = tseed;
+        cx.rated_power = (float)wg_tab_interp<double>(d.tab_ws_d, d.tab_power_d, p.n_tab, ws);   // :700
+        cx.n_pushed = 0; cx.pend_farm_n = 0; cx.pend_base_n = 0; cx.episode_tag = episode_tag;
+    }
+    ws = __shfl(ws, 0, 64); ti = __shfl(ti, 0, 64); wd = __shfl(wd, 0, 64);
+    // flow frame: rotate the layout by theta = 270 - wd about the farm centre
+    const double th = (270.0 - wd) * (WG_PI_D / 180.0);
+    const double cth = cos(th), sth = sin(th);
+    const double cx0 = p.cx0, cy0 = p.cy0;
+    double xmin = 1e300, xmax = -1e300;
+    for (int t = lane; t < N; t += WG_WAVE) {
+        const double dx = d.x_pos[t] - cx0, dy = d.y_pos[t] - cy0;
+        const double xr = cx0 + dx * cth + dy * sth;
+        const double yr = cy0 - dx * sth + dy * cth;
+        d.xr[(size_t)ctx_id * N + t] = xr;
+        d.yr[(size_t)ctx_id * N + t] = yr;
+        xmin = fmin(xmin, xr); xmax = fmax(xmax, xr);
+    }
+    xmin = wg_wave_min_d(xmin); xmax = wg_wave_max_d(xmax);
+    // chain pruning: a particle of turbine t that is older than jneed[t] has passed the most downstream turbine of
+    // the farm (the bracket of the farthest target uses ages floor(dx / dpart) and + 1) and can never reach a rotor
+    // again -> the advection pass stops streaming it.  Every output of step() is unchanged.
+    for (int t = lane; t < N; t += WG_WAVE) {
+        const double dx = d.x_pos[t] - cx0, dy = d.y_pos[t] - cy0;
+        const double dxm = xmax - (cx0 + dx * cth + dy * sth);
+        d.jneed[(size_t)ctx_id * N + t] = p.full_chains ? p.P : (int)(dxm / p.dpart) + 2;
+    }
+    if (lane == 0) {
+        cx.dist = xmax - xmin;                                                     // :723-724
+        const double t_inflow = (xmax - xmin) / ws;                                // :727
+        cx.t_inflow = t_inflow;
+        const int t_developed = (int)(t_inflow * 2);                               // :729
+        cx.t_developed = t_developed;
+        cx.time_max = p.never_truncate ? 9999999 : (int)(t_inflow * p.n_passthrough);   // :732
+        int n_dev = (int)ceil((double)t_developed / p.dt_d - 1e-9);
+        if (d.script_uvw) n_dev = 0;
+        for (int f = f_lo; f < f_hi; ++f) {
+            WgSlot& s = d.slot[ctx_id * F + f];
+            s.head = p.P - 1; s.n_valid = 0; s.s_off = 0.0; s.time = 0.0; s.istep = 0;
+            s.dev_remaining = n_dev;
+            s.fill_remaining = f == 0 ? p.fill_a : p.fill_b;
+        }
+    }
+    for (int f = f_lo; f < f_hi; ++f) {
+        const size_t tb = (size_t)(ctx_id * F + f) * N;
+        const int cursor = d.script_uvw ? d.slot[ctx_id * F + f].cursor : 0;
+        for (int t = lane; t < N; t += WG_WAVE) {
+            float u = (float)ws, v = 0.f, w = 0.f, pw = 0.f;
+            if (d.script_uvw) {
+                int row = cursor < p.script_rows ? cursor : p.script_rows - 1;
+                size_t base = (((size_t)f * p.script_rows + row) * p.B + e) * N;
+                u = d.script_uvw[(base + t) * 3]; v = d.script_uvw[(base + t) * 3 + 1];
+                w = d.script_uvw[(base + t) * 3 + 2]; pw = d.script_power[base + t];
+            }
+            d.u[tb + t] = u; d.v[tb + t] = v; d.w[tb + t] = w;
+            d.ti_loc[tb + t] = (float)ti; d.power[tb + t] = pw; d.ct[tb + t] = 0.f;
+            d.bnd[(tb + t) * 3] = 0.f; d.bnd[(tb + t) * 3 + 1] = 0.f; d.bnd[(tb + t) * 3 + 2] = 0.f;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

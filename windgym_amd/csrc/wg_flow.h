@@ -51,6 +51,11 @@ struct FlowPtrs {
     const float *rotor_dy, *rotor_dz, *tab_power, *tab_ct;   // tab_*: resampled on the uniform grid
     const float *script_uvw, *script_power;
     long long* dbg;               // WG_TIMELINE debug builds: [n_blocks][12] phase stamps
+    // device-resident copies of the full parameter / pointer blocks: read (scalar loads) only on the rare episode
+    // initialisation path at the head of k_flow, so that the hot path keeps its slim kernel arguments
+    const WgParams* gp;
+    const WgPtrs* gd;
+    WgEnv* env_rw;                // == env; the initialising workgroup of farm 0 commits the advanced generator
 };
 
 // sizeof(TurbLds) in wg_flow.hip; kept here so the host can size the dynamic LDS

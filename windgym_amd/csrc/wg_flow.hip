@@ -668,6 +668,20 @@ __device__ __forceinline__ void script_step(const FlowP& p, const FlowPtrs& d, T
         return wg_wave_sum(_s);                                                             \
     }())
 
+// Rare path at the head of k_flow (WgCtx::init_pending): one wave sets up the episode a retired context will hold.
+// Kept out of line so that its register needs (128-bit PCG64 arithmetic, double-precision sin / cos) stay out of the
+// hot path's allocation.
+__device__ __attribute__((noinline)) void flow_init_episode(const WgParams* gp, const WgPtrs* gd, WgEnv* env_rw,
+                                                            const int e, const int c, const int farm, const int lane) {
+    const WgCtx& cx = gd->ctx[e * 2 + c];
+    WgRng rng{cx.snap_state, cx.snap_inc, cx.snap_has32, cx.snap_u32};
+    wg_ctx_init(*gp, *gd, rng, e, c, lane, cx.episode_tag, farm, farm + 1);
+    if (farm == 0 && lane == 0) {
+        env_rw->rng_state = rng.rng_state; env_rw->rng_inc = rng.rng_inc;
+        env_rw->rng_has32 = rng.rng_has32; env_rw->rng_u32 = rng.rng_u32;
+    }
+}
+
 template <int NT, int TURB, bool REPLAY, bool NOISE>
 __global__ void __launch_bounds__(NT, TURB != WG_TURB_NONE ? WG_BOX_WAVES : (NT == 128 ? WG_FLOW_WAVES_128 : WG_FLOW_WAVES))
 k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict__ actions,
@@ -708,51 +722,76 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     const int env_live = env.live, env_done = env.done, env_shadow_iters = env.shadow_iters;
     const uint64_t noise_key = env.noise_key;
     WgSlot& slot = d.slot[slot_id];
-    int dev_rem = slot.dev_remaining, fill_rem = slot.fill_remaining;
-    SlotRegs sr{slot.s_off, slot.time, slot.head, slot.n_valid, slot.istep};
-    int cursor = slot.cursor;
     WgCtx& cx = d.ctx[ctx_id];
-    const double ws = cx.ws;
-    const float ti_f = (float)cx.ti;
-    const float wd_env = (float)cx.wd;
-    int n_pushed = cx.n_pushed;
-    int pend_farm_n = cx.pend_farm_n, pend_base_n = cx.pend_base_n;
-    const uint32_t episode_tag = (uint32_t)cx.episode_tag;
-    TurbCtx tc;
-    tc.seed = cx.turb_seed; tc.ox = cx.box_ox; tc.oy = cx.box_oy; tc.ws = ws;
-    tc.sig = (float)(cx.ti * ws);
-    tc.alpha = TURB == WG_TURB_NONE ? 0.f
-                                    : (float)(1.0 - exp(-2.0 * WG_PI_D * (ws / (p.fc_scale * p.D_d)) * p.dt_d));
+    const int init_pending = cx.init_pending;
     const uint8_t masked_out = (mode == WG_MODE_RESET && mask) ? (uint8_t)(mask[e] == 0) : (uint8_t)0;
+    const int t_own = tid < N ? tid : 0;
+    int dev_rem, fill_rem, cursor, n_pushed, pend_farm_n, pend_base_n;
+    SlotRegs sr;
+    double ws;
+    float ti_f, wd_env;
+    uint32_t episode_tag;
+    TurbCtx tc;
     double l_xr = 0, l_yr = 0;
     float l_yaw = 0, l_u = 0, l_v = 0, l_w = 0, l_ti = 0, l_pow = 0, l_ct = 0, l_act = 0;
     float l_bd = 0, l_bk = 0, l_be = 0;
     int l_jn = 0;
-    const int t_own = tid < N ? tid : 0;
-    {
+    auto load_state = [&]() __attribute__((always_inline)) {
+        dev_rem = slot.dev_remaining; fill_rem = slot.fill_remaining;
+        sr = SlotRegs{slot.s_off, slot.time, slot.head, slot.n_valid, slot.istep};
+        cursor = slot.cursor;
+        ws = cx.ws;
+        ti_f = (float)cx.ti;
+        wd_env = (float)cx.wd;
+        n_pushed = cx.n_pushed;
+        pend_farm_n = cx.pend_farm_n; pend_base_n = cx.pend_base_n;
+        episode_tag = (uint32_t)cx.episode_tag;
+        tc.seed = cx.turb_seed; tc.ox = cx.box_ox; tc.oy = cx.box_oy; tc.ws = ws;
+        tc.sig = (float)(cx.ti * ws);
+        tc.alpha = TURB == WG_TURB_NONE ? 0.f
+                                        : (float)(1.0 - exp(-2.0 * WG_PI_D * (ws / (p.fc_scale * p.D_d)) * p.dt_d));
         l_xr = d.xr[(size_t)ctx_id * N + t_own];
         l_yr = d.yr[(size_t)ctx_id * N + t_own];
         l_yaw = d.yaw[tb + t_own]; l_u = d.u[tb + t_own]; l_v = d.v[tb + t_own]; l_w = d.w[tb + t_own];
         l_ti = d.ti_loc[tb + t_own]; l_pow = d.power[tb + t_own]; l_ct = d.ct[tb + t_own];
         l_bd = d.bnd[(tb + t_own) * 3]; l_bk = d.bnd[(tb + t_own) * 3 + 1]; l_be = d.bnd[(tb + t_own) * 3 + 2];
         if (NT == 256) l_jn = d.jneed[(size_t)ctx_id * N + t_own];      // chain pruning: large-farm variant only
-        if (mode == WG_MODE_STEP && farm == 0) l_act = actions[(size_t)e * N + t_own];
-    }
+    };
+    load_state();
+    if (mode == WG_MODE_STEP && farm == 0) l_act = actions[(size_t)e * N + t_own];
 
     const bool is_live = (c == env_live);
-    const bool ready = (dev_rem == 0 && fill_rem == 0);
     int budget = 0;
     const bool live_step = (mode == WG_MODE_STEP) && is_live;
     if (mode == WG_MODE_STEP) {
         if (is_live) {
             if (env_done) return;
         } else {
-            if (!p.autoreset || ready) return;
-            budget = env_shadow_iters;
+            if (!p.autoreset) return;
+            if (init_pending) {
+                // Rare path (one context per truncation): the episode this context will hold has not been set up yet
+                // — k_glue flagged it when it retired the finished episode.  Wave 0 of BOTH farm workgroups runs the
+                // same initialisation from the generator snapshot k_glue left in the context: identical context-level
+                // values are written by both (a benign same-value race), each initialises only its own farm's slot
+                // and turbine arrays, farm 0 commits the advanced generator.  The flag is cleared by the next k_glue.
+                const WgParams& gp = *d.gp;
+                if (tid < WG_WAVE) flow_init_episode(d.gp, d.gd, d.env_rw + e, e, c, farm, tid);
+                full_barrier<NT>();
+                load_state();
+                // first share of the background work, planned here because k_glue could not know it yet
+                const int fill_max = F == 2 ? max(gp.fill_a, gp.fill_b) : gp.fill_a;
+                const int inc = 1 + (gp.extra_inc ? 1 : 0);
+                const int tm = d.ctx[e * 2 + env_live].time_max;
+                const long total = (long)((tm + inc - 1) / inc) + 1;
+                budget = wg_shadow_share(dev_rem + p.K * fill_max, total - env.steps_done, env.steps_done, e);
+            } else {
+                if (dev_rem == 0 && fill_rem == 0) return;
+                budget = env_shadow_iters;
+            }
             if (budget <= 0) return;
         }
     } else {
-        if (!is_live || ready || masked_out) return;
+        if (!is_live || (dev_rem == 0 && fill_rem == 0) || masked_out) return;
         budget = chunk;
     }
 

@@ -12,104 +12,6 @@
 #include "wg_device.h"
 
 // ===================================================================================================
-// episode context initialisation (wave-cooperative): WindFarmEnv.reset up to fs.run (:689-732)
-// ===================================================================================================
-__device__ inline void ctx_init(const WgParams& p, const WgPtrs& d, WgEnv& env, int e, int c, int lane, int episode_tag) {
-    const int N = p.N, F = p.F;
-    const int ctx_id = e * 2 + c;
-    WgCtx& cx = d.ctx[ctx_id];
-    double ws = 0, ti = 0, wd = 0;
-    if (lane == 0) {
-        ws = wg_pcg_uniform(env, p.ws_min, p.ws_max);     // _set_windconditions (:564-568)
-        ti = wg_pcg_uniform(env, p.ti_min, p.ti_max);
-        wd = wg_pcg_uniform(env, p.wd_min, p.wd_max);
-        if (d.wind_override) {                            // FarmEval.set_wind_vals, per env
-            const double *ov = d.wind_override + (size_t)e * 3;
-            if (ov[0] == ov[0]) ws = ov[0];
-            if (ov[1] == ov[1]) wd = ov[1];
-            if (ov[2] == ov[2]) ti = ov[2];
-        }
-        uint32_t tseed = 0;
-        if (p.turb_mode == WG_TURB_RANDOM || p.turb_mode == WG_TURB_BOX_SHIFT)
-            tseed = wg_pcg_integers(env, 100000);                                  // _def_site (:623, :642)
-        cx.box_ox = 0.0; cx.box_oy = 0.0;
-        if (p.turb_mode == WG_TURB_BOX_SHIFT && p.bnx > 0) {
-            uint32_t a, b;
-            wg_philox_turb(tseed, 0u, 0u, 0u, 0x4fu, a, b);
-            cx.box_ox = (double)a * (1.0 / 4294967296.0) * p.bnx * p.bdx;
-            cx.box_oy = (double)b * (1.0 / 4294967296.0) * p.bny * p.bdy;
-        }
-        for (int t = 0; t < N; ++t) {                     // yaw init (:715-720)
-            float y0 = 0.f;
-            if (p.yaw_init == WG_YAWINIT_RANDOM) y0 = (float)wg_pcg_uniform(env, -p.yaw_start, p.yaw_start);
-            else if (p.yaw_init == WG_YAWINIT_DEFINED && p.has_yaw_defined) y0 = (float)d.yaw_defined[t];
-            d.yaw[(size_t)(ctx_id * F) * N + t] = y0;
-        }
-        cx.ws = ws; cx.ti = ti; cx.wd = wd; cx.turb_seed = tseed;
-        cx.rated_power = (float)wg_tab_interp<double>(d.tab_ws_d, d.tab_power_d, p.n_tab, ws);   // :700
-        cx.n_pushed = 0; cx.pend_farm_n = 0; cx.pend_base_n = 0; cx.episode_tag = episode_tag;
-    }
-    ws = __shfl(ws, 0, 64); ti = __shfl(ti, 0, 64); wd = __shfl(wd, 0, 64);
-    // flow frame: rotate the layout by theta = 270 - wd about the farm centre
-    const double th = (270.0 - wd) * (WG_PI_D / 180.0);
-    const double cth = cos(th), sth = sin(th);
-    double cx0 = 0, cy0 = 0;
-    for (int t = 0; t < N; ++t) { cx0 += d.x_pos[t]; cy0 += d.y_pos[t]; }
-    cx0 /= N; cy0 /= N;
-    double xmin = 1e300, xmax = -1e300;
-    for (int t = lane; t < N; t += WG_WAVE) {
-        const double dx = d.x_pos[t] - cx0, dy = d.y_pos[t] - cy0;
-        const double xr = cx0 + dx * cth + dy * sth;
-        const double yr = cy0 - dx * sth + dy * cth;
-        d.xr[(size_t)ctx_id * N + t] = xr;
-        d.yr[(size_t)ctx_id * N + t] = yr;
-        xmin = fmin(xmin, xr); xmax = fmax(xmax, xr);
-    }
-    xmin = wg_wave_min_d(xmin); xmax = wg_wave_max_d(xmax);
-    // chain pruning: a particle of turbine t that is older than jneed[t] has passed the most downstream turbine of
-    // the farm (the bracket of the farthest target uses ages floor(dx / dpart) and + 1) and can never reach a rotor
-    // again -> the advection pass stops streaming it.  Every output of step() is unchanged.
-    for (int t = lane; t < N; t += WG_WAVE) {
-        const double dxm = xmax - d.xr[(size_t)ctx_id * N + t];
-        d.jneed[(size_t)ctx_id * N + t] = p.full_chains ? p.P : (int)(dxm / p.dpart) + 2;
-    }
-    int n_dev = 0;
-    if (lane == 0) {
-        cx.dist = xmax - xmin;                                                     // :723-724
-        cx.t_inflow = cx.dist / ws;                                                // :727
-        cx.t_developed = (int)(cx.t_inflow * 2);                                   // :729
-        cx.time_max = p.never_truncate ? 9999999 : (int)(cx.t_inflow * p.n_passthrough);   // :732
-        n_dev = (int)ceil((double)cx.t_developed / p.dt_d - 1e-9);
-        if (d.script_uvw) n_dev = 0;
-        for (int f = 0; f < F; ++f) {
-            WgSlot& s = d.slot[ctx_id * F + f];
-            s.head = p.P - 1; s.n_valid = 0; s.s_off = 0.0; s.time = 0.0; s.istep = 0;
-            s.dev_remaining = n_dev;
-            s.fill_remaining = f == 0 ? p.fill_a : p.fill_b;
-        }
-    }
-    __threadfence_block();
-    for (int f = 0; f < F; ++f) {
-        const size_t tb = (size_t)(ctx_id * F + f) * N;
-        const int cursor = d.slot[ctx_id * F + f].cursor;
-        for (int t = lane; t < N; t += WG_WAVE) {
-            float y0 = d.yaw[(size_t)(ctx_id * F) * N + t];   // :781 baseline starts from the agent's yaws
-            d.yaw[tb + t] = y0;
-            float u = (float)ws, v = 0.f, w = 0.f, pw = 0.f;
-            if (d.script_uvw) {
-                int row = cursor < p.script_rows ? cursor : p.script_rows - 1;
-                size_t base = (((size_t)f * p.script_rows + row) * p.B + e) * N;
-                u = d.script_uvw[(base + t) * 3]; v = d.script_uvw[(base + t) * 3 + 1];
-                w = d.script_uvw[(base + t) * 3 + 2]; pw = d.script_power[base + t];
-            }
-            d.u[tb + t] = u; d.v[tb + t] = v; d.w[tb + t] = w;
-            d.ti_loc[tb + t] = (float)ti; d.power[tb + t] = pw; d.ct[tb + t] = 0.f;
-            d.bnd[(tb + t) * 3] = 0.f; d.bnd[(tb + t) * 3 + 1] = 0.f; d.bnd[(tb + t) * 3 + 2] = 0.f;
-        }
-    }
-}
-
-// ===================================================================================================
 // observation (farm_mes.get_measurements(scaled=True) + clip, MesClass.py:679-703, Wind_Farm_Env.py:513-520)
 // ===================================================================================================
 // `raw`: unscaled, unclipped sensor values in the same layout (the "... measured" entries of the info dict,
@@ -235,20 +137,47 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
 }
 
 // copy one context's sensor rings into this wave's LDS region with coalesced loads (the window loops of
-// build_obs would otherwise issue long chains of dependent global loads); returns the bases to read from
+// build_obs would otherwise issue long chains of dependent global loads); returns the bases to read from.
+// Only what the observation reads is staged (WgParams::stage_ch, decided on the host from the sensor config): a
+// channel whose windows / TI are observed is copied whole, a channel observed through its `current` value only
+// contributes its newest sample, an unobserved channel (Env1.yaml: wd and power, 30 of the 65 floats per turbine)
+// is not touched.  The LDS copy keeps the global layout, so build_obs indexes it unchanged.
 __device__ inline void stage_rings(const WgParams& p, const WgPtrs& d, int ctx_id, int lane, float* lds,
-                                   const float*& rbase, const float*& fbase) {
+                                   const float*& rbase, const float*& fbase, const int n_pushed) {
     const float* gr = d.ring + (size_t)ctx_id * p.ring_stride;
     const float* gf = d.fring + (size_t)ctx_id * p.fring_stride;
     if (lds == nullptr) { rbase = gr; fbase = gf; return; }
+    const int N = p.N;
+    // compact index space over the fully staged channels
+    const int l0 = p.stage_ch[0] == 2 ? N * p.ch[0].history_len : 0, l1 = p.stage_ch[1] == 2 ? N * p.ch[1].history_len : 0;
+    const int l2 = p.stage_ch[2] == 2 ? N * p.ch[2].history_len : 0, l3 = p.stage_ch[3] == 2 ? N * p.ch[3].history_len : 0;
+    const int c1 = l0, c2 = c1 + l1, c3 = c2 + l2, total = c3 + l3;
+    const int d0 = p.ring_off[0], d1 = p.ring_off[1] - c1, d2 = p.ring_off[2] - c2, d3 = p.ring_off[3] - c3;
     // 16 loads in flight per lane (a plain copy loop waits for every load before its LDS store)
     constexpr int U = 16;
-    for (int b0 = lane; b0 < p.ring_stride; b0 += WG_WAVE * U) {
+    for (int b0 = lane; b0 < total; b0 += WG_WAVE * U) {
         float v[U];
+        int gi[U];
 #pragma unroll
-        for (int k = 0; k < U; ++k) { const int i = b0 + k * WG_WAVE; v[k] = i < p.ring_stride ? gr[i] : 0.f; }
+        for (int k = 0; k < U; ++k) {
+            const int i = b0 + k * WG_WAVE;
+            gi[k] = i + (i >= c3 ? d3 : (i >= c2 ? d2 : (i >= c1 ? d1 : d0)));
+            v[k] = i < total ? gr[gi[k]] : 0.f;
+        }
 #pragma unroll
-        for (int k = 0; k < U; ++k) { const int i = b0 + k * WG_WAVE; if (i < p.ring_stride) lds[i] = v[k]; }
+        for (int k = 0; k < U; ++k) { const int i = b0 + k * WG_WAVE; if (i < total) lds[gi[k]] = v[k]; }
+    }
+    if (n_pushed > 0) {
+#pragma unroll
+        for (int ch = 0; ch < WG_N_CH; ++ch) {
+            if (p.stage_ch[ch] != 1) continue;
+            const int H = p.ch[ch].history_len;
+            const int newest = (n_pushed - 1) % H;
+            for (int t = lane; t < N; t += WG_WAVE) {
+                const int idx = p.ring_off[ch] + t * H + newest;
+                lds[idx] = gr[idx];
+            }
+        }
     }
     for (int b0 = lane; b0 < p.fring_stride; b0 += WG_WAVE * U) {
         float v[U];
@@ -272,26 +201,6 @@ __device__ inline float deque_at(const float* dq, int n_total, int maxlen, int q
     return dq[(n_total - n + q) % maxlen];
 }
 
-// Share of the background episode's remaining work (flow sub-steps) to run during the next step(), `left` steps
-// before the running episode truncates.  work/left per step on average, spread EVENLY: floor(work/left + phi) with a
-// low-discrepancy dither phi (golden-ratio sequence over the step index, de-phased per env).  The ratio is recomputed
-// from the remaining quantities every step, so the schedule is self-correcting, and at left == 1 it returns all that
-// remains: the episode is ready exactly at truncation.  (ceil(work/left) — the first version — front-loads: a
-// background episode needing 280 steps during a 600-step episode ran on each of the first 280 launches, so after a
-// synchronised start every launch carried twice the flow work of the steady state.)
-__device__ inline int shadow_share(const int work, long left, const int steps_done, const int e) {
-    if (work <= 0) return 0;
-    if (left < 1) left = 1;
-    const uint32_t phi24 = ((uint32_t)steps_done * 2654435769u + (uint32_t)e * 0x9E3779B1u) >> 8;   // [0, 2^24)
-    // float arithmetic (a 64-bit integer division costs ~150 instructions on this kernel's latency chain): rcp(1) is
-    // exact, so left == 1 still returns exactly `work`; elsewhere an off-by-one in the floor is absorbed by the
-    // next step's recomputed ratio
-    const float share = (float)work * __builtin_amdgcn_rcpf((float)left) + (float)phi24 * (1.0f / 16777216.0f);
-    int it = (int)share;
-    if (left == 1) it = work;
-    return it > work ? work : it;
-}
-
 // plan how many flow sub-steps the background episode must advance during the next step() so that it is
 // ready exactly when the running episode truncates
 __device__ inline int plan_shadow(const WgParams& p, const WgPtrs& d, const int live, const int steps_done, int e) {
@@ -306,7 +215,7 @@ __device__ inline int plan_shadow(const WgParams& p, const WgPtrs& d, const int 
     const int inc = 1 + (p.extra_inc ? 1 : 0);
     const int tm = d.ctx[e * 2 + live].time_max;
     const long total = (long)((tm + inc - 1) / inc) + 1;
-    return shadow_share(work, total - steps_done, steps_done, e);
+    return wg_shadow_share(work, total - steps_done, steps_done, e);
 }
 
 // Write the env header back from the wave's register copy.  `env = ev` by lane 0 compiled into ~26 dependent
@@ -389,9 +298,10 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
             env.shadow_iters = p.autoreset ? plan_shadow(p, d, env.live, env.steps_done, e) : 0;
         }
         if (obs) {
-            stage_rings(p, d, ctx_id, lane, my_lds, rbase, fbase);
+            const int np1 = cx.n_pushed;
+            stage_rings(p, d, ctx_id, lane, my_lds, rbase, fbase, np1);
             build_obs(p, d, ctx_id, lane, obs, nullptr, rbase, fbase, false,
-                      d.multi_out ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr);
+                      d.multi_out ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr, np1);
         }
         return;
     }
@@ -429,6 +339,11 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     }
     float* met = d.metrics + (size_t)e * WG_N_METRICS;
     float l_met = lane < WG_N_METRICS ? met[lane] : 0.f;
+    // a background context flagged at the previous truncation has been initialised by the k_flow launch of this step
+    if (p.autoreset && lane == 0) {
+        WgCtx& bcx = d.ctx[e * 2 + (live ^ 1)];
+        if (bcx.init_pending) bcx.init_pending = 0;
+    }
     int l_work = 0;                       // background-episode work of farm `lane` (plan_shadow)
     if (p.autoreset && lane < p.F) {
         const WgSlot& sl = d.slot[(e * 2 + (live ^ 1)) * p.F + lane];
@@ -475,7 +390,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     // observation (:983)
     float* fin = final_obs_out ? final_obs_out + (size_t)e * p.obs_dim : nullptr;
     if (WG_GLUE_ABLATE == 2) return;
-    stage_rings(p, d, ctx_id, lane, my_lds, rbase, fbase);
+    stage_rings(p, d, ctx_id, lane, my_lds, rbase, fbase, n_pushed_live);
     if (WG_GLUE_ABLATE == 3) return;
     build_obs(p, d, ctx_id, lane, obs, fin, rbase, fbase, false,
               d.multi_out ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr, n_pushed_live);
@@ -544,40 +459,44 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         const int nxt = live ^ 1;
         const int nctx = e * 2 + nxt;
         WgCtx& ncx = d.ctx[nctx];
-        const int pfn = ncx.pend_farm_n, pbn = ncx.pend_base_n;
+        const int pfn = ncx.pend_farm_n, pbn = ncx.pend_base_n, nnp = ncx.n_pushed;
         const int nf = pfn < p.power_avg ? pfn : p.power_avg;
         const int nb = pbn < p.power_avg ? pbn : p.power_avg;
-        if (lane == 0) {
-            bool ok = true;
-            for (int f = 0; f < p.F; ++f) {
-                const WgSlot& sl = d.slot[nctx * p.F + f];
-                ok = ok && sl.dev_remaining == 0 && sl.fill_remaining == 0;
-            }
-            if (!ok) atomicMin(d.status, (int)WG_ERR_STATE);
-            for (int q = 0; q < nf; ++q)
-                fq[(ev.farm_pow_n + q) % p.power_avg] = deque_at(d.pend_farm + (size_t)nctx * p.power_avg, pfn, p.power_avg, q);
-            for (int q = 0; q < nb; ++q)
-                bq[(ev.base_pow_n + q) % p.power_avg] = deque_at(d.pend_base + (size_t)nctx * p.power_avg, pbn, p.power_avg, q);
-            ncx.pend_farm_n = 0; ncx.pend_base_n = 0;
+        // readiness of the developed episode (lane f checks farm f) and the deferred power-deque pushes of its window
+        // fill (:766, :796; lane q moves entry q): independent loads, one round trip
+        if (lane < p.F) {
+            const WgSlot& sl = d.slot[nctx * p.F + lane];
+            if (sl.dev_remaining != 0 || sl.fill_remaining != 0) atomicMin(d.status, (int)WG_ERR_STATE);
         }
+        for (int q = lane; q < nf; q += WG_WAVE)
+            fq[(ev.farm_pow_n + q) % p.power_avg] = deque_at(d.pend_farm + (size_t)nctx * p.power_avg, pfn, p.power_avg, q);
+        for (int q = lane; q < nb; q += WG_WAVE)
+            bq[(ev.base_pow_n + q) % p.power_avg] = deque_at(d.pend_base + (size_t)nctx * p.power_avg, pbn, p.power_avg, q);
+        if (lane == 0) { ncx.pend_farm_n = 0; ncx.pend_base_n = 0; }
         ev.farm_pow_n += nf; ev.base_pow_n += nb;
         ev.live = nxt; ev.timestep = 0; ev.steps_done = 0;
-        __threadfence_block();
-        if (obs) {
-            stage_rings(p, d, nctx, lane, my_lds, rbase, fbase);
-            build_obs(p, d, nctx, lane, obs, nullptr, rbase, fbase, false,
-                      d.multi_out ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr);
+        // The retired context will hold the episode after the next one.  Its initialisation (sampling from the env's
+        // PCG64, layout rotation, slot set-up) is NOT done here, on this kernel's one-wave-per-env latency chain: the
+        // context is flagged and the generator snapshotted; the two farm workgroups of that context run wg_ctx_init
+        // at the head of the next k_flow launch (WgCtx::init_pending).
+        if (lane == 0) {
+            WgCtx& rcx = d.ctx[e * 2 + live];
+            rcx.init_pending = 1;
+            rcx.episode_tag = ev.episode + 1;
+            rcx.snap_state = env.rng_state; rcx.snap_inc = env.rng_inc;
+            rcx.snap_has32 = env.rng_has32; rcx.snap_u32 = env.rng_u32;
         }
-        // the retired context starts developing the episode after the next one (lane 0 draws from the env's PCG64,
-        // in place in global memory: rare path)
-        ctx_init(p, d, env, e, live, lane, ev.episode + 1);
-        __threadfence_block();
+        if (obs) {
+            stage_rings(p, d, nctx, lane, my_lds, rbase, fbase, nnp);
+            build_obs(p, d, nctx, lane, obs, nullptr, rbase, fbase, false,
+                      d.multi_out ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr, nnp);
+        }
     }
     if (WG_GLUE_ABLATE == 7) return;
     if (!p.autoreset) {
         ev.shadow_iters = 0;
     } else if (truncated) {
-        ev.shadow_iters = plan_shadow(p, d, ev.live, ev.steps_done, e);   // contexts were swapped / re-initialised
+        ev.shadow_iters = 0;      // the initialising workgroups of the next k_flow launch plan their own first share
     } else {
         int work = l_work;                                        // max over the farms of the background ctx
         for (int o = 1; o < 4; o <<= 1) work = max(work, __shfl_xor(work, o, 64));
@@ -586,7 +505,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         else {
             const int inc = 1 + (p.extra_inc ? 1 : 0);
             const long total = (long)((time_max + inc - 1) / inc) + 1;
-            ev.shadow_iters = shadow_share(work, total - ev.steps_done, ev.steps_done, e);
+            ev.shadow_iters = wg_shadow_share(work, total - ev.steps_done, ev.steps_done, e);
         }
     }
     if (WG_GLUE_ABLATE == 8) return;
@@ -612,8 +531,9 @@ k_init(const WgParams p, const WgPtrs d, const uint8_t* __restrict__ mask, const
     }
     __threadfence_block();
     const int live = env.live;
-    ctx_init(p, d, env, e, live, lane, env.episode);
-    if (p.autoreset) ctx_init(p, d, env, e, live ^ 1, lane, env.episode + 1);
+    wg_ctx_init(p, d, env, e, live, lane, env.episode, 0, p.F);
+    if (p.autoreset) wg_ctx_init(p, d, env, e, live ^ 1, lane, env.episode + 1, 0, p.F);
+    if (lane < 2) d.ctx[e * 2 + lane].init_pending = 0;
 }
 
 // wg_reset: number of live farm slots of the masked envs whose episode is not fully developed yet

@@ -62,6 +62,8 @@ struct WgParams {
     double bdx, bdy, bdz;
     // replay mode
     int script_rows;
+    int stage_ch[WG_N_CH];   // k_glue ring staging per channel: 0 = not observed, 1 = newest sample only, 2 = whole ring
+    double cx0, cy0;     // farm centre (mean of the layout), the pivot of the flow-frame rotation
 };
 
 // per farm slot
@@ -90,6 +92,13 @@ struct WgCtx {
     int episode_tag;     // episode index this ctx belongs to (noise counter)
     // fill pushes into the env-level power deques are deferred until the ctx goes live
     int pend_farm_n, pend_base_n;
+    // Pipelined autoreset: at truncation k_glue only flags the retired context (init_pending = 1) and snapshots the
+    // env's generator; the sampling + layout rotation + slot initialisation of the episode after next then run at the
+    // head of the NEXT k_flow launch, in the two farm workgroups of that context (throughput-hidden among thousands of
+    // workgroups instead of sitting on k_glue's one-wave-per-env latency chain).  The following k_glue clears the flag.
+    int init_pending;
+    uint32_t snap_has32, snap_u32;
+    wg_u128 snap_state, snap_inc;
 };
 
 // per env
