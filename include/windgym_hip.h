@@ -165,7 +165,13 @@ typedef enum wg_info_field {
     WG_INFO_ROTOR_UVW_AGENT = 18, /* fs.windTurbines.rotor_avg_windspeed  f32[B,N,3] */
     WG_INFO_ROTOR_UVW_BASE = 19,  /* fs_baseline ...                      f32[B,N,3] */
     WG_INFO_RATED_POWER = 20,     /* turbine.power(ws) (:700)      f32[B]   */
-    WG_INFO_WIND_F64 = 21         /* (ws, wd, ti) as sampled, in double precision  f64[B,3] */
+    WG_INFO_WIND_F64 = 21,        /* (ws, wd, ti) as sampled, in double precision  f64[B,3] */
+    /* farm power of the step just taken, BEFORE a same-step autoreset swapped the next episode in: what
+     * infos["Power agent"] of a vector env must carry so that RecordEpisodeVals (wrappers/recordEpisodeVals.py:43-46)
+     * adds the terminal step's power to the episode that ended.  Equal to POWER_AGENT / POWER_BASE for envs that did
+     * not truncate.                                                                                            */
+    WG_INFO_STEP_POWER_AGENT = 22, /* f32[B] */
+    WG_INFO_STEP_POWER_BASE = 23   /* f32[B] */
 } wg_info_field;
 
 /* number of floats of the episode-metric vector produced by wg_metrics (the all-reduce payload;

@@ -1123,6 +1123,8 @@ int WGO(get_info)(void* h, int field, double* out) {
             for (int t = 0; t < N; ++t) { out[(b * N + t) * 3] = fb->u[t]; out[(b * N + t) * 3 + 1] = fb->v[t]; out[(b * N + t) * 3 + 2] = fb->w[t]; }
             break;
         case WG_INFO_RATED_POWER: out[b] = x->rated_power; break;
+        case WG_INFO_STEP_POWER_AGENT: out[b] = e->last_pnow; break;
+        case WG_INFO_STEP_POWER_BASE: out[b] = e->last_pbase; break;
         default: return WG_ERR_INVALID;
         }
     }

@@ -487,9 +487,122 @@ def mes_unit_cases(mods):
     print(f"mes_windows.json: {len(rows)} known-answer rows")
 
 
+def record_episode_vals_case():
+    """Golden vector for the reference's RecordEpisodeVals (wrappers/recordEpisodeVals.py:8-64), the host-side form of
+    the episode metrics that get all-reduced across GPUs.
+
+    The wrapper subclasses gymnasium.wrappers.vector.RecordEpisodeStatistics, which is not installed here.  The base
+    class below restates the bookkeeping of gymnasium 1.x that the subclass relies on (num_envs, prev_dones,
+    episode_returns / episode_lengths with the NEXT-step autoreset convention: the step after a done is the reset step
+    and is not counted); the subclass itself is the reference's file, imported unmodified.  The vector env is a scripted
+    double: rewards, infos["Power agent"] and dones come from pre-drawn tables."""
+    from collections import deque
+    gym = sys.modules["gymnasium"]
+
+    class RecordEpisodeStatistics:
+        def __init__(self, env, buffer_length=100, stats_key="episode"):
+            self.env = env
+            self.num_envs = env.num_envs
+            self.episode_returns = np.zeros(())
+            self.episode_lengths = np.zeros((), dtype=int)
+            self.prev_dones = np.zeros((), dtype=bool)
+            self.return_queue = deque(maxlen=buffer_length)
+            self.length_queue = deque(maxlen=buffer_length)
+
+        def reset(self, seed=None, options=None):
+            obs, info = self.env.reset(seed=seed, options=options)
+            self.episode_returns = np.zeros(self.num_envs)
+            self.episode_lengths = np.zeros(self.num_envs, dtype=int)
+            self.prev_dones = np.zeros(self.num_envs, dtype=bool)
+            return obs, info
+
+        def step(self, actions):
+            obs, rewards, terminations, truncations, infos = self.env.step(actions)
+            self.episode_returns[self.prev_dones] = 0
+            self.episode_returns[~self.prev_dones] += rewards[~self.prev_dones]
+            self.episode_lengths[self.prev_dones] = 0
+            self.episode_lengths[~self.prev_dones] += 1
+            self.prev_dones = dones = np.logical_or(terminations, truncations)
+            if np.sum(dones):
+                for i in np.where(dones):
+                    self.return_queue.extend(self.episode_returns[i])
+                    self.length_queue.extend(self.episode_lengths[i])
+            return obs, rewards, terminations, truncations, infos
+
+    wrappers = types.ModuleType("gymnasium.wrappers")
+    wvec = types.ModuleType("gymnasium.wrappers.vector")
+    wvec.RecordEpisodeStatistics = RecordEpisodeStatistics
+    wrappers.vector = wvec
+    gym.wrappers = wrappers
+    vec = types.ModuleType("gymnasium.vector")
+    vvenv = types.ModuleType("gymnasium.vector.vector_env")
+    vvenv.ArrayType = np.ndarray
+    vvenv.VectorEnv = object
+    vec.vector_env = vvenv
+    core = types.ModuleType("gymnasium.core")
+    core.ActType = object
+    core.ObsType = object
+    gym.core = core
+    for name, mod in (("gymnasium.wrappers", wrappers), ("gymnasium.wrappers.vector", wvec), ("gymnasium.vector", vec),
+                      ("gymnasium.vector.vector_env", vvenv), ("gymnasium.core", core)):
+        sys.modules[name] = mod
+    pkg = types.ModuleType("WindGym.wrappers")
+    pkg.__path__ = [os.path.join(REF, "WindGym", "wrappers")]
+    sys.modules["WindGym.wrappers"] = pkg
+    rev = importlib.import_module("WindGym.wrappers.recordEpisodeVals")
+
+    B, T = 6, 400
+    rng = np.random.default_rng(2024)
+    ep_len = rng.integers(3, 40, size=(B, 64))              # scripted episode lengths per env
+    power = rng.uniform(0.2e6, 7.5e6, size=(T, B))
+    reward = rng.normal(0.0, 0.3, size=(T, B))
+    done = np.zeros((T, B), dtype=bool)                      # next-step autoreset stream: done, then one reset row
+    is_reset_row = np.zeros((T, B), dtype=bool)
+    for b in range(B):
+        t, k = 0, 0
+        while True:
+            t += int(ep_len[b, k])
+            if t - 1 >= T:
+                break
+            done[t - 1, b] = True
+            if t < T:
+                is_reset_row[t, b] = True
+            t += 1                                           # the reset step
+            k += 1
+
+    class ScriptedVecEnv:
+        num_envs = B
+
+        def __init__(self):
+            self.t = -1
+
+        def reset(self, seed=None, options=None):
+            self.t = -1
+            return np.zeros((B, 1)), {}
+
+        def step(self, actions):
+            self.t += 1
+            return (np.zeros((B, 1)), reward[self.t].copy(), np.zeros(B, dtype=bool), done[self.t].copy(),
+                    {"Power agent": power[self.t].copy()})
+
+    w = rev.RecordEpisodeVals(ScriptedVecEnv(), buffer_length=10000)
+    w.reset()
+    q_len = np.zeros(T, dtype=np.int64)
+    for t in range(T):
+        w.step(None)
+        q_len[t] = len(w.mean_power_queue)
+    np.savez_compressed(os.path.join(OUT, "record_episode_vals.npz"), power=power, reward=reward, done=done,
+                        is_reset_row=is_reset_row, queue_len=q_len,
+                        mean_power_queue=np.asarray(w.mean_power_queue, dtype=np.float64),
+                        return_queue=np.asarray(w.return_queue, dtype=np.float64),
+                        length_queue=np.asarray(w.length_queue, dtype=np.int64))
+    print(f"record_episode_vals.npz: {len(w.mean_power_queue)} episodes over {T} steps x {B} envs")
+
+
 def main():
     mods = import_reference()
     mes_unit_cases(mods)
+    record_episode_vals_case()
     # the three shipped example configurations (Baseline reward -> two farms)
     run_case(mods, "env1", cfg_env1(), dict(n_passthrough=2), 400, seed=1, script_seed=100, n_episodes=2)
     run_case(mods, "2turb", cfg_2turb(), dict(n_passthrough=2), 260, seed=3, script_seed=101, n_episodes=2)

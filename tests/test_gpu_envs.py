@@ -131,7 +131,7 @@ def test_vec_env_autoreset_and_episode_stats(wg, tmp_path):
     d["ActionMethod"] = "yaw"
     venv = wg.WindFarmVecEnv(wg.V80(), 64, yaml_path=_yaml(tmp_path, d), turbtype="None", n_passthrough=1, seed=7,
                              as_torch=True)
-    rec = RecordEpisodeVals(venv)
+    rec = RecordEpisodeVals(venv, buffer_length=100000)
     obs, infos = rec.reset()
     assert obs.shape == (64, venv.single_observation_space.shape[0]) and obs.is_cuda
     n_done = 0
@@ -143,10 +143,16 @@ def test_vec_env_autoreset_and_episode_stats(wg, tmp_path):
         n_done += int(trunc.sum())
         assert (infos["Power agent"] >= 0).all()
     venv.batch.check()
-    assert n_done >= 64 and len(rec.mean_power_queue) == min(n_done, 100)
+    assert n_done >= 64 and len(rec.mean_power_queue) == n_done
     m = venv.metrics()
     assert m["n_episodes"] == n_done and m["n_steps"] == 400 * 64
-    assert abs(m["mean_episode_power"] - np.mean(rec.mean_power_queue)) / m["mean_episode_power"] < 0.2
+    # the device accumulators ARE the wrapper's queues in reduced form (recordEpisodeVals.py:43-56; the wrapper's own
+    # semantics are pinned against the reference's file in tests/test_record_episode_vals.py): infos["Power agent"] of a
+    # truncated env is the terminal step's power, so both sides average the same steps — fp32 running sums on the
+    # device, float64 on the host
+    np.testing.assert_allclose(m["ep_mean_power_sum"], np.sum(rec.mean_power_queue), rtol=2e-6)
+    np.testing.assert_allclose(m["ep_return_sum"], np.sum(rec.return_queue), rtol=1e-4, atol=1e-3)
+    assert m["ep_length_sum"] == np.sum(rec.length_queue)
     # SB3-style access
     venv.step_async(np.zeros((64, venv.n_turb), dtype=np.float32))
     o, r, dones, inf = venv.step_wait()

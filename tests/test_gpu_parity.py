@@ -24,6 +24,21 @@ def hip():
     return binding
 
 
+BLOCKS = [64, 128, 256]          # every workgroup size launch_nt can select (wg_flow.hip)
+
+
+def _make_env(hip, cfg, block=None):
+    """HipBatch whose k_flow runs the given workgroup-size instantiation (WG_FLOW_BLOCK is read at wg_create)."""
+    import os
+    if block is None:
+        return hip.HipBatch(cfg)
+    os.environ["WG_FLOW_BLOCK"] = str(block)
+    try:
+        return hip.HipBatch(cfg)
+    finally:
+        del os.environ["WG_FLOW_BLOCK"]
+
+
 def _t(hip, a):
     import torch
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device="cuda")
@@ -43,6 +58,11 @@ def test_hip_glue_matches_reference_golden(hip, name, n_envs):
         obs0 = env.reset(seeds=[meta["seed"]] * n_envs if ep == 0 else None).cpu().numpy()
         env.check()
         assert np.allclose(env.info("ws_global").cpu().numpy(), g["ws"][ep], rtol=1e-7)
+        # the sampled (ws, wd, ti) in double precision are BIT-identical to what the reference drew from np_random
+        w64 = env.info("wind_f64").cpu().numpy()
+        assert w64.dtype == np.float64
+        for b in range(n_envs):
+            assert w64[b, 0] == g["ws"][ep] and w64[b, 1] == g["wd"][ep] and w64[b, 2] == g["ti"][ep], (w64[b], ep)
         assert np.all(env.info("time_max").cpu().numpy() == int(g["time_max"][ep]))
         np.testing.assert_allclose(env.info("yaw_agent").cpu().numpy()[0], g["yaw_init"][ep], atol=1e-5)
         for b in range(n_envs):
@@ -102,11 +122,13 @@ def _compare_step(env, orc, a, step, check_flow=True):
                                    rtol=1e-4, atol=1e-4)
 
 
-def test_hip_physics_matches_oracle_step_for_step(hip, oracle_lib):
-    """cfg2-shaped farm (4x4, yaw action, two farms), B=6, 300 steps on identical seeds and actions."""
+@pytest.mark.parametrize("block", BLOCKS)
+def test_hip_physics_matches_oracle_step_for_step(hip, oracle_lib, block):
+    """cfg2-shaped farm (4x4, yaw action, two farms), B=6, 300 steps on identical seeds and actions — in each of the
+    three workgroup-size instantiations of k_flow (128 is what cfg2 / cfg4 run, 256 what cfg3 runs)."""
     B = 6
     cfg = _physics_cfg(B, autoreset=False, n_passthrough=5)
-    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    env, orc = _make_env(hip, cfg, block), oracle_lib.Oracle(cfg)
     seeds = 1234 + np.arange(B)
     obs0 = env.reset(seeds=seeds).cpu().numpy()
     o0 = orc.reset(seeds=seeds)
@@ -366,7 +388,8 @@ def test_fused_per_agent_observations_equal_the_explicit_packing(hip, oracle_lib
     env.check()
 
 
-def test_noise_normal_matches_oracle_stream(hip, oracle_lib):
+@pytest.mark.parametrize("block", BLOCKS)
+def test_noise_normal_matches_oracle_stream(hip, oracle_lib, block):
     """noise: "Normal" (2turb.yaml / 4turb.yaml): the Philox/Box-Muller stream is the same on both sides; the
     kernel evaluates log/cos in fast fp32 -> tolerance 2e-3 deg on the 2-deg wd noise (1e-4 of the wd scale)."""
     from windgym_amd.config import EnvConfig
@@ -376,7 +399,7 @@ def test_noise_normal_matches_oracle_stream(hip, oracle_lib):
     d["mes_level"].update(turb_wd=True)
     d["wd_mes"].update(wd_current=True, wd_rolling_mean=True)
     cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_envs=5, autoreset=True, n_passthrough=1)
-    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    env, orc = _make_env(hip, cfg, block), oracle_lib.Oracle(cfg)
     seeds = 11 + np.arange(5)
     g0, o0 = env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds)
     np.testing.assert_allclose(g0, o0, rtol=0, atol=5e-4)
@@ -434,11 +457,13 @@ def _compare_turb(env, orc, steps, rng, n_turb, B):
     return n_tr
 
 
-def test_random_inflow_matches_oracle(hip, oracle_lib):
-    """turbtype "Random": counter-based gusts at the rotors and at the wake particles (meandering)."""
+@pytest.mark.parametrize("block", BLOCKS)
+def test_random_inflow_matches_oracle(hip, oracle_lib, block):
+    """turbtype "Random": counter-based gusts at the rotors and at the wake particles (meandering); every
+    k_flow<NT, RANDOM> instantiation."""
     B = 6
     cfg = _turb_cfg("Random", B)
-    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    env, orc = _make_env(hip, cfg, block), oracle_lib.Oracle(cfg)
     seeds = 300 + np.arange(B)
     np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=TURB_OBS_ATOL)
     v = env.info("rotor_uvw_agent").cpu().numpy()[..., 1]
@@ -448,14 +473,16 @@ def test_random_inflow_matches_oracle(hip, oracle_lib):
     assert n_tr >= B
 
 
+@pytest.mark.parametrize("block", BLOCKS)
 @pytest.mark.parametrize("turbtype", ["MannFixed", "MannGenerate"])
-def test_mann_box_inflow_matches_oracle(hip, oracle_lib, small_mann_box, turbtype):
+def test_mann_box_inflow_matches_oracle(hip, oracle_lib, small_mann_box, turbtype, block):
     """BASELINE.json configs[4] at test size: frozen Mann box (trilinear, periodic, Taylor advection), DWM
-    meandering of the wake particles through the low-pass filtered transverse inflow."""
+    meandering of the wake particles through the low-pass filtered transverse inflow; every k_flow<NT, BOX>
+    instantiation (256: chain pruning and the 16-byte record copy together with turbulence)."""
     box, spacing = small_mann_box
     B = 5
     cfg = _turb_cfg(turbtype, B)
-    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    env, orc = _make_env(hip, cfg, block), oracle_lib.Oracle(cfg)
     env.set_turbulence_box(box, spacing), orc.set_turbulence_box(box, spacing)
     seeds = 700 + np.arange(B)
     np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=TURB_OBS_ATOL)
@@ -465,6 +492,31 @@ def test_mann_box_inflow_matches_oracle(hip, oracle_lib, small_mann_box, turbtyp
     # the wake centre lines meander: particle positions leave the hub height / the turbine's y
     u = env.info("rotor_uvw_agent").cpu().numpy()
     assert np.std(u[..., 0]) > 0.05 and np.std(u[..., 2]) > 0.005
+
+
+@pytest.mark.parametrize("dims,spacing", [((256, 64, 32), (3.0, 3.0, 3.0)),      # coarse copy 64 x 16 x 8: masks
+                                          ((240, 72, 40), (3.0, 3.0, 3.0))])     # coarse copy 60 x 18 x 10: modulo
+@pytest.mark.parametrize("turbtype", ["MannGenerate", "Random"])
+def test_cfg5_shape_runs_the_instantiation_the_bench_runs(hip, oracle_lib, dims, spacing, turbtype):
+    """BASELINE.json configs[4] at its real farm shape: 4 x 4 turbines x P = 128 (N P = 2048) selects
+    k_flow<128, BOX> — the instantiation bench.py --workload cfg5 times — here against the oracle, with a box whose
+    block-averaged meandering copy has power-of-two dims and one whose copy has not (both divisible by 4).  "Random"
+    covers k_flow<128, RANDOM> at the same shape."""
+    from windgym_amd.mann import generate_mann_box
+    if turbtype == "Random" and dims[0] != 256:
+        pytest.skip("no box for Random inflow")
+    B = 4
+    cfg = _turb_cfg(turbtype, B, nx=4, ny=4)
+    assert cfg.n_turb * cfg.n_particles == 2048
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    if turbtype != "Random":
+        box = generate_mann_box(dims, spacing, seed=77)
+        env.set_turbulence_box(box, spacing), orc.set_turbulence_box(box, spacing)
+    seeds = 500 + np.arange(B)
+    np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=TURB_OBS_ATOL)
+    n_tr = _compare_turb(env, orc, 330, np.random.default_rng(14), cfg.n_turb, B)
+    env.check()
+    assert n_tr >= 1
 
 
 def test_mann_box_ragged_dims_matches_oracle(hip, oracle_lib):

@@ -263,6 +263,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     A(farm_pow, (size_t)p.B * p.power_avg, true); A(base_pow, (size_t)p.B * p.power_avg, true);
     A(old_yaw, (size_t)p.B * p.N, true);
     A(step_farm_pow, (size_t)p.B, true); A(step_base_pow, (size_t)p.B, true);
+    A(last_pow_agent, (size_t)p.B, true); A(last_pow_base, (size_t)p.B, true);
     A(metrics, (size_t)p.B * WG_N_METRICS, true);
     A(status, 1, true);
 #undef A
@@ -697,7 +698,7 @@ extern "C" int wg_get_windspeed(wg_handle h, int env, int farm, const float* x_d
 extern "C" int wg_get_info(wg_handle h, wg_info_field field, void* out_dev, void* stream) {
     if (!h || !out_dev) return fail(WG_ERR_INVALID, "null argument");
     if (int rc = use_device(h)) return rc;
-    if ((int)field < 0 || (int)field > WG_INFO_WIND_F64) return fail(WG_ERR_INVALID, "unknown info field");
+    if ((int)field < 0 || (int)field > WG_INFO_STEP_POWER_BASE) return fail(WG_ERR_INVALID, "unknown info field");
     wg_launch_info(&h->p, &h->d, (int)field, out_dev, (hipStream_t)stream);
     return 0;
 }

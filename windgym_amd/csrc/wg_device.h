@@ -81,8 +81,12 @@ __device__ inline uint32_t wg_pcg_next32(R& e) {
 }
 template <class R>
 __device__ inline double wg_pcg_uniform(R& e, double low, double high) {
-    double u = (double)(wg_pcg_next64(e) >> 11) * (1.0 / 9007199254740992.0);
-    return low + (high - low) * u;
+    // numpy rounds the product and the sum separately (random_uniform: off + rng * next_double): no fma contraction
+    // here — it would differ by 1 ulp on some draws (HIP's __dmul_rn / __dadd_rn are plain operators and contract too)
+#pragma clang fp contract(off)
+    const double u = (double)(wg_pcg_next64(e) >> 11) * (1.0 / 9007199254740992.0);
+    const double scaled = (high - low) * u;
+    return low + scaled;
 }
 template <class R>
 __device__ inline uint32_t wg_pcg_integers(R& e, uint32_t high) {

@@ -138,6 +138,7 @@ struct WgPtrs {
     float *farm_pow, *base_pow;     // [B][power_avg]
     float *old_yaw;           // [B][N]
     float *step_farm_pow, *step_base_pow;   // [B] produced by the flow kernel, consumed by the glue kernel
+    float *last_pow_agent, *last_pow_base;  // [B] farm power of the step just taken (before an autoreset swap)
     float* metrics;           // [B][WG_N_METRICS] running per-env sums
     int* status;              // sticky error word
     const double* wind_override;   // [B][3] (ws, wd, ti) or null; NaN = keep the sampled value

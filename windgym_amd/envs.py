@@ -191,13 +191,16 @@ class WindFarmVecEnv:
             self._site.refresh()
         obs, rew, trunc, fin = self.batch.step(actions)
         term = t.zeros_like(trunc, dtype=t.bool)                         # terminated is always False (:1029)
-        infos = self.infos()
+        infos = self.infos(step=True)
         infos["final_obs"] = self._out(fin)
         return self._out(obs), self._out(rew), self._out(term), self._out(trunc.bool()), infos
 
-    def infos(self):
-        """Lazy info dict: values are fetched from the device on first access (keys of _get_info)."""
-        return _LazyInfo(self)
+    def infos(self, step=False):
+        """Lazy info dict: values are fetched from the device on first access (keys of _get_info).  After a step(),
+        "Power agent" / "Power baseline" are the farm powers of the step just taken — for an env that truncated, the
+        terminal step of the episode that ended, not the first state of the swapped-in episode — which is what
+        RecordEpisodeVals adds to the finished episode (wrappers/recordEpisodeVals.py:43-46)."""
+        return _LazyInfo(self, step=step)
 
     def metrics(self, reset_after=True):
         from .parallel import ShardedMetrics
@@ -257,10 +260,13 @@ _BASE_ONLY = {"yaw angles base", "Power baseline", "Power pr turbine baseline", 
 class _LazyInfo(dict):
     """Batched info dict with the reference's keys; each value is copied from the device when first read."""
 
-    def __init__(self, venv: WindFarmVecEnv):
+    _STEP_FIELDS = {"Power agent": "step_power_agent", "Power baseline": "step_power_base"}
+
+    def __init__(self, venv: WindFarmVecEnv, step=False):
         super().__init__()
         self._v = venv
         self._two = venv.cfg.baseline_comp
+        self._step = step
 
     def _keys(self):
         return [k for k in _INFO_KEYS if self._two or k not in _BASE_ONLY]
@@ -268,7 +274,8 @@ class _LazyInfo(dict):
     def __missing__(self, key):
         if key not in _INFO_KEYS or (key in _BASE_ONLY and not self._two):
             raise KeyError(key)
-        val = self._v.batch.info(_INFO_KEYS[key])
+        field = self._STEP_FIELDS.get(key, _INFO_KEYS[key]) if self._step else _INFO_KEYS[key]
+        val = self._v.batch.info(field)
         val = val if self._v.as_torch else _np(val)
         self[key] = val
         return val
