@@ -4,7 +4,7 @@ TAG=$1; shift
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python bench.py --steps 100 --warmup 10 --no-cpu $@"
+BENCH="python bench.py --steps 100 --warmup 10 --reps 1 --preroll 300 --no-cpu $@"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $BENCH > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $OUT/pmc1 -o p -- $BENCH > $OUT/bench_pmc1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM -d $OUT/pmc2 -o p -- $BENCH > $OUT/bench_pmc2.log 2>&1

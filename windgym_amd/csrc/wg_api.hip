@@ -3,6 +3,7 @@
 // the kernels of wg_kernels.hip on the caller's stream.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -247,16 +248,26 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     const size_t n_slots = (size_t)p.B * 2 * p.F, n_ctx = (size_t)p.B * 2;
     int rc = 0;
 #define A(field, n, st) if (!rc) rc = dev_alloc(h, &d.field, (n), (st))
-    A(py, n_slots * p.NP, true); A(rec_a, n_slots * p.NP, true); A(rec_b, n_slots * p.NP, true);
+    // Particle blocks of consecutive farm slots are `pstride` floats apart: N x P rounded up to an ODD multiple of
+    // 256 bytes.  The compact rings of a farm use only the front of its block; an odd multiple of the 256-byte granule
+    // keeps the touched parts from aliasing onto the same residues of the HBM channel interleave (measured: no
+    // difference on cfg2 either way; kept as the safe choice).
+    size_t pstride = ((size_t)p.NP + 63) / 64;      // in 256-byte granules
+    if (pstride % 2 == 0) pstride += 1;
+    pstride *= 64;
+    if (const char* ev = getenv("WG_PSTRIDE_PAD")) pstride = (size_t)p.NP + (size_t)atoi(ev);
+    h->fp.pstride = (int)pstride;
+    A(py, n_slots * pstride, true); A(rec_a, n_slots * pstride, true); A(rec_b, n_slots * pstride, true);
 
     if (p.turb_mode != WG_TURB_NONE) {
-        A(pz, n_slots * p.NP, true); A(vlp, n_slots * p.NP, true); A(wlp, n_slots * p.NP, true);
+        A(pz, n_slots * pstride, true); A(vlp, n_slots * pstride, true); A(wlp, n_slots * pstride, true);
     }
     A(yaw, n_slots * p.N, true); A(u, n_slots * p.N, true); A(v, n_slots * p.N, true); A(w, n_slots * p.N, true);
     A(ti_loc, n_slots * p.N, true); A(power, n_slots * p.N, true); A(ct, n_slots * p.N, true);
     A(bnd, n_slots * p.N * 3, true);
     A(slot, n_slots, true); A(ctx, n_ctx, true); A(env, (size_t)p.B, true);
     A(xr, n_ctx * p.N, true); A(yr, n_ctx * p.N, true); A(jneed, n_ctx * p.N, true);
+    A(roff, n_ctx * (p.N + 1), true); A(qown, n_ctx * (size_t)(p.NP / 4), true);
     A(ring, n_ctx * p.ring_stride, true); A(fring, n_ctx * p.fring_stride, true);
     A(cur_ws, n_ctx * p.N, true); A(cur_wd, n_ctx * p.N, true);
     A(pend_farm, n_ctx * p.power_avg, true); A(pend_base, n_ctx * p.power_avg, true);
@@ -322,7 +333,9 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         if (!rc) rc = dev_upload<float>(h, &tcu, cu.data(), (size_t)nu);
         if (rc) { wg_destroy(h); return rc; }
         FlowP& f = h->fp;
+        const size_t pstride_keep = (size_t)f.pstride;
         memset(&f, 0, sizeof(f));
+        f.pstride = (int)pstride_keep;
         f.B = p.B; f.N = p.N; f.F = p.F; f.K = p.K; f.P = p.P; f.S = p.S; f.NP = p.NP; f.n_tab = nu;
         f.S_pad = 1; f.S_shift = 0;
         while (f.S_pad < p.S) { f.S_pad <<= 1; f.S_shift++; }
@@ -331,19 +344,27 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         int tc = 1024 / p.N; if (tc < 1) tc = 1; if (tc > p.N) tc = p.N;
         // phase B maps one thread per (target, sample): keep a chunk's items a multiple of the sample group
         f.target_chunk = tc;
-        // workgroup size: small farms are latency-bound around their phase boundaries -> more, smaller
-        // workgroups per CU (a single-wave workgroup needs no barriers at all); big farms want more lanes
-        f.block = p.NP <= 1024 ? 64 : (p.NP <= 8192 ? 128 : 256);   // measured on cfg2 (NP = 2048): 128 best
-        if (const char* ev = getenv("WG_FLOW_BLOCK")) { int b = atoi(ev); if (b == 64 || b == 128 || b == 256) f.block = b; }
-        // frozen-record layout for the deficit gathers follows the workgroup size (k_flow<256> reads rec4)
-        if (f.block == 256) { if (!rc) rc = dev_alloc(h, &d.rec4, n_slots * p.NP, true); }
-        else { if (!rc) rc = dev_alloc(h, &d.u_e, n_slots * p.NP, true); }
-        if (rc) { wg_destroy(h); return rc; }
+        // Kernel variant.  Small farms (N <= 32: all N x N pairs are staged at once): compact per-turbine rings +
+        // pair-major deficit phases, 64 threads for tiny farms, 128 otherwise.  Large farms: uniform P-slot rings with
+        // predicate pruning, (target, sample)-major deficit phases, 256 threads.
         size_t off = sizeof(float) * 4 * (size_t)tc * p.N;
         f.lds_off_turb = (int)off; off += (size_t)WG_TURB_LDS_BYTES * p.N;
         off = (off + 15) & ~(size_t)15;
         f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S) + sizeof(unsigned) * WG_MASK_WORDS * (size_t)tc + sizeof(float) * (size_t)tc * p.N;
-        off += sizeof(int) * ((size_t)p.N + 1);      // chain-pruning ages + the particle counter
+        off += sizeof(int) * ((size_t)p.N + 2);      // chain-pruning ages + the particle counter + the candidate counter
+        const bool small = p.N <= 32 && tc == p.N;
+        f.res = small ? 1 : 0;
+        f.block = small ? (p.NP <= 1024 ? 64 : 128) : 256;
+        if (const char* ev = getenv("WG_FLOW_BLOCK")) {       // tests: force an instantiation
+            const int b = atoi(ev);
+            if (b == 256) { f.res = 0; f.block = 256; }
+            else if ((b == 64 || b == 128) && small) { f.res = 1; f.block = b; }
+        }
+        p.compact = f.res;
+        // frozen-record layout for the deficit gathers of the large-farm variant: 16-byte AoS copy (rec4)
+        if (!f.res) { if (!rc) rc = dev_alloc(h, &d.rec4, n_slots * pstride_keep, true); }
+        else { if (!rc) rc = dev_alloc(h, &d.u_e, n_slots * pstride_keep, true); }
+        if (rc) { wg_destroy(h); return rc; }
         f.lds_bytes = (int)((off + 15) & ~(size_t)15);
         f.dt = p.dt; f.D = p.D; f.inv_D = p.inv_D; f.hub = p.hub; f.dpart_f = (float)p.dpart; f.R_rot = 0.5f * p.D;
         f.inv_N = 1.0f / (float)p.N; f.inv_S = 1.0f / (float)p.S; f.inv_P = 1.0f / (float)p.P;
@@ -377,6 +398,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         g.step_farm_pow = d.step_farm_pow; g.step_base_pow = d.step_base_pow;
         g.rotor_dy = d.rotor_dy; g.rotor_dz = d.rotor_dz; g.tab_power = tpu; g.tab_ct = tcu;
         g.gp = h->p_dev; g.gd = h->d_dev; g.env_rw = d.env;
+        g.roff = d.roff; g.qown = d.qown; g.status = d.status;
     }
 
     // how many RESET-mode launches develop the slowest possible episode: the chain needs
@@ -415,6 +437,10 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         }
     }
     if (const char* ev = getenv("WG_STEP_GRAPH")) h->graph_mode = atoi(ev) != 0;
+    if (getenv("WG_DEBUG"))
+        fprintf(stderr, "[windgym] k_flow variant: %s, %d threads, LDS %d B per workgroup, slot stride %d floats\n",
+                h->fp.res ? "compact rings / pair-major" : "uniform rings / sample-major", h->fp.block, h->fp.lds_bytes,
+                h->fp.pstride);
     *out = h;
     return 0;
 }
@@ -801,8 +827,7 @@ extern "C" int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, do
     // (counted on the device by the pruning-capable 256-thread variant; the others stream all N x P slots per farm step)
     if (particles_per_launch) {
         const double per_launch = h->n_step_launches ? 1.0 / h->n_step_launches : 0.0;
-        *particles_per_launch = h->fp.block == 256 ? (double)(pt_now - h->particles_mark) * per_launch
-                                                   : (double)(fs_now - h->flow_steps_mark) * per_launch * h->p.N * h->p.P;
+        *particles_per_launch = (double)(pt_now - h->particles_mark) * per_launch;
     }
     h->n_step_launches = 0;
     h->flow_steps_mark = fs_now;

@@ -293,6 +293,44 @@ __device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, c
         const double dxm = xmax - (cx0 + dx * cth + dy * sth);
         d.jneed[(size_t)ctx_id * N + t] = p.full_chains ? p.P : (int)(dxm / p.dpart) + 2;
     }
+    if (p.compact) {
+        // compact rings: turbine t keeps ages 0 .. jneed[t] (R_t = jneed[t] + 1 rounded up to a multiple of 4, at
+        // most P); exclusive prefix sum over the turbines (wave scan per 64 turbines, running base), then the owner
+        // of every quad of ring slots by binary search in the offsets
+        int* ro = d.roff + (size_t)ctx_id * (N + 1);
+        int base = 0;
+        for (int t0 = 0; t0 < N; t0 += WG_WAVE) {
+            const int t = t0 + lane;
+            int len = 0;
+            if (t < N) {
+                const double dx = d.x_pos[t] - cx0, dy = d.y_pos[t] - cy0;
+                const double dxm = xmax - (cx0 + dx * cth + dy * sth);
+                const int jn = p.full_chains ? p.P : (int)(dxm / p.dpart) + 2;
+                len = (jn + 1 + 3) & ~3;
+                if (len > p.P) len = p.P;
+            }
+            int incl = len;
+#pragma unroll
+            for (int o = 1; o < WG_WAVE; o <<= 1) {
+                const int v = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += v;
+            }
+            if (t < N) ro[t] = base + incl - len;
+            base += __shfl(incl, WG_WAVE - 1, 64);
+        }
+        if (lane == 0) ro[N] = base;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own stores visible to own loads below
+        uint8_t* own = d.qown + (size_t)ctx_id * (p.NP >> 2);
+        for (int q = lane; q < (base >> 2); q += WG_WAVE) {
+            int lo = 0, hi = N;                    // ro[lo] <= 4 q < ro[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (ro[mid] <= 4 * q) lo = mid; else hi = mid;
+            }
+            own[q] = (uint8_t)lo;
+        }
+    }
     if (lane == 0) {
         cx.dist = xmax - xmin;                                                     // :723-724
         const double t_inflow = (xmax - xmin) / ws;                                // :727
@@ -304,7 +342,7 @@ __device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, c
         if (d.script_uvw) n_dev = 0;
         for (int f = f_lo; f < f_hi; ++f) {
             WgSlot& s = d.slot[ctx_id * F + f];
-            s.head = p.P - 1; s.n_valid = 0; s.s_off = 0.0; s.time = 0.0; s.istep = 0;
+            s.head = p.P - 1; s.n_valid = 0; s.s_off = 0.0; s.time = 0.0; s.istep = 0; s.n_emitted = 0;
             s.dev_remaining = n_dev;
             s.fill_remaining = f == 0 ? p.fill_a : p.fill_b;
         }

@@ -8,6 +8,9 @@
 #ifndef WG_FLOW_WAVES_128
 #define WG_FLOW_WAVES_128 6   // 128-thread variants stream one quad per lane at a time (QB = 1): 80 VGPRs, 6 waves/SIMD
 #endif
+#ifndef WG_FLOW_WAVES_CG
+#define WG_FLOW_WAVES_CG 5    // small-farm variants (compact rings, 64 / 128 threads): 96 VGPRs; measured 4 / 5 / 6 waves: 104 / 93.5 / 96 us on cfg2
+#endif
 #ifndef WG_FLOW_WAVES
 #define WG_FLOW_WAVES 5   // min waves/SIMD the register allocator must leave room for (5 -> <= 96 VGPRs; measured best)
 #endif
@@ -16,6 +19,8 @@ struct FlowP {
     int B, N, F, K, P, S, S_pad, S_shift, NP, n_tab;
     int autoreset, action_method, base_controller, power_avg, script_rows, noise;
     int block;                    // threads per workgroup: 64, 128 or 256
+    int res;                      // 1: compact per-turbine rings + pair-major deficit phases (small farms), 0: legacy streaming variant
+    int pstride;                  // floats between the particle blocks of consecutive farm slots (>= NP, see wg_create)
     int target_chunk;             // targets whose pair parameters are staged in LDS at once
     int lds_off_turb, lds_off_tab, lds_bytes;
     float dt, D, inv_D, hub, dpart_f, R_rot, inv_N, inv_S, inv_P;
@@ -47,6 +52,9 @@ struct FlowPtrs {
     const WgEnv* env;
     const double *xr, *yr;
     const int* jneed;             // [B*2][N] chain pruning: ages above this are not advected (see ctx_init)
+    const int* roff;              // [B*2][N+1] compact ring offsets (res)
+    const uint8_t* qown;          // [B*2][NP/4] owner turbine of every quad of ring slots (res)
+    int* status;                  // sticky error word
     float *ring, *fring, *cur_ws, *cur_wd, *pend_farm, *pend_base, *old_yaw, *step_farm_pow, *step_base_pow;
     const float *rotor_dy, *rotor_dz, *tab_power, *tab_ct;   // tab_*: resampled on the uniform grid
     const float *script_uvw, *script_power;
@@ -59,6 +67,6 @@ struct FlowPtrs {
 };
 
 // sizeof(TurbLds) in wg_flow.hip; kept here so the host can size the dynamic LDS
-#define WG_TURB_LDS_BYTES 104
+#define WG_TURB_LDS_BYTES 120
 // per-target bit mask of contributing sources: 32-bit words per target (N <= 32 * WG_MASK_WORDS)
 #define WG_MASK_WORDS 4

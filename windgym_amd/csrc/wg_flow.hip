@@ -34,7 +34,10 @@ struct __attribute__((aligned(8))) TurbLds {
     // lateral (and vertical) excursion from the turbine's (y, z_hub), wake-growth rate k, initial width eps.
     // They let phase A discard a (target, source) pair BEFORE touching particle memory.
     float bd, bk, be;
-};   // 25 dwords (odd stride): lanes t = 0..31 of a column access hit distinct banks
+    // compact rings (small-farm variant): offset / length of this turbine's ring inside the farm's particle arrays,
+    // ring slot of its newest particle before (head) and after (head_n) the emissions of the current flow step
+    int roff, rlen, head, head_n;
+};
 static_assert(sizeof(TurbLds) == WG_TURB_LDS_BYTES, "keep WG_TURB_LDS_BYTES in sync");
 
 __device__ __forceinline__ float m0_cfrac(float ct, float sp) {
@@ -106,6 +109,16 @@ struct SlotRegs {
     double s_off, time;
     int head, n_valid;
     unsigned istep;
+    unsigned n_emitted;
+};
+
+// A farm's particle state in the compact-ring layout (small farms): SoA over the concatenated per-turbine rings of
+// the farm slot, in global memory
+struct PartLds {
+    float* py; unsigned* ra; unsigned* rb; float* ue;
+    float *pz, *vl, *wl;        // turbulent inflow only
+    const uint8_t* own;         // [L/4] owner turbine of a quad
+    int L;                      // ring slots of the farm = roff[N]
 };
 
 // per-episode inflow context (uniform over the workgroup)
@@ -229,17 +242,28 @@ __device__ __forceinline__ void full_barrier() {
 
 // One DWMFlowSimulation.step() of model M0 up to the new rotor inflow (T[t].u/v/w/ti); power and the
 // measurement are done by the caller's per-turbine tail.
-template <int NT, int TURB>
+template <int NT, int TURB, bool RES>
 __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, TurbLds* __restrict__ T,
                                           const float* __restrict__ tabct,
                                           const float* __restrict__ rdy, const float* __restrict__ rdz,
                                           float4* __restrict__ pair, float* __restrict__ tiap,
                                           unsigned* __restrict__ tmask, const int* __restrict__ jnl,
                                           const size_t pbase, const double ws,
-                                          const float ti_f, const float ti_pow, const TurbCtx& tc, SlotRegs& sr) {
+                                          const float ti_f, const float ti_pow, const TurbCtx& tc, SlotRegs& sr,
+                                          const PartLds& pl) {
     const int tid = threadIdx.x;
     const int N = p.N, P = p.P;
     const int TC = p.target_chunk;
+
+    // travel of the chains over this step: particles released when the newest one is d_particle away
+    const int head = sr.head, n_valid = sr.n_valid;
+    double s_new = sr.s_off + ws * p.dt_d;
+    int n_emit = 0;
+    while (s_new >= p.dpart) { s_new -= p.dpart; ++n_emit; }
+    if (n_emit > P) n_emit = P;
+    int new_head = head + n_emit; if (new_head >= P) new_head -= P;
+    int new_valid = n_valid + n_emit; if (new_valid > P) new_valid = P;
+    const float s_off_f = (float)sr.s_off;
 
     // (1) emission records of this step, sin/cos of the yaw; clear the source masks
     for (int t = tid; t < N; t += NT) {
@@ -259,20 +283,13 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         q.sg = sg;
         q.bk = fmaxf(q.bk, q.rk + WG_K_MAX / 65535.0f);
         q.be = fmaxf(q.be, q.reps + 1.0f / 65535.0f);
+        if (RES) q.head_n = (q.head + n_emit) % q.rlen;
     }
     for (int i = tid; i < TC * WG_MASK_WORDS; i += NT) tmask[i] = 0u;
     lds_barrier<NT>();
     WG_STAMP(2);
 
-    // (2) streaming pass over the particle SoA: advect over dt, release the new particles
-    const int head = sr.head, n_valid = sr.n_valid;
-    double s_new = sr.s_off + ws * p.dt_d;
-    int n_emit = 0;
-    while (s_new >= p.dpart) { s_new -= p.dpart; ++n_emit; }
-    if (n_emit > P) n_emit = P;
-    int new_head = head + n_emit; if (new_head >= P) new_head -= P;
-    int new_valid = n_valid + n_emit; if (new_valid > P) new_valid = P;
-    const float s_off_f = (float)sr.s_off;
+    // (2) pass over the particle SoA: advect over dt, release the new particles
 
     float* __restrict__ gpy = d.py + pbase;
     unsigned* __restrict__ gra = d.rec_a + pbase;
@@ -285,7 +302,125 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     constexpr bool PRUNE = (NT == 256);
     uint4* __restrict__ gr4 = d.rec4 + pbase;
     float* __restrict__ gue = d.u_e + pbase;
-    if (TURB != WG_TURB_NONE) {
+    if (RES && TURB == WG_TURB_NONE) {
+        // compact rings, steady inflow: a thread owns quads of 4 consecutive ring slots (one owner turbine per quad:
+        // ring lengths are multiples of 4).  Only chains of yawed turbines move (hv != 0); a quad that neither moves nor
+        // receives a new particle costs one 16-byte LDS read.
+        const int L4 = pl.L >> 2;
+        for (int q = tid; q < ((WG_ABLATE & 1) ? 0 : L4); q += NT) {
+            const int t = pl.own[q];
+            TurbLds& tq = T[t];
+            const int R = tq.rlen, hd = tq.head;
+            const int r0 = 4 * q - tq.roff;
+            int j0 = hd - r0; if (j0 < 0) j0 += R;             // age of ring slot r0 (slot r0+i: j0-i)
+            int e0 = r0 - hd - 1; if (e0 < 0) e0 += R;         // emission index of slot r0 (r0+i: e0+i)
+            const bool emits = (e0 < n_emit) || (n_emit > 0 && e0 + 3 >= R);   // wraps past R-1 -> 0
+            const uint4 rb = reinterpret_cast<const uint4*>(pl.rb)[q];
+            if (!(emits || rec_moves(rb.x) | rec_moves(rb.y) | rec_moves(rb.z) | rec_moves(rb.w))) continue;
+            const float4 py = reinterpret_cast<const float4*>(pl.py)[q];
+            const uint4 ra = reinterpret_cast<const uint4*>(pl.ra)[q];
+            float pyv[4] = {py.x, py.y, py.z, py.w};
+            unsigned rav[4] = {ra.x, ra.y, ra.z, ra.w};
+            unsigned rbv[4] = {rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int j = j0 - i; if (j < 0) j += R;
+                if (j < n_valid) {
+                    const float xrel = s_off_f + (float)j * p.dpart_f;
+                    const float sp = rec_k(rav[i]) * (xrel * p.inv_D) + rec_eps(rbv[i]);
+                    pyv[i] += rec_hv(rbv[i]) * m0_cfrac(rec_ct(rav[i]), sp) * p.dt;
+                }
+            }
+            const float y0 = (float)tq.yr;
+            if (emits) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int ei = e0 + i; if (ei >= R) ei -= R;
+                    if (ei < n_emit) {
+                        pyv[i] = y0; rav[i] = pack_a(tq.rct, tq.rk); rbv[i] = pack_b(tq.reps, tq.rhv);
+                        pl.ue[4 * q + i] = tq.rue;
+                    }
+                }
+                reinterpret_cast<uint4*>(pl.ra)[q] = make_uint4(rav[0], rav[1], rav[2], rav[3]);
+                reinterpret_cast<uint4*>(pl.rb)[q] = make_uint4(rbv[0], rbv[1], rbv[2], rbv[3]);
+            }
+            reinterpret_cast<float4*>(pl.py)[q] = make_float4(pyv[0], pyv[1], pyv[2], pyv[3]);
+            const float ex = fmaxf(fmaxf(fabsf(pyv[0] - y0), fabsf(pyv[1] - y0)), fmaxf(fabsf(pyv[2] - y0), fabsf(pyv[3] - y0)));
+            if (ex > tq.bd) atomicMax(reinterpret_cast<int*>(&tq.bd), __float_as_int(ex));   // ex >= 0: int order == float order
+        }
+    } else if (RES) {
+        // compact rings, turbulent inflow: every valid particle meanders.  One ring slot per lane and sub-iteration
+        // (consecutive lanes = consecutive particles of a chain, 0.2 D apart along x: the box gathers of a wave share
+        // cache lines); the lookups of U slots are issued together, then the filter / position updates.
+        const double xshift = tc.ox - tc.ws * sr.time;
+        // "Random" gusts are keyed by the particle's slot in the oracle's full P-slot ring: its newest particle sits at
+        // (emission count - 1) mod P
+        const int hfull = sr.n_emitted == 0u ? P - 1 : (int)((sr.n_emitted - 1u) % (unsigned)P);
+        auto turbulent_res = [&](auto coarse_tag, auto pow2_tag) {
+            constexpr bool COARSE = decltype(coarse_tag)::value;
+            constexpr bool POW2 = decltype(pow2_tag)::value;
+            constexpr int U = 4;
+            for (int b0 = tid; b0 < pl.L; b0 += NT * U) {
+                float pyv[U], pzv[U], fv[U], fw[U];
+                int jv[U], tv[U], ev[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ix = min(b0 + u * NT, pl.L - 1);
+                    const int t = pl.own[ix >> 2];
+                    const TurbLds& tq = T[t];
+                    const int R = tq.rlen;
+                    const int r = ix - tq.roff;
+                    int j = tq.head - r; if (j < 0) j += R;
+                    jv[u] = j; tv[u] = t; ev[u] = R - 1 - j;       // = (r - head - 1) mod R: emission index of this slot
+                    pyv[u] = pl.py[ix]; pzv[u] = pl.pz[ix];
+                    if (TURB != WG_TURB_RANDOM) {
+                        const float xrel = s_off_f + (float)j * p.dpart_f;
+                        const double bx = tq.xr + (double)xrel + xshift, by = (double)pyv[u] + tc.oy, bz = (double)pzv[u];
+                        if (WG_ABLATE & 4) { fv[u] = (float)bx * 1e-6f; fw[u] = (float)(by + bz) * 1e-6f; }
+                        else if (COARSE) cbox_lookup_vw<POW2>(d.box4c, p, bx, by, bz, fv[u], fw[u]);
+                        else { float f3[3]; box_lookup<POW2>(d.box4, p, bx, by, bz, f3); fv[u] = f3[1]; fw[u] = f3[2]; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ix = b0 + u * NT;
+                    if (ix >= pl.L) continue;
+                    const int j = jv[u];
+                    TurbLds& tq = T[tv[u]];
+                    float vlv = pl.vl[ix], wlv = pl.wl[ix];
+                    const unsigned rav = pl.ra[ix], rbv = pl.rb[ix];
+                    if (j < n_valid) {
+                        const float xrel = s_off_f + (float)j * p.dpart_f;
+                        const float sp = rec_k(rav) * (xrel * p.inv_D) + rec_eps(rbv);
+                        if (TURB == WG_TURB_RANDOM) {
+                            int rfull = hfull - j; if (rfull < 0) rfull += P;
+                            const uint32_t key = (uint32_t)(tv[u] * P + rfull);
+                            fv[u] = wg_turb_normal(tc.seed, sr.istep, key, 1u, 0x50u);
+                            fw[u] = wg_turb_normal(tc.seed, sr.istep, key, 2u, 0x50u);
+                        }
+                        vlv += tc.alpha * (tc.sig * fv[u] - vlv);
+                        wlv += tc.alpha * (tc.sig * fw[u] - wlv);
+                        pyv[u] += (rec_hv(rbv) * m0_cfrac(rec_ct(rav), sp) + vlv) * p.dt;
+                        pzv[u] += wlv * p.dt;
+                    }
+                    const float y0 = (float)tq.yr;
+                    if (ev[u] < n_emit) {
+                        pyv[u] = y0; pzv[u] = p.hub; vlv = 0.f; wlv = 0.f;
+                        pl.ra[ix] = pack_a(tq.rct, tq.rk); pl.rb[ix] = pack_b(tq.reps, tq.rhv);
+                        pl.ue[ix] = tq.rue;
+                    }
+                    const float ex = fabsf(pyv[u] - y0) + fabsf(pzv[u] - p.hub);
+                    if (ex > tq.bd) atomicMax(reinterpret_cast<int*>(&tq.bd), __float_as_int(ex));
+                    pl.py[ix] = pyv[u]; pl.pz[ix] = pzv[u]; pl.vl[ix] = vlv; pl.wl[ix] = wlv;
+                }
+            }
+        };
+        if (TURB == WG_TURB_BOX && p.coarse) {
+            if (p.cbox_pow2) turbulent_res(std::true_type{}, std::true_type{});
+            else turbulent_res(std::true_type{}, std::false_type{});
+        } else if (TURB == WG_TURB_BOX && p.box_pow2) turbulent_res(std::false_type{}, std::true_type{});
+        else turbulent_res(std::false_type{}, std::false_type{});
+    } else if (TURB != WG_TURB_NONE) {
         // turbulent inflow: every valid particle meanders -> all state arrays are streamed (py, pz, vlp, wlp r/w,
         // record read) and the transverse inflow at the particle is looked up (frozen box: 8 corners x 2
         // components, L2/MALL-resident shared box; "Random": counter-based normals)
@@ -491,12 +626,157 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         }
     }
     sr.head = new_head; sr.n_valid = new_valid; sr.s_off = s_new; sr.time += p.dt_d; sr.istep += 1u;
+    sr.n_emitted += (unsigned)n_emit;
     WG_STAMP(3);
     full_barrier<NT>();
     WG_STAMP(4);   // this workgroup's particle stores are visible to its own gathers below
 
     // (3)+(4) rotor-averaged inflow
     const float ws_f = (float)ws;
+    if (RES) {
+        // small-farm variant: PAIR-major.  In a small farm only a few (target, source) pairs interact (the same
+        // column of a grid, its diagonal neighbours), so the pairs that pass a cheap conservative test are compacted
+        // into a list and only those get the exact evaluation — one thread per candidate: bracketing particles
+        // (L2 hits: this workgroup just streamed them), interpolation, lateral cut-off, then the Gaussian deficit at all S rotor points summed in the thread.
+        // Thread t finally subtracts its sources' contributions in ascending source order (deterministic).
+        // Staging (the `pair` region): cl[N*N] u16 candidate list | def[N*N] rotor-mean deficit | tiav[N*N] added TI.
+        unsigned short* cl = reinterpret_cast<unsigned short*>(pair);
+        float* def = reinterpret_cast<float*>(cl + ((N * N + 7) & ~7));
+        float* tiav = def + N * N;
+        int* ncand = const_cast<int*>(jnl) + N + 1;
+        const int npairs = N * N;
+        // ambient inflow at the rotors (no wakes): thread t / the (t, sample) threads
+        if (TURB == WG_TURB_BOX) {
+            const int nitems = N << p.S_shift;
+            for (int it = tid; it < ((nitems + NT - 1) & ~(NT - 1)); it += NT) {
+                const int t = it >> p.S_shift, s = it & (p.S_pad - 1);
+                const bool live = (it < nitems) && (s < p.S);
+                float amb[3] = {0.f, 0.f, 0.f};
+                if (live) {
+                    const double bx = T[t].xr - tc.ws * sr.time + tc.ox;
+                    const double by = T[t].yr + (double)(rdy[s] * T[t].cg) + tc.oy, bz = p.hub_d + (double)rdz[s];
+                    if (p.box_pow2) box_lookup<true>(d.box4, p, bx, by, bz, amb);
+                    else box_lookup<false>(d.box4, p, bx, by, bz, amb);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+                    for (int o = p.S_pad >> 1; o > 0; o >>= 1) amb[cc] += __shfl_xor(amb[cc], o, 64);
+                if (live && s == 0) {
+                    T[t].u = ws_f + tc.sig * amb[0] * p.inv_S; T[t].v = tc.sig * amb[1] * p.inv_S; T[t].w = tc.sig * amb[2] * p.inv_S;
+                }
+            }
+        } else {
+            for (int t = tid; t < N; t += NT) {
+                float au = 0.f, av = 0.f, aw = 0.f;
+                if (TURB == WG_TURB_RANDOM) {
+                    // i.i.d. gusts at the S rotor points: their mean is one normal of variance sigma^2 / S
+                    const float sc = tc.sig * p.inv_sqrt_S;
+                    au = sc * wg_turb_normal(tc.seed, sr.istep, (uint32_t)t, 0u, 0x52u);
+                    av = sc * wg_turb_normal(tc.seed, sr.istep, (uint32_t)t, 1u, 0x52u);
+                    aw = sc * wg_turb_normal(tc.seed, sr.istep, (uint32_t)t, 2u, 0x52u);
+                }
+                T[t].u = ws_f + au; T[t].v = av; T[t].w = aw;
+            }
+        }
+        if (tid == 0) *ncand = 0;
+        for (int i = tid; i < N * WG_MASK_WORDS; i += NT) tmask[i] = 0u;
+        lds_barrier<NT>();
+        // pass 1: conservative test on every pair -> candidate list
+        for (int i0 = 0; i0 < ((WG_ABLATE & 2) ? 0 : npairs); i0 += NT) {
+            const int i = i0 + tid;
+            bool cand = false;
+            if (i < npairs) {
+                const int tl = (int)(((float)i + 0.5f) * p.inv_N);
+                const int s2 = i - tl * N;
+                const double dx = T[tl].xr - T[s2].xr;
+                cand = (s2 != tl) && (dx > 0.0);
+                if (cand) {
+                    const TurbLds& src = T[s2];
+                    const float sig_max = (src.bk * ((float)dx * p.inv_D) + src.be) * p.D;
+                    const float gap = fabsf((float)(T[tl].yr - src.yr)) - (p.R_rot + 5.0f * sig_max + src.bd);
+                    cand = gap <= 1.0e-3f * p.D;      // small margin for fp32 rounding of the bound itself
+                }
+            }
+            const unsigned long long bal = __ballot(cand);
+            if (bal) {
+                const int lane = tid & 63;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(ncand, __popcll(bal));
+                base = __shfl(base, 0, 64);
+                if (cand) cl[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)i;
+            }
+        }
+        lds_barrier<NT>();
+        // pass 2: exact evaluation of the candidates
+        const int nc = *ncand;
+        for (int c = tid; c < nc; c += NT) {
+            const int i = cl[c];
+            const int t = (int)(((float)i + 0.5f) * p.inv_N);
+            const int s2 = i - t * N;
+            const TurbLds& src = T[s2];
+            const double dx = T[t].xr - src.xr;
+            const double xi = (dx - s_new) * p.inv_dpart;
+            const double jf = floor(xi);
+            float wgt = (float)(xi - jf);
+            int j = (int)jf;
+            if (j < 0) { j = 0; wgt = 0.f; }
+            if (j + 1 > new_valid - 1) continue;          // the chain has not reached the target yet
+            const int Rs = src.rlen;
+            int r0 = src.head_n - j; if (r0 < 0) r0 += Rs;
+            int r1 = r0 - 1; if (r1 < 0) r1 += Rs;
+            const int i0 = src.roff + r0, i1 = src.roff + r1;
+            const float py0 = pl.py[i0], py1 = pl.py[i1];
+            const float u0 = pl.ue[i0], u1 = pl.ue[i1];
+            const unsigned a0 = pl.ra[i0], a1 = pl.ra[i1], b0_ = pl.rb[i0], b1_ = pl.rb[i1];
+            const float w0 = 1.0f - wgt, w1 = wgt;
+            const float yc = w0 * py0 + w1 * py1;
+            float zc = p.hub;
+            if (TURB != WG_TURB_NONE) zc = w0 * pl.pz[i0] + w1 * pl.pz[i1];
+            const float kv = w0 * rec_k(a0) + w1 * rec_k(a1);
+            const float epv = w0 * rec_eps(b0_) + w1 * rec_eps(b1_);
+            const float xd = (float)dx * p.inv_D;
+            const float sp = kv * xd + epv;
+            const float sig = sp * p.D;
+            const float yt = (float)T[t].yr;
+            const float rc2 = (yt - yc) * (yt - yc) + (p.hub - zc) * (p.hub - zc);
+            const float rcut = p.R_rot + 5.0f * sig;
+            if (rc2 > rcut * rcut) continue;
+            const float ctv = w0 * rec_ct(a0) + w1 * rec_ct(a1);
+            const float uev = w0 * u0 + w1 * u1;
+            const float cf = m0_cfrac(ctv, sp);
+            const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sig * sig);
+            // wake-added turbulence (Crespo-Hernandez), Gaussian-weighted at the hub
+            const float ind = 0.5f * (1.0f - __builtin_amdgcn_sqrtf(1.0f - ctv));
+            tiav[i] = p.tia * fast_pow(ind, p.tib) * ti_pow * fast_pow(fmaxf(xd, 1.0f), p.tid) * __expf(-rc2 * inv2s2);
+            // Gaussian deficit at the S rotor points of the target (lateral offsets scaled by cos(yaw_t))
+            const float cgt = T[t].cg, amp = uev * cf;
+            float acc = 0.f;
+            for (int sI = 0; sI < p.S; ++sI) {
+                const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
+                acc += amp * __expf(-(dy * dy + dz * dz) * inv2s2);
+            }
+            def[i] = acc * p.inv_S;
+            atomicOr(&tmask[t * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
+        }
+        lds_barrier<NT>();
+        // thread t: superposition in ascending source order
+        for (int t = tid; t < N; t += NT) {
+            float dsum = 0.f, tia_max = 0.f;
+            for (int wd = 0; wd * 32 < N; ++wd) {
+                unsigned m = tmask[t * WG_MASK_WORDS + wd];
+                while (m) {
+                    const int s2 = wd * 32 + __builtin_ctz(m);
+                    m &= m - 1;
+                    dsum += def[t * N + s2];
+                    tia_max = fmaxf(tia_max, tiav[t * N + s2]);
+                }
+            }
+            T[t].u -= dsum;
+            T[t].ti = __builtin_amdgcn_sqrtf(ti_f * ti_f + tia_max * tia_max);
+        }
+        lds_barrier<NT>();
+        return;
+    }
     for (int t0 = 0; t0 < ((WG_ABLATE & 2) ? 0 : N); t0 += TC) {
         const int nt = (N - t0) < TC ? (N - t0) : TC;
         const int npairs = nt * N;
@@ -528,18 +808,23 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 int j = (int)jf;
                 if (j < 0) { j = 0; wgt = 0.f; }
                 if (j + 1 <= new_valid - 1) {
-                    int r0 = new_head - j; if (r0 < 0) r0 += P;
-                    int r1 = r0 - 1; if (r1 < 0) r1 += P;
-                    const unsigned i0 = (unsigned)(s2 * P + r0), i1 = (unsigned)(s2 * P + r1);
+                    const int Rs = RES ? T[s2].rlen : P;
+                    int r0 = (RES ? T[s2].head_n : new_head) - j; if (r0 < 0) r0 += Rs;
+                    int r1 = r0 - 1; if (r1 < 0) r1 += Rs;
+                    const unsigned sb = RES ? (unsigned)T[s2].roff : (unsigned)(s2 * P);
+                    const unsigned i0 = sb + (unsigned)r0, i1 = sb + (unsigned)r1;
                     // one round of gathers.  Small farms: the lines were streamed by this workgroup a moment ago (L2
                     // hits).  Large farms (AOS): the particle state of the resident workgroups exceeds L2, every gather
                     // line comes from HBM and these gathers were half of the kernel's traffic -> the frozen record is
                     // read from its 16-byte copy (written once, at emission): the two bracketing particles are 32
                     // contiguous bytes, a pair touches two lines (record, py) instead of four (py, u_e, rec_a, rec_b)
-                    const float py0 = gpy[i0], py1 = gpy[i1];
+                    const float py0 = RES ? pl.py[i0] : gpy[i0], py1 = RES ? pl.py[i1] : gpy[i1];
                     float u0, u1;
                     unsigned a0, a1, b0_, b1_;
-                    if (AOS) {
+                    if (RES) {      // the farm's particle state is in LDS: no global gathers at all
+                        u0 = pl.ue[i0]; u1 = pl.ue[i1];
+                        a0 = pl.ra[i0]; a1 = pl.ra[i1]; b0_ = pl.rb[i0]; b1_ = pl.rb[i1];
+                    } else if (AOS) {
                         const uint4 q0 = gr4[i0], q1 = gr4[i1];
                         u0 = __uint_as_float(q0.z); u1 = __uint_as_float(q1.z);
                         a0 = q0.x; a1 = q1.x; b0_ = q0.y; b1_ = q1.y;
@@ -552,7 +837,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     const float w0 = 1.0f - wgt, w1 = wgt;
                     const float yc = w0 * py0 + w1 * py1;
                     float zc = p.hub;
-                    if (TURB != WG_TURB_NONE) zc = w0 * d.pz[pbase + i0] + w1 * d.pz[pbase + i1];
+                    if (TURB != WG_TURB_NONE) zc = RES ? w0 * pl.pz[i0] + w1 * pl.pz[i1] : w0 * d.pz[pbase + i0] + w1 * d.pz[pbase + i1];
                     const float kv = w0 * k0 + w1 * k1;
                     const float epv = w0 * e0 + w1 * e1;
                     const float xd = (float)dx * p.inv_D;
@@ -682,8 +967,8 @@ __device__ __attribute__((noinline)) void flow_init_episode(const WgParams* gp, 
     }
 }
 
-template <int NT, int TURB, bool REPLAY, bool NOISE>
-__global__ void __launch_bounds__(NT, TURB != WG_TURB_NONE ? WG_BOX_WAVES : (NT == 128 ? WG_FLOW_WAVES_128 : WG_FLOW_WAVES))
+template <int NT, int TURB, bool REPLAY, bool NOISE, bool RES>
+__global__ void __launch_bounds__(NT, TURB != WG_TURB_NONE ? WG_BOX_WAVES : (RES ? WG_FLOW_WAVES_CG : WG_FLOW_WAVES))
 k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict__ actions,
        const uint8_t* __restrict__ mask, const int chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -714,7 +999,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     const int ctx_id = e * 2 + c;
     const int slot_id = ctx_id * F + farm;
     const size_t tb = (size_t)slot_id * N;
-    const size_t pbase = (size_t)slot_id * p.NP;
+    const size_t pbase = (size_t)slot_id * p.pstride;
 
     WG_STAMP(0);
     // ---- prologue: issue every independent global load up front (ONE exposed memory round trip) -------
@@ -735,10 +1020,14 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     double l_xr = 0, l_yr = 0;
     float l_yaw = 0, l_u = 0, l_v = 0, l_w = 0, l_ti = 0, l_pow = 0, l_ct = 0, l_act = 0;
     float l_bd = 0, l_bk = 0, l_be = 0;
-    int l_jn = 0;
+    int l_jn = 0, l_roff = 0, l_rnext = 0, L_ring = 0;
     auto load_state = [&]() __attribute__((always_inline)) {
         dev_rem = slot.dev_remaining; fill_rem = slot.fill_remaining;
-        sr = SlotRegs{slot.s_off, slot.time, slot.head, slot.n_valid, slot.istep};
+        sr = SlotRegs{slot.s_off, slot.time, slot.head, slot.n_valid, slot.istep, slot.n_emitted};
+        if (RES) {
+            const int* ro = d.roff + (size_t)ctx_id * (N + 1);
+            l_roff = ro[t_own]; l_rnext = ro[t_own + 1]; L_ring = ro[N];
+        }
         cursor = slot.cursor;
         ws = cx.ws;
         ti_f = (float)cx.ti;
@@ -755,7 +1044,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         l_yaw = d.yaw[tb + t_own]; l_u = d.u[tb + t_own]; l_v = d.v[tb + t_own]; l_w = d.w[tb + t_own];
         l_ti = d.ti_loc[tb + t_own]; l_pow = d.power[tb + t_own]; l_ct = d.ct[tb + t_own];
         l_bd = d.bnd[(tb + t_own) * 3]; l_bk = d.bnd[(tb + t_own) * 3 + 1]; l_be = d.bnd[(tb + t_own) * 3 + 2];
-        if (NT == 256) l_jn = d.jneed[(size_t)ctx_id * N + t_own];      // chain pruning: large-farm variant only
+        if (!RES) l_jn = d.jneed[(size_t)ctx_id * N + t_own];      // chain pruning by predicate: streaming variant only
     };
     load_state();
     if (mode == WG_MODE_STEP && farm == 0) l_act = actions[(size_t)e * N + t_own];
@@ -768,7 +1057,11 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             if (env_done) return;
         } else {
             if (!p.autoreset) return;
+#ifdef WG_NO_INIT_PATH
+            if (false) {
+#else
             if (init_pending) {
+#endif
                 // Rare path (one context per truncation): the episode this context will hold has not been set up yet
                 // — k_glue flagged it when it retired the finished episode.  Wave 0 of BOTH farm workgroups runs the
                 // same initialisation from the generator snapshot k_glue left in the context: identical context-level
@@ -795,6 +1088,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         budget = chunk;
     }
 
+    if ((WG_ABLATE & 8) && mode == WG_MODE_STEP) return;      // profiling: cost of launch + first round trip
     // LDS carve: pair[target_chunk * N] | T[N] | tabp[n_tab] | tabct[n_tab] | rdy[S] | rdz[S] | tmask
     float4* pair = reinterpret_cast<float4*>(smem);
     TurbLds* T = reinterpret_cast<TurbLds*>(smem + p.lds_off_turb);
@@ -805,24 +1099,43 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     unsigned* tmask = reinterpret_cast<unsigned*>(rdz + p.S);
     float* tiap = reinterpret_cast<float*>(tmask + p.target_chunk * WG_MASK_WORDS);
     int* jnl = reinterpret_cast<int*>(tiap + p.target_chunk * N);          // [N] chain pruning ages
-
+    PartLds pl;
+    if (RES) {
+        pl.py = d.py + pbase; pl.ra = d.rec_a + pbase; pl.rb = d.rec_b + pbase; pl.ue = d.u_e + pbase;
+        pl.pz = TURB != WG_TURB_NONE ? d.pz + pbase : nullptr;
+        pl.vl = TURB != WG_TURB_NONE ? d.vlp + pbase : nullptr;
+        pl.wl = TURB != WG_TURB_NONE ? d.wlp + pbase : nullptr;
+        pl.own = d.qown + (size_t)ctx_id * (p.NP >> 2);
+        pl.L = L_ring;
+    }
     for (int t = tid; t < N; t += NT) {
         TurbLds& q = T[t];
         if (t == tid && tid < N) {
             q.xr = l_xr; q.yr = l_yr; q.yaw = l_yaw; q.u = l_u; q.v = l_v; q.w = l_w; q.ti = l_ti; q.pow = l_pow; q.ct = l_ct;
             q.bd = l_bd; q.bk = l_bk; q.be = l_be;
-            if (NT == 256) jnl[t] = l_jn;
+            if (!RES) jnl[t] = l_jn;
+            if (RES) {
+                q.roff = l_roff; q.rlen = l_rnext - l_roff;
+                q.head = sr.n_emitted == 0u ? q.rlen - 1 : (int)((sr.n_emitted - 1u) % (unsigned)q.rlen);
+                q.head_n = q.head;
+            }
         }
         if (t >= NT) {   // N > 256 (not the common case): remaining turbines loaded the slow way
             q.xr = d.xr[(size_t)ctx_id * N + t]; q.yr = d.yr[(size_t)ctx_id * N + t];
             q.yaw = d.yaw[tb + t]; q.u = d.u[tb + t]; q.v = d.v[tb + t]; q.w = d.w[tb + t];
             q.ti = d.ti_loc[tb + t]; q.pow = d.power[tb + t]; q.ct = d.ct[tb + t];
             q.bd = d.bnd[(tb + t) * 3]; q.bk = d.bnd[(tb + t) * 3 + 1]; q.be = d.bnd[(tb + t) * 3 + 2];
-            if (NT == 256) jnl[t] = d.jneed[(size_t)ctx_id * N + t];
+            if (!RES) jnl[t] = d.jneed[(size_t)ctx_id * N + t];
+            if (RES) {
+                const int* ro = d.roff + (size_t)ctx_id * (N + 1);
+                q.roff = ro[t]; q.rlen = ro[t + 1] - ro[t];
+                q.head = sr.n_emitted == 0u ? q.rlen - 1 : (int)((sr.n_emitted - 1u) % (unsigned)q.rlen);
+                q.head_n = q.head;
+            }
         }
         q.sws = 0.f; q.swd = 0.f; q.syaw = 0.f; q.sp = 0.f;
     }
-    if (NT == 256 && tid == 0) jnl[N] = 0;
+    if (tid == 0) jnl[N] = 0;
     for (int i = tid; i < p.n_tab; i += NT) { tabp[i] = d.tab_power[i]; tabct[i] = d.tab_ct[i]; }
     for (int i = tid; i < p.S; i += NT) { rdy[i] = d.rotor_dy[i]; rdz[i] = d.rotor_dz[i]; }
 
@@ -849,6 +1162,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     }
     lds_barrier<NT>();   // publishes T, the tables and the rotor offsets
     WG_STAMP(1);
+    if ((WG_ABLATE & 16) && mode == WG_MODE_STEP) return;     // profiling: + state set-up and stream-in
 
     // live:   one env step = K sub-steps with measurement (Wind_Farm_Env.py:932-979)
     // else:   background development of a not-yet-live episode: flow-development steps (fs.run), then
@@ -880,10 +1194,10 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             // sin/cos are not needed in replay mode: power comes from the script
             script_step<NT>(p, d, T, e, farm, cursor, sr.time);
         } else {
-            flow_step<NT, TURB>(p, d, T, tabct, rdy, rdz, pair, tiap, tmask, jnl, pbase, ws, ti_f, ti_pow, tc, sr);
-            if (NT == 256 && tid < WG_WAVE) {   // roofline accounting: particles that can still reach a rotor
+            flow_step<NT, TURB, RES>(p, d, T, tabct, rdy, rdz, pair, tiap, tmask, jnl, pbase, ws, ti_f, ti_pow, tc, sr, pl);
+            if (tid < WG_WAVE) {   // roofline accounting: particles that can still reach a rotor
                 int cnt = 0;
-                for (int t = tid; t < N; t += WG_WAVE) cnt += min(sr.n_valid, jnl[t] + 1);
+                for (int t = tid; t < N; t += WG_WAVE) cnt += min(sr.n_valid, RES ? T[t].rlen : jnl[t] + 1);
                 cnt = wg_wave_sum_i(cnt);
                 if (tid == 0) jnl[N] += cnt;          // only thread 0 ever touches this word
             }
@@ -899,6 +1213,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         float* __restrict__ rbase = d.ring + (size_t)ctx_id * p.ring_stride;
         for (int t = tid; t < N; t += NT) {
             TurbLds& q = T[t];
+            if (RES) q.head = q.head_n;          // the step's emissions are in the ring now
             if (!(REPLAY && !is_dev)) {
                 const float wsn = fmaxf(q.u * q.cg + q.v * q.sg, 0.0f);
                 q.pow = tab_lookup(tabp, p, wsn);
@@ -977,9 +1292,9 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         d.bnd[(tb + t) * 3] = q.bd; d.bnd[(tb + t) * 3 + 1] = q.bk; d.bnd[(tb + t) * 3 + 2] = q.be;
     }
     if (tid == 0) {
-        if (NT == 256) slot.part_count += (unsigned)jnl[N];
+        slot.part_count += (unsigned)jnl[N];
         slot.head = sr.head; slot.n_valid = sr.n_valid; slot.s_off = sr.s_off; slot.time = sr.time;
-        slot.istep = sr.istep;
+        slot.istep = sr.istep; slot.n_emitted = sr.n_emitted;
         slot.cursor = cursor;
         slot.dev_remaining = dev_rem; slot.fill_remaining = fill_rem;
         if (farm == 0) { cx.n_pushed = n_pushed; cx.pend_farm_n = pend_farm_n; }
@@ -994,14 +1309,14 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     }
 }
 
-template <int NT>
+template <int NT, bool RES>
 static void launch_nt(const FlowP* p, const FlowPtrs* d, int mode, const float* actions, const uint8_t* mask,
                       int chunk, hipStream_t st) {
     const int grid = p->B * 2 * p->F;
     const size_t lds = p->lds_bytes;
     const bool replay = d->script_uvw != nullptr, noise = p->noise != 0;
 #define WG_LAUNCH(TURB, REPLAY, NOISE) \
-    hipLaunchKernelGGL((k_flow<NT, TURB, REPLAY, NOISE>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk)
+    hipLaunchKernelGGL((k_flow<NT, TURB, REPLAY, NOISE, RES>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk)
     const int turb = (p->turb_mode == WG_TURB_BOX_SHIFT) ? WG_TURB_BOX : p->turb_mode;
     if (replay) {                       // replay mode ignores the physics
         if (noise) WG_LAUNCH(WG_TURB_NONE, true, true); else WG_LAUNCH(WG_TURB_NONE, true, false);
@@ -1015,12 +1330,17 @@ static void launch_nt(const FlowP* p, const FlowPtrs* d, int mode, const float* 
 #undef WG_LAUNCH
 }
 
-// one workgroup per farm slot; its size (64 / 128 / 256 threads) is chosen on the host (FlowP.block)
+// One workgroup per farm slot.  Small farms (N <= 32): compact per-turbine rings + pair-major deficit phases, 64 or 128
+// threads; large farms: uniform rings with predicate pruning + (target, sample)-major deficit phases, 256 threads.
+// Chosen on the host (FlowP.res / FlowP.block).
 extern "C" void wg_launch_flow(const FlowP* p, const FlowPtrs* d, int mode, const float* actions,
                                const uint8_t* mask, int chunk, hipStream_t st) {
-    if (p->block == 64) launch_nt<64>(p, d, mode, actions, mask, chunk, st);
-    else if (p->block == 128) launch_nt<128>(p, d, mode, actions, mask, chunk, st);
-    else launch_nt<256>(p, d, mode, actions, mask, chunk, st);
+    if (p->res) {
+        if (p->block == 64) launch_nt<64, true>(p, d, mode, actions, mask, chunk, st);
+        else launch_nt<128, true>(p, d, mode, actions, mask, chunk, st);
+    } else {
+        launch_nt<256, false>(p, d, mode, actions, mask, chunk, st);
+    }
 }
 
 // ===================================================================================================
@@ -1040,7 +1360,7 @@ k_windspeed(const FlowP p, const FlowPtrs d, const int e, const int farm, const 
     const int N = p.N, P = p.P;
     const int ctx_id = e * 2 + d.env[e].live;
     const int slot_id = ctx_id * p.F + farm;
-    const size_t pbase = (size_t)slot_id * p.NP;
+    const size_t pbase = (size_t)slot_id * p.pstride;
     const WgSlot& slot = d.slot[slot_id];
     const WgCtx& cx = d.ctx[ctx_id];
     const double s_off = slot.s_off;
@@ -1065,9 +1385,22 @@ k_windspeed(const FlowP p, const FlowPtrs d, const int e, const int farm, const 
         long long j = (long long)jf;
         if (j < 0) { j = 0; wgt = 0.f; }
         if (j + 1 > n_valid - 1) continue;
-        int r0 = head - (int)j; if (r0 < 0) r0 += P;
-        int r1 = r0 - 1; if (r1 < 0) r1 += P;
-        const size_t i0 = pbase + (size_t)s2 * P + r0, i1 = pbase + (size_t)s2 * P + r1;
+        size_t i0, i1;
+        if (p.res) {
+            // compact rings: turbine s2 keeps its R youngest particles (those that can still reach a rotor); the field
+            // behind the last turbine row needs wg_config.full_chains
+            const int* ro = d.roff + (size_t)ctx_id * (N + 1);
+            const int R = ro[s2 + 1] - ro[s2];
+            if (j + 1 >= R) continue;
+            const int hd = (int)((slot.n_emitted - 1u) % (unsigned)R);       // n_valid > 0 here: something was emitted
+            int r0 = hd - (int)j; if (r0 < 0) r0 += R;
+            int r1 = r0 - 1; if (r1 < 0) r1 += R;
+            i0 = pbase + (size_t)ro[s2] + r0; i1 = pbase + (size_t)ro[s2] + r1;
+        } else {
+            int r0 = head - (int)j; if (r0 < 0) r0 += P;
+            int r1 = r0 - 1; if (r1 < 0) r1 += P;
+            i0 = pbase + (size_t)s2 * P + r0; i1 = pbase + (size_t)s2 * P + r1;
+        }
         unsigned a0, a1, b0, b1;
         float ue0, ue1;
         if (d.rec4) {

@@ -62,6 +62,7 @@ struct WgParams {
     double bdx, bdy, bdz;
     // replay mode
     int script_rows;
+    int compact;         // 1: per-turbine ring lengths (small-farm k_flow variant), see WgPtrs::roff
     int stage_ch[WG_N_CH];   // k_glue ring staging per channel: 0 = not observed, 1 = newest sample only, 2 = whole ring
     double cx0, cy0;     // farm centre (mean of the layout), the pivot of the flow-frame rotation
 };
@@ -78,6 +79,8 @@ struct WgSlot {
     unsigned flow_count; // flow_step() executions of this slot (roofline accounting; summed on the host)
     unsigned istep;      // flow steps since the farm was built (counter of the inflow random stream)
     unsigned part_count; // particles the advection passes streamed (roofline accounting, like flow_count)
+    unsigned n_emitted;  // compact rings: particles each chain has emitted so far (ring head of turbine t = (n_emitted - 1) mod R_t)
+    unsigned pad_;
 };
 
 // per episode context
@@ -132,6 +135,11 @@ struct WgPtrs {
     double *xr, *yr;          // [B*2][N] flow-frame positions
     float* multi_out;         // optional [B][N][obs_dim_multi]: per-agent observations written by the glue every step
     int* jneed;               // [B*2][N] oldest particle age of a chain that can still reach a rotor (chain pruning)
+    // Compact rings (small farms): turbine t of a context keeps only the R_t = roff[t+1] - roff[t]
+    // youngest particles of its chain — the ones that can still reach a rotor — at [slot base + roff[t], + R_t); R_t
+    // is a multiple of 4 set per episode from the rotated layout.  qown[q] = owner turbine of quad q (4 ring slots).
+    int* roff;                // [B*2][N+1]
+    uint8_t* qown;            // [B*2][NP/4]
     float *ring, *fring;      // [B*2][ring_stride], [B*2][fring_stride]
     float *cur_ws, *cur_wd;   // [B*2][N] last sub-step measurement (info dict)
     float *pend_farm, *pend_base;   // [B*2][power_avg]
