@@ -149,6 +149,9 @@ class EnvConfig:
     extra_timestep_inc: bool = False
     advect_full_chains: bool = False             # True: no chain pruning (exact flow-field view behind the last row)
     yaw_defined: Optional[Sequence[float]] = None
+    # constants of flow model M0, keys of wg_config without the m0_ prefix: ka, kb, eps, hill, ti_a ...
+    # ti_d, fc_scale; missing keys keep the documented defaults (a calibrated M0 is configuration, not code)
+    model_constants: Optional[dict] = None
     _keep: list = field(default_factory=list, repr=False)
 
     def __post_init__(self):
@@ -350,4 +353,8 @@ class EnvConfig:
         c.extra_timestep_inc = int(bool(self.extra_timestep_inc))
         c.turb_mode = TURB[self.turbtype]
         c.full_chains = int(bool(self.advect_full_chains))
+        for k, v in (self.model_constants or {}).items():
+            if not hasattr(c, "m0_" + k):
+                raise ValueError(f"unknown model constant {k!r}")
+            setattr(c, "m0_" + k, float(v))
         return c
