@@ -67,8 +67,10 @@ enum { WG_PEN_CHANGE = 0, WG_PEN_TOTAL = 1 };             /* _action_penalty, :8
 enum { WG_NOISE_NONE = 0, WG_NOISE_NORMAL = 1 };          /* farm_mes noise, MesClass.py:436-444    */
 /* turbtype (:598-668): "None" -> NONE; "Random" -> RANDOM (draws a seed, :642); "MannFixed" -> BOX (the same
  * frozen box every episode, no draw, :646-657); "MannGenerate"/"MannLoad" -> BOX_SHIFT (draws a seed like :623
- * and uses it as a random horizontal offset into the one shared box instead of generating 0.8 GB per env). */
-enum { WG_TURB_NONE = 0, WG_TURB_RANDOM = 1, WG_TURB_BOX = 2, WG_TURB_BOX_SHIFT = 3 };
+ * and uses it as a random horizontal offset into the one shared box instead of generating 0.8 GB per env);
+ * "MannLoad" -> BOX_POOL: a pool of K boxes (the TF_* files) resident on the GPU, one drawn per episode exactly like
+ * tf_file = self.np_random.choice(self.TF_files) (:614 — the same PCG64 draw as integers(0, K)). */
+enum { WG_TURB_NONE = 0, WG_TURB_RANDOM = 1, WG_TURB_BOX = 2, WG_TURB_BOX_SHIFT = 3, WG_TURB_BOX_POOL = 4 };
 
 typedef struct wg_config {
     int32_t abi_version;       /* must be WG_ABI_VERSION */
@@ -171,7 +173,8 @@ typedef enum wg_info_field {
      * adds the terminal step's power to the episode that ended.  Equal to POWER_AGENT / POWER_BASE for envs that did
      * not truncate.                                                                                            */
     WG_INFO_STEP_POWER_AGENT = 22, /* f32[B] */
-    WG_INFO_STEP_POWER_BASE = 23   /* f32[B] */
+    WG_INFO_STEP_POWER_BASE = 23,  /* f32[B] */
+    WG_INFO_BOX_ID = 24            /* index of the turbulence box the running episode drew from the pool  i32[B] */
 } wg_info_field;
 
 /* number of floats of the episode-metric vector produced by wg_metrics (the all-reduce payload;
@@ -200,6 +203,13 @@ int wg_hist_max(wg_handle h, int* hist_max);
  * released afterwards).  Must be called before wg_reset in the box modes.                               */
 int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, int ny, int nz,
                           double dx, double dy, double dz);
+
+/* Pool of n_boxes frozen boxes of equal shape for turb_mode BOX_POOL (turbtype "MannLoad": one of the TF_* files per
+ * reset, Wind_Farm_Env.py:611-618).  boxes_dev: HOST array of n_boxes DEVICE pointers, each 3 planes like above.  The
+ * library keeps its own interleaved copies (n_boxes x 1.07 GB for the reference's 2048 x 512 x 64 boxes — sized for
+ * 288 GB of HBM).  wg_set_turbulence_box is the pool of one.                                                */
+int wg_set_turbulence_boxes(wg_handle h, const float* const* boxes_dev, int n_boxes, int nx, int ny, int nz,
+                            double dx, double dy, double dz);
 
 /* Evaluation sweeps (FarmEval.set_wind_vals for a whole batch, FarmEval.py:63-78): fix the wind conditions of
  * env b to wind_host[b] = (ws, wd, ti) for every following episode; NaN entries keep the sampled value.  The env's

@@ -51,7 +51,7 @@ class Oracle:
         L = lib()
         pre = "wgo_" if precision == "f64" else "wgof_"
         self._f = {n: getattr(L, pre + n) for n in (
-            "create", "destroy", "obs_dim", "hist_max", "set_flow_script", "set_turbulence_box", "reset",
+            "create", "destroy", "obs_dim", "hist_max", "set_flow_script", "set_turbulence_box", "set_turbulence_boxes", "reset",
             "step", "obs_multi", "get_obs", "get_info", "metrics", "get_chain", "set_threads", "max_threads",
             "get_windspeed")}
         self._f["create"].restype = C.c_void_p
@@ -101,6 +101,16 @@ class Oracle:
         self._f["set_turbulence_box"](self._h, box.ctypes.data_as(C.c_void_p), C.c_int(box.shape[1]),
                                       C.c_int(box.shape[2]), C.c_int(box.shape[3]), C.c_double(spacing[0]),
                                       C.c_double(spacing[1]), C.c_double(spacing[2]))
+
+    def set_turbulence_boxes(self, boxes, spacing):
+        bs = [np.ascontiguousarray(b, dtype=np.float32) for b in boxes]
+        assert all(b.shape == bs[0].shape and b.ndim == 4 and b.shape[0] == 3 for b in bs)
+        self._box = bs
+        ptrs = (C.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
+        rc = self._f["set_turbulence_boxes"](self._h, ptrs, C.c_int(len(bs)), C.c_int(bs[0].shape[1]), C.c_int(bs[0].shape[2]),
+                                             C.c_int(bs[0].shape[3]), C.c_double(spacing[0]), C.c_double(spacing[1]),
+                                             C.c_double(spacing[2]))
+        assert rc == 0
 
     def windspeed(self, env, x, y, z=None, farm=0, include_wakes=True):
         """(u, v, w)[3, nx, ny] of one farm of one env on an XY grid at height z (flow frame)."""

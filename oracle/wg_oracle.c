@@ -58,6 +58,7 @@ typedef double real;
 
 /* ------------------------------------------------------------------------------------------------ */
 #define WG_COARSE 4   /* block size of the meandering (particle) box */
+#define WGO_MAX_BOXES 64
 typedef struct farm_t {
     /* wake-particle chains: ring of P slots per turbine, [N*P], slot index = t*P + r */
     real *py, *pz, *vlp, *wlp;           /* transverse position, low-pass filtered transverse velocity */
@@ -80,6 +81,7 @@ typedef struct ctx_t {
     double rated_power;
     uint32_t turb_seed;
     double box_ox, box_oy;               /* horizontal offset of this episode into the shared box (m)   */
+    int box_id;                          /* which box of the pool this episode uses (MannLoad, :611-618) */
     farm_t farm[2];
     /* MesClass state: rings [4][N][H_c] + farm-level rings ws, wd, power */
     double* ring[WG_N_CH];
@@ -118,8 +120,12 @@ typedef struct oracle_t {
     const double *script_uvw, *script_power;
     long script_rows;
     double metrics[WG_N_METRICS];
-    /* optional frozen turbulence box (unit variance), host memory */
+    /* optional frozen turbulence box(es) (unit variance), host memory; pool of n_boxes boxes of equal
+     * shape for turbtype "MannLoad" (one TF_* file drawn per reset with np_random.choice, :611-618) */
     const float* box;
+    const float* box_pool[WGO_MAX_BOXES];
+    float* cbox_pool[WGO_MAX_BOXES];
+    int n_boxes;
     int bnx, bny, bnz;
     double bdx, bdy, bdz;
     /* meandering box: the same field block-averaged over WG_COARSE^3 cells (model M0 §2.6: the wake particles
@@ -243,7 +249,7 @@ void WGO(destroy)(void* h) {
         free(e->farm_pow); free(e->base_pow); free(e->old_yaws);
     }
     free(o->env);
-    free(o->cbox);
+    for (int k = 0; k < WGO_MAX_BOXES; ++k) free(o->cbox_pool[k]);
     free(o->x_pos); free(o->y_pos); free(o->rotor_dy); free(o->rotor_dz);
     free(o->tab_ws); free(o->tab_power); free(o->tab_ct); free(o->yaw_defined);
     free(o);
@@ -261,30 +267,44 @@ void WGO(set_flow_script)(void* h, const double* uvw, const double* power, long 
     oracle_t* o = (oracle_t*)h;
     o->script_uvw = uvw; o->script_power = power; o->script_rows = n_rows;
 }
-void WGO(set_turbulence_box)(void* h, const float* box, int nx, int ny, int nz, double dx, double dy,
-                             double dz) {
+static float* coarsen_box(oracle_t* o, const float* box, int nx, int ny, int nz) {
+    const size_t nc = (size_t)o->cnx * o->cny * o->cnz, nf = (size_t)nx * ny * nz;
+    float* cb = (float*)malloc(sizeof(float) * 3 * nc);
+    for (int c = 0; c < 3; ++c)
+        for (int i = 0; i < o->cnx; ++i)
+            for (int j = 0; j < o->cny; ++j)
+                for (int k = 0; k < o->cnz; ++k) {
+                    /* fixed summation order (x, y, z innermost) in float, like the device kernel */
+                    float acc = 0.f;
+                    for (int a = 0; a < WG_COARSE; ++a)
+                        for (int b = 0; b < WG_COARSE; ++b)
+                            for (int cc = 0; cc < WG_COARSE; ++cc)
+                                acc += box[c * nf + ((size_t)(i * WG_COARSE + a) * ny + (j * WG_COARSE + b)) * nz + (k * WG_COARSE + cc)];
+                    cb[c * nc + ((size_t)i * o->cny + j) * o->cnz + k] = acc * (1.0f / (WG_COARSE * WG_COARSE * WG_COARSE));
+                }
+    return cb;
+}
+/* pool of n_boxes boxes of equal shape (n_boxes = 1: the single shared box of MannFixed / MannGenerate) */
+int WGO(set_turbulence_boxes)(void* h, const float* const* boxes, int n_boxes, int nx, int ny, int nz, double dx,
+                              double dy, double dz) {
     oracle_t* o = (oracle_t*)h;
-    o->box = box; o->bnx = nx; o->bny = ny; o->bnz = nz; o->bdx = dx; o->bdy = dy; o->bdz = dz;
-    free(o->cbox); o->cbox = NULL;
+    if (n_boxes < 1 || n_boxes > WGO_MAX_BOXES) return -1;
+    o->box = boxes[0]; o->bnx = nx; o->bny = ny; o->bnz = nz; o->bdx = dx; o->bdy = dy; o->bdz = dz;
+    o->n_boxes = n_boxes;
     o->coarse = (nx % WG_COARSE == 0 && ny % WG_COARSE == 0 && nz % WG_COARSE == 0 &&
                  nx >= 2 * WG_COARSE && ny >= 2 * WG_COARSE && nz >= 2 * WG_COARSE);
-    if (o->coarse) {
-        o->cnx = nx / WG_COARSE; o->cny = ny / WG_COARSE; o->cnz = nz / WG_COARSE;
-        const size_t nc = (size_t)o->cnx * o->cny * o->cnz, nf = (size_t)nx * ny * nz;
-        o->cbox = (float*)malloc(sizeof(float) * 3 * nc);
-        for (int c = 0; c < 3; ++c)
-            for (int i = 0; i < o->cnx; ++i)
-                for (int j = 0; j < o->cny; ++j)
-                    for (int k = 0; k < o->cnz; ++k) {
-                        /* fixed summation order (x, y, z innermost) in float, like the device kernel */
-                        float acc = 0.f;
-                        for (int a = 0; a < WG_COARSE; ++a)
-                            for (int b = 0; b < WG_COARSE; ++b)
-                                for (int cc = 0; cc < WG_COARSE; ++cc)
-                                    acc += box[c * nf + ((size_t)(i * WG_COARSE + a) * ny + (j * WG_COARSE + b)) * nz + (k * WG_COARSE + cc)];
-                        o->cbox[c * nc + ((size_t)i * o->cny + j) * o->cnz + k] = acc * (1.0f / (WG_COARSE * WG_COARSE * WG_COARSE));
-                    }
+    if (o->coarse) { o->cnx = nx / WG_COARSE; o->cny = ny / WG_COARSE; o->cnz = nz / WG_COARSE; }
+    for (int k = 0; k < WGO_MAX_BOXES; ++k) { free(o->cbox_pool[k]); o->cbox_pool[k] = NULL; o->box_pool[k] = NULL; }
+    for (int k = 0; k < n_boxes; ++k) {
+        o->box_pool[k] = boxes[k];
+        if (o->coarse) o->cbox_pool[k] = coarsen_box(o, boxes[k], nx, ny, nz);
     }
+    return 0;
+}
+void WGO(set_turbulence_box)(void* h, const float* box, int nx, int ny, int nz, double dx, double dy,
+                             double dz) {
+    const float* one[1] = {box};
+    WGO(set_turbulence_boxes)(h, one, 1, nx, ny, nz, dx, dy, dz);
 }
 
 /* ================================================================================================== */
@@ -305,7 +325,7 @@ static inline real m0_cfrac(real ct, real sp) {
 
 /* trilinear, periodic lookup of one component of the frozen box at (x,y,z) metres; cell coordinates are
  * formed in double precision (x - U t reaches 1e5 m), the interpolation weights in `real` */
-static inline real cbox_lookup(const oracle_t* o, int comp, double x, double y, double z) {
+static inline real cbox_lookup(const oracle_t* o, int bid, int comp, double x, double y, double z) {
     /* coarse cell i averages fine cells [4i, 4i+3], i.e. it is centred at fine index 4i + 1.5 */
     const double h = 0.5 * (WG_COARSE - 1);
     double fx = (x / o->bdx - h) / WG_COARSE, fy = (y / o->bdy - h) / WG_COARSE, fz = (z / o->bdz - h) / WG_COARSE;
@@ -315,7 +335,7 @@ static inline real cbox_lookup(const oracle_t* o, int comp, double x, double y, 
     long j0 = (long)fmod(iy, (double)o->cny); if (j0 < 0) j0 += o->cny;
     long k0 = (long)fmod(iz, (double)o->cnz); if (k0 < 0) k0 += o->cnz;
     long i1 = (i0 + 1) % o->cnx, j1 = (j0 + 1) % o->cny, k1 = (k0 + 1) % o->cnz;
-    const float* p = o->cbox + (size_t)comp * o->cnx * o->cny * o->cnz;
+    const float* p = o->cbox_pool[bid] + (size_t)comp * o->cnx * o->cny * o->cnz;
 #define BX(i, j, k) ((real)p[((size_t)(i) * o->cny + (j)) * o->cnz + (k)])
     real c00 = BX(i0, j0, k0) + tx * (BX(i1, j0, k0) - BX(i0, j0, k0));
     real c10 = BX(i0, j1, k0) + tx * (BX(i1, j1, k0) - BX(i0, j1, k0));
@@ -327,7 +347,7 @@ static inline real cbox_lookup(const oracle_t* o, int comp, double x, double y, 
     return c0 + tz * (c1 - c0);
 }
 
-static inline real box_lookup(const oracle_t* o, int comp, double x, double y, double z) {
+static inline real box_lookup(const oracle_t* o, int bid, int comp, double x, double y, double z) {
     double fx = x / o->bdx, fy = y / o->bdy, fz = z / o->bdz;
     double ix = floor(fx), iy = floor(fy), iz = floor(fz);
     real tx = (real)(fx - ix), ty = (real)(fy - iy), tz = (real)(fz - iz);
@@ -335,7 +355,7 @@ static inline real box_lookup(const oracle_t* o, int comp, double x, double y, d
     long j0 = (long)fmod(iy, (double)o->bny); if (j0 < 0) j0 += o->bny;
     long k0 = (long)fmod(iz, (double)o->bnz); if (k0 < 0) k0 += o->bnz;
     long i1 = (i0 + 1) % o->bnx, j1 = (j0 + 1) % o->bny, k1 = (k0 + 1) % o->bnz;
-    const float* p = o->box + (size_t)comp * o->bnx * o->bny * o->bnz;
+    const float* p = o->box_pool[bid] + (size_t)comp * o->bnx * o->bny * o->bnz;
 #define BX(i, j, k) ((real)p[((size_t)(i) * o->bny + (j)) * o->bnz + (k)])
     real c00 = BX(i0, j0, k0) + tx * (BX(i1, j0, k0) - BX(i0, j0, k0));
     real c10 = BX(i0, j1, k0) + tx * (BX(i1, j1, k0) - BX(i0, j1, k0));
@@ -348,20 +368,20 @@ static inline real box_lookup(const oracle_t* o, int comp, double x, double y, d
 }
 
 static inline int has_box(const oracle_t* o) {
-    return (o->cfg.turb_mode == WG_TURB_BOX || o->cfg.turb_mode == WG_TURB_BOX_SHIFT) && o->box;
+    return (o->cfg.turb_mode == WG_TURB_BOX || o->cfg.turb_mode == WG_TURB_BOX_SHIFT || o->cfg.turb_mode == WG_TURB_BOX_POOL) && o->box;
 }
 
 /* frozen-box fluctuation (one component) at a point of the flow frame at time `time`: Taylor's hypothesis,
  * the unit-variance box is scaled to TI*U (MannTurbulenceField.scale_TI, Wind_Farm_Env.py:617, :637, :658) */
 static inline real box_fluct(const oracle_t* o, const ctx_t* x, int comp, double time, double px, double py,
                              double pz) {
-    return (real)(x->ti * x->ws) * box_lookup(o, comp, px - x->ws * time + x->box_ox, py + x->box_oy, pz);
+    return (real)(x->ti * x->ws) * box_lookup(o, x->box_id, comp, px - x->ws * time + x->box_ox, py + x->box_oy, pz);
 }
 /* the same for the wake particles: coarse (block-averaged) box when the box is divisible by WG_COARSE */
 static inline real box_fluct_particle(const oracle_t* o, const ctx_t* x, int comp, double time, double px, double py,
                                       double pz) {
     const double bx = px - x->ws * time + x->box_ox, by = py + x->box_oy;
-    return (real)(x->ti * x->ws) * (o->coarse ? cbox_lookup(o, comp, bx, by, pz) : box_lookup(o, comp, bx, by, pz));
+    return (real)(x->ti * x->ws) * (o->coarse ? cbox_lookup(o, x->box_id, comp, bx, by, pz) : box_lookup(o, x->box_id, comp, bx, by, pz));
 }
 
 /* what a particle emitted *now* by turbine t would carry (uses the turbine's last rotor wind and its
@@ -899,7 +919,9 @@ static void reset_env(oracle_t* o, int b, uint64_t seed, int reseed) {
     x->ti = wgo_pcg64_uniform(&e->rng, c->ti_min, c->ti_max);
     x->wd = wgo_pcg64_uniform(&e->rng, c->wd_min, c->wd_max);
     /* _def_site (:598-678): "Random" draws a turbulence seed; "None"/"MannFixed" draw nothing */
-    x->turb_seed = 0; x->box_ox = 0; x->box_oy = 0;
+    x->turb_seed = 0; x->box_ox = 0; x->box_oy = 0; x->box_id = 0;
+    if (c->turb_mode == WG_TURB_BOX_POOL)       /* tf_file = self.np_random.choice(self.TF_files) (:614) */
+        x->box_id = (int)wgo_pcg64_integers(&e->rng, (uint32_t)(o->n_boxes > 0 ? o->n_boxes : 1));
     if (c->turb_mode == WG_TURB_RANDOM || c->turb_mode == WG_TURB_BOX_SHIFT)
         x->turb_seed = wgo_pcg64_integers(&e->rng, 100000);
     if (c->turb_mode == WG_TURB_BOX_SHIFT && o->box) {
@@ -1123,6 +1145,7 @@ int WGO(get_info)(void* h, int field, double* out) {
             for (int t = 0; t < N; ++t) { out[(b * N + t) * 3] = fb->u[t]; out[(b * N + t) * 3 + 1] = fb->v[t]; out[(b * N + t) * 3 + 2] = fb->w[t]; }
             break;
         case WG_INFO_RATED_POWER: out[b] = x->rated_power; break;
+        case WG_INFO_BOX_ID: out[b] = x->box_id; break;
         case WG_INFO_STEP_POWER_AGENT: out[b] = e->last_pnow; break;
         case WG_INFO_STEP_POWER_BASE: out[b] = e->last_pbase; break;
         default: return WG_ERR_INVALID;
@@ -1146,7 +1169,7 @@ int WGO(get_windspeed)(void* h, int b, int fi, const double* xs, int nx, const d
     const int N = o->N, P = o->P;
     const real D = (real)c->rotor_diameter, inv_D = (real)1 / D;
     const double dpart = c->d_particle * c->rotor_diameter, inv_dpart = 1.0 / dpart;
-    const int box = has_box(o) && (c->turb_mode == WG_TURB_BOX || c->turb_mode == WG_TURB_BOX_SHIFT);
+    const int box = has_box(o);
     const size_t plane = (size_t)nx * ny;
     for (int ix = 0; ix < nx; ++ix)
         for (int iy = 0; iy < ny; ++iy) {

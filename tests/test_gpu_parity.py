@@ -691,3 +691,37 @@ def test_soak_many_episode_rollovers_at_bench_scale(hip):
     u = env.info("rotor_uvw_agent").cpu().numpy()[..., 0]
     ws = env.info("ws_global").cpu().numpy()
     assert (u.max(axis=1) <= ws * (1 + 1e-5)).all() and (u.min(axis=1) < ws - 0.02).all()   # every farm is waked
+
+
+def test_box_pool_draws_like_np_random_choice_and_matches_oracle(hip, oracle_lib):
+    """turbtype "MannLoad" with K = 3 boxes (row f2): every reset picks a box with the env's own PCG64 stream exactly
+    like tf_file = self.np_random.choice(self.TF_files) (Wind_Farm_Env.py:614), and the flow then reads THAT box —
+    checked step for step against the oracle, which holds the same pool on the host."""
+    import torch
+    from windgym_amd.mann import generate_mann_box
+    spacing = (3.0, 3.0, 3.0)
+    boxes = [generate_mann_box((128, 64, 32), spacing, seed=s) for s in (1, 2, 3)]
+    B = 6
+    cfg = _turb_cfg("MannLoad", B)
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    env.set_turbulence_boxes(boxes, spacing), orc.set_turbulence_boxes(boxes, spacing)
+    seeds = 2100 + np.arange(B)
+    np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=TURB_OBS_ATOL)
+    # the draw: ws, ti, wd = three uniforms, then choice(3 files) == integers(0, 3) on the same generator
+    want = []
+    for s in seeds:
+        g = np.random.default_rng(int(s))
+        g.uniform(), g.uniform(), g.uniform()
+        want.append(int(g.choice(np.arange(3))))
+    np.testing.assert_array_equal(env.info("box_id").cpu().numpy(), want)
+    np.testing.assert_array_equal(orc.info("box_id").astype(int), want)
+    n_tr = _compare_turb(env, orc, 200, np.random.default_rng(15), cfg.n_turb, B)
+    env.check()
+    assert n_tr >= B and len(set(want)) >= 2
+    # a pool of one consumes no draw (numpy's bounded integers with range 0), like choice() on a one-file list
+    env1, orc1 = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    env1.set_turbulence_boxes(boxes[:1], spacing), orc1.set_turbulence_boxes(boxes[:1], spacing)
+    np.testing.assert_allclose(env1.reset(seeds=seeds).cpu().numpy(), orc1.reset(seeds=seeds), rtol=0, atol=TURB_OBS_ATOL)
+    g = np.random.default_rng(int(seeds[0]))
+    ws = g.uniform(cfg.ws_min, cfg.ws_max)
+    assert env1.info("wind_f64").cpu().numpy()[0, 0] == ws

@@ -21,7 +21,7 @@ UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 # every symbol include/windgym_hip.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = (
     "wg_last_error", "wg_abi_version", "wg_create", "wg_destroy", "wg_obs_dim", "wg_hist_max",
-    "wg_set_turbulence_box", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_set_step_graph", "wg_check", "wg_obs_multi", "wg_set_obs_multi_buffer",
+    "wg_set_turbulence_box", "wg_set_turbulence_boxes", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_set_step_graph", "wg_check", "wg_obs_multi", "wg_set_obs_multi_buffer",
     "wg_get_info", "wg_get_measurements", "wg_get_windspeed", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_algorithmic_bytes",
 )
 
@@ -53,6 +53,8 @@ def load_library():
     L.wg_hist_max.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.wg_set_turbulence_box.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
                                         C.c_double, C.c_double]
+    L.wg_set_turbulence_boxes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_double, C.c_double, C.c_double]
     L.wg_set_flow_script.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.wg_set_wind.argtypes = [C.c_void_p, C.c_void_p]
     L.wg_set_wind_device.argtypes = [C.c_void_p, C.c_void_p]
@@ -278,6 +280,21 @@ class HipBatch:
         _chk(self.L.wg_set_turbulence_box(self._h, C.c_void_p(b.data_ptr()), int(b.shape[1]), int(b.shape[2]),
                                           int(b.shape[3]), float(spacing[0]), float(spacing[1]),
                                           float(spacing[2])), "wg_set_turbulence_box")
+
+    def set_turbulence_boxes(self, boxes, spacing):
+        """Pool of K boxes of equal shape (turbtype "MannLoad": one TF_* file drawn per reset, :611-618)."""
+        t = self.torch
+        bs = []
+        for box in boxes:
+            b = box if isinstance(box, t.Tensor) else t.as_tensor(np.ascontiguousarray(box, dtype=np.float32))
+            b = b.to(self.device, dtype=t.float32).contiguous()
+            assert b.ndim == 4 and b.shape[0] == 3 and (not bs or b.shape == bs[0].shape)
+            bs.append(b)
+        ptrs = (C.c_void_p * len(bs))(*[b.data_ptr() for b in bs])
+        _chk(self.L.wg_set_turbulence_boxes(self._h, ptrs, len(bs), int(bs[0].shape[1]), int(bs[0].shape[2]),
+                                            int(bs[0].shape[3]), float(spacing[0]), float(spacing[1]),
+                                            float(spacing[2])), "wg_set_turbulence_boxes")
+        self._box = bs[0]      # (the library keeps its own copies; the caller's tensors may go)
 
     def get_state(self) -> bytes:
         n = C.c_size_t(0)

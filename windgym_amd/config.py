@@ -31,16 +31,16 @@ PEN = {"Change": 0, "Total": 1}
 NOISE = {"None": 0, "Normal": 1}
 # turbtype -> inflow mode of the build.  The three Mann variants share one frozen box per GPU
 # (DESIGN.md §2.5); "Random" = i.i.d. gusts; "None" = uniform inflow.
-TURB = {"None": 0, "Random": 1, "MannFixed": 2, "MannGenerate": 3, "MannLoad": 3}
+TURB = {"None": 0, "Random": 1, "MannFixed": 2, "MannGenerate": 3, "MannLoad": 4}
 
 # wg_info_field
 INFO = dict(
     yaw_agent=0, yaw_base=1, ws_global=2, wd_global=3, ti_global=4, ws_turb=5, wd_turb=6,
     power_turb_agent=7, power_turb_base=8, power_agent=9, power_base=10, ws_turb_base=11,
     turb_x=12, turb_y=13, timestep=14, time_max=15, fs_time=16, episode=17, rotor_uvw_agent=18,
-    rotor_uvw_base=19, rated_power=20, wind_f64=21, step_power_agent=22, step_power_base=23,
+    rotor_uvw_base=19, rated_power=20, wind_f64=21, step_power_agent=22, step_power_base=23, box_id=24,
 )
-INFO_INT = {"timestep", "time_max", "episode"}
+INFO_INT = {"timestep", "time_max", "episode", "box_id"}
 
 
 class CChannel(C.Structure):

@@ -171,7 +171,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     if (c->reward_mode == WG_REW_BASELINE && c->n_farms != 2)
         return fail(WG_ERR_INVALID, "Baseline reward needs the baseline farm (n_farms = 2)");
     if (c->power_avg < 1) return fail(WG_ERR_INVALID, "Power_avg must be >= 1");
-    if (c->turb_mode < WG_TURB_NONE || c->turb_mode > WG_TURB_BOX_SHIFT) return fail(WG_ERR_INVALID, "Invalid turbulence type specified");
+    if (c->turb_mode < WG_TURB_NONE || c->turb_mode > WG_TURB_BOX_POOL) return fail(WG_ERR_INVALID, "Invalid turbulence type specified");
     for (int i = 0; i < WG_N_CH; ++i)
         if (c->ch[i].history_len < 1 || c->ch[i].window_len < 1 || c->ch[i].history_n < 1)
             return fail(WG_ERR_INVALID, "sensor history/window lengths must be >= 1");
@@ -478,11 +478,13 @@ extern "C" int wg_hist_max(wg_handle h, int* hist_max) {
     return 0;
 }
 
-extern "C" int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, int ny, int nz, double dx,
-                                     double dy, double dz) {
+extern "C" int wg_set_turbulence_boxes(wg_handle h, const float* const* boxes_dev, int n_boxes, int nx, int ny, int nz,
+                                       double dx, double dy, double dz) {
     if (!h) return fail(WG_ERR_INVALID, "null handle");
-    if (!box_dev || nx < 2 || ny < 2 || nz < 2 || !(dx > 0) || !(dy > 0) || !(dz > 0))
-        return fail(WG_ERR_INVALID, "turbulence box: null pointer or bad dimensions");
+    if (!boxes_dev || n_boxes < 1 || n_boxes > 64 || nx < 2 || ny < 2 || nz < 2 || !(dx > 0) || !(dy > 0) || !(dz > 0))
+        return fail(WG_ERR_INVALID, "turbulence box: null pointer, bad pool size (1..64) or bad dimensions");
+    for (int k = 0; k < n_boxes; ++k)
+        if (!boxes_dev[k]) return fail(WG_ERR_INVALID, "turbulence box: null pointer in the pool");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
     drop_step_graphs(h);           // the kernel arguments captured in them are about to change
@@ -491,27 +493,39 @@ extern "C" int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, 
     if (h->box4) { void* q = h->box4; h->box4 = nullptr; HIPCHK(hipFree(q)); }
     if (h->box4c) { void* q = h->box4c; h->box4c = nullptr; HIPCHK(hipFree(q)); }
     const size_t n_cells = (size_t)nx * ny * nz;
-    HIPCHK(hipMalloc(&h->box4, n_cells * 16));
-    wg_launch_box_repack(box_dev, h->box4, n_cells, nullptr);
+    HIPCHK(hipMalloc(&h->box4, n_cells * 16 * (size_t)n_boxes));
+    for (int k = 0; k < n_boxes; ++k)
+        wg_launch_box_repack(boxes_dev[k], (char*)h->box4 + (size_t)k * n_cells * 16, n_cells, nullptr);
     HIPCHK(hipDeviceSynchronize());
-    h->d.box = box_dev;
+    h->d.box = boxes_dev[0];
+    h->p.n_boxes = n_boxes;
     h->p.bnx = nx; h->p.bny = ny; h->p.bnz = nz; h->p.bdx = dx; h->p.bdy = dy; h->p.bdz = dz;
     h->fd.box4 = (const float4*)h->box4;
-    h->fp.bnx = nx; h->fp.bny = ny; h->fp.bnz = nz;
+    h->fp.bnx = nx; h->fp.bny = ny; h->fp.bnz = nz; h->fp.box_cells = (long long)n_cells;
     h->fp.box_pow2 = ((nx & (nx - 1)) == 0) && ((ny & (ny - 1)) == 0) && ((nz & (nz - 1)) == 0);
     h->fp.coarse = (nx % 4 == 0 && ny % 4 == 0 && nz % 4 == 0 && nx >= 8 && ny >= 8 && nz >= 8);
     h->fd.box4c = nullptr;
     if (h->fp.coarse) {
         const int cx = nx / 4, cy = ny / 4, cz = nz / 4;
-        HIPCHK(hipMalloc(&h->box4c, (size_t)cx * cy * cz * 16));
-        wg_launch_box_coarsen(h->box4, h->box4c, nx, ny, nz, nullptr);
+        const size_t c_cells = (size_t)cx * cy * cz;
+        HIPCHK(hipMalloc(&h->box4c, c_cells * 16 * (size_t)n_boxes));
+        for (int k = 0; k < n_boxes; ++k)
+            wg_launch_box_coarsen((const char*)h->box4 + (size_t)k * n_cells * 16, (char*)h->box4c + (size_t)k * c_cells * 16,
+                                  nx, ny, nz, nullptr);
         HIPCHK(hipDeviceSynchronize());
-        h->fp.cnx = cx; h->fp.cny = cy; h->fp.cnz = cz;
+        h->fp.cnx = cx; h->fp.cny = cy; h->fp.cnz = cz; h->fp.cbox_cells = (long long)c_cells;
         h->fp.cbox_pow2 = ((cx & (cx - 1)) == 0) && ((cy & (cy - 1)) == 0) && ((cz & (cz - 1)) == 0);
         h->fd.box4c = (const float4*)h->box4c;
     }
     h->fp.inv_bdx = 1.0 / dx; h->fp.inv_bdy = 1.0 / dy; h->fp.inv_bdz = 1.0 / dz;
     return sync_dev_params(h);
+}
+
+extern "C" int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, int ny, int nz, double dx,
+                                     double dy, double dz) {
+    const float* one[1] = {box_dev};
+    if (!box_dev) return fail(WG_ERR_INVALID, "turbulence box: null pointer or bad dimensions");
+    return wg_set_turbulence_boxes(h, one, 1, nx, ny, nz, dx, dy, dz);
 }
 
 extern "C" int wg_set_wind(wg_handle h, const double* wind_host) {
@@ -570,7 +584,7 @@ extern "C" int wg_reset(wg_handle h, const uint8_t* env_mask_host, const uint64_
     if (!h) return fail(WG_ERR_INVALID, "null handle");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipSetDevice(h->device));
-    if ((h->p.turb_mode == WG_TURB_BOX || h->p.turb_mode == WG_TURB_BOX_SHIFT) && !h->d.box)
+    if (h->p.turb_mode >= WG_TURB_BOX && !h->d.box)
         return fail(WG_ERR_INVALID, "turbtype Mann*: call wg_set_turbulence_box before wg_reset");
     const uint8_t* mask = nullptr;
     const uint64_t* seeds = nullptr;
@@ -724,7 +738,7 @@ extern "C" int wg_get_windspeed(wg_handle h, int env, int farm, const float* x_d
 extern "C" int wg_get_info(wg_handle h, wg_info_field field, void* out_dev, void* stream) {
     if (!h || !out_dev) return fail(WG_ERR_INVALID, "null argument");
     if (int rc = use_device(h)) return rc;
-    if ((int)field < 0 || (int)field > WG_INFO_STEP_POWER_BASE) return fail(WG_ERR_INVALID, "unknown info field");
+    if ((int)field < 0 || (int)field > WG_INFO_BOX_ID) return fail(WG_ERR_INVALID, "unknown info field");
     wg_launch_info(&h->p, &h->d, (int)field, out_dev, (hipStream_t)stream);
     return 0;
 }

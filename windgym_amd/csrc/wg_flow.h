@@ -35,6 +35,7 @@ struct FlowP {
     // turbulent inflow (Random / frozen Mann box)
     int turb_mode, bnx, bny, bnz, box_pow2;
     int coarse, cnx, cny, cnz, cbox_pow2;   // block-averaged (4^3) copy of the box for the particle lookups
+    long long box_cells, cbox_cells;        // cells of one box of the pool (fine / block-averaged): box k starts at k * cells
     double inv_bdx, inv_bdy, inv_bdz, fc_scale, D_d, hub_d;
     float inv_sqrt_S;
 };

@@ -128,6 +128,8 @@ struct TurbCtx {
     float sig;           // TI * U: standard deviation the unit-variance inflow is scaled to
     float alpha;         // low-pass coefficient of the meandering filter
     double ws;
+    const float4* box4;  // the episode's box of the pool (fine / block-averaged copy)
+    const float4* box4c;
 };
 
 // trilinear, periodic lookup of the frozen box at (x, y, z) metres.  The box is stored interleaved
@@ -377,8 +379,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                         const float xrel = s_off_f + (float)j * p.dpart_f;
                         const double bx = tq.xr + (double)xrel + xshift, by = (double)pyv[u] + tc.oy, bz = (double)pzv[u];
                         if (WG_ABLATE & 4) { fv[u] = (float)bx * 1e-6f; fw[u] = (float)(by + bz) * 1e-6f; }
-                        else if (COARSE) cbox_lookup_vw<POW2>(d.box4c, p, bx, by, bz, fv[u], fw[u]);
-                        else { float f3[3]; box_lookup<POW2>(d.box4, p, bx, by, bz, f3); fv[u] = f3[1]; fw[u] = f3[2]; }
+                        else if (COARSE) cbox_lookup_vw<POW2>(tc.box4c, p, bx, by, bz, fv[u], fw[u]);
+                        else { float f3[3]; box_lookup<POW2>(tc.box4, p, bx, by, bz, f3); fv[u] = f3[1]; fw[u] = f3[2]; }
                     }
                 }
 #pragma unroll
@@ -491,8 +493,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     const float xrel = s_off_f + (float)j * p.dpart_f;
                     const double bx = T[t].xr + (double)xrel + xshift, by = (double)pyv[u] + tc.oy, bz = (double)pzv[u];
                     if (WG_ABLATE & 4) { fv[u] = (float)bx * 1e-6f; fw[u] = (float)(by + bz) * 1e-6f; }
-                    else if (COARSE) cbox_lookup_vw<POW2>(d.box4c, p, bx, by, bz, fv[u], fw[u]);
-                    else { float f3[3]; box_lookup<POW2>(d.box4, p, bx, by, bz, f3); fv[u] = f3[1]; fw[u] = f3[2]; }
+                    else if (COARSE) cbox_lookup_vw<POW2>(tc.box4c, p, bx, by, bz, fv[u], fw[u]);
+                    else { float f3[3]; box_lookup<POW2>(tc.box4, p, bx, by, bz, f3); fv[u] = f3[1]; fw[u] = f3[2]; }
                 }
             }
 #pragma unroll
@@ -655,8 +657,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 if (live) {
                     const double bx = T[t].xr - tc.ws * sr.time + tc.ox;
                     const double by = T[t].yr + (double)(rdy[s] * T[t].cg) + tc.oy, bz = p.hub_d + (double)rdz[s];
-                    if (p.box_pow2) box_lookup<true>(d.box4, p, bx, by, bz, amb);
-                    else box_lookup<false>(d.box4, p, bx, by, bz, amb);
+                    if (p.box_pow2) box_lookup<true>(tc.box4, p, bx, by, bz, amb);
+                    else box_lookup<false>(tc.box4, p, bx, by, bz, amb);
                 }
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc)
@@ -883,8 +885,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     // first, the scattered HBM reads overlap the wake sum below
                     const double bx = T[t].xr - tc.ws * sr.time + tc.ox;
                     const double by = T[t].yr + (double)(rdy[s] * T[t].cg) + tc.oy, bz = p.hub_d + (double)rdz[s];
-                    if (p.box_pow2) box_lookup<true>(d.box4, p, bx, by, bz, amb);
-                    else box_lookup<false>(d.box4, p, bx, by, bz, amb);
+                    if (p.box_pow2) box_lookup<true>(tc.box4, p, bx, by, bz, amb);
+                    else box_lookup<false>(tc.box4, p, bx, by, bz, amb);
                 }
                 for (int wd = 0; wd * 32 < N; ++wd) {
                     unsigned m = tmask[tl * WG_MASK_WORDS + wd];
@@ -1036,6 +1038,8 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         pend_farm_n = cx.pend_farm_n; pend_base_n = cx.pend_base_n;
         episode_tag = (uint32_t)cx.episode_tag;
         tc.seed = cx.turb_seed; tc.ox = cx.box_ox; tc.oy = cx.box_oy; tc.ws = ws;
+        tc.box4 = TURB == WG_TURB_BOX ? d.box4 + (size_t)cx.box_id * p.box_cells : nullptr;
+        tc.box4c = TURB == WG_TURB_BOX && d.box4c ? d.box4c + (size_t)cx.box_id * p.cbox_cells : nullptr;
         tc.sig = (float)(cx.ti * ws);
         tc.alpha = TURB == WG_TURB_NONE ? 0.f
                                         : (float)(1.0 - exp(-2.0 * WG_PI_D * (ws / (p.fc_scale * p.D_d)) * p.dt_d));
@@ -1317,7 +1321,7 @@ static void launch_nt(const FlowP* p, const FlowPtrs* d, int mode, const float* 
     const bool replay = d->script_uvw != nullptr, noise = p->noise != 0;
 #define WG_LAUNCH(TURB, REPLAY, NOISE) \
     hipLaunchKernelGGL((k_flow<NT, TURB, REPLAY, NOISE, RES>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk)
-    const int turb = (p->turb_mode == WG_TURB_BOX_SHIFT) ? WG_TURB_BOX : p->turb_mode;
+    const int turb = (p->turb_mode >= WG_TURB_BOX) ? WG_TURB_BOX : p->turb_mode;
     if (replay) {                       // replay mode ignores the physics
         if (noise) WG_LAUNCH(WG_TURB_NONE, true, true); else WG_LAUNCH(WG_TURB_NONE, true, false);
     } else if (turb == WG_TURB_NONE) {
@@ -1366,11 +1370,12 @@ k_windspeed(const FlowP p, const FlowPtrs d, const int e, const int farm, const 
     const double s_off = slot.s_off;
     const int head = slot.head, n_valid = slot.n_valid;
     float amb[3] = {0.f, 0.f, 0.f};
-    const bool boxm = (p.turb_mode == WG_TURB_BOX || p.turb_mode == WG_TURB_BOX_SHIFT) && d.box4 != nullptr;
+    const bool boxm = p.turb_mode >= WG_TURB_BOX && d.box4 != nullptr;
     if (boxm) {
         const double bx = px - cx.ws * slot.time + cx.box_ox, by = pyd + cx.box_oy;
-        if (p.box_pow2) box_lookup<true>(d.box4, p, bx, by, (double)z, amb);
-        else box_lookup<false>(d.box4, p, bx, by, (double)z, amb);
+        const float4* b4 = d.box4 + (size_t)cx.box_id * p.box_cells;
+        if (p.box_pow2) box_lookup<true>(b4, p, bx, by, (double)z, amb);
+        else box_lookup<false>(b4, p, bx, by, (double)z, amb);
         const float sig = (float)(cx.ti * cx.ws);
         amb[0] *= sig; amb[1] *= sig; amb[2] *= sig;
     }

@@ -637,6 +637,7 @@ __global__ void k_info(const WgParams p, const WgPtrs d, const int field, void* 
     case WG_INFO_ROTOR_UVW_AGENT: fo[i * 3] = d.u[ta]; fo[i * 3 + 1] = d.v[ta]; fo[i * 3 + 2] = d.w[ta]; break;
     case WG_INFO_ROTOR_UVW_BASE: fo[i * 3] = d.u[tbs]; fo[i * 3 + 1] = d.v[tbs]; fo[i * 3 + 2] = d.w[tbs]; break;
     case WG_INFO_RATED_POWER: fo[i] = cx.rated_power; break;
+    case WG_INFO_BOX_ID: io[i] = cx.box_id; break;
     case WG_INFO_STEP_POWER_AGENT: fo[i] = d.last_pow_agent[e]; break;
     case WG_INFO_STEP_POWER_BASE: fo[i] = d.last_pow_base[e]; break;
     case WG_INFO_WIND_F64: { double* dd = (double*)out; dd[i * 3] = cx.ws; dd[i * 3 + 1] = cx.wd; dd[i * 3 + 2] = cx.ti; break; }

@@ -57,7 +57,8 @@ struct WgParams {
     int ring_stride;         // floats per ctx of turbine rings
     int fring_off[WG_N_CH];
     int fring_stride;
-    // frozen turbulence box
+    // frozen turbulence box(es)
+    int n_boxes;
     int bnx, bny, bnz;
     double bdx, bdy, bdz;
     // replay mode
@@ -100,6 +101,7 @@ struct WgCtx {
     // head of the NEXT k_flow launch, in the two farm workgroups of that context (throughput-hidden among thousands of
     // workgroups instead of sitting on k_glue's one-wave-per-env latency chain).  The following k_glue clears the flag.
     int init_pending;
+    int box_id;          // which box of the pool this episode uses (turb_mode BOX_POOL)
     uint32_t snap_has32, snap_u32;
     wg_u128 snap_state, snap_inc;
 };

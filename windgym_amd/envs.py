@@ -38,30 +38,56 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-def _attach_box(batch: HipBatch, cfg: EnvConfig, turbulence_box=None):
-    """Mann turbtypes need the frozen box on the device (MannTurbulenceField.generate / from_netcdf,
-    Wind_Farm_Env.py:611-659).  `turbulence_box` = (array-like [3,Nx,Ny,Nz], (dx,dy,dz)) or None: generate the
-    reference's box for this turbtype on the GPU (hipFFT)."""
+MAX_BOX_POOL = 16
+
+
+def _resolve_turbulence(cfg: EnvConfig, turbulence_box=None):
+    """Decide, BEFORE the device batch is created, where the frozen turbulence comes from (Wind_Farm_Env.py:197-213,
+    :611-659).  Returns None, ("one", box, spacing) or ("pool", [boxes], spacing).
+
+    turbtype "MannLoad": `turbulence_box` (a (box, spacing) pair or a ([boxes], spacing) pool) or the TurbBox file /
+    directory of TF_* files — all readable files of equal shape (at most MAX_BOX_POOL) become a device-resident pool and
+    every reset draws one like np_random.choice(self.TF_files) (:614).  Without files the reference switches to
+    turbtype "MannGenerate" (:207-212), and so does this build: `cfg.turbtype` is changed, so the per-episode draw is
+    the seed of :623 again.  Generated boxes (MannFixed / MannGenerate) are made on the GPU when the batch exists."""
     if cfg.turbtype not in ("MannFixed", "MannGenerate", "MannLoad"):
-        return
-    if turbulence_box is None and cfg.turbtype == "MannLoad":
-        # TurbBox = a box file or a directory of TF_* files (:197-213).  ONE box is shared by all envs of the handle
-        # (episodes differ by their random offset into it), so the first readable file is loaded; without files the
-        # reference falls back to generated turbulence, and so does this build.
+        return None
+    if turbulence_box is not None:
+        first = turbulence_box[0]
+        if isinstance(first, (list, tuple)):
+            return ("pool", list(first), turbulence_box[1])
+        return ("one", first, turbulence_box[1])
+    if cfg.turbtype == "MannLoad":
         from .mann import find_box_files, load_box
-        for f in find_box_files(getattr(cfg, "TurbBox", None)):
-            turbulence_box = load_box(f)
-            break
-        else:
-            print("Coudnt find the turbulence box file(s), so we switch to generated turbulence")
-    if turbulence_box is None:
+        pool, spacing = [], None
+        for f in find_box_files(getattr(cfg, "TurbBox", None))[:MAX_BOX_POOL]:
+            b, sp = load_box(f)
+            if pool and (np.shape(b) != np.shape(pool[0]) or tuple(sp) != tuple(spacing)):
+                print(f"{f}: shape / spacing differs from the first box of the pool, skipped")
+                continue
+            pool.append(b)
+            spacing = sp
+        if pool:
+            return ("pool", pool, spacing)
+        print("Coudnt find the turbulence box file(s), so we switch to generated turbulence")
+        cfg.turbtype = "MannGenerate"
+    return ("generate",)
+
+
+def _attach_box(batch: HipBatch, cfg: EnvConfig, source):
+    """Put the resolved turbulence source on the device (wg_set_turbulence_box / wg_set_turbulence_boxes); returns the
+    source with a generated box filled in, so that a rebuild of the batch reuses it."""
+    if source is None:
+        return None
+    if source[0] == "generate":
         from .mann import generate_mann_box_torch, reference_box_spec
         spec = reference_box_spec(cfg.turbtype, cfg.D)
-        box = generate_mann_box_torch(device=batch.device, **spec)
-        spacing = spec["dxyz"]
+        source = ("one", generate_mann_box_torch(device=batch.device, **spec), spec["dxyz"])
+    if source[0] == "pool":
+        batch.set_turbulence_boxes(source[1], source[2])
     else:
-        box, spacing = turbulence_box
-    batch.set_turbulence_box(box, spacing)
+        batch.set_turbulence_box(source[1], source[2])
+    return source
 
 
 class _TurbinesProxy:
@@ -130,8 +156,9 @@ class WindFarmVecEnv:
                  as_torch: bool = False, autoreset: bool = True, turbulence_box=None, sample_site=None, **kwargs):
         self.cfg = EnvConfig(turbine=turbine, yaml_path=yaml_path, n_envs=int(n_envs), autoreset=autoreset,
                              seed=seed, **kwargs)
+        source = _resolve_turbulence(self.cfg, turbulence_box)
         self.batch = HipBatch(self.cfg, device=device)
-        _attach_box(self.batch, self.cfg, turbulence_box)
+        _attach_box(self.batch, self.cfg, source)
         # site-based wind sampling (Wind_Farm_Env.py:569-594) for the whole batch: a device-resident override table
         # refreshed with torch ops before every step, so every episode initialisation sees an independent draw
         self._site = None
@@ -348,19 +375,13 @@ class WindFarmEnv(_EnvBase):
         if old is not None:
             old.close()
         self.cfg = cfg
+        if getattr(self, "_turb_source", None) is None:
+            self._turb_source = _resolve_turbulence(cfg, self._turbulence_box)
+            self._turbtype_resolved = cfg.turbtype
+        else:
+            cfg.turbtype = self._turbtype_resolved                              # (MannLoad -> MannGenerate fallback)
         self._batch = HipBatch(cfg, device=self._device)
-        if self._turbulence_box is None and cfg.turbtype == "MannLoad":
-            from .mann import find_box_files, load_box                         # TurbBox file / directory (:197-213)
-            files = find_box_files(getattr(cfg, "TurbBox", None))
-            if files:
-                self._turbulence_box = load_box(files[0])
-            else:
-                print("Coudnt find the turbulence box file(s), so we switch to generated turbulence")
-        if self._turbulence_box is None and cfg.turbtype in ("MannFixed", "MannGenerate", "MannLoad"):
-            from .mann import generate_mann_box_torch, reference_box_spec      # generated once, reused on rebuilds
-            spec = reference_box_spec(cfg.turbtype, cfg.D)
-            self._turbulence_box = (generate_mann_box_torch(device=self._batch.device, **spec), spec["dxyz"])
-        _attach_box(self._batch, cfg, self._turbulence_box)
+        self._turb_source = _attach_box(self._batch, cfg, self._turb_source)   # generated once, reused on rebuilds
         c = cfg
         # attributes callers read
         self.n_turb, self.x_pos, self.y_pos = c.n_turb, c.x_pos, c.y_pos
