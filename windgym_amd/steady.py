@@ -1,12 +1,18 @@
-"""Steady-state limit of model M0 and the serial-refine yaw optimiser built on it.
+"""Steady-state wake models and the serial-refine yaw optimiser built on them.
 
-The reference's `PyWakeAgent` (WindGym/Agents/PyWakeAgent.py) optimises yaw set-points with the Serial-Refine
-Method over a py_wake steady-state Gaussian wake model (Blondel-Cathelain + Jimenez + Crespo-Hernandez).
-py_wake is not available; the build uses the steady state of its own flow model instead, which is what the
-dynamic env converges to for constant yaws: Gaussian wakes whose centre line is displaced by the
-integrated Hill-vortex deflection speed, wake-added turbulence as in §2.4, tabular P/Ct.  Everything is batched
-over arbitrary leading dimensions with torch (CPU or GPU), so all wind conditions and all candidate yaw offsets
-of a refine step are evaluated in one call.
+The reference's `PyWakeAgent` (WindGym/Agents/PyWakeAgent.py:21-143) optimises yaw set-points with the Serial-Refine
+Method (:144-288) over py_wake's `Blondel_Cathelain_2020(site, turbine, turbulenceModel=CrespoHernandez(),
+deflectionModel=JimenezWakeDeflection())`.  py_wake is not installed here, so the published models are restated:
+
+  * `blondel_jimenez_power` — the wake model `PyWakeAgent` uses: super-Gaussian deficit of Blondel & Cathelain (2020,
+    Wind Energ. Sci. 5, 1225-1236) evaluated at the rotor centre, linear superposition, free-stream reference speed,
+    ambient TI in the wake width (py_wake defaults), Jimenez et al. (2010) deflection with beta = 0.1, tabular P / Ct at
+    ws cos(yaw) with Ct cos^2(yaw).  Its momentum balance is checked numerically in tests/test_steady_optimizer.py.
+  * `steady_state_power` — the steady state of the build's own dynamic model M0 (what the batched env converges to for
+    constant yaws, pinned against the converged oracle): `SteadyStateYawAgent`.
+
+Everything is batched over arbitrary leading dimensions with torch (CPU or GPU), so all wind conditions and all
+candidate yaw offsets of a refine step are evaluated in one call.
 """
 from __future__ import annotations
 
@@ -98,10 +104,84 @@ def steady_state_power(x, y, ws, wd, ti, yaw, turbine=None, n_rotor_pts=16, n_qu
     return _interp(torch.clamp(u * cg, min=0.0), tws, tp)
 
 
-def yaw_optimizer_srf(x, y, ws, wd, ti, turbine=None, refine_pass_n=8, yaw_n=9, yaw_max=30.0, device="cpu"):
-    """Serial-Refine yaw optimisation (PyWakeAgent.py:144-288) for a batch of wind conditions at once.
-    ws, wd, ti: arrays of the same length C.  Returns yaw [C, N] in degrees."""
+# constants of Blondel & Cathelain (2020), Table 2 / py_wake BlondelSuperGaussianDeficit2020 defaults
+BC_A_S, BC_B_S, BC_C_S = 0.17, 0.005, 0.2          # characteristic width sigma/D = (a_s TI + b_s) x/D + c_s sqrt(beta)
+BC_A_F, BC_B_F, BC_C_F = 3.11, -0.68, 2.41         # super-Gaussian order n = a_f exp(b_f x/D) + c_f
+JIMENEZ_BETA = 0.1                                  # wake-expansion factor of the deflection model (py_wake default)
+
+
+def blondel_centre_deficit(ct, sigma, n):
+    """Centre-line deficit fraction C of the super-Gaussian wake (Blondel & Cathelain 2020, eq. 6), from mass and
+    momentum conservation: C = 2^(2/n - 1) - sqrt(2^(4/n - 2) - n ct / (16 Gamma(2/n) sigma^(4/n))); n = 2 gives the
+    Gaussian wake of Bastankhah & Porte-Agel."""
     import torch
+    a1 = 2.0 ** (2.0 / n - 1.0)
+    a2 = 2.0 ** (4.0 / n - 2.0)
+    g = torch.exp(torch.lgamma(2.0 / n))
+    return a1 - torch.sqrt(torch.clamp(a2 - n * ct / (16.0 * g * sigma ** (4.0 / n)), min=0.0))
+
+
+def blondel_jimenez_power(x, y, ws, wd, ti, yaw, turbine=None, n_quad=20, device="cpu"):
+    """Per-turbine power [..., N] of the steady-state model behind the reference's PyWakeAgent (see the module
+    docstring).  x, y [N]; ws, wd, ti broadcastable to the batch shape; yaw [..., N] degrees."""
+    import torch
+    tab = as_tabular(turbine if turbine is not None else V80())
+    dt = torch.float64
+    dev = torch.device(device)
+    T = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64), dtype=dt, device=dev)   # noqa: E731
+    x, y, yaw = T(x), T(y), (yaw.to(dev, dt) if isinstance(yaw, torch.Tensor) else T(yaw))
+    batch = yaw.shape[:-1]
+    N = yaw.shape[-1]
+    ws, wd, ti = ((a.to(dev, dt) if isinstance(a, torch.Tensor) else T(a)).expand(batch) for a in (ws, wd, ti))
+    D = float(tab.diameter())
+    tws, tp, tc = T(tab.ws_tab), T(tab.power_tab), T(tab.ct_tab)
+    th = torch.deg2rad(270.0 - wd)[..., None]
+    cx, cy = x.mean(), y.mean()
+    xr = cx + (x - cx) * torch.cos(th) + (y - cy) * torch.sin(th)
+    yr = cy - (x - cx) * torch.sin(th) + (y - cy) * torch.cos(th)
+    order = torch.argsort(xr, dim=-1)
+    g = torch.deg2rad(yaw)
+    cg, sg = torch.cos(g), torch.sin(g)
+    u = ws[..., None].expand(batch + (N,)).clone()          # effective wind speed of every turbine
+    ct = torch.zeros_like(u)
+    # py_wake's quadrature of the Jimenez angle: points clustered towards the rotor
+    s01 = (torch.logspace(0.0, 1.1, n_quad, dtype=dt, device=dev) - 1.0) / (10.0 ** 1.1 - 1.0)
+    for pos in range(N):
+        t = order[..., pos:pos + 1]
+        xt, yt = xr.gather(-1, t), yr.gather(-1, t)
+        dx = xt - xr
+        up = dx > 1e-9
+        xd = torch.clamp(dx, min=1e-9) / D
+        q = torch.sqrt(1.0 - torch.clamp(ct, max=0.999))
+        beta = 0.5 * (1.0 + q) / q
+        sigma = (BC_A_S * ti[..., None] + BC_B_S) * xd + BC_C_S * torch.sqrt(beta)
+        n = BC_A_F * torch.exp(BC_B_F * xd) + BC_C_F
+        C = blondel_centre_deficit(ct, sigma, n)
+        # Jimenez: initial skew angle cos^2 sin ct/2, decaying with (1 + beta x/D)^-2; the deflection is its integral
+        xq = torch.clamp(dx, min=0.0)[..., None] * s01
+        alpha = (cg ** 2 * sg * ct * 0.5)[..., None] / (1.0 + JIMENEZ_BETA * xq / D) ** 2
+        defl = -torch.trapezoid(torch.sin(alpha), xq, dim=-1)       # positive yaw pushes the wake towards -y (env frame)
+        r = torch.abs(yt - (yr + defl)) / D
+        dfc = torch.where(up, ws[..., None] * C * torch.exp(-r ** n / (2.0 * sigma ** 2)), torch.zeros_like(r))
+        ut = ws[..., None] - dfc.sum(dim=-1, keepdim=True)
+        cgt = cg.gather(-1, t)
+        ctt = torch.clamp(_interp(torch.clamp(ut * cgt, min=0.0), tws, tc) * cgt ** 2, 0.0, 0.999)
+        u = u.scatter(-1, t, ut)
+        ct = ct.scatter(-1, t, ctt)
+    return _interp(torch.clamp(u * cg, min=0.0), tws, tp)
+
+
+WAKE_MODELS = {"m0": None, "blondel_jimenez": blondel_jimenez_power}
+
+
+def yaw_optimizer_srf(x, y, ws, wd, ti, turbine=None, refine_pass_n=8, yaw_n=9, yaw_max=30.0, device="cpu",
+                      model="m0"):
+    """Serial-Refine yaw optimisation (PyWakeAgent.py:144-288) for a batch of wind conditions at once.
+    ws, wd, ti: arrays of the same length C.  Returns yaw [C, N] in degrees.  model: "m0" (steady state of the build's
+    dynamic model) or "blondel_jimenez" (the reference agent's py_wake model)."""
+    import torch
+    fn = WAKE_MODELS[model]
+    steady_state_power = fn if fn is not None else globals()["steady_state_power"]
     ws, wd, ti = (np.atleast_1d(np.asarray(a, dtype=np.float64)) for a in (ws, wd, ti))
     C, N = len(ws), len(x)
     wd = wd + 1e-3                                   # break the two-maxima tie of perfectly aligned rows (:188-189)
@@ -129,11 +209,15 @@ def yaw_optimizer_srf(x, y, ws, wd, ti, turbine=None, refine_pass_n=8, yaw_n=9, 
 
 
 class SteadyStateYawAgent(BaseAgent):
-    """Drop-in for the reference's PyWakeAgent (same constructor, `update_wind`, `optimize`, `optimized_yaws`,
-    `predict`), with the steady state of model M0 as the wake model."""
+    """Serial-Refine yaw agent with the reference PyWakeAgent's interface (same constructor, `update_wind`, `optimize`,
+    `optimized_yaws`, `predict`); `model` selects the wake model: "m0" = steady state of the env's own flow model (the
+    yaws that are optimal FOR THE ENV), "blondel_jimenez" = the model the reference agent uses."""
+    model = "m0"
 
     def __init__(self, x_pos, y_pos, wind_speed=8, wind_dir=270, TI=0.07, yaw_max=45, yaw_min=-45, refine_pass_n=8,
-                 yaw_n=9, turbine=None, device="cpu"):
+                 yaw_n=9, turbine=None, device="cpu", model=None):
+        if model is not None:
+            self.model = model
         super().__init__(yaw_max, yaw_min)
         self.pywakeagent = True
         self.optimized = False
@@ -155,13 +239,14 @@ class SteadyStateYawAgent(BaseAgent):
 
     def optimize(self):
         self.optimized_yaws = yaw_optimizer_srf(self.x_pos, self.y_pos, self.wsp, self.wdir, [self.TI], self.turbine,
-                                                self.refine_pass_n, self.yaw_n, device=self.device)[0]
+                                                self.refine_pass_n, self.yaw_n, device=self.device, model=self.model)[0]
         self.action = self.scale_yaw(self.optimized_yaws).astype(np.float32)
         self.optimized = True
 
     def power(self, yaws):
-        return float(steady_state_power(self.x_pos, self.y_pos, self.wsp[0], self.wdir[0], self.TI,
-                                        np.asarray(yaws, dtype=float), self.turbine, device=self.device).sum())
+        fn = WAKE_MODELS[self.model] or steady_state_power
+        return float(fn(self.x_pos, self.y_pos, self.wsp[0], self.wdir[0], self.TI, np.asarray(yaws, dtype=float),
+                        self.turbine, device=self.device).sum())
 
     def predict(self, *args, **kwargs):
         if not self.optimized:
@@ -169,4 +254,8 @@ class SteadyStateYawAgent(BaseAgent):
         return self.action, None
 
 
-PyWakeAgent = SteadyStateYawAgent
+class PyWakeAgent(SteadyStateYawAgent):
+    """The reference's PyWakeAgent (WindGym/Agents/PyWakeAgent.py): Serial-Refine over Blondel-Cathelain (2020) +
+    Jimenez deflection, restated from the publications (py_wake itself is not installed: values are not pinned against
+    py_wake, only against the equations — tests/test_steady_optimizer.py)."""
+    model = "blondel_jimenez"
