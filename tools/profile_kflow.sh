@@ -1,4 +1,5 @@
-# usage: bash gpurun_prof.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/summary.txt
+# usage (GPU box): bash tools/profile_kflow.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/{summary.txt,traffic.json}
+# (kernel trace and every --pmc set in separate runs; the raw databases are deleted, only the summaries travel back)
 cd $GRAFT_REPO_ROOT
 TAG=$1; shift
 export TMPDIR=/tmp
@@ -17,6 +18,7 @@ rocprofv3 --pmc TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TCP_PENDING_STALL_CYCLES
 python - > $OUT/summary.txt <<PY
 import sqlite3, collections, glob
 out = "$OUT"
+vals = {}
 db = sqlite3.connect(out + '/trace/t_results.db'); cur = db.cursor()
 print("# rocprofv3 --kernel-trace --stats : top kernels (name, calls, total_us, avg_us, pct)")
 for r in cur.execute("select * from top_kernels limit 8"): print(r)
@@ -32,6 +34,15 @@ for n in sorted(glob.glob(out + '/pmc*/p_results.db')):
     for r in cur.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection order by dispatch_id"):
         if 'k_flow' in r[0]: acc[r[1]].append(r[2])
     for k,v in sorted(acc.items()):
-        v = v[-100:]; print(k, round(sum(v)/len(v),1))
+        v = v[-100:]; print(k, round(sum(v)/len(v),1)); vals[k] = sum(v)/len(v)
+import json
+if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
+    # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 B (MI355X_MICROARCH.md, HBM): x2
+    hbm = (2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024
+    json.dump({"hbm_bytes_per_launch": hbm, "fetch_kib": vals['FETCH_SIZE'], "write_kib": vals['WRITE_SIZE'],
+               "rdreq_x128B": vals.get('TCC_EA0_RDREQ_sum', 0) * 128, "kernel": "k_flow (STEP-mode launches, last 100)",
+               "kflow_avg_us": sum(fl[-100:]) / 100, "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x 2 (gfx950 correction)"},
+              open(out + '/traffic.json', 'w'), indent=1)
 PY
+rm -rf $OUT/trace $OUT/pmc*
 cat $OUT/summary.txt; tail -1 $OUT/bench_trace.log | cut -c1-600
