@@ -305,9 +305,14 @@ def test_step_after_truncation_is_an_error(hip):
         env.check()
 
 
-def test_horns_rev_80_turbines_matches_oracle(hip, oracle_lib):
+@pytest.mark.parametrize("variant", ["default", "compact_pairmajor"])
+def test_horns_rev_80_turbines_matches_oracle(hip, oracle_lib, variant):
     """BASELINE.json configs[2] at test size: Horns Rev 1 layout (N = 80 > one wave, P = 416, target chunking
-    in phase A), B = 3, autoreset on."""
+    in the deficit phases), B = 3, autoreset on.  "default" = the large-farm variant bench.py --workload cfg3 runs
+    (uniform rings, (target, sample)-major); "compact_pairmajor" = the small-farm variant forced onto the large farm
+    (WG_FLOW_RES=1: compact rings, pair-major phases in chunks of targets, 256 threads) — measured slower on cfg3
+    (its four SoA gathers cost more lines than the 16-byte record copy), kept correct."""
+    import os
     from windgym_amd.config import EnvConfig
     from windgym_amd.presets import horns_rev1_layout, horns_rev_config
     from windgym_amd.turbine import V80
@@ -315,7 +320,13 @@ def test_horns_rev_80_turbines_matches_oracle(hip, oracle_lib):
     cfg = EnvConfig(turbine=V80(), yaml_dict=horns_rev_config(), turbtype="None", n_envs=3, autoreset=True,
                     n_passthrough=0.2, x_pos=x, y_pos=y)
     assert cfg.n_turb == 80
-    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    if variant == "compact_pairmajor":
+        os.environ["WG_FLOW_RES"] = "1"
+    try:
+        env = hip.HipBatch(cfg)
+    finally:
+        os.environ.pop("WG_FLOW_RES", None)
+    orc = oracle_lib.Oracle(cfg)
     seeds = 500 + np.arange(3)
     np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=OBS_ATOL)
     rng = np.random.default_rng(4)

@@ -360,6 +360,9 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             if (b == 256) { f.res = 0; f.block = 256; }
             else if ((b == 64 || b == 128) && small) { f.res = 1; f.block = b; }
         }
+        if (const char* ev = getenv("WG_FLOW_RES")) {          // experiments: compact / pair-major variant for any farm size
+            if (atoi(ev) != 0 && p.N <= 255) { f.res = 1; if (!small) f.block = 256; } else if (atoi(ev) == 0) { f.res = 0; f.block = 256; }
+        }
         p.compact = f.res;
         // frozen-record layout for the deficit gathers of the large-farm variant: 16-byte AoS copy (rec4)
         if (!f.res) { if (!rc) rc = dev_alloc(h, &d.rec4, n_slots * pstride_keep, true); }

@@ -641,12 +641,11 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         // into a list and only those get the exact evaluation — one thread per candidate: bracketing particles
         // (L2 hits: this workgroup just streamed them), interpolation, lateral cut-off, then the Gaussian deficit at all S rotor points summed in the thread.
         // Thread t finally subtracts its sources' contributions in ascending source order (deterministic).
-        // Staging (the `pair` region): cl[N*N] u16 candidate list | def[N*N] rotor-mean deficit | tiav[N*N] added TI.
+        // Staging (the `pair` region, per chunk of TC targets): cl[TC*N] u16 candidate list | def[TC*N] rotor-mean deficit | tiav[TC*N] added TI.
         unsigned short* cl = reinterpret_cast<unsigned short*>(pair);
-        float* def = reinterpret_cast<float*>(cl + ((N * N + 7) & ~7));
-        float* tiav = def + N * N;
+        float* def = reinterpret_cast<float*>(cl + ((TC * N + 7) & ~7));
+        float* tiav = def + TC * N;
         int* ncand = const_cast<int*>(jnl) + N + 1;
-        const int npairs = N * N;
         // ambient inflow at the rotors (no wakes): thread t / the (t, sample) threads
         if (TURB == WG_TURB_BOX) {
             const int nitems = N << p.S_shift;
@@ -680,8 +679,13 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 T[t].u = ws_f + au; T[t].v = av; T[t].w = aw;
             }
         }
+        // targets in chunks of TC (small farms: one chunk = all N x N pairs)
+        for (int t0 = 0; t0 < N; t0 += TC) {
+        const int nt = (N - t0) < TC ? (N - t0) : TC;
+        const int npairs = nt * N;
+        if (t0 > 0) lds_barrier<NT>();          // the previous chunk's sums are done with the staging arrays
         if (tid == 0) *ncand = 0;
-        for (int i = tid; i < N * WG_MASK_WORDS; i += NT) tmask[i] = 0u;
+        for (int i = tid; i < nt * WG_MASK_WORDS; i += NT) tmask[i] = 0u;
         lds_barrier<NT>();
         // pass 1: conservative test on every pair -> candidate list
         for (int i0 = 0; i0 < ((WG_ABLATE & 2) ? 0 : npairs); i0 += NT) {
@@ -690,12 +694,13 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             if (i < npairs) {
                 const int tl = (int)(((float)i + 0.5f) * p.inv_N);
                 const int s2 = i - tl * N;
-                const double dx = T[tl].xr - T[s2].xr;
-                cand = (s2 != tl) && (dx > 0.0);
+                const int tg = t0 + tl;
+                const double dx = T[tg].xr - T[s2].xr;
+                cand = (s2 != tg) && (dx > 0.0);
                 if (cand) {
                     const TurbLds& src = T[s2];
                     const float sig_max = (src.bk * ((float)dx * p.inv_D) + src.be) * p.D;
-                    const float gap = fabsf((float)(T[tl].yr - src.yr)) - (p.R_rot + 5.0f * sig_max + src.bd);
+                    const float gap = fabsf((float)(T[tg].yr - src.yr)) - (p.R_rot + 5.0f * sig_max + src.bd);
                     cand = gap <= 1.0e-3f * p.D;      // small margin for fp32 rounding of the bound itself
                 }
             }
@@ -713,8 +718,9 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         const int nc = *ncand;
         for (int c = tid; c < nc; c += NT) {
             const int i = cl[c];
-            const int t = (int)(((float)i + 0.5f) * p.inv_N);
-            const int s2 = i - t * N;
+            const int tl = (int)(((float)i + 0.5f) * p.inv_N);
+            const int s2 = i - tl * N;
+            const int t = t0 + tl;
             const TurbLds& src = T[s2];
             const double dx = T[t].xr - src.xr;
             const double xi = (dx - s_new) * p.inv_dpart;
@@ -758,24 +764,25 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 acc += amp * __expf(-(dy * dy + dz * dz) * inv2s2);
             }
             def[i] = acc * p.inv_S;
-            atomicOr(&tmask[t * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
+            atomicOr(&tmask[tl * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
         }
         lds_barrier<NT>();
         // thread t: superposition in ascending source order
-        for (int t = tid; t < N; t += NT) {
+        for (int tl = tid; tl < nt; tl += NT) {
             float dsum = 0.f, tia_max = 0.f;
             for (int wd = 0; wd * 32 < N; ++wd) {
-                unsigned m = tmask[t * WG_MASK_WORDS + wd];
+                unsigned m = tmask[tl * WG_MASK_WORDS + wd];
                 while (m) {
                     const int s2 = wd * 32 + __builtin_ctz(m);
                     m &= m - 1;
-                    dsum += def[t * N + s2];
-                    tia_max = fmaxf(tia_max, tiav[t * N + s2]);
+                    dsum += def[tl * N + s2];
+                    tia_max = fmaxf(tia_max, tiav[tl * N + s2]);
                 }
             }
-            T[t].u -= dsum;
-            T[t].ti = __builtin_amdgcn_sqrtf(ti_f * ti_f + tia_max * tia_max);
+            T[t0 + tl].u -= dsum;
+            T[t0 + tl].ti = __builtin_amdgcn_sqrtf(ti_f * ti_f + tia_max * tia_max);
         }
+        }   // target chunks
         lds_barrier<NT>();
         return;
     }
@@ -1341,7 +1348,8 @@ extern "C" void wg_launch_flow(const FlowP* p, const FlowPtrs* d, int mode, cons
                                const uint8_t* mask, int chunk, hipStream_t st) {
     if (p->res) {
         if (p->block == 64) launch_nt<64, true>(p, d, mode, actions, mask, chunk, st);
-        else launch_nt<128, true>(p, d, mode, actions, mask, chunk, st);
+        else if (p->block == 128) launch_nt<128, true>(p, d, mode, actions, mask, chunk, st);
+        else launch_nt<256, true>(p, d, mode, actions, mask, chunk, st);
     } else {
         launch_nt<256, false>(p, d, mode, actions, mask, chunk, st);
     }
