@@ -310,8 +310,8 @@ def test_horns_rev_80_turbines_matches_oracle(hip, oracle_lib, variant):
     """BASELINE.json configs[2] at test size: Horns Rev 1 layout (N = 80 > one wave, P = 416, target chunking
     in the deficit phases), B = 3, autoreset on.  "default" = the large-farm variant bench.py --workload cfg3 runs
     (uniform rings, (target, sample)-major); "compact_pairmajor" = the small-farm variant forced onto the large farm
-    (WG_FLOW_RES=1: compact rings, pair-major phases in chunks of targets, 256 threads) — measured slower on cfg3
-    (its four SoA gathers cost more lines than the 16-byte record copy), kept correct."""
+    (WG_FLOW_RES=1: compact rings, pair-major phases in chunks of targets, 16-byte record gathers, 256 threads) — a tie
+    with the default on cfg3, kept correct."""
     import os
     from windgym_amd.config import EnvConfig
     from windgym_amd.presets import horns_rev1_layout, horns_rev_config

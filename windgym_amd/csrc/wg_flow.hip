@@ -118,6 +118,7 @@ struct PartLds {
     float* py; unsigned* ra; unsigned* rb; float* ue;
     float *pz, *vl, *wl;        // turbulent inflow only
     const uint8_t* own;         // [L/4] owner turbine of a quad
+    uint4* r4;                  // large farms: 16-byte gather copy of the frozen record (rec_a, rec_b, bits of u_e, 0) or null
     int L;                      // ring slots of the farm = roff[N]
 };
 
@@ -340,7 +341,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     int ei = e0 + i; if (ei >= R) ei -= R;
                     if (ei < n_emit) {
                         pyv[i] = y0; rav[i] = pack_a(tq.rct, tq.rk); rbv[i] = pack_b(tq.reps, tq.rhv);
-                        pl.ue[4 * q + i] = tq.rue;
+                        if (pl.r4) pl.r4[4 * q + i] = make_uint4(rav[i], rbv[i], __float_as_uint(tq.rue), 0u);
+                        else pl.ue[4 * q + i] = tq.rue;
                     }
                 }
                 reinterpret_cast<uint4*>(pl.ra)[q] = make_uint4(rav[0], rav[1], rav[2], rav[3]);
@@ -408,8 +410,10 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     const float y0 = (float)tq.yr;
                     if (ev[u] < n_emit) {
                         pyv[u] = y0; pzv[u] = p.hub; vlv = 0.f; wlv = 0.f;
-                        pl.ra[ix] = pack_a(tq.rct, tq.rk); pl.rb[ix] = pack_b(tq.reps, tq.rhv);
-                        pl.ue[ix] = tq.rue;
+                        const unsigned na = pack_a(tq.rct, tq.rk), nb = pack_b(tq.reps, tq.rhv);
+                        pl.ra[ix] = na; pl.rb[ix] = nb;
+                        if (pl.r4) pl.r4[ix] = make_uint4(na, nb, __float_as_uint(tq.rue), 0u);
+                        else pl.ue[ix] = tq.rue;
                     }
                     const float ex = fabsf(pyv[u] - y0) + fabsf(pzv[u] - p.hub);
                     if (ex > tq.bd) atomicMax(reinterpret_cast<int*>(&tq.bd), __float_as_int(ex));
@@ -734,8 +738,15 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             int r1 = r0 - 1; if (r1 < 0) r1 += Rs;
             const int i0 = src.roff + r0, i1 = src.roff + r1;
             const float py0 = pl.py[i0], py1 = pl.py[i1];
-            const float u0 = pl.ue[i0], u1 = pl.ue[i1];
-            const unsigned a0 = pl.ra[i0], a1 = pl.ra[i1], b0_ = pl.rb[i0], b1_ = pl.rb[i1];
+            float u0, u1;
+            unsigned a0, a1, b0_, b1_;
+            if (pl.r4) {       // large farms: the two bracketing records are 32 contiguous bytes (one line, not three)
+                const uint4 g0 = pl.r4[i0], g1 = pl.r4[i1];
+                a0 = g0.x; b0_ = g0.y; u0 = __uint_as_float(g0.z); a1 = g1.x; b1_ = g1.y; u1 = __uint_as_float(g1.z);
+            } else {
+                u0 = pl.ue[i0]; u1 = pl.ue[i1];
+                a0 = pl.ra[i0]; a1 = pl.ra[i1]; b0_ = pl.rb[i0]; b1_ = pl.rb[i1];
+            }
             const float w0 = 1.0f - wgt, w1 = wgt;
             const float yc = w0 * py0 + w1 * py1;
             float zc = p.hub;
@@ -1112,7 +1123,8 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     int* jnl = reinterpret_cast<int*>(tiap + p.target_chunk * N);          // [N] chain pruning ages
     PartLds pl;
     if (RES) {
-        pl.py = d.py + pbase; pl.ra = d.rec_a + pbase; pl.rb = d.rec_b + pbase; pl.ue = d.u_e + pbase;
+        pl.py = d.py + pbase; pl.ra = d.rec_a + pbase; pl.rb = d.rec_b + pbase;
+        pl.ue = d.u_e ? d.u_e + pbase : nullptr; pl.r4 = d.rec4 ? d.rec4 + pbase : nullptr;
         pl.pz = TURB != WG_TURB_NONE ? d.pz + pbase : nullptr;
         pl.vl = TURB != WG_TURB_NONE ? d.vlp + pbase : nullptr;
         pl.wl = TURB != WG_TURB_NONE ? d.wlp + pbase : nullptr;
