@@ -264,7 +264,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     }
     A(yaw, n_slots * p.N, true); A(u, n_slots * p.N, true); A(v, n_slots * p.N, true); A(w, n_slots * p.N, true);
     A(ti_loc, n_slots * p.N, true); A(power, n_slots * p.N, true); A(ct, n_slots * p.N, true);
-    A(bnd, n_slots * p.N * 3, true);
+    A(bnd, n_slots * p.N * 4, true);
     A(slot, n_slots, true); A(ctx, n_ctx, true); A(env, (size_t)p.B, true);
     A(xr, n_ctx * p.N, true); A(yr, n_ctx * p.N, true); A(jneed, n_ctx * p.N, true);
     A(roff, n_ctx * (p.N + 1), true); A(qown, n_ctx * (size_t)(p.NP / 4), true);
@@ -347,11 +347,6 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         // Kernel variant.  Small farms (N <= 32: all N x N pairs are staged at once): compact per-turbine rings +
         // pair-major deficit phases, single-wave workgroups (128 threads selectable for tests).  Large farms: uniform P-slot rings with
         // predicate pruning, (target, sample)-major deficit phases, 256 threads.
-        size_t off = sizeof(float) * 4 * (size_t)tc * p.N;
-        f.lds_off_turb = (int)off; off += (size_t)WG_TURB_LDS_BYTES * p.N;
-        off = (off + 15) & ~(size_t)15;
-        f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S) + sizeof(unsigned) * WG_MASK_WORDS * (size_t)tc + sizeof(float) * (size_t)tc * p.N;
-        off += sizeof(int) * ((size_t)p.N + 2);      // chain-pruning ages + the particle counter + the candidate counter
         const bool small = p.N <= 32 && tc == p.N;
         f.res = small ? 1 : 0;
         f.block = small ? 64 : 256;        // small farms: single-wave workgroups (no s_barrier at all): cfg2 80 vs 91 us at 128 threads
@@ -364,6 +359,14 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             if (atoi(ev) != 0 && p.N <= 255) { f.res = 1; if (!small) f.block = 256; } else if (atoi(ev) == 0) { f.res = 0; f.block = 256; }
         }
         p.compact = f.res;
+        // LDS carve.  The staging region of the deficit phases doubles as the quad list of the compact steady advection
+        // pass (one 32-bit entry per quad of the farm's rings: at most NP bytes)
+        size_t off = sizeof(float) * 4 * (size_t)tc * p.N;
+        if (f.res) off = std::max(off, ((size_t)p.NP + 15) & ~(size_t)15);
+        f.lds_off_turb = (int)off; off += (size_t)WG_TURB_LDS_BYTES * p.N;
+        off = (off + 15) & ~(size_t)15;
+        f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S) + sizeof(unsigned) * WG_MASK_WORDS * (size_t)tc + sizeof(float) * (size_t)tc * p.N;
+        off += sizeof(int) * ((size_t)p.N + 2);      // chain-pruning ages + the particle counter + the candidate counter
         // frozen-record layout for the deficit gathers of the large-farm variant: 16-byte AoS copy (rec4)
         if (!f.res || !small) { if (!rc) rc = dev_alloc(h, &d.rec4, n_slots * pstride_keep, true); }
         else { if (!rc) rc = dev_alloc(h, &d.u_e, n_slots * pstride_keep, true); }

@@ -362,7 +362,7 @@ __device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, c
             }
             d.u[tb + t] = u; d.v[tb + t] = v; d.w[tb + t] = w;
             d.ti_loc[tb + t] = (float)ti; d.power[tb + t] = pw; d.ct[tb + t] = 0.f;
-            d.bnd[(tb + t) * 3] = 0.f; d.bnd[(tb + t) * 3 + 1] = 0.f; d.bnd[(tb + t) * 3 + 2] = 0.f;
+            d.bnd[(tb + t) * 4] = 0.f; d.bnd[(tb + t) * 4 + 1] = 0.f; d.bnd[(tb + t) * 4 + 2] = 0.f; d.bnd[(tb + t) * 4 + 3] = 0.f;
         }
     }
 }

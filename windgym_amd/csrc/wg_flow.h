@@ -47,7 +47,7 @@ struct FlowPtrs {
     const float4* box4;          // interleaved copy of the turbulence box: [Nx][Ny][Nz] x (u, v, w, 0)
     const float4* box4c;         // the same block-averaged over 4x4x4 cells
     float *yaw, *u, *v, *w, *ti_loc, *power, *ct;
-    float* bnd;                   // [n_slots][N][3] conservative chain bounds (excursion, k, eps)
+    float* bnd;                   // [n_slots][N][4] conservative chain bounds (excursion, k, eps) + last moving emission (uint bits)
     WgSlot* slot;
     WgCtx* ctx;
     const WgEnv* env;

@@ -37,6 +37,9 @@ struct __attribute__((aligned(8))) TurbLds {
     // compact rings (small-farm variant): offset / length of this turbine's ring inside the farm's particle arrays,
     // ring slot of its newest particle before (head) and after (head_n) the emissions of the current flow step
     int roff, rlen, head, head_n;
+    // emission count (SlotRegs::n_emitted) right after this turbine's last emission of a MOVING record (hv != 0), 0 =
+    // never: the chain holds a moving particle while fewer than rlen particles followed that one
+    unsigned mvl;
 };
 static_assert(sizeof(TurbLds) == WG_TURB_LDS_BYTES, "keep WG_TURB_LDS_BYTES in sync");
 
@@ -286,7 +289,10 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         q.sg = sg;
         q.bk = fmaxf(q.bk, q.rk + WG_K_MAX / 65535.0f);
         q.be = fmaxf(q.be, q.reps + 1.0f / 65535.0f);
-        if (RES) q.head_n = (q.head + n_emit) % q.rlen;
+        if (RES) {
+            q.head_n = (q.head + n_emit) % q.rlen;
+            if (n_emit > 0 && rec_moves(pack_b(q.reps, q.rhv))) q.mvl = sr.n_emitted + (unsigned)n_emit;
+        }
     }
     for (int i = tid; i < TC * WG_MASK_WORDS; i += NT) tmask[i] = 0u;
     lds_barrier<NT>();
@@ -306,22 +312,49 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     uint4* __restrict__ gr4 = d.rec4 + pbase;
     float* __restrict__ gue = d.u_e + pbase;
     if (RES && TURB == WG_TURB_NONE) {
-        // compact rings, steady inflow: a thread owns quads of 4 consecutive ring slots (one owner turbine per quad:
-        // ring lengths are multiples of 4).  Only chains of yawed turbines move (hv != 0); a quad that neither moves nor
-        // receives a new particle costs one 16-byte LDS read.
-        const int L4 = pl.L >> 2;
-        for (int q = tid; q < ((WG_ABLATE & 1) ? 0 : L4); q += NT) {
-            const int t = pl.own[q];
+        // compact rings, steady inflow: the unit of work is a quad of 4 consecutive ring slots (one owner turbine per
+        // quad: ring lengths are multiples of 4).  Only chains that hold a particle of a yawed turbine move (hv != 0),
+        // and whether a chain does is known WITHOUT reading it: TurbLds::mvl remembers the emission count at the
+        // chain's last moving emission, and that particle is still in the ring while fewer than R_t particles
+        // followed it.  Pass A (LDS only): turbine t lists its quads — all of them if the chain may move, otherwise
+        // just the quads that receive this step's new particles.  Pass B: one listed quad per lane, its three words
+        // (py, rec_a, rec_b) requested together — one memory round trip per 64 quads, none for a resting chain.
+        unsigned* ql = reinterpret_cast<unsigned*>(pair);
+        int* nq = const_cast<int*>(jnl) + N + 1;
+        if (tid == 0) *nq = 0;
+        lds_barrier<NT>();
+        for (int t = tid; t < ((WG_ABLATE & 1) ? 0 : N); t += NT) {
+            const TurbLds& tq = T[t];
+            const int R = tq.rlen, q0 = tq.roff >> 2, nqd = R >> 2;
+            const bool moving = tq.mvl != 0u && (int)(sr.n_emitted - tq.mvl) < R;
+            const unsigned tag = (unsigned)t << 24;
+            if (moving || n_emit >= 4 || n_emit >= R) {
+                const int base = atomicAdd(nq, nqd);
+                for (int i = 0; i < nqd; ++i) ql[base + i] = tag | (unsigned)(q0 + i);
+            } else if (n_emit > 0) {
+                int prev = -1;
+                for (int e = 0; e < n_emit; ++e) {
+                    int r = tq.head + 1 + e; if (r >= R) r -= R;
+                    const int qd = q0 + (r >> 2);
+                    if (qd != prev) ql[atomicAdd(nq, 1)] = tag | (unsigned)qd;
+                    prev = qd;
+                }
+            }
+        }
+        lds_barrier<NT>();
+        const int nlist = *nq;
+        for (int c = tid; c < nlist; c += NT) {
+            const unsigned ent = ql[c];
+            const int q = (int)(ent & 0xffffffu), t = (int)(ent >> 24);
+            const float4 py = reinterpret_cast<const float4*>(pl.py)[q];
+            const uint4 ra = reinterpret_cast<const uint4*>(pl.ra)[q];
+            const uint4 rb = reinterpret_cast<const uint4*>(pl.rb)[q];
             TurbLds& tq = T[t];
             const int R = tq.rlen, hd = tq.head;
             const int r0 = 4 * q - tq.roff;
             int j0 = hd - r0; if (j0 < 0) j0 += R;             // age of ring slot r0 (slot r0+i: j0-i)
             int e0 = r0 - hd - 1; if (e0 < 0) e0 += R;         // emission index of slot r0 (r0+i: e0+i)
             const bool emits = (e0 < n_emit) || (n_emit > 0 && e0 + 3 >= R);   // wraps past R-1 -> 0
-            const uint4 rb = reinterpret_cast<const uint4*>(pl.rb)[q];
-            if (!(emits || rec_moves(rb.x) | rec_moves(rb.y) | rec_moves(rb.z) | rec_moves(rb.w))) continue;
-            const float4 py = reinterpret_cast<const float4*>(pl.py)[q];
-            const uint4 ra = reinterpret_cast<const uint4*>(pl.ra)[q];
             float pyv[4] = {py.x, py.y, py.z, py.w};
             unsigned rav[4] = {ra.x, ra.y, ra.z, ra.w};
             unsigned rbv[4] = {rb.x, rb.y, rb.z, rb.w};
@@ -1039,7 +1072,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     TurbCtx tc;
     double l_xr = 0, l_yr = 0;
     float l_yaw = 0, l_u = 0, l_v = 0, l_w = 0, l_ti = 0, l_pow = 0, l_ct = 0, l_act = 0;
-    float l_bd = 0, l_bk = 0, l_be = 0;
+    float4 l_bnd = make_float4(0.f, 0.f, 0.f, 0.f);
     int l_jn = 0, l_roff = 0, l_rnext = 0, L_ring = 0;
     auto load_state = [&]() __attribute__((always_inline)) {
         dev_rem = slot.dev_remaining; fill_rem = slot.fill_remaining;
@@ -1065,7 +1098,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         l_yr = d.yr[(size_t)ctx_id * N + t_own];
         l_yaw = d.yaw[tb + t_own]; l_u = d.u[tb + t_own]; l_v = d.v[tb + t_own]; l_w = d.w[tb + t_own];
         l_ti = d.ti_loc[tb + t_own]; l_pow = d.power[tb + t_own]; l_ct = d.ct[tb + t_own];
-        l_bd = d.bnd[(tb + t_own) * 3]; l_bk = d.bnd[(tb + t_own) * 3 + 1]; l_be = d.bnd[(tb + t_own) * 3 + 2];
+        l_bnd = reinterpret_cast<const float4*>(d.bnd)[tb + t_own];
         if (!RES) l_jn = d.jneed[(size_t)ctx_id * N + t_own];      // chain pruning by predicate: streaming variant only
     };
     load_state();
@@ -1135,7 +1168,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         TurbLds& q = T[t];
         if (t == tid && tid < N) {
             q.xr = l_xr; q.yr = l_yr; q.yaw = l_yaw; q.u = l_u; q.v = l_v; q.w = l_w; q.ti = l_ti; q.pow = l_pow; q.ct = l_ct;
-            q.bd = l_bd; q.bk = l_bk; q.be = l_be;
+            q.bd = l_bnd.x; q.bk = l_bnd.y; q.be = l_bnd.z; q.mvl = __float_as_uint(l_bnd.w);
             if (!RES) jnl[t] = l_jn;
             if (RES) {
                 q.roff = l_roff; q.rlen = l_rnext - l_roff;
@@ -1147,7 +1180,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             q.xr = d.xr[(size_t)ctx_id * N + t]; q.yr = d.yr[(size_t)ctx_id * N + t];
             q.yaw = d.yaw[tb + t]; q.u = d.u[tb + t]; q.v = d.v[tb + t]; q.w = d.w[tb + t];
             q.ti = d.ti_loc[tb + t]; q.pow = d.power[tb + t]; q.ct = d.ct[tb + t];
-            q.bd = d.bnd[(tb + t) * 3]; q.bk = d.bnd[(tb + t) * 3 + 1]; q.be = d.bnd[(tb + t) * 3 + 2];
+            { const float4 b4 = reinterpret_cast<const float4*>(d.bnd)[tb + t]; q.bd = b4.x; q.bk = b4.y; q.be = b4.z; q.mvl = __float_as_uint(b4.w); }
             if (!RES) jnl[t] = d.jneed[(size_t)ctx_id * N + t];
             if (RES) {
                 const int* ro = d.roff + (size_t)ctx_id * (N + 1);
@@ -1312,7 +1345,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         const TurbLds& q = T[t];
         d.yaw[tb + t] = q.yaw; d.u[tb + t] = q.u; d.v[tb + t] = q.v; d.w[tb + t] = q.w;
         d.ti_loc[tb + t] = q.ti; d.power[tb + t] = q.pow; d.ct[tb + t] = q.ct;
-        d.bnd[(tb + t) * 3] = q.bd; d.bnd[(tb + t) * 3 + 1] = q.bk; d.bnd[(tb + t) * 3 + 2] = q.be;
+        reinterpret_cast<float4*>(d.bnd)[tb + t] = make_float4(q.bd, q.bk, q.be, __uint_as_float(q.mvl));
     }
     if (tid == 0) {
         slot.part_count += (unsigned)jnl[N];

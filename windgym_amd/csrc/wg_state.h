@@ -130,7 +130,7 @@ struct WgPtrs {
     unsigned *rec_a, *rec_b;   // packed emission record: ct|k and eps|hv as 16-bit fixed point
     // turbines [n_slots][N]
     float *yaw, *u, *v, *w, *ti_loc, *power, *ct;
-    float* bnd;               // [n_slots][N][3]: running maxima over a chain: excursion, k, eps (pruning bounds)
+    float* bnd;               // [n_slots][N][4]: running maxima over a chain: excursion, k, eps (pruning bounds); [3] = bits of the emission count at the chain's last moving emission (TurbLds::mvl)
     WgSlot* slot;
     WgCtx* ctx;
     WgEnv* env;
