@@ -299,6 +299,11 @@ int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, double* glue_
 /* Algorithmic HBM bytes one wg_step() moves (the figure bench.py's roofline uses).       */
 int wg_algorithmic_bytes(wg_handle h, double* bytes_per_step);
 
+/* Which k_flow variant the handle launches (diagnostics / tests; chosen in wg_create from the farm geometry, env
+ * overrides WG_FLOW_BLOCK / WG_FLOW_RES / WG_FLOW_DUO): threads per workgroup, 1 = compact per-turbine rings with
+ * pair-major deficit phases (small farms), 1 = both farms of a context share one workgroup (k_flow_duo).  */
+int wg_flow_variant(wg_handle h, int* block, int* compact, int* duo);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,9 @@ def hip():
     return binding
 
 
-BLOCKS = [64, 128, 256]          # every workgroup size launch_nt can select (wg_flow.hip)
+# every k_flow variant the host can select (wg_flow.hip): one workgroup of 64 / 128 / 256 threads per farm slot, and
+# "duo" = k_flow_duo, both farms of a context in one 64-lane workgroup (two-farm configs; falls back to 64 otherwise)
+BLOCKS = [64, 128, 256, "duo"]
 
 
 def _make_env(hip, cfg, block=None):
@@ -32,11 +34,21 @@ def _make_env(hip, cfg, block=None):
     import os
     if block is None:
         return hip.HipBatch(cfg)
-    os.environ["WG_FLOW_BLOCK"] = str(block)
+    os.environ["WG_FLOW_BLOCK"] = "64" if block == "duo" else str(block)
+    os.environ["WG_FLOW_DUO"] = "1" if block == "duo" else "0"
     try:
-        return hip.HipBatch(cfg)
+        env = hip.HipBatch(cfg)
     finally:
         del os.environ["WG_FLOW_BLOCK"]
+        del os.environ["WG_FLOW_DUO"]
+    # the variant asked for is the one that runs (a silent fallback would test the wrong kernel)
+    threads, compact, duo = env.flow_variant()
+    two_farms = bool(cfg.baseline_comp)
+    if block == "duo":
+        assert threads == 64 and compact and duo == two_farms
+    else:
+        assert threads == block and not duo
+    return env
 
 
 def _t(hip, a):

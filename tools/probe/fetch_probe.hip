@@ -1,0 +1,43 @@
+// FETCH_SIZE / WRITE_SIZE unit check on this GPU: stream-read N bytes (coalesced 16 B per lane), scattered 4-byte
+// reads one per 128-byte line, and stream-write N bytes.  Build: hipcc --offload-arch=gfx950 -O3 -o fetch_probe fetch_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+__global__ void k_stream_read(const float4* __restrict__ in, float* __restrict__ out, size_t n4) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    float acc = 0.f;
+    for (; i < n4; i += (size_t)gridDim.x * blockDim.x) { float4 v = in[i]; acc += v.x + v.y + v.z + v.w; }
+    if (acc == 1.2345f) out[0] = acc;
+}
+__global__ void k_line_read(const float* __restrict__ in, float* __restrict__ out, size_t nlines) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    float acc = 0.f;
+    for (; i < nlines; i += (size_t)gridDim.x * blockDim.x) acc += in[i * 32];     // one float per 128-byte line
+    if (acc == 1.2345f) out[0] = acc;
+}
+__global__ void k_stream_write(float4* __restrict__ out, size_t n4) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i < n4; i += (size_t)gridDim.x * blockDim.x) out[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+__global__ void k_line_write4(float* __restrict__ out, size_t nlines) {          // 4 bytes per 128-byte line
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i < nlines; i += (size_t)gridDim.x * blockDim.x) out[i * 32] = 1.f;
+}
+__global__ void k_line_write64(float4* __restrict__ out, size_t nlines) {        // 64 of every 128 bytes, 16 B per lane
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i < nlines * 4; i += (size_t)gridDim.x * blockDim.x) out[(i >> 2) * 8 + (i & 3)] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+int main() {
+    const size_t bytes = 1ull << 30;
+    float4 *a; float* o;
+    hipMalloc(&a, bytes); hipMalloc(&o, 64);
+    hipMemset(a, 0, bytes);
+    hipDeviceSynchronize();
+    k_stream_read<<<4096, 256>>>(a, o, bytes / 16);
+    k_line_read<<<4096, 256>>>((const float*)a, o, bytes / 128);
+    k_stream_write<<<4096, 256>>>(a, bytes / 16);
+    k_line_write4<<<4096, 256>>>((float*)a, bytes / 128);
+    k_line_write64<<<4096, 256>>>(a, bytes / 128);
+    hipDeviceSynchronize();
+    printf("bytes per kernel: %zu (= %zu KiB)\n", bytes, bytes >> 10);
+    return 0;
+}

@@ -22,7 +22,7 @@ UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 ABI_SYMBOLS = (
     "wg_last_error", "wg_abi_version", "wg_create", "wg_destroy", "wg_obs_dim", "wg_hist_max",
     "wg_set_turbulence_box", "wg_set_turbulence_boxes", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_set_step_graph", "wg_check", "wg_obs_multi", "wg_set_obs_multi_buffer",
-    "wg_get_info", "wg_get_measurements", "wg_get_windspeed", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_algorithmic_bytes",
+    "wg_get_info", "wg_get_measurements", "wg_get_windspeed", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_algorithmic_bytes", "wg_flow_variant",
 )
 
 _lib = None
@@ -74,6 +74,7 @@ def load_library():
     L.wg_kernel_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.wg_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.wg_flow_variant.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -318,3 +319,9 @@ class HipBatch:
         v = C.c_double()
         _chk(self.L.wg_algorithmic_bytes(self._h, C.byref(v)), "wg_algorithmic_bytes")
         return v.value
+
+    def flow_variant(self):
+        """(threads per k_flow workgroup, compact rings / pair-major phases?, both farms of a context per workgroup?)"""
+        b, r, d = C.c_int(), C.c_int(), C.c_int()
+        _chk(self.L.wg_flow_variant(self._h, C.byref(b), C.byref(r), C.byref(d)), "wg_flow_variant")
+        return b.value, bool(r.value), bool(d.value)

@@ -367,6 +367,26 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         off = (off + 15) & ~(size_t)15;
         f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S) + sizeof(unsigned) * WG_MASK_WORDS * (size_t)tc + sizeof(float) * (size_t)tc * p.N;
         off += sizeof(int) * ((size_t)p.N + 2);      // chain-pruning ages + the particle counter + the candidate counter
+        // k_flow_duo: both farms of a context in one single-wave workgroup (lane = farm * N + turbine).  It executes 37 %
+        // fewer VALU instructions per farm step, which pays where the per-workgroup fixed costs dominate (cfg4, 3x3 x P=96:
+        // 43.6 -> 37.7 us) and not where the particle traffic does (cfg2 4x4 x P=128: 75 -> 78 us, cfg5 frozen box:
+        // 157 -> 172 us): default for steady inflow up to 1024 ring slots per farm.  WG_FLOW_DUO=1 / 0 forces it on
+        // (where eligible) / off (tests run both).
+        const bool duo_ok = f.res && small && f.block == 64 && p.F == 2 && 2 * p.N <= 64 && p.P <= 4096;
+        f.duo = (duo_ok && p.NP <= 1024 && p.turb_mode == WG_TURB_NONE) ? 1 : 0;
+        if (const char* ev = getenv("WG_FLOW_DUO")) f.duo = (duo_ok && atoi(ev) != 0) ? 1 : 0;
+        {
+            const size_t n2 = 2 * (size_t)p.N;
+            const size_t ccap = (size_t)p.N * (p.N - 1);            // candidate pairs of both farms
+            size_t o = std::max(((2 * ccap + 3) & ~(size_t)3) + 8 * ccap, (size_t)p.NP);   // | 16-bit quad list of both farms
+            o = (o + 15) & ~(size_t)15;
+            f.duo_off_turb = (int)o;
+            o = (o + WG_TURB_LDS_BYTES * n2 + 15) & ~(size_t)15;        // tables
+            o += 4 * (2 * (size_t)nu + 2 * (size_t)p.S);                  // candidate ranges
+            o = (o + 8 * n2 + 7) & ~(size_t)7;                            // per-farm clocks
+            o += 2 * 72 + 16;                                             // (sizeof(FarmLds) = 72) + counters
+            f.duo_lds = (int)((o + 15) & ~(size_t)15);
+        }
         // frozen-record layout for the deficit gathers of the large-farm variant: 16-byte AoS copy (rec4)
         if (!f.res || !small) { if (!rc) rc = dev_alloc(h, &d.rec4, n_slots * pstride_keep, true); }
         else { if (!rc) rc = dev_alloc(h, &d.u_e, n_slots * pstride_keep, true); }
@@ -445,8 +465,9 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     if (const char* ev = getenv("WG_STEP_GRAPH")) h->graph_mode = atoi(ev) != 0;
     if (getenv("WG_DEBUG"))
         fprintf(stderr, "[windgym] k_flow variant: %s, %d threads, LDS %d B per workgroup, slot stride %d floats\n",
-                h->fp.res ? "compact rings / pair-major" : "uniform rings / sample-major", h->fp.block, h->fp.lds_bytes,
-                h->fp.pstride);
+                h->fp.duo ? "compact rings / pair-major, both farms of a context per wave"
+                          : (h->fp.res ? "compact rings / pair-major" : "uniform rings / sample-major"),
+                h->fp.block, h->fp.duo ? h->fp.duo_lds : h->fp.lds_bytes, h->fp.pstride);
     *out = h;
     return 0;
 }
@@ -864,6 +885,14 @@ extern "C" int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, do
         }
         h->ev_kind.assign(WG_MAX_TIMING_EVENTS / 2, 0);
     }
+    return 0;
+}
+
+extern "C" int wg_flow_variant(wg_handle h, int* block, int* compact, int* duo) {
+    if (!h) return fail(WG_ERR_INVALID, "null handle");
+    if (block) *block = h->fp.block;
+    if (compact) *compact = h->fp.res;
+    if (duo) *duo = h->fp.duo;
     return 0;
 }
 
