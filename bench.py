@@ -293,10 +293,12 @@ def main():
         bytes_per_flow_step = alg_bytes_flow / flow_steps if flow_steps > 0 else 0.0
         achieved = alg_bytes_flow / (flow_ms * 1e-3) / 1e9 if flow_ms > 0 else 0.0
         # HBM bytes per k_flow launch from the rocprofv3 PMC passes of this same command (separate runs:
-        # tools/profile_kflow.sh -> profiles/r02_kflow_traffic.json); only quoted for the profiled workload
+        # tools/profile_kflow.sh -> profiles/r02_kflow_traffic.json, r02_<cfgN>_kflow_traffic.json); only quoted for the
+        # profiled workloads at their profiled size (the workload's default env count, baseline farm on)
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r02_kflow_traffic.json")
-        if os.path.exists(tf) and B == 4096 and F == 2 and args.workload == "cfg2":
+        tf = os.path.join(ROOT, "profiles", "r02_kflow_traffic.json" if args.workload == "cfg2"
+                          else f"r02_{args.workload}_kflow_traffic.json")
+        if os.path.exists(tf) and args.envs is None and F == 2:
             try:
                 traffic = json.load(open(tf))["hbm_bytes_per_launch"]
             except Exception:
