@@ -231,7 +231,14 @@ int wg_set_flow_script(wg_handle h, const float* uvw_dev, const float* power_dev
 /* reset(): WindFarmEnv.reset (:680-802) for the envs whose mask byte is non-zero (NULL = all).
  * seeds: host array [B] of uint64 or NULL.  seeds[b] == UINT64_MAX keeps env b's generator running
  * (gymnasium reset(seed=None)); otherwise the env's PCG64 generator is re-seeded exactly like
- * gymnasium's np_random (np.random.default_rng(seed)).  Outputs may be NULL.                            */
+ * gymnasium's np_random (np.random.default_rng(seed)).  Outputs may be NULL.
+ * With autoreset on, a reset initialises BOTH episode contexts of a masked env — the episode that starts now and the
+ * look-ahead episode that is developed in the background — so it consumes two episodes' worth of draws from the env's
+ * generator: episode k of an env always uses draws k of its stream (one draw set per episode, in order), but an explicit
+ * reset(seed=None) in the middle of an autoreset run discards the look-ahead episode that was already drawn, i.e. the
+ * stream then runs one episode ahead of a reference env that was reset at the same moments.  A wind override set after
+ * a reset is seen from the episode after the look-ahead one.  The sensor-noise stream is keyed by (env seed, episode
+ * index, push index): an explicit reset starts a new episode index, so noise sequences are not replayed.   */
 int wg_reset(wg_handle h, const uint8_t* env_mask_host, const uint64_t* seeds_host,
              float* obs_dev /*[B,O]*/, void* stream);
 

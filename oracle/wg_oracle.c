@@ -998,6 +998,9 @@ int WGO(reset)(void* h, const uint8_t* mask, const uint64_t* seeds, double* obs)
     for (int b = 0; b < o->B; ++b) {
         if (mask && !mask[b]) continue;
         int reseed = seeds && seeds[b] != UINT64_MAX;
+        /* an explicit reset that abandons a running episode starts a new episode index: the sensor-noise stream is
+         * keyed by (seed, episode index, push index) and must not replay the abandoned episode's sequence */
+        if (!reseed && !o->env[b].done && o->env[b].timestep > 0) o->env[b].episode++;
         reset_env(o, b, reseed ? seeds[b] : 0, reseed);
         o->env[b].ep_return = 0; o->env[b].ep_power_sum = 0; o->env[b].ep_len = 0;
     }

@@ -153,11 +153,26 @@ def test_vec_env_autoreset_and_episode_stats(wg, tmp_path):
     np.testing.assert_allclose(m["ep_mean_power_sum"], np.sum(rec.mean_power_queue), rtol=2e-6)
     np.testing.assert_allclose(m["ep_return_sum"], np.sum(rec.return_queue), rtol=1e-4, atol=1e-3)
     assert m["ep_length_sum"] == np.sum(rec.length_queue)
-    # SB3-style access
-    venv.step_async(np.zeros((64, venv.n_turb), dtype=np.float32))
-    o, r, dones, inf = venv.step_wait()
-    assert o.shape[0] == 64 and len(inf) == 64 and "Power agent" in inf[0]
-    venv.close()
+    # stable-baselines3's VecEnv protocol: reset() returns the observations only, per-env spaces,
+    # step_async / step_wait with a list of per-env info dicts and terminal_observation on same-step resets
+    sb3 = venv.as_sb3()
+    assert sb3.num_envs == 64 and sb3.observation_space.shape == (venv.batch.obs_dim,)
+    assert sb3.action_space.shape == (venv.n_turb,)
+    o = sb3.reset()
+    assert isinstance(o, np.ndarray) and o.shape == (64, venv.batch.obs_dim)
+    n_term = 0
+    for _ in range(200):
+        sb3.step_async(np.zeros((64, venv.n_turb), dtype=np.float32))
+        o, r, dones, inf = sb3.step_wait()
+        assert o.shape == (64, venv.batch.obs_dim) and r.shape == (64,) and dones.dtype == bool
+        assert len(inf) == 64 and "Power agent" in inf[0]
+        for i in np.nonzero(dones)[0]:
+            assert inf[i]["TimeLimit.truncated"] and inf[i]["terminal_observation"].shape == (venv.batch.obs_dim,)
+            n_term += 1
+        assert all("terminal_observation" not in inf[i] for i in np.nonzero(~dones)[0])
+    assert n_term > 0
+    assert sb3.env_is_wrapped(object) == [False] * 64 and len(sb3.get_attr("n_turb")) == 64
+    sb3.close()
 
 
 def test_mann_box_generators_agree_statistically(wg):

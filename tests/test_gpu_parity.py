@@ -438,6 +438,44 @@ def test_noise_normal_matches_oracle_stream(hip, oracle_lib, block):
     env.check()
 
 
+def test_midepisode_reset_starts_a_new_noise_stream(hip, oracle_lib):
+    """an explicit reset(seed=None) that abandons running episodes starts a new episode index on both sides
+    (the sensor-noise stream is keyed by it, so the abandoned episode's noise is not replayed) and the two stay in step.
+    autoreset off: with it on, the device has already drawn the look-ahead episode and an explicit reset re-draws both
+    contexts — the documented one-episode lead of the generator (include/windgym_hip.h, wg_reset)."""
+    import torch
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.presets import four_turb_config
+    from windgym_amd.turbine import V80
+    d = four_turb_config()
+    d["mes_level"].update(turb_wd=True)
+    d["wd_mes"].update(wd_current=True, wd_rolling_mean=True)
+    cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_envs=5, autoreset=False, n_passthrough=2)
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    seeds = 11 + np.arange(5)
+    np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=5e-4)
+    rng = np.random.default_rng(8)
+    first = []
+    for step in range(12):
+        a = rng.uniform(-1, 1, size=(5, 4)).astype(np.float32)
+        obs, rew, tr, _ = env.step(torch.as_tensor(a, device="cuda"))
+        o_obs, o_rew, o_tr, _ = orc.step(a)
+        assert not o_tr.any()
+        np.testing.assert_allclose(obs.cpu().numpy(), o_obs, rtol=0, atol=5e-4)
+        first.append(o_obs.copy())
+    ep_before = env.info("episode").cpu().numpy().copy()
+    g1, o1 = env.reset().cpu().numpy(), orc.reset()
+    np.testing.assert_allclose(g1, o1, rtol=0, atol=5e-4)
+    np.testing.assert_array_equal(env.info("episode").cpu().numpy(), orc.info("episode"))
+    np.testing.assert_array_equal(env.info("episode").cpu().numpy(), ep_before + 1)
+    for step in range(12):
+        a = rng.uniform(-1, 1, size=(5, 4)).astype(np.float32)
+        obs, rew, tr, _ = env.step(torch.as_tensor(a, device="cuda"))
+        o_obs, o_rew, o_tr, _ = orc.step(a)
+        np.testing.assert_allclose(obs.cpu().numpy(), o_obs, rtol=0, atol=5e-4)
+    env.check()
+
+
 def _turb_cfg(turbtype, n_envs, autoreset=True, n_passthrough=1.0, nx=3, ny=2):
     from windgym_amd.config import EnvConfig
     from windgym_amd.presets import env1_config

@@ -527,6 +527,10 @@ k_init(const WgParams p, const WgPtrs d, const uint8_t* __restrict__ mask, const
         if (seeds && seeds[e] != 0xFFFFFFFFFFFFFFFFull) {
             wg_pcg_seed(env, seeds[e]);
             env.noise_key = seeds[e];
+        } else if (!env.done && env.timestep > 0) {
+            // an explicit reset that abandons a running episode starts a new episode index: the sensor-noise stream is
+            // keyed by (seed, episode index, push index) and must not replay the abandoned episode's sequence
+            env.episode += 1;
         }
         env.done = 0;
     }

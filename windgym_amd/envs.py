@@ -1,7 +1,7 @@
 """Drop-in host classes: the reference's Gymnasium / PettingZoo surface over the batched HIP transition.
 
 * :class:`WindFarmVecEnv`   — the native batched env (thousands of farms per GPU, same-step autoreset);
-                              gymnasium ``VectorEnv``-style ``reset/step`` plus SB3 ``VecEnv`` duck-typing.
+                              gymnasium ``VectorEnv``-style ``reset/step``; ``as_sb3()`` gives the SB3 ``VecEnv`` protocol.
 * :class:`WindFarmEnv`      — single-env facade with the reference's constructor, attributes, ``reset`` /
                               ``step`` return types and info-dict keys (WindGym/Wind_Farm_Env.py:47-1034).
 * :class:`FarmEval`         — evaluation subclass (WindGym/FarmEval.py:10-90).
@@ -179,7 +179,6 @@ class WindFarmVecEnv:
         self._global_offset = 0          # first global env index of this shard (set by shard())
         self._actions = self.torch.zeros((self.num_envs, self.n_turb), dtype=self.torch.float32,
                                          device=self.batch.device)
-        self._sb3_actions = None
 
     # -- sharding: env i of the *global* batch is always seeded base_seed + i ------------------------
     def shard(self, rank: int, world: int, n_envs_total: Optional[int] = None):
@@ -236,32 +235,97 @@ class WindFarmVecEnv:
     def close(self):
         self.batch.close()
 
-    # -- SB3 VecEnv duck-typing (examples/longer_steps_example.py:194-209 uses make_vec_env) -----------
-    def step_async(self, actions):
-        self._sb3_actions = actions
-
-    def step_wait(self):
-        obs, rew, term, trunc, infos = self.step(self._sb3_actions)
-        obs, rew, trunc = (np.asarray(_np(x) if self.as_torch else x) for x in (obs, rew, trunc))
-        fin = infos["final_obs"]
-        fin = _np(fin) if self.as_torch else fin
-        power = infos["Power agent"]
-        power = _np(power) if self.as_torch else np.asarray(power)
-        out = [{"Power agent": float(power[i]), "TimeLimit.truncated": bool(trunc[i])} for i in range(self.num_envs)]
-        for i in np.nonzero(trunc)[0]:
-            out[i]["terminal_observation"] = fin[i]
-        return obs, rew, trunc.astype(bool), out
-
-    def env_is_wrapped(self, wrapper_class, indices=None):
-        return [False] * self.num_envs
-
-    def get_attr(self, name, indices=None):
-        return [getattr(self, name)] * self.num_envs
+    def as_sb3(self):
+        """The same batch behind stable-baselines3's ``VecEnv`` protocol (see :class:`SB3VecEnv`)."""
+        return SB3VecEnv(self)
 
     def seed(self, seed=None):
         self._base_seed = seed
         self._was_reset = False
         return [seed] * self.num_envs
+
+
+def _sb3_base():
+    try:                                           # subclass the real thing when it is installed, so that SB3's
+        from stable_baselines3.common.vec_env import VecEnv      # isinstance checks pass and nothing re-wraps the env
+        return VecEnv
+    except Exception:
+        return object
+
+
+class SB3VecEnv(_sb3_base()):
+    """stable-baselines3 ``VecEnv`` over a :class:`WindFarmVecEnv` — what ``make_vec_env(..., n_envs=n)`` +
+    ``SubprocVecEnv`` give the reference's training scripts (examples/longer_steps_example.py:194-209), as one GPU handle.
+
+    SB3's protocol, not gymnasium's: ``reset()`` returns the observations only; ``step_wait()`` returns
+    ``(obs, rewards, dones, infos)`` with ``infos`` a list of per-env dicts, ``dones = truncations`` (the env never
+    terminates, :1029), ``infos[i]["TimeLimit.truncated"]`` and — for an env that was reset in the same step —
+    ``infos[i]["terminal_observation"]``.  Arrays are numpy on the host (SB3's buffers are).
+    """
+
+    def __init__(self, venv: "WindFarmVecEnv"):
+        self.venv = venv
+        self.num_envs = venv.num_envs
+        self.observation_space = venv.single_observation_space
+        self.action_space = venv.single_action_space
+        self.render_mode = None
+        self._actions = None
+        base = type(self).__mro__[1]
+        if base is not object:
+            base.__init__(self, venv.num_envs, self.observation_space, self.action_space)
+
+    def reset(self):
+        obs, _ = self.venv.reset()
+        return np.asarray(_np(obs) if self.venv.as_torch else obs)
+
+    def step_async(self, actions):
+        self._actions = actions
+
+    def step_wait(self):
+        v = self.venv
+        obs, rew, term, trunc, infos = v.step(self._actions)
+        obs, rew, trunc = (np.asarray(_np(x) if v.as_torch else x) for x in (obs, rew, trunc))
+        fin = infos["final_obs"]
+        fin = _np(fin) if v.as_torch else fin
+        power = infos["Power agent"]
+        power = _np(power) if v.as_torch else np.asarray(power)
+        out = [{"Power agent": float(power[i]), "TimeLimit.truncated": bool(trunc[i])} for i in range(self.num_envs)]
+        for i in np.nonzero(trunc)[0]:
+            out[i]["terminal_observation"] = fin[i]
+        return obs, rew, trunc.astype(bool), out
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        self.venv.close()
+
+    def seed(self, seed=None):
+        return self.venv.seed(seed)
+
+    def _indices(self, indices):
+        if indices is None:
+            return range(self.num_envs)
+        return [indices] if isinstance(indices, int) else indices
+
+    def get_attr(self, attr_name, indices=None):
+        return [getattr(self.venv, attr_name) for _ in self._indices(indices)]
+
+    def set_attr(self, attr_name, value, indices=None):
+        raise NotImplementedError("the farms of a batch share one configuration; construct a new WindFarmVecEnv")
+
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        raise NotImplementedError("per-env method calls do not exist on a batched GPU env; use the WindFarmVecEnv API")
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False for _ in self._indices(indices)]
+
+    def get_images(self):
+        return [None] * self.num_envs
+
+    def render(self, mode=None):
+        return None
 
 
 _INFO_KEYS = {
