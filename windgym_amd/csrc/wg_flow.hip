@@ -249,11 +249,14 @@ __device__ __forceinline__ void full_barrier() {
 // One DWMFlowSimulation.step() of model M0 up to the new rotor inflow (T[t].u/v/w/ti); power and the
 // measurement are done by the caller's per-turbine tail.
 template <int NT, int TURB, bool RES>
-__device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, TurbLds* __restrict__ T,
+// (the LDS arrays that lanes exchange data through — T, pair, tiap, tmask, jnl — are deliberately NOT __restrict__: for a
+// noalias pointer the compiler may carry a value this lane loaded earlier across lds_barrier()'s memory clobber and miss
+// what another lane stored in between; the read-only tables may be)
+__device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, TurbLds* T,
                                           const float* __restrict__ tabct,
                                           const float* __restrict__ rdy, const float* __restrict__ rdz,
-                                          float4* __restrict__ pair, float* __restrict__ tiap,
-                                          unsigned* __restrict__ tmask, const int* __restrict__ jnl,
+                                          float4* pair, float* tiap,
+                                          unsigned* tmask, int* jnl,
                                           const size_t pbase, const double ws,
                                           const float ti_f, const float ti_pow, const TurbCtx& tc, SlotRegs& sr,
                                           const PartLds& pl) {
@@ -320,7 +323,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         // just the quads that receive this step's new particles.  Pass B: one listed quad per lane, its three words
         // (py, rec_a, rec_b) requested together — one memory round trip per 64 quads, none for a resting chain.
         unsigned* ql = reinterpret_cast<unsigned*>(pair);
-        int* nq = const_cast<int*>(jnl) + N + 1;
+        int* nq = jnl + N + 1;              // (the same word serves as the candidate counter of the deficit phase)
         if (tid == 0) *nq = 0;
         lds_barrier<NT>();
         for (int t = tid; t < ((WG_ABLATE & 1) ? 0 : N); t += NT) {
@@ -682,7 +685,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         unsigned short* cl = reinterpret_cast<unsigned short*>(pair);
         float* def = reinterpret_cast<float*>(cl + ((TC * N + 7) & ~7));
         float* tiav = def + TC * N;
-        int* ncand = const_cast<int*>(jnl) + N + 1;
+        int* ncand = jnl + N + 1;
         // ambient inflow at the rotors (no wakes): thread t / the (t, sample) threads
         if (TURB == WG_TURB_BOX) {
             const int nitems = N << p.S_shift;
