@@ -387,6 +387,23 @@ struct WgRing {
     }
 };
 
+// sum of ring samples q = lo .. hi-1 in ascending order (bit-identical to the plain loop): the samples of a chunk of 8
+// are requested together, then added one after the other — a plain `s += r.at(q)` loop is a chain of dependent
+// LDS round trips (k_glue's observation phase: 25 + 10 of them per turbine for Env1.yaml).  Every index read is inside
+// [lo, hi): surplus entries of the last chunk re-read sample hi-1 and are ignored.
+__device__ inline float wg_ring_sum(const WgRing& r, const int lo, const int hi) {
+    float s = 0.f;
+    for (int q = lo; q < hi; q += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = r.at(min(q + k, hi - 1));
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (q + k < hi) s += v[k];
+    }
+    return s;
+}
+
 // turb_mes._scale_val in float32 (MesClass.py:324-326)
 __device__ inline float wg_scale(float v, float mn, float rng) {
     float t = v - mn;
@@ -419,8 +436,7 @@ __device__ inline int wg_mes_get(const wg_channel& c, bool cur_on, bool rol_on, 
                 if (pos > avail - W) pos = avail - W;
                 lo = pos; hi = pos + W;
             }
-            float s = 0.f;
-            for (int q = lo; q < hi; ++q) s += r.at(q);
+            const float s = wg_ring_sum(r, lo, hi);
             out[n++] = wg_scale(s / (float)(hi - lo), mn, rng);
         }
     }
@@ -430,13 +446,16 @@ __device__ inline int wg_mes_get(const wg_channel& c, bool cur_on, bool rol_on, 
 // turb_mes.calc_TI (MesClass.py:220-237), unscaled
 __device__ inline float wg_calc_ti(const WgRing& r) {
     const int avail = r.avail();
-    float U = 0.f;
-    for (int q = 0; q < avail; ++q) U += r.at(q);
+    float U = wg_ring_sum(r, 0, avail);
     U /= (float)avail;
     float m2 = 0.f;
-    for (int q = 0; q < avail; ++q) {
-        float dv = r.at(q) - U;
-        m2 += dv * dv;
+    for (int q = 0; q < avail; q += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = r.at(min(q + k, avail - 1));
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (q + k < avail) { const float dv = v[k] - U; m2 += dv * dv; }
     }
     return sqrtf(m2 / (float)avail) / U;
 }

@@ -67,8 +67,7 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
                         int pos = i * spacing; if (pos > avail - W) pos = avail - W;
                         lo = pos; hi = pos + W;
                     }
-                    float s = 0.f;
-                    for (int q = lo; q < hi; ++q) s += r.at(q);
+                    const float s = wg_ring_sum(r, lo, hi);
                     float v = WG_OBSV(s / (float)(hi - lo), p.sc_min[ch], p.sc_rng[ch]);
                     o[n] = v; if (obs2) obs2[(size_t)t * p.turb_obs + n] = v;
                     if (obs_m) obs_m[(size_t)t * p.obs_dim_multi + n] = v;
@@ -125,8 +124,7 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
                             int pos = i * spacing; if (pos > avail - W) pos = avail - W;
                             lo = pos; hi = pos + W;
                         }
-                        float s = 0.f;
-                        for (int q = lo; q < hi; ++q) s += r.at(q);
+                        const float s = wg_ring_sum(r, lo, hi);
                         float v = WG_OBSV(s / (float)(hi - lo), p.sc_min[ch], rng);
                         o[n] = v; if (o2) o2[n] = v; ++n;
                     }
@@ -179,7 +177,10 @@ __device__ inline void stage_rings(const WgParams& p, const WgPtrs& d, int ctx_i
             }
         }
     }
-    for (int b0 = lane; b0 < p.fring_stride; b0 += WG_WAVE * U) {
+    // (the farm rings are staged only if something reads them: farm-level observations, the per-agent blocks of the
+    // PettingZoo facade — Env1.yaml observes turbines only, and the copy is a memory round trip of its own)
+    const int n_farm = (p.farm_obs > 0 || d.multi_out != nullptr) ? p.fring_stride : 0;
+    for (int b0 = lane; b0 < n_farm; b0 += WG_WAVE * U) {
         float v[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) { const int i = b0 + k * WG_WAVE; v[k] = i < p.fring_stride ? gf[i] : 0.f; }
@@ -256,7 +257,8 @@ __device__ inline void env_writeback(WgEnv& env, const EnvHot& ev, const int lan
 // ===================================================================================================
 // k_glue: one wave per env.  phase 0 = after a flow step (step()); phase 1 = end of reset().
 // ===================================================================================================
-__global__ void __launch_bounds__(WG_BLOCK)
+// (4 waves per SIMD = 16 per CU: at 4096 envs per GPU every env's wave is resident at once)
+__global__ void __launch_bounds__(WG_BLOCK, 4)
 k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restrict__ mask,
        float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out,
        float* __restrict__ final_obs_out, const int lds_floats_per_wave) {
@@ -339,6 +341,9 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     }
     float* met = d.metrics + (size_t)e * WG_N_METRICS;
     float l_met = lane < WG_N_METRICS ? met[lane] : 0.f;
+    // (first 64 elements of the power deques: requested with the loads above, consumed by the deque loop below)
+    const float pf_f = lane < p.power_avg ? fq[lane] : 0.f;
+    const float pf_b = (p.F == 2 && lane < p.power_avg) ? bq[lane] : 0.f;
     // a background context flagged at the previous truncation has been initialised by the k_flow launch of this step
     if (p.autoreset && lane == 0) {
         WgCtx& bcx = d.ctx[e * 2 + (live ^ 1)];
@@ -361,10 +366,10 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         const int nb = ev.base_pow_n < p.power_avg ? ev.base_pow_n : p.power_avg;
         const int wsz = p.power_avg / 10;
         for (int i = lane; i < p.power_avg; i += WG_WAVE) {
-            const float fv = i == fslot ? fp : fq[i];
+            const float fv = i == fslot ? fp : (i == lane ? pf_f : fq[i]);
             if (i < nf) fsum += (double)fv;
             if (p.F == 2) {
-                const float bv = i == bslot ? bp : bq[i];
+                const float bv = i == bslot ? bp : (i == lane ? pf_b : bq[i]);
                 if (i < nb) bsum += (double)bv;
             }
             if (p.reward_mode == WG_REW_POWER_DIFF && i < nf) {
