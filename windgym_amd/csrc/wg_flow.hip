@@ -1105,6 +1105,10 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         if (!RES) l_jn = d.jneed[(size_t)ctx_id * N + t_own];      // chain pruning by predicate: streaming variant only
     };
     load_state();
+    // (first elements of the read-only tables: requested with the state loads — copied to LDS after the decision below, a
+    // separate copy loop there costs every workgroup a second memory round trip)
+    const float pf_tp = tid < p.n_tab ? d.tab_power[tid] : 0.f, pf_tc = tid < p.n_tab ? d.tab_ct[tid] : 0.f;
+    const float pf_dy = tid < p.S ? d.rotor_dy[tid] : 0.f, pf_dz = tid < p.S ? d.rotor_dz[tid] : 0.f;
     if (mode == WG_MODE_STEP && farm == 0) l_act = actions[(size_t)e * N + t_own];
 
     const bool is_live = (c == env_live);
@@ -1195,8 +1199,10 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         q.sws = 0.f; q.swd = 0.f; q.syaw = 0.f; q.sp = 0.f;
     }
     if (tid == 0) jnl[N] = 0;
-    for (int i = tid; i < p.n_tab; i += NT) { tabp[i] = d.tab_power[i]; tabct[i] = d.tab_ct[i]; }
-    for (int i = tid; i < p.S; i += NT) { rdy[i] = d.rotor_dy[i]; rdz[i] = d.rotor_dz[i]; }
+    if (tid < p.n_tab) { tabp[tid] = pf_tp; tabct[tid] = pf_tc; }
+    if (tid < p.S) { rdy[tid] = pf_dy; rdz[tid] = pf_dz; }
+    for (int i = tid + NT; i < p.n_tab; i += NT) { tabp[i] = d.tab_power[i]; tabct[i] = d.tab_ct[i]; }
+    for (int i = tid + NT; i < p.S; i += NT) { rdy[i] = d.rotor_dy[i]; rdz[i] = d.rotor_dz[i]; }
 
     const float ti_pow = fast_pow(ti_f, p.tic);
 
