@@ -5,9 +5,9 @@ export TMPDIR=/tmp WG_NOCHECK=1
 for n in "$@"; do
   if [ "$n" = "tree" ]; then lib=""; else lib=$PWD/windgym_amd/variants/lib_$n.so; fi
   export WG_LIB=$lib
-  python3 bench.py --no-cpu --reps 3 2>/dev/null | python tools/benchline.py $n
+  python3 bench.py --no-cpu --reps 3 $BARGS 2>/dev/null | python tools/benchline.py $n
   for c in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/abl; rocprofv3 --pmc $c -d /tmp/abl -o p -- python3 bench.py --steps 60 --warmup 10 --reps 1 --preroll 300 --no-cpu > /dev/null 2>&1
+    rm -rf /tmp/abl; rocprofv3 --pmc $c -d /tmp/abl -o p -- python3 bench.py --steps 60 --warmup 10 --reps 1 --preroll 300 --no-cpu $BARGS > /dev/null 2>&1
     python3 - <<PY
 import sqlite3, glob
 db = sqlite3.connect(glob.glob('/tmp/abl/**/p_results.db', recursive=True)[0])
