@@ -886,29 +886,17 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     // line comes from HBM and these gathers were half of the kernel's traffic -> the frozen record is
                     // read from its 16-byte copy (written once, at emission): the two bracketing particles are 32
                     // contiguous bytes, a pair touches two lines (record, py) instead of four (py, u_e, rec_a, rec_b)
-                    float py0 = 0.f, py1 = 0.f, u0, u1;
+                    const float py0 = RES ? pl.py[i0] : gpy[i0], py1 = RES ? pl.py[i1] : gpy[i1];
+                    float u0, u1;
                     unsigned a0, a1, b0_, b1_;
-                    bool go = true;
-                    if (RES) {
-                        py0 = pl.py[i0]; py1 = pl.py[i1];
+                    if (RES) {      // the farm's particle state is in LDS: no global gathers at all
                         u0 = pl.ue[i0]; u1 = pl.ue[i1];
                         a0 = pl.ra[i0]; a1 = pl.ra[i1]; b0_ = pl.rb[i0]; b1_ = pl.rb[i1];
                     } else if (AOS) {
-                        // two stages: the record line first — with the ACTUAL wake width of the bracketing particles the
-                        // chain's excursion bound excludes three of four candidates (cfg3: 1970 gathered pairs per farm
-                        // step, 500 contributing: the pre-check above has to use the chain's largest k ever) — and the
-                        // py line only for the pairs that survive.  |y_t - y_c| >= |y_t - y_s| - bd, so a rejected pair
-                        // could not have passed the exact cut-off either: the result is unchanged.
                         const uint4 q0 = gr4[i0], q1 = gr4[i1];
                         u0 = __uint_as_float(q0.z); u1 = __uint_as_float(q1.z);
                         a0 = q0.x; a1 = q1.x; b0_ = q0.y; b1_ = q1.y;
-                        const float sp_r = ((1.0f - wgt) * rec_k(a0) + wgt * rec_k(a1)) * ((float)dx * p.inv_D) +
-                                           ((1.0f - wgt) * rec_eps(b0_) + wgt * rec_eps(b1_));
-                        const float dy_min = fabsf((float)(T[t].yr - T[s2].yr)) - T[s2].bd;
-                        go = dy_min <= p.R_rot + 5.0f * sp_r * p.D + 1.0e-3f * p.D;
-                        if (go) { py0 = gpy[i0]; py1 = gpy[i1]; }
                     } else {
-                        py0 = gpy[i0]; py1 = gpy[i1];
                         u0 = gue[i0]; u1 = gue[i1];
                         a0 = gra[i0]; a1 = gra[i1]; b0_ = grb[i0]; b1_ = grb[i1];
                     }
@@ -917,7 +905,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     const float w0 = 1.0f - wgt, w1 = wgt;
                     const float yc = w0 * py0 + w1 * py1;
                     float zc = p.hub;
-                    if (TURB != WG_TURB_NONE && go) zc = RES ? w0 * pl.pz[i0] + w1 * pl.pz[i1] : w0 * d.pz[pbase + i0] + w1 * d.pz[pbase + i1];
+                    if (TURB != WG_TURB_NONE) zc = RES ? w0 * pl.pz[i0] + w1 * pl.pz[i1] : w0 * d.pz[pbase + i0] + w1 * d.pz[pbase + i1];
                     const float kv = w0 * k0 + w1 * k1;
                     const float epv = w0 * e0 + w1 * e1;
                     const float xd = (float)dx * p.inv_D;
@@ -926,7 +914,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     const float yt = (float)T[t].yr;
                     const float rc2 = (yt - yc) * (yt - yc) + (p.hub - zc) * (p.hub - zc);
                     const float rcut = p.R_rot + 5.0f * sig;
-                    if (go && rc2 <= rcut * rcut) {
+                    if (rc2 <= rcut * rcut) {
                         const float ctv = w0 * c0 + w1 * c1;
                         const float uev = w0 * u0 + w1 * u1;
                         const float cf = m0_cfrac(ctv, sp);
