@@ -350,6 +350,15 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         const bool small = p.N <= 32 && tc == p.N;
         f.res = small ? 1 : 0;
         f.block = small ? 64 : 256;        // small farms: single-wave workgroups (no s_barrier at all): cfg2 80 vs 91 us at 128 threads
+        // large farms with steady inflow: the compact / pair-major variant at 256 threads, pairs staged per chunk of
+        // targets (cfg3: 206 vs 224 us once the candidate pre-check is tight — the compacted candidate list then holds
+        // ~520 of the 6400 pairs, which the sample-major phases walk in full); turbulent large farms keep the legacy one
+        if (!small && p.N <= 255 && p.turb_mode == WG_TURB_NONE) f.res = 1;
+        // the compact steady advection lists (turbine, quad-in-ring) in 16 bits: both must fit
+        int ql_shift = 0;
+        while ((1 << ql_shift) < p.P / 4) ++ql_shift;
+        const bool ql_fits = ((long)p.N << ql_shift) <= 65536;
+        if (!ql_fits) { f.res = 0; f.block = 256; }
         if (const char* ev = getenv("WG_FLOW_BLOCK")) {       // tests: force an instantiation
             const int b = atoi(ev);
             if (b == 256) { f.res = 0; f.block = 256; }
@@ -358,11 +367,13 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         if (const char* ev = getenv("WG_FLOW_RES")) {          // experiments: compact / pair-major variant for any farm size
             if (atoi(ev) != 0 && p.N <= 255) { f.res = 1; if (!small) f.block = 256; } else if (atoi(ev) == 0) { f.res = 0; f.block = 256; }
         }
+        if (f.res && !ql_fits) { f.res = 0; f.block = 256; }       // (after the env overrides too)
+        f.ql_shift = ql_shift;
         p.compact = f.res;
         // LDS carve.  The staging region of the deficit phases doubles as the quad list of the compact steady advection
-        // pass (one 32-bit entry per quad of the farm's rings: at most NP bytes)
+        // pass (one 16-bit entry per quad of the farm's rings: at most NP / 2 bytes)
         size_t off = sizeof(float) * 4 * (size_t)tc * p.N;
-        if (f.res) off = std::max(off, ((size_t)p.NP + 15) & ~(size_t)15);
+        if (f.res) off = std::max(off, ((size_t)p.NP / 2 + 15) & ~(size_t)15);
         f.lds_off_turb = (int)off; off += (size_t)WG_TURB_LDS_BYTES * p.N;
         off = (off + 15) & ~(size_t)15;
         f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S) + sizeof(unsigned) * WG_MASK_WORDS * (size_t)tc + sizeof(float) * (size_t)tc * p.N;

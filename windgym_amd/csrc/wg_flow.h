@@ -23,6 +23,7 @@ struct FlowP {
     int pstride;                  // floats between the particle blocks of consecutive farm slots (>= NP, see wg_create)
     int target_chunk;             // targets whose pair parameters are staged in LDS at once
     int lds_off_turb, lds_off_tab, lds_bytes;
+    int ql_shift;                 // compact steady advection: quad-list entry = turbine << ql_shift | quad index in its ring (16 bits)
     int duo, duo_off_turb, duo_lds;   // k_flow_duo (both farms of a context in one wave): enabled, LDS carve (wg_flow_duo.inc)
     float dt, D, inv_D, hub, dpart_f, R_rot, inv_N, inv_S, inv_P;
     double dt_d, dpart, inv_dpart;

@@ -322,24 +322,27 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         // followed it.  Pass A (LDS only): turbine t lists its quads — all of them if the chain may move, otherwise
         // just the quads that receive this step's new particles.  Pass B: one listed quad per lane, its three words
         // (py, rec_a, rec_b) requested together — one memory round trip per 64 quads, none for a resting chain.
-        unsigned* ql = reinterpret_cast<unsigned*>(pair);
+        // (16-bit list entries: turbine << ql_shift | quad index inside the turbine's ring; the host selects this variant
+        // only where both fit)
+        unsigned short* ql = reinterpret_cast<unsigned short*>(pair);
+        const int qsh = p.ql_shift;
         int* nq = jnl + N + 1;              // (the same word serves as the candidate counter of the deficit phase)
         if (tid == 0) *nq = 0;
         lds_barrier<NT>();
         for (int t = tid; t < ((WG_ABLATE & 1) ? 0 : N); t += NT) {
             const TurbLds& tq = T[t];
-            const int R = tq.rlen, q0 = tq.roff >> 2, nqd = R >> 2;
+            const int R = tq.rlen, nqd = R >> 2;
             const bool moving = tq.mvl != 0u && (int)(sr.n_emitted - tq.mvl) < R;
-            const unsigned tag = (unsigned)t << 24;
+            const unsigned tag = (unsigned)t << qsh;
             if (moving || n_emit >= 4 || n_emit >= R) {
                 const int base = atomicAdd(nq, nqd);
-                for (int i = 0; i < nqd; ++i) ql[base + i] = tag | (unsigned)(q0 + i);
+                for (int i = 0; i < nqd; ++i) ql[base + i] = (unsigned short)(tag | (unsigned)i);
             } else if (n_emit > 0) {
                 int prev = -1;
                 for (int e = 0; e < n_emit; ++e) {
                     int r = tq.head + 1 + e; if (r >= R) r -= R;
-                    const int qd = q0 + (r >> 2);
-                    if (qd != prev) ql[atomicAdd(nq, 1)] = tag | (unsigned)qd;
+                    const int qd = r >> 2;
+                    if (qd != prev) ql[atomicAdd(nq, 1)] = (unsigned short)(tag | (unsigned)qd);
                     prev = qd;
                 }
             }
@@ -348,13 +351,14 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         const int nlist = *nq;
         for (int c = tid; c < nlist; c += NT) {
             const unsigned ent = ql[c];
-            const int q = (int)(ent & 0xffffffu), t = (int)(ent >> 24);
+            const int t = (int)(ent >> qsh), kq = (int)(ent & ((1u << qsh) - 1u));
+            TurbLds& tq = T[t];
+            const int q = (tq.roff >> 2) + kq;
             const float4 py = reinterpret_cast<const float4*>(pl.py)[q];
             const uint4 ra = reinterpret_cast<const uint4*>(pl.ra)[q];
             const uint4 rb = reinterpret_cast<const uint4*>(pl.rb)[q];
-            TurbLds& tq = T[t];
             const int R = tq.rlen, hd = tq.head;
-            const int r0 = 4 * q - tq.roff;
+            const int r0 = 4 * kq;
             int j0 = hd - r0; if (j0 < 0) j0 += R;             // age of ring slot r0 (slot r0+i: j0-i)
             int e0 = r0 - hd - 1; if (e0 < 0) e0 += R;         // emission index of slot r0 (r0+i: e0+i)
             const bool emits = (e0 < n_emit) || (n_emit > 0 && e0 + 3 >= R);   // wraps past R-1 -> 0
