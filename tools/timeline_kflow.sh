@@ -27,3 +27,4 @@ for x in range(8):
     span = e1.max() - s1.min()
     print(f'XCD {x}: active blocks {len(s1):5d}  span {span:8d} ticks  mean block {t1.mean():7.0f}  resident = sum/span {t1.sum()/span:6.1f}  '
           f'last start at {100*(s1.max()-s1.min())/span:5.1f}% of span')
+PY
