@@ -412,8 +412,17 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             constexpr bool POW2 = decltype(pow2_tag)::value;
             constexpr int U = 4;
             for (int b0 = tid; b0 < pl.L; b0 += NT * U) {
-                float pyv[U], pzv[U], fv[U], fw[U];
+                float pyv[U], pzv[U], fv[U], fw[U], vls[U], wls[U];
+                unsigned ras[U], rbs[U];
                 int jv[U], tv[U], ev[U];
+                // (every streamed word of the U slots is requested before the first box lookup waits for py / pz: the
+                // filter state and the record then arrive under the lookups' round trip instead of after it)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ix = min(b0 + u * NT, pl.L - 1);
+                    pyv[u] = pl.py[ix]; pzv[u] = pl.pz[ix];
+                    vls[u] = pl.vl[ix]; wls[u] = pl.wl[ix]; ras[u] = pl.ra[ix]; rbs[u] = pl.rb[ix];
+                }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int ix = min(b0 + u * NT, pl.L - 1);
@@ -423,7 +432,6 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     const int r = ix - tq.roff;
                     int j = tq.head - r; if (j < 0) j += R;
                     jv[u] = j; tv[u] = t; ev[u] = R - 1 - j;       // = (r - head - 1) mod R: emission index of this slot
-                    pyv[u] = pl.py[ix]; pzv[u] = pl.pz[ix];
                     if (TURB != WG_TURB_RANDOM) {
                         const float xrel = s_off_f + (float)j * p.dpart_f;
                         const double bx = tq.xr + (double)xrel + xshift, by = (double)pyv[u] + tc.oy, bz = (double)pzv[u];
@@ -438,8 +446,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     if (ix >= pl.L) continue;
                     const int j = jv[u];
                     TurbLds& tq = T[tv[u]];
-                    float vlv = pl.vl[ix], wlv = pl.wl[ix];
-                    const unsigned rav = pl.ra[ix], rbv = pl.rb[ix];
+                    float vlv = vls[u], wlv = wls[u];
+                    const unsigned rav = ras[u], rbv = rbs[u];
                     if (j < n_valid) {
                         const float xrel = s_off_f + (float)j * p.dpart_f;
                         const float sp = rec_k(rav) * (xrel * p.inv_D) + rec_eps(rbv);
