@@ -372,11 +372,23 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         p.compact = f.res;
         // LDS carve.  The staging region of the deficit phases doubles as the quad list of the compact steady advection
         // pass (one 16-bit entry per quad of the farm's rings: at most NP / 2 bytes)
+        // Compact variant: the staging of a chunk of targets is 10 bytes per (target, source) pair (16-bit candidate
+        // list, deficit, added TI) and the per-pair added-TI array of the sample-major phases is not needed — large farms
+        // spend that room on more targets per chunk (cfg3: 27 instead of 12 -> 3 chunks instead of 7, same LDS).
         size_t off = sizeof(float) * 4 * (size_t)tc * p.N;
-        if (f.res) off = std::max(off, ((size_t)p.NP / 2 + 15) & ~(size_t)15);
+        if (f.res) {
+            const size_t ql = ((size_t)p.NP / 2 + 15) & ~(size_t)15;
+            if (!small) {
+                const size_t budget = std::max(ql, off) + sizeof(float) * (size_t)tc * p.N;
+                const int fit = (int)((budget - 16) / (10 * (size_t)p.N));
+                tc = std::max(tc, std::min(p.N, fit));
+                f.target_chunk = tc;
+            }
+            off = std::max(ql, ((size_t)10 * tc * p.N + 16 + 15) & ~(size_t)15);
+        }
         f.lds_off_turb = (int)off; off += (size_t)WG_TURB_LDS_BYTES * p.N;
         off = (off + 15) & ~(size_t)15;
-        f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S) + sizeof(unsigned) * WG_MASK_WORDS * (size_t)tc + sizeof(float) * (size_t)tc * p.N;
+        f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S) + sizeof(unsigned) * WG_MASK_WORDS * (size_t)tc + (f.res ? 0 : sizeof(float) * (size_t)tc * p.N);
         off += sizeof(int) * ((size_t)p.N + 2);      // chain-pruning ages + the particle counter + the candidate counter
         // k_flow_duo: both farms of a context in one single-wave workgroup (lane = farm * N + turbine).  It executes 37 %
         // fewer VALU instructions per farm step, which pays where the per-workgroup fixed costs dominate (cfg4, 3x3 x P=96:

@@ -1184,7 +1184,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     float* rdz = rdy + p.S;
     unsigned* tmask = reinterpret_cast<unsigned*>(rdz + p.S);
     float* tiap = reinterpret_cast<float*>(tmask + p.target_chunk * WG_MASK_WORDS);
-    int* jnl = reinterpret_cast<int*>(tiap + p.target_chunk * N);          // [N] chain pruning ages
+    int* jnl = reinterpret_cast<int*>(tiap + (RES ? 0 : p.target_chunk * N));   // [N] chain pruning ages (tiap: sample-major phases only)
     PartLds pl;
     if (RES) {
         pl.py = d.py + pbase; pl.ra = d.rec_a + pbase; pl.rb = d.rec_b + pbase;
