@@ -91,37 +91,74 @@ def host_cores():
     return max(1, n)
 
 
+def _cpu_rate(orc, acts, seconds, max_steps):
+    """env-steps/s of the oracle over >= `seconds` of wall time (3 untimed steps first)."""
+    n_act = len(acts)
+    for i in range(3):
+        orc.step(acts[i % n_act])
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        orc.step(acts[steps % n_act])
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or (max_steps and steps >= max_steps):
+            break
+    return orc.B * steps / el, steps, el
+
+
 def cpu_baseline(args):
-    """The oracle's C port (OpenMP over envs, one thread per usable core, passive waits) on a bounded sample of
-    the same workload: >= 2 envs per thread, ~10-15 s of CPU work."""
+    """The oracle's C port timed on the host cores of this box, in this run (SURVEY.md §8d "CPU reference timing"):
+      * the SAME workload as the GPU line, envs spread over all usable cores with OpenMP (one thread per core, passive
+        waits), fp64 (`value`) and fp32 (`f32_value`);
+      * cfg1 (BASELINE.json configs[0]: 2 turbines, 2turb.yaml sensors, B = 1) on ONE core, fp64 and fp32 — the analogue
+        of one reference env process.
+    Each leg runs for a fixed wall time (no step cap), so the sample is seconds of CPU work, and the env count is large
+    enough (>= 8 per thread) that the synchronous resets of single envs average out."""
     import numpy as np
     from oracle import oracle as om
     om.build()
     cores = min(host_cores(), 64)
-    n = args.cpu_envs if args.cpu_envs else max(64, 2 * cores)
-    cfg = make_cfg(n, autoreset=True, farms2=not args.one_farm, workload=args.workload)
-    orc = om.Oracle(cfg, "f32" if args.cpu_f32 else "f64")
-    orc.set_threads(cores)
-    if args.workload == "cfg5":
-        from windgym_amd.mann import generate_mann_box
-        orc.set_turbulence_box(generate_mann_box((512, 128, 32), (3.0, 3.0, 3.0), seed=1234), (3.0, 3.0, 3.0))
-    orc.reset(seeds=1234 + np.arange(n))
+    n = args.cpu_envs if args.cpu_envs else max(128, 8 * cores)
     rng = np.random.default_rng(0)
-    acts = rng.uniform(-1, 1, size=(8, n, cfg.n_turb)).astype(np.float32)
-    for i in range(3):
-        orc.step(acts[i % 8])
-    t0 = time.perf_counter()
-    steps = 0
-    while True:
-        orc.step(acts[steps % 8])
-        steps += 1
-        el = time.perf_counter() - t0
-        if el > args.cpu_seconds or steps >= args.cpu_max_steps:
-            break
-    return {"value": n * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {steps} steps of the same {args.workload} workload (oracle C port, "
-                      f"{'fp32' if args.cpu_f32 else 'fp64'}, OpenMP over envs on {cores} threads = usable cores "
-                      f"(affinity mask capped by the cgroup quota), passive waits, after reset)"}
+    legs = {}
+    for prec in ("f64", "f32"):
+        cfg = make_cfg(n, autoreset=True, farms2=not args.one_farm, workload=args.workload)
+        orc = om.Oracle(cfg, prec)
+        orc.set_threads(cores)
+        if args.workload == "cfg5":
+            from windgym_amd.mann import generate_mann_box
+            orc.set_turbulence_box(generate_mann_box((512, 128, 32), (3.0, 3.0, 3.0), seed=1234), (3.0, 3.0, 3.0))
+        orc.reset(seeds=1234 + np.arange(n))
+        acts = rng.uniform(-1, 1, size=(8, n, cfg.n_turb)).astype(np.float32)
+        legs[prec] = _cpu_rate(orc, acts, args.cpu_seconds if prec == "f64" else 0.6 * args.cpu_seconds,
+                               args.cpu_max_steps)
+        orc.close()
+    # cfg1: the reference's own CPU-runnable case, one env on one core
+    from windgym_amd import presets
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.turbine import V80
+    cfg1 = {}
+    for prec in ("f64", "f32"):
+        c1 = EnvConfig(turbine=V80(), yaml_dict=presets.two_turb_config(), turbtype="None", n_envs=1, autoreset=True,
+                       n_passthrough=5, n_rotor_pts=16)
+        orc = om.Oracle(c1, prec)
+        orc.set_threads(1)
+        orc.reset(seeds=[1234])
+        acts = rng.uniform(-1, 1, size=(64, 1, c1.n_turb)).astype(np.float32)
+        cfg1[prec] = _cpu_rate(orc, acts, 0.25 * args.cpu_seconds, 0)
+        orc.close()
+    v64, s64, e64 = legs["f64"]
+    v32, s32, e32 = legs["f32"]
+    return {"value": v64, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "f32_value": v32,
+            "cfg1_f64": cfg1["f64"][0], "cfg1_f32": cfg1["f32"][0], "cfg1_cores": 1,
+            "seconds": {"f64": e64, "f32": e32, "cfg1_f64": cfg1["f64"][2], "cfg1_f32": cfg1["f32"][2]},
+            "sample": f"{n} envs x {s64} steps ({e64:.1f} s, fp64) and x {s32} steps ({e32:.1f} s, fp32) of the same "
+                      f"{args.workload} workload: oracle C port, OpenMP over envs on {cores} threads = usable cores "
+                      f"(affinity mask capped by the cgroup quota), passive waits, after reset, synchronous per-env "
+                      f"resets inside the sample; cfg1 = 2 turbines / 2turb.yaml sensors (O=200) / B=1 on one core, "
+                      f"{cfg1['f64'][1]} + {cfg1['f32'][1]} steps, incl. one ctypes call per step"}
 
 
 def free_port():
@@ -149,10 +186,13 @@ def parse():
     ap.add_argument("--full-chains", action="store_true", help="no chain pruning: advect all P slots of every chain")
     ap.add_argument("--no-autoreset", action="store_true",
                     help="diagnostic only: no background episodes (the run must stay shorter than the shortest episode)")
-    ap.add_argument("--cpu-envs", type=int, default=0, help="envs of the CPU sample (default: max(64, 2 x cores))")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--cpu-max-steps", type=int, default=400)
-    ap.add_argument("--cpu-f32", action="store_true")
+    ap.add_argument("--cpu-envs", type=int, default=0, help="envs of the CPU sample (default: max(128, 8 x cores))")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0,
+                    help="wall time of the fp64 leg of the CPU sample (fp32: 0.6 x, cfg1 legs: 0.25 x each)")
+    ap.add_argument("--cpu-max-steps", type=int, default=0, help="optional step cap of the CPU legs (0 = none)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="weak: --envs (default: the workload's) per GPU; strong: that many envs in TOTAL, split over "
+                         "the N ranks (BASELINE.json's '4096 envs sharded across 8')")
     return ap.parse_args()
 
 
@@ -205,7 +245,16 @@ def main():
 
     from windgym_amd import binding
     from windgym_amd.parallel import ShardedMetrics
-    B = args.envs if args.envs else WORKLOADS[args.workload][0]
+    from windgym_amd.parallel import shard_range
+    B_flag = args.envs if args.envs else WORKLOADS[args.workload][0]
+    if args.scaling == "strong":
+        # a fixed global batch, rank g owns the contiguous shard [lo, hi) of the env axis
+        env_lo, env_hi = shard_range(B_flag, rank, world)
+        if env_hi <= env_lo:
+            sys.exit(f"bench.py: --scaling strong: {B_flag} envs cannot be split over {world} ranks")
+    else:
+        env_lo, env_hi = rank * B_flag, (rank + 1) * B_flag
+    B = env_hi - env_lo
     cfg = make_cfg(B, autoreset=not args.no_autoreset, farms2=not args.one_farm, workload=args.workload)
     cfg.advect_full_chains = bool(args.full_chains)
     env = binding.HipBatch(cfg, device=dev.index)
@@ -216,7 +265,7 @@ def main():
         spec = reference_box_spec("MannFixed", cfg.D)
         env.set_turbulence_box(generate_mann_box_torch(device=dev, **spec), spec["dxyz"])
     # env i of the global batch is seeded 1234 + i regardless of the number of GPUs
-    seeds = 1234 + rank * B + np.arange(B)
+    seeds = 1234 + env_lo + np.arange(B)
     env.reset(seeds=seeds)
     gen = torch.Generator(device="cpu").manual_seed(0 + rank)
     n_act = 16
@@ -275,7 +324,7 @@ def main():
     m = metrics.all_reduce()            # the only collective on the path: 8 floats
 
     el_med = sorted(rep_s)[len(rep_s) // 2]
-    total_envs = B * world
+    total_envs = B_flag if args.scaling == "strong" else B * world
     value = total_envs * args.steps / el_med
 
     if rank == 0:
@@ -289,30 +338,36 @@ def main():
         per_particle = 16.0 + (24.0 + 64.0 if args.workload == "cfg5" else 0.0)
         per_farm_step = cfg.n_turb * 72.0 + (cfg.n_turb * cfg.n_rotor_pts * 96.0 if args.workload == "cfg5" else 0.0)
         alg_bytes_flow = particles * per_particle + flow_steps * per_farm_step
-        slot_bytes_flow = flow_steps * (cfg.n_turb * cfg.n_particles * per_particle + per_farm_step)
         bytes_per_flow_step = alg_bytes_flow / flow_steps if flow_steps > 0 else 0.0
         achieved = alg_bytes_flow / (flow_ms * 1e-3) / 1e9 if flow_ms > 0 else 0.0
-        # HBM bytes per k_flow launch from the rocprofv3 PMC passes of this same command (separate runs:
-        # tools/profile_kflow.sh -> profiles/r02_kflow_traffic.json, r02_<cfgN>_kflow_traffic.json); only quoted for the
-        # profiled workloads at their profiled size (the workload's default env count, baseline farm on)
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r02_kflow_traffic.json" if args.workload == "cfg2"
-                          else f"r02_{args.workload}_kflow_traffic.json")
-        if os.path.exists(tf) and args.envs is None and F == 2:
-            try:
-                traffic = json.load(open(tf))["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+        # HBM bytes per k_flow launch: NOT measured in this run — read from the committed summary of the rocprofv3 PMC
+        # passes of this same command (separate runs, as the counters require: tools/profile_kflow.sh ->
+        # profiles/r03_<cfgN>_kflow_traffic.json); `traffic_source` names the file.  Only quoted for the profiled
+        # workloads at their profiled size (the workload's default env count, baseline farm on, one GPU).
+        traffic = traffic_source = None
+        for rnd in ("r03", "r02"):
+            tf = os.path.join(ROOT, "profiles", f"{rnd}_kflow_traffic.json" if args.workload == "cfg2" and rnd == "r02"
+                              else f"{rnd}_{args.workload}_kflow_traffic.json")
+            if os.path.exists(tf) and args.envs is None and F == 2 and world == 1:
+                try:
+                    traffic = json.load(open(tf))["hbm_bytes_per_launch"]
+                    traffic_source = (f"{os.path.relpath(tf, ROOT)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "
+                                      f"this command, FETCH_SIZE x 2 (gfx950); not collected in this run")
+                    break
+                except Exception:
+                    traffic = traffic_source = None
         out = {
             "metric": "env-steps/sec (whole node), 16-turbine farm x 4096 envs" if args.workload == "cfg2"
                       else f"env-steps/sec (whole node), {args.workload}",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": el_med / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": el_med / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "storage": "state fp32; the frozen emission record of a wake particle (ct, k, eps, hv) is stored as 4 x 16-bit "
+                       "fixed point (8 B per particle), positions in fp64",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload][1]} "
                                    f"(O={env.obs_dim}), {B} envs/GPU, F={F} farms/env "
                                    f"({'Baseline reward' if F == 2 else 'Power_avg reward'}), P={cfg.n_particles}, "
-                                   f"S={cfg.n_rotor_pts}, same-step autoreset on",
+                                   f"S={cfg.n_rotor_pts}, same-step autoreset on; f32 arithmetic, u16 emission record",
                        "envs_per_gpu": B, "n_turb": cfg.n_turb, "farms_per_env": F,
                        "parallelism": f"env-axis shard x{world}"},
             "reps": args.reps, "preroll": preroll,
@@ -320,13 +375,13 @@ def main():
             "gpu_ms_per_step": flow_ms + glue_ms,
             "rccl": rccl,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic, "kernel": "k_flow",
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "k_flow_duo" if env.flow_variant()[2] else "k_flow",
                          "kernel_ms": flow_ms, "glue_kernel_ms": glue_ms, "launches_timed": n_launch,
                          "algorithmic_bytes_per_launch": alg_bytes_flow, "farm_flow_steps_per_launch": flow_steps,
                          "particles_needed_per_launch": particles,
                          "particle_slots_per_launch": flow_steps * cfg.n_turb * cfg.n_particles,
-                         "bytes_per_farm_flow_step": bytes_per_flow_step,
-                         "frac_all_slots": (slot_bytes_flow / (flow_ms * 1e-3) / 1e9 / 8000.0) if flow_ms > 0 else 0.0},
+                         "bytes_per_farm_flow_step": bytes_per_flow_step},
             "episode_metrics": {k: float(v) for k, v in m.items()},
         }
         if world == 1 and not args.no_cpu:

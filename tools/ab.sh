@@ -4,6 +4,6 @@ args=$1; shift
 for rep in 1 2; do
   for n in "$@"; do
     if [ "$n" = "tree" ]; then lib=""; else lib=$PWD/windgym_amd/variants/lib_$n.so; fi
-    WG_LIB=$lib python3 bench.py --no-cpu $args 2>/dev/null | python tools/benchline.py $n
+    WG_DEBUG_HOOKS=1 WG_LIB=$lib python3 bench.py --no-cpu $args 2>/dev/null | python tools/benchline.py $n
   done
 done

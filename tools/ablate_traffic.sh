@@ -1,7 +1,7 @@
 # usage (GPU box): bash tools/ablate_traffic.sh name1 name2 ...  (variants built with tools/build_variant.sh; "tree" = in-tree lib)
 # -> per variant: bench line (k_flow us) and FETCH_SIZE / WRITE_SIZE per k_flow launch (KiB)
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp WG_NOCHECK=1
+export TMPDIR=/tmp WG_NOCHECK=1 WG_DEBUG_HOOKS=1
 for n in "$@"; do
   if [ "$n" = "tree" ]; then lib=""; else lib=$PWD/windgym_amd/variants/lib_$n.so; fi
   export WG_LIB=$lib

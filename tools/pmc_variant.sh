@@ -1,6 +1,6 @@
 # usage (GPU box): bash tools/pmc_variant.sh "<counters>" name1 name2 ...  -> per-launch averages for k_flow
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp WG_NOCHECK=1
+export TMPDIR=/tmp WG_NOCHECK=1 WG_DEBUG_HOOKS=1
 C=$1; shift
 for n in "$@"; do
   if [ "$n" = "tree" ]; then lib=""; else lib=$PWD/windgym_amd/variants/lib_$n.so; fi

@@ -8,14 +8,24 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
 from .config import INFO, INFO_INT, WG_N_METRICS, CConfig, EnvConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# WG_LIB: alternative build of the same library (same-box A/B measurements of kernel variants, tools/ab.sh)
-LIB_PATH = os.environ.get("WG_LIB") or os.path.join(_HERE, "libwindgym_hip.so")
+# Measurement hooks, honoured ONLY with WG_DEBUG_HOOKS=1 (tools/ab.sh sets it) and announced on stderr when active:
+#   WG_LIB      alternative build of the same library (same-box A/B measurements of kernel variants)
+#   WG_NOCHECK  HipBatch.check() only synchronises (profiling builds that ablate parts of the kernels)
+_HOOKS = os.environ.get("WG_DEBUG_HOOKS") == "1"
+LIB_PATH = os.path.join(_HERE, "libwindgym_hip.so")
+if _HOOKS and os.environ.get("WG_LIB"):
+    LIB_PATH = os.environ["WG_LIB"]
+    print(f"[windgym] WG_DEBUG_HOOKS: loading {LIB_PATH} instead of the in-tree library", file=sys.stderr)
+_NOCHECK = bool(_HOOKS and os.environ.get("WG_NOCHECK"))
+if _NOCHECK:
+    print("[windgym] WG_DEBUG_HOOKS: WG_NOCHECK set — HipBatch.check() does not read the device error word", file=sys.stderr)
 UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 
 # every symbol include/windgym_hip.h declares (tests check the built library exports all of them)
@@ -169,7 +179,7 @@ class HipBatch:
         _chk(self.L.wg_set_step_graph(self._h, int(bool(enable))), "wg_set_step_graph")
 
     def check(self):
-        if os.environ.get("WG_NOCHECK"):          # profiling builds that ablate parts of the kernels (tools/ab.sh)
+        if _NOCHECK:          # profiling builds that ablate parts of the kernels (tools/ab.sh)
             self.torch.cuda.synchronize()
             return
         _chk(self.L.wg_check(self._h, self._stream()), "wg_check")

@@ -91,6 +91,8 @@ static const size_t WG_MAX_STEP_GRAPHS = 32;   // distinct (actions, obs, reward
 static const size_t WG_MAX_TIMING_EVENTS = 4096;
 
 static void drop_step_graphs(wg_env_s* h) {
+    // a cached exec may still be in flight on the caller's stream: destroying it under a running launch is undefined
+    if (!h->graphs.empty()) { hipSetDevice(h->device); hipDeviceSynchronize(); }
     for (auto& g : h->graphs) {
         hipGraphExecDestroy(g.exec);
         hipGraphDestroy(g.graph);
@@ -375,21 +377,47 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         // Compact variant: the staging of a chunk of targets is 10 bytes per (target, source) pair (16-bit candidate
         // list, deficit, added TI) and the per-pair added-TI array of the sample-major phases is not needed — large farms
         // spend that room on more targets per chunk (cfg3: 27 instead of 12 -> 3 chunks instead of 7, same LDS).
-        size_t off = sizeof(float) * 4 * (size_t)tc * p.N;
-        if (f.res) {
-            const size_t ql = ((size_t)p.NP / 2 + 15) & ~(size_t)15;
-            if (!small) {
-                const size_t budget = std::max(ql, off) + sizeof(float) * (size_t)tc * p.N;
-                const int fit = (int)((budget - 16) / (10 * (size_t)p.N));
-                tc = std::max(tc, std::min(p.N, fit));
-                f.target_chunk = tc;
+        const int tc0 = tc;
+        auto carve = [&]() -> size_t {
+            tc = tc0;
+            f.target_chunk = tc;
+            size_t off = sizeof(float) * 4 * (size_t)tc * p.N;
+            if (f.res) {
+                const size_t ql = ((size_t)p.NP / 2 + 15) & ~(size_t)15;
+                if (!small) {
+                    const size_t budget = std::max(ql, off) + sizeof(float) * (size_t)tc * p.N;
+                    const int fit = (int)((budget - 16) / (10 * (size_t)p.N));
+                    tc = std::max(tc, std::min(p.N, fit));
+                    f.target_chunk = tc;
+                }
+                off = std::max(ql, ((size_t)10 * tc * p.N + 16 + 15) & ~(size_t)15);
             }
-            off = std::max(ql, ((size_t)10 * tc * p.N + 16 + 15) & ~(size_t)15);
+            f.lds_off_turb = (int)off; off += (size_t)WG_TURB_LDS_BYTES * p.N;
+            off = (off + 15) & ~(size_t)15;
+            f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S) + sizeof(unsigned) * WG_MASK_WORDS * (size_t)tc + (f.res ? 0 : sizeof(float) * (size_t)tc * p.N);
+            off += sizeof(int) * ((size_t)p.N + 2);      // chain-pruning ages + the particle counter + the candidate counter
+            return (off + 15) & ~(size_t)15;
+        };
+        // The compact variant's quad list grows with N * P (NP / 2 bytes): a configuration whose carve exceeds what a
+        // workgroup may allocate falls back to the uniform-ring variant (LDS independent of P), and one that fits
+        // neither is refused here — not at the first launch, where the failure would be silent.
+        int lds_limit = 65536;
+        {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0)
+                lds_limit = std::min(v, 65536);      // (no kernel opts in to more than the default 64 KB of dynamic LDS)
         }
-        f.lds_off_turb = (int)off; off += (size_t)WG_TURB_LDS_BYTES * p.N;
-        off = (off + 15) & ~(size_t)15;
-        f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S) + sizeof(unsigned) * WG_MASK_WORDS * (size_t)tc + (f.res ? 0 : sizeof(float) * (size_t)tc * p.N);
-        off += sizeof(int) * ((size_t)p.N + 2);      // chain-pruning ages + the particle counter + the candidate counter
+        size_t off = carve();
+        if (f.res && off > (size_t)lds_limit) {
+            f.res = 0; f.block = 256;
+            p.compact = 0;
+            off = carve();
+        }
+        if (off > (size_t)lds_limit) {
+            wg_destroy(h);
+            return fail(WG_ERR_UNSUPPORTED, "wg_create: k_flow needs " + std::to_string(off) + " bytes of LDS per workgroup (limit " +
+                                            std::to_string(lds_limit) + "): too many turbines for one workgroup");
+        }
         // k_flow_duo: both farms of a context in one single-wave workgroup (lane = farm * N + turbine).  It executes 37 %
         // fewer VALU instructions per farm step, which pays where the per-workgroup fixed costs dominate (cfg4, 3x3 x P=96:
         // 43.6 -> 37.7 us) and not where the particle traffic does (cfg2 4x4 x P=128: 75 -> 78 us, cfg5 frozen box:
@@ -398,6 +426,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         const bool duo_ok = f.res && small && f.block == 64 && p.F == 2 && 2 * p.N <= 64 && p.P <= 4096;
         f.duo = (duo_ok && p.NP <= 1024 && p.turb_mode == WG_TURB_NONE) ? 1 : 0;
         if (const char* ev = getenv("WG_FLOW_DUO")) f.duo = (duo_ok && atoi(ev) != 0) ? 1 : 0;
+        bool duo_fits = true;
         {
             const size_t n2 = 2 * (size_t)p.N;
             const size_t ccap = (size_t)p.N * (p.N - 1);            // candidate pairs of both farms
@@ -409,7 +438,9 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             o = (o + 8 * n2 + 7) & ~(size_t)7;                            // per-farm clocks
             o += 2 * 72 + 16;                                             // (sizeof(FarmLds) = 72) + counters
             f.duo_lds = (int)((o + 15) & ~(size_t)15);
+            duo_fits = f.duo_lds <= lds_limit;
         }
+        if (!duo_fits) f.duo = 0;
         // frozen-record layout for the deficit gathers of the large-farm variant: 16-byte AoS copy (rec4)
         if (!f.res || !small) { if (!rc) rc = dev_alloc(h, &d.rec4, n_slots * pstride_keep, true); }
         else { if (!rc) rc = dev_alloc(h, &d.u_e, n_slots * pstride_keep, true); }
@@ -662,6 +693,10 @@ extern "C" int wg_reset(wg_handle h, const uint8_t* env_mask_host, const uint64_
     int batch = n_plan;
     for (;;) {
         for (int i = 0; i < batch; ++i) wg_launch_flow(&h->fp, &h->fd, WG_MODE_RESET, nullptr, mask, h->reset_chunk, st);
+        {
+            const hipError_t le = hipGetLastError();
+            if (le != hipSuccess) return fail(WG_ERR_HIP, std::string("wg_reset: k_flow launch failed: ") + hipGetErrorString(le));
+        }
         launched += batch;
         int unready = 0;
         HIPCHK(hipMemsetAsync(h->unready_dev, 0, sizeof(int), st));
@@ -697,6 +732,9 @@ extern "C" int wg_step(wg_handle h, const float* actions_dev, float* obs_dev, fl
     h->n_step_launches++;
     if (!h->graph_mode || sample) {
         launch_step(h, actions_dev, obs_dev, reward_dev, truncated_dev, final_obs_dev, st, sample);
+        // a rejected launch (bad configuration, out-of-resources) must not pass for a step that returned stale outputs
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return fail(WG_ERR_HIP, std::string("wg_step: kernel launch failed: ") + hipGetErrorString(le));
         return 0;
     }
     // graph mode: one hipGraphLaunch per step.  A graph is captured once per distinct set of I/O pointers (a training
@@ -711,19 +749,38 @@ extern "C" int wg_step(wg_handle h, const float* actions_dev, float* obs_dev, fl
             size_t lru = 0;
             for (size_t i = 1; i < h->graphs.size(); ++i)
                 if (h->graphs[i].last_use < h->graphs[lru].last_use) lru = i;
+            hipDeviceSynchronize();          // (the evicted exec may still be running)
             hipGraphExecDestroy(h->graphs[lru].exec);
             hipGraphDestroy(h->graphs[lru].graph);
             h->graphs.erase(h->graphs.begin() + lru);
         }
         wg_env_s::StepGraph ng;
         memcpy(ng.key, key, sizeof(key));
-        HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-        launch_step(h, actions_dev, obs_dev, reward_dev, truncated_dev, final_obs_dev, h->cap_stream, false);
-        HIPCHK(hipStreamEndCapture(h->cap_stream, &ng.graph));
-        hipError_t e = hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0);
-        if (e != hipSuccess) {
-            hipGraphDestroy(ng.graph);
-            return fail(WG_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        // Whatever fails between Begin and End, the capture is always ended (a stream left in capture mode would break
+        // every later graph-mode step) and the partial graph destroyed; the step then falls back to direct launches
+        // and graph mode is switched off for the handle.
+        hipError_t e = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal);
+        bool ok = e == hipSuccess;
+        if (ok) {
+            launch_step(h, actions_dev, obs_dev, reward_dev, truncated_dev, final_obs_dev, h->cap_stream, false);
+            const hipError_t le = hipGetLastError();
+            ng.graph = nullptr;
+            e = hipStreamEndCapture(h->cap_stream, &ng.graph);
+            ok = le == hipSuccess && e == hipSuccess && ng.graph != nullptr;
+            if (ok) {
+                e = hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0);
+                ok = e == hipSuccess;
+            }
+            if (!ok && ng.graph) hipGraphDestroy(ng.graph);
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            h->graph_mode = false;
+            if (getenv("WG_DEBUG")) fprintf(stderr, "[windgym] step-graph capture failed; using direct launches\n");
+            launch_step(h, actions_dev, obs_dev, reward_dev, truncated_dev, final_obs_dev, st, false);
+            const hipError_t le = hipGetLastError();
+            if (le != hipSuccess) return fail(WG_ERR_HIP, std::string("wg_step: kernel launch failed: ") + hipGetErrorString(le));
+            return 0;
         }
         h->graphs.push_back(ng);
         g = &h->graphs.back();
@@ -806,6 +863,7 @@ extern "C" int wg_metrics(wg_handle h, float* out_dev, int reset_after, void* st
 struct StateHeader {
     uint32_t magic;
     int32_t abi, B, N, F, P, S, K, turb_mode, block, ring_stride, fring_stride, power_avg, n_allocs;
+    int32_t res, duo, pstride, n_boxes;      // particle-ring layout (uniform / compact rings, one or two farms per workgroup)
     uint64_t payload;
 };
 static const uint32_t WG_STATE_MAGIC = 0x53474757u;   // "WGGS"
@@ -816,6 +874,7 @@ static StateHeader state_header(const wg_env_s* h) {
     sh.B = h->p.B; sh.N = h->p.N; sh.F = h->p.F; sh.P = h->p.P; sh.S = h->p.S; sh.K = h->p.K;
     sh.turb_mode = h->p.turb_mode; sh.block = h->fp.block; sh.ring_stride = h->p.ring_stride;
     sh.fring_stride = h->p.fring_stride; sh.power_avg = h->p.power_avg; sh.n_allocs = (int32_t)h->state_idx.size();
+    sh.res = h->fp.res; sh.duo = h->fp.duo; sh.pstride = h->fp.pstride; sh.n_boxes = h->p.n_boxes;
     for (size_t i : h->state_idx) sh.payload += h->allocs[i].bytes;
     return sh;
 }

@@ -270,7 +270,12 @@ __device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, c
         }
         cx.ws = ws; cx.ti = ti; cx.wd = wd; cx.turb_seed = tseed;
         cx.rated_power = (float)wg_tab_interp<double>(d.tab_ws_d, d.tab_power_d, p.n_tab, ws);   // :700
-        cx.n_pushed = 0; cx.pend_farm_n = 0; cx.pend_base_n = 0; cx.episode_tag = episode_tag;
+        // the context-level counters have ONE writer each: n_pushed / pend_farm_n belong to farm 0's workgroup (it also
+        // advances them in its epilogue), pend_base_n to the last farm's — a late initialising workgroup of the other
+        // farm must not zero what the first one has already advanced (pipelined set-up at the head of k_flow)
+        if (f_lo == 0) { cx.n_pushed = 0; cx.pend_farm_n = 0; }
+        if (f_hi == F) cx.pend_base_n = 0;
+        cx.episode_tag = episode_tag;
     }
     ws = __shfl(ws, 0, 64); ti = __shfl(ti, 0, 64); wd = __shfl(wd, 0, 64);
     // flow frame: rotate the layout by theta = 270 - wd about the farm centre

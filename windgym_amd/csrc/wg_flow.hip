@@ -74,6 +74,21 @@ __device__ __forceinline__ float rec_eps(unsigned b) { return (float)(b & 0xffff
 __device__ __forceinline__ float rec_hv(unsigned b) { return (float)((int)b >> 16) * (WG_HV_MAX / 32767.0f); }
 __device__ __forceinline__ bool rec_moves(unsigned b) { return (b >> 16) != 0u; }
 
+// lateral position of a wake particle of age j (pre-step clock s_off) after one step of Hill-vortex deflection.  ONE
+// definition with explicit fused operations: the advection pass stores this value and the deficit phase of the steady
+// compact variant recomputes it for the particles it brackets (see flow_step) — both must produce the same bits
+// whatever the surrounding code lets the compiler contract.
+__device__ __forceinline__ float m0_advect(float py, unsigned ra, unsigned rb, int j, float s_off_f, float dpart_f,
+                                           float inv_D, float dt) {
+    const float xrel = __builtin_fmaf((float)j, dpart_f, s_off_f);
+    const float sp = __builtin_fmaf(rec_k(ra), xrel * inv_D, rec_eps(rb));
+    return __builtin_fmaf(rec_hv(rb) * m0_cfrac(rec_ct(ra), sp), dt, py);
+}
+
+#ifndef WG_PAIR_FIRST
+#define WG_PAIR_FIRST 1   // steady compact variant: deficit phase BEFORE the advection pass (0 = round-2 order, for A/B builds)
+#endif
+
 // x^y for x >= 0 via v_log_f32 / v_exp_f32 (HIP's __powf expands to the full-precision routine)
 __device__ __forceinline__ float fast_pow(float x, float y) {
     return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
@@ -259,7 +274,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                                           unsigned* tmask, int* jnl,
                                           const size_t pbase, const double ws,
                                           const float ti_f, const float ti_pow, const TurbCtx& tc, SlotRegs& sr,
-                                          const PartLds& pl) {
+                                          const PartLds& pl, const bool first_step) {
     const int tid = threadIdx.x;
     const int N = p.N, P = p.P;
     const int TC = p.target_chunk;
@@ -300,6 +315,207 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     for (int i = tid; i < TC * WG_MASK_WORDS; i += NT) tmask[i] = 0u;
     lds_barrier<NT>();
     WG_STAMP(2);
+
+    // (3)+(4) rotor-averaged inflow of the compact variants, as a closure: the steady variant runs it BEFORE the advection
+    // pass (PRE), the turbulent ones after it.
+    // PRE (steady inflow): the bracketing particles are gathered in their PRE-step state and advanced by the same
+    // m0_advect() the advection pass applies (a particle's step is a function of its own record and age only; a particle
+    // emitted in this step is the turbine's record in LDS).  The phase then depends on nothing the advection pass writes:
+    // no wait for the pass's stores, the gathers are in flight before the streaming loads of the same lines (which then
+    // hit in L2 instead of the other way round, after L2 has lost them), and a live workgroup's latency chain is three
+    // memory round trips (state, gathers, stream) instead of five.
+    constexpr bool PRE = RES && TURB == WG_TURB_NONE && (WG_PAIR_FIRST != 0);
+    const float ws_f = (float)ws;
+    auto res_pair_phase = [&](auto pre_tag) __attribute__((always_inline)) {
+        constexpr bool PREV = decltype(pre_tag)::value;
+        const float move_max = fabsf(p.hill) * ws_f * p.dt;
+        // small-farm variant: PAIR-major.  In a small farm only a few (target, source) pairs interact (the same
+        // column of a grid, its diagonal neighbours), so the pairs that pass a cheap conservative test are compacted
+        // into a list and only those get the exact evaluation — one thread per candidate: bracketing particles
+        // (L2 hits: this workgroup just streamed them), interpolation, lateral cut-off, then the Gaussian deficit at all S rotor points summed in the thread.
+        // Thread t finally subtracts its sources' contributions in ascending source order (deterministic).
+        // Staging (the `pair` region, per chunk of TC targets): cl[TC*N] u16 candidate list | def[TC*N] rotor-mean deficit | tiav[TC*N] added TI.
+        unsigned short* cl = reinterpret_cast<unsigned short*>(pair);
+        float* def = reinterpret_cast<float*>(cl + ((TC * N + 7) & ~7));
+        float* tiav = def + TC * N;
+        int* ncand = jnl + N + 1;
+        // ambient inflow at the rotors (no wakes): thread t / the (t, sample) threads
+        if (TURB == WG_TURB_BOX) {
+            const int nitems = N << p.S_shift;
+            for (int it = tid; it < ((nitems + NT - 1) & ~(NT - 1)); it += NT) {
+                const int t = it >> p.S_shift, s = it & (p.S_pad - 1);
+                const bool live = (it < nitems) && (s < p.S);
+                float amb[3] = {0.f, 0.f, 0.f};
+                if (live) {
+                    const double bx = T[t].xr - tc.ws * sr.time + tc.ox;
+                    const double by = T[t].yr + (double)(rdy[s] * T[t].cg) + tc.oy, bz = p.hub_d + (double)rdz[s];
+                    if (p.box_pow2) box_lookup<true>(tc.box4, p, bx, by, bz, amb);
+                    else box_lookup<false>(tc.box4, p, bx, by, bz, amb);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+                    for (int o = p.S_pad >> 1; o > 0; o >>= 1) amb[cc] += __shfl_xor(amb[cc], o, 64);
+                if (live && s == 0) {
+                    T[t].u = ws_f + tc.sig * amb[0] * p.inv_S; T[t].v = tc.sig * amb[1] * p.inv_S; T[t].w = tc.sig * amb[2] * p.inv_S;
+                }
+            }
+        } else {
+            for (int t = tid; t < N; t += NT) {
+                float au = 0.f, av = 0.f, aw = 0.f;
+                if (TURB == WG_TURB_RANDOM) {
+                    // i.i.d. gusts at the S rotor points: their mean is one normal of variance sigma^2 / S
+                    const float sc = tc.sig * p.inv_sqrt_S;
+                    au = sc * wg_turb_normal(tc.seed, sr.istep, (uint32_t)t, 0u, 0x52u);
+                    av = sc * wg_turb_normal(tc.seed, sr.istep, (uint32_t)t, 1u, 0x52u);
+                    aw = sc * wg_turb_normal(tc.seed, sr.istep, (uint32_t)t, 2u, 0x52u);
+                }
+                T[t].u = ws_f + au; T[t].v = av; T[t].w = aw;
+            }
+        }
+        // targets in chunks of TC (small farms: one chunk = all N x N pairs)
+        for (int t0 = 0; t0 < N; t0 += TC) {
+        const int nt = (N - t0) < TC ? (N - t0) : TC;
+        const int npairs = nt * N;
+        if (t0 > 0) lds_barrier<NT>();          // the previous chunk's sums are done with the staging arrays
+        if (tid == 0) *ncand = 0;
+        for (int i = tid; i < nt * WG_MASK_WORDS; i += NT) tmask[i] = 0u;
+        lds_barrier<NT>();
+        // pass 1: conservative test on every pair -> candidate list
+        for (int i0 = 0; i0 < ((WG_ABLATE & 2) ? 0 : npairs); i0 += NT) {
+            const int i = i0 + tid;
+            bool cand = false;
+            if (i < npairs) {
+                const int tl = (int)(((float)i + 0.5f) * p.inv_N);
+                const int s2 = i - tl * N;
+                const int tg = t0 + tl;
+                const double dx = T[tg].xr - T[s2].xr;
+                cand = (s2 != tg) && (dx > 0.0);
+                if (cand) {
+                    const TurbLds& src = T[s2];
+                    const float sig_max = (src.bk * ((float)dx * p.inv_D) + src.be) * p.D;
+                    // PRE: src.bd is the excursion bound BEFORE this step's advection; a particle moves by
+                    // |hv C| dt <= |hill| u_e dt <= |hill| U dt in one step (steady inflow: u_e <= U, C <= 1)
+                    const float bd = PREV ? src.bd + (src.mvl != 0u ? move_max : 0.f) : src.bd;
+                    const float gap = fabsf((float)(T[tg].yr - src.yr)) - (p.R_rot + 5.0f * sig_max + bd);
+                    cand = gap <= 1.0e-3f * p.D;      // small margin for fp32 rounding of the bound itself
+                }
+            }
+            const unsigned long long bal = __ballot(cand);
+            if (bal) {
+                const int lane = tid & 63;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(ncand, __popcll(bal));
+                base = __shfl(base, 0, 64);
+                if (cand) cl[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)i;
+            }
+        }
+        lds_barrier<NT>();
+        // pass 2: exact evaluation of the candidates
+        const int nc = *ncand;
+        for (int c = tid; c < nc; c += NT) {
+            const int i = cl[c];
+            const int tl = (int)(((float)i + 0.5f) * p.inv_N);
+            const int s2 = i - tl * N;
+            const int t = t0 + tl;
+            const TurbLds& src = T[s2];
+            const double dx = T[t].xr - src.xr;
+            const double xi = (dx - s_new) * p.inv_dpart;
+            const double jf = floor(xi);
+            float wgt = (float)(xi - jf);
+            int j = (int)jf;
+            if (j < 0) { j = 0; wgt = 0.f; }
+            if (j + 1 > new_valid - 1) continue;          // the chain has not reached the target yet
+            const int Rs = src.rlen;
+            float py0, py1, u0, u1, pz0 = 0.f, pz1 = 0.f;
+            unsigned a0, a1, b0_, b1_;
+            if (PREV) {
+                // ages j, j + 1 after the step are ages jp, jp + 1 = j - n_emit, ... before it (negative: released in this
+                // step — the turbine's record, at the turbine)
+                const int jp0 = j - n_emit, jp1 = jp0 + 1;
+                int r0 = src.head - jp0; if (r0 < 0) r0 += Rs;
+                int r1 = src.head - jp1; if (r1 < 0) r1 += Rs;
+                const int i0 = src.roff + r0, i1 = src.roff + r1;
+                const bool g0 = jp0 >= 0, g1 = jp1 >= 0;
+                py0 = py1 = (float)src.yr; u0 = u1 = src.rue;
+                a0 = a1 = pack_a(src.rct, src.rk); b0_ = b1_ = pack_b(src.reps, src.rhv);
+                if (pl.r4) {
+                    if (g0) { const uint4 q0 = pl.r4[i0]; a0 = q0.x; b0_ = q0.y; u0 = __uint_as_float(q0.z); py0 = pl.py[i0]; }
+                    if (g1) { const uint4 q1 = pl.r4[i1]; a1 = q1.x; b1_ = q1.y; u1 = __uint_as_float(q1.z); py1 = pl.py[i1]; }
+                } else {
+                    if (g0) { py0 = pl.py[i0]; u0 = pl.ue[i0]; a0 = pl.ra[i0]; b0_ = pl.rb[i0]; }
+                    if (g1) { py1 = pl.py[i1]; u1 = pl.ue[i1]; a1 = pl.ra[i1]; b1_ = pl.rb[i1]; }
+                }
+                if (g0 && jp0 < n_valid) py0 = m0_advect(py0, a0, b0_, jp0, s_off_f, p.dpart_f, p.inv_D, p.dt);
+                if (g1 && jp1 < n_valid) py1 = m0_advect(py1, a1, b1_, jp1, s_off_f, p.dpart_f, p.inv_D, p.dt);
+            } else {
+                int r0 = src.head_n - j; if (r0 < 0) r0 += Rs;
+                int r1 = r0 - 1; if (r1 < 0) r1 += Rs;
+                const int i0 = src.roff + r0, i1 = src.roff + r1;
+                py0 = pl.py[i0]; py1 = pl.py[i1];
+                if (TURB != WG_TURB_NONE) { pz0 = pl.pz[i0]; pz1 = pl.pz[i1]; }
+                if (pl.r4) {       // large farms: the two bracketing records are 32 contiguous bytes (one line, not three)
+                    const uint4 g0 = pl.r4[i0], g1 = pl.r4[i1];
+                    a0 = g0.x; b0_ = g0.y; u0 = __uint_as_float(g0.z); a1 = g1.x; b1_ = g1.y; u1 = __uint_as_float(g1.z);
+                } else {
+                    u0 = pl.ue[i0]; u1 = pl.ue[i1];
+                    a0 = pl.ra[i0]; a1 = pl.ra[i1]; b0_ = pl.rb[i0]; b1_ = pl.rb[i1];
+                }
+            }
+            const float w0 = 1.0f - wgt, w1 = wgt;
+            const float yc = w0 * py0 + w1 * py1;
+            float zc = p.hub;
+            if (TURB != WG_TURB_NONE) zc = w0 * pz0 + w1 * pz1;
+            const float kv = w0 * rec_k(a0) + w1 * rec_k(a1);
+            const float epv = w0 * rec_eps(b0_) + w1 * rec_eps(b1_);
+            const float xd = (float)dx * p.inv_D;
+            const float sp = kv * xd + epv;
+            const float sig = sp * p.D;
+            const float yt = (float)T[t].yr;
+            const float rc2 = (yt - yc) * (yt - yc) + (p.hub - zc) * (p.hub - zc);
+            const float rcut = p.R_rot + 5.0f * sig;
+            if (rc2 > rcut * rcut) continue;
+            const float ctv = w0 * rec_ct(a0) + w1 * rec_ct(a1);
+            const float uev = w0 * u0 + w1 * u1;
+            const float cf = m0_cfrac(ctv, sp);
+            const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sig * sig);
+            // wake-added turbulence (Crespo-Hernandez), Gaussian-weighted at the hub
+            const float ind = 0.5f * (1.0f - __builtin_amdgcn_sqrtf(1.0f - ctv));
+            tiav[i] = p.tia * fast_pow(ind, p.tib) * ti_pow * fast_pow(fmaxf(xd, 1.0f), p.tid) * __expf(-rc2 * inv2s2);
+            // Gaussian deficit at the S rotor points of the target (lateral offsets scaled by cos(yaw_t))
+            const float cgt = T[t].cg, amp = uev * cf;
+            float acc = 0.f;
+            for (int sI = 0; sI < p.S; ++sI) {
+                const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
+                acc += amp * __expf(-(dy * dy + dz * dz) * inv2s2);
+            }
+            def[i] = acc * p.inv_S;
+            atomicOr(&tmask[tl * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
+        }
+        lds_barrier<NT>();
+        // thread t: superposition in ascending source order
+        for (int tl = tid; tl < nt; tl += NT) {
+            float dsum = 0.f, tia_max = 0.f;
+            for (int wd = 0; wd * 32 < N; ++wd) {
+                unsigned m = tmask[tl * WG_MASK_WORDS + wd];
+                while (m) {
+                    const int s2 = wd * 32 + __builtin_ctz(m);
+                    m &= m - 1;
+                    dsum += def[tl * N + s2];
+                    tia_max = fmaxf(tia_max, tiav[tl * N + s2]);
+                }
+            }
+            T[t0 + tl].u -= dsum;
+            T[t0 + tl].ti = __builtin_amdgcn_sqrtf(ti_f * ti_f + tia_max * tia_max);
+        }
+        }   // target chunks
+        lds_barrier<NT>();
+    };
+    if (PRE) {
+        // (a further flow step of the same launch — background development, reset — gathers what the previous step's
+        // advection pass stored)
+        if (!first_step) full_barrier<NT>();
+        res_pair_phase(std::true_type{});
+    }
 
     // (2) pass over the particle SoA: advect over dt, release the new particles
 
@@ -368,11 +584,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int j = j0 - i; if (j < 0) j += R;
-                if (j < n_valid) {
-                    const float xrel = s_off_f + (float)j * p.dpart_f;
-                    const float sp = rec_k(rav[i]) * (xrel * p.inv_D) + rec_eps(rbv[i]);
-                    pyv[i] += rec_hv(rbv[i]) * m0_cfrac(rec_ct(rav[i]), sp) * p.dt;
-                }
+                if (j < n_valid) pyv[i] = m0_advect(pyv[i], rav[i], rbv[i], j, s_off_f, p.dpart_f, p.inv_D, p.dt);
             }
             const float y0 = (float)tq.yr;
             if (emits) {
@@ -698,163 +910,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     WG_STAMP(4);   // this workgroup's particle stores are visible to its own gathers below
 
     // (3)+(4) rotor-averaged inflow
-    const float ws_f = (float)ws;
     if (RES) {
-        // small-farm variant: PAIR-major.  In a small farm only a few (target, source) pairs interact (the same
-        // column of a grid, its diagonal neighbours), so the pairs that pass a cheap conservative test are compacted
-        // into a list and only those get the exact evaluation — one thread per candidate: bracketing particles
-        // (L2 hits: this workgroup just streamed them), interpolation, lateral cut-off, then the Gaussian deficit at all S rotor points summed in the thread.
-        // Thread t finally subtracts its sources' contributions in ascending source order (deterministic).
-        // Staging (the `pair` region, per chunk of TC targets): cl[TC*N] u16 candidate list | def[TC*N] rotor-mean deficit | tiav[TC*N] added TI.
-        unsigned short* cl = reinterpret_cast<unsigned short*>(pair);
-        float* def = reinterpret_cast<float*>(cl + ((TC * N + 7) & ~7));
-        float* tiav = def + TC * N;
-        int* ncand = jnl + N + 1;
-        // ambient inflow at the rotors (no wakes): thread t / the (t, sample) threads
-        if (TURB == WG_TURB_BOX) {
-            const int nitems = N << p.S_shift;
-            for (int it = tid; it < ((nitems + NT - 1) & ~(NT - 1)); it += NT) {
-                const int t = it >> p.S_shift, s = it & (p.S_pad - 1);
-                const bool live = (it < nitems) && (s < p.S);
-                float amb[3] = {0.f, 0.f, 0.f};
-                if (live) {
-                    const double bx = T[t].xr - tc.ws * sr.time + tc.ox;
-                    const double by = T[t].yr + (double)(rdy[s] * T[t].cg) + tc.oy, bz = p.hub_d + (double)rdz[s];
-                    if (p.box_pow2) box_lookup<true>(tc.box4, p, bx, by, bz, amb);
-                    else box_lookup<false>(tc.box4, p, bx, by, bz, amb);
-                }
-#pragma unroll
-                for (int cc = 0; cc < 3; ++cc)
-                    for (int o = p.S_pad >> 1; o > 0; o >>= 1) amb[cc] += __shfl_xor(amb[cc], o, 64);
-                if (live && s == 0) {
-                    T[t].u = ws_f + tc.sig * amb[0] * p.inv_S; T[t].v = tc.sig * amb[1] * p.inv_S; T[t].w = tc.sig * amb[2] * p.inv_S;
-                }
-            }
-        } else {
-            for (int t = tid; t < N; t += NT) {
-                float au = 0.f, av = 0.f, aw = 0.f;
-                if (TURB == WG_TURB_RANDOM) {
-                    // i.i.d. gusts at the S rotor points: their mean is one normal of variance sigma^2 / S
-                    const float sc = tc.sig * p.inv_sqrt_S;
-                    au = sc * wg_turb_normal(tc.seed, sr.istep, (uint32_t)t, 0u, 0x52u);
-                    av = sc * wg_turb_normal(tc.seed, sr.istep, (uint32_t)t, 1u, 0x52u);
-                    aw = sc * wg_turb_normal(tc.seed, sr.istep, (uint32_t)t, 2u, 0x52u);
-                }
-                T[t].u = ws_f + au; T[t].v = av; T[t].w = aw;
-            }
-        }
-        // targets in chunks of TC (small farms: one chunk = all N x N pairs)
-        for (int t0 = 0; t0 < N; t0 += TC) {
-        const int nt = (N - t0) < TC ? (N - t0) : TC;
-        const int npairs = nt * N;
-        if (t0 > 0) lds_barrier<NT>();          // the previous chunk's sums are done with the staging arrays
-        if (tid == 0) *ncand = 0;
-        for (int i = tid; i < nt * WG_MASK_WORDS; i += NT) tmask[i] = 0u;
-        lds_barrier<NT>();
-        // pass 1: conservative test on every pair -> candidate list
-        for (int i0 = 0; i0 < ((WG_ABLATE & 2) ? 0 : npairs); i0 += NT) {
-            const int i = i0 + tid;
-            bool cand = false;
-            if (i < npairs) {
-                const int tl = (int)(((float)i + 0.5f) * p.inv_N);
-                const int s2 = i - tl * N;
-                const int tg = t0 + tl;
-                const double dx = T[tg].xr - T[s2].xr;
-                cand = (s2 != tg) && (dx > 0.0);
-                if (cand) {
-                    const TurbLds& src = T[s2];
-                    const float sig_max = (src.bk * ((float)dx * p.inv_D) + src.be) * p.D;
-                    const float gap = fabsf((float)(T[tg].yr - src.yr)) - (p.R_rot + 5.0f * sig_max + src.bd);
-                    cand = gap <= 1.0e-3f * p.D;      // small margin for fp32 rounding of the bound itself
-                }
-            }
-            const unsigned long long bal = __ballot(cand);
-            if (bal) {
-                const int lane = tid & 63;
-                int base = 0;
-                if (lane == 0) base = atomicAdd(ncand, __popcll(bal));
-                base = __shfl(base, 0, 64);
-                if (cand) cl[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)i;
-            }
-        }
-        lds_barrier<NT>();
-        // pass 2: exact evaluation of the candidates
-        const int nc = *ncand;
-        for (int c = tid; c < nc; c += NT) {
-            const int i = cl[c];
-            const int tl = (int)(((float)i + 0.5f) * p.inv_N);
-            const int s2 = i - tl * N;
-            const int t = t0 + tl;
-            const TurbLds& src = T[s2];
-            const double dx = T[t].xr - src.xr;
-            const double xi = (dx - s_new) * p.inv_dpart;
-            const double jf = floor(xi);
-            float wgt = (float)(xi - jf);
-            int j = (int)jf;
-            if (j < 0) { j = 0; wgt = 0.f; }
-            if (j + 1 > new_valid - 1) continue;          // the chain has not reached the target yet
-            const int Rs = src.rlen;
-            int r0 = src.head_n - j; if (r0 < 0) r0 += Rs;
-            int r1 = r0 - 1; if (r1 < 0) r1 += Rs;
-            const int i0 = src.roff + r0, i1 = src.roff + r1;
-            const float py0 = pl.py[i0], py1 = pl.py[i1];
-            float u0, u1;
-            unsigned a0, a1, b0_, b1_;
-            if (pl.r4) {       // large farms: the two bracketing records are 32 contiguous bytes (one line, not three)
-                const uint4 g0 = pl.r4[i0], g1 = pl.r4[i1];
-                a0 = g0.x; b0_ = g0.y; u0 = __uint_as_float(g0.z); a1 = g1.x; b1_ = g1.y; u1 = __uint_as_float(g1.z);
-            } else {
-                u0 = pl.ue[i0]; u1 = pl.ue[i1];
-                a0 = pl.ra[i0]; a1 = pl.ra[i1]; b0_ = pl.rb[i0]; b1_ = pl.rb[i1];
-            }
-            const float w0 = 1.0f - wgt, w1 = wgt;
-            const float yc = w0 * py0 + w1 * py1;
-            float zc = p.hub;
-            if (TURB != WG_TURB_NONE) zc = w0 * pl.pz[i0] + w1 * pl.pz[i1];
-            const float kv = w0 * rec_k(a0) + w1 * rec_k(a1);
-            const float epv = w0 * rec_eps(b0_) + w1 * rec_eps(b1_);
-            const float xd = (float)dx * p.inv_D;
-            const float sp = kv * xd + epv;
-            const float sig = sp * p.D;
-            const float yt = (float)T[t].yr;
-            const float rc2 = (yt - yc) * (yt - yc) + (p.hub - zc) * (p.hub - zc);
-            const float rcut = p.R_rot + 5.0f * sig;
-            if (rc2 > rcut * rcut) continue;
-            const float ctv = w0 * rec_ct(a0) + w1 * rec_ct(a1);
-            const float uev = w0 * u0 + w1 * u1;
-            const float cf = m0_cfrac(ctv, sp);
-            const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sig * sig);
-            // wake-added turbulence (Crespo-Hernandez), Gaussian-weighted at the hub
-            const float ind = 0.5f * (1.0f - __builtin_amdgcn_sqrtf(1.0f - ctv));
-            tiav[i] = p.tia * fast_pow(ind, p.tib) * ti_pow * fast_pow(fmaxf(xd, 1.0f), p.tid) * __expf(-rc2 * inv2s2);
-            // Gaussian deficit at the S rotor points of the target (lateral offsets scaled by cos(yaw_t))
-            const float cgt = T[t].cg, amp = uev * cf;
-            float acc = 0.f;
-            for (int sI = 0; sI < p.S; ++sI) {
-                const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
-                acc += amp * __expf(-(dy * dy + dz * dz) * inv2s2);
-            }
-            def[i] = acc * p.inv_S;
-            atomicOr(&tmask[tl * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
-        }
-        lds_barrier<NT>();
-        // thread t: superposition in ascending source order
-        for (int tl = tid; tl < nt; tl += NT) {
-            float dsum = 0.f, tia_max = 0.f;
-            for (int wd = 0; wd * 32 < N; ++wd) {
-                unsigned m = tmask[tl * WG_MASK_WORDS + wd];
-                while (m) {
-                    const int s2 = wd * 32 + __builtin_ctz(m);
-                    m &= m - 1;
-                    dsum += def[tl * N + s2];
-                    tia_max = fmaxf(tia_max, tiav[tl * N + s2]);
-                }
-            }
-            T[t0 + tl].u -= dsum;
-            T[t0 + tl].ti = __builtin_amdgcn_sqrtf(ti_f * ti_f + tia_max * tia_max);
-        }
-        }   // target chunks
-        lds_barrier<NT>();
+        if (!PRE) res_pair_phase(std::false_type{});
         return;
     }
     for (int t0 = 0; t0 < ((WG_ABLATE & 2) ? 0 : N); t0 += TC) {
@@ -1283,7 +1340,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             // sin/cos are not needed in replay mode: power comes from the script
             script_step<NT>(p, d, T, e, farm, cursor, sr.time);
         } else {
-            flow_step<NT, TURB, RES>(p, d, T, tabct, rdy, rdz, pair, tiap, tmask, jnl, pbase, ws, ti_f, ti_pow, tc, sr, pl);
+            flow_step<NT, TURB, RES>(p, d, T, tabct, rdy, rdz, pair, tiap, tmask, jnl, pbase, ws, ti_f, ti_pow, tc, sr, pl, n_flow == 0);
             if (tid < WG_WAVE) {   // roofline accounting: particles that can still reach a rotor
                 int cnt = 0;
                 for (int t = tid; t < N; t += WG_WAVE) cnt += min(sr.n_valid, RES ? T[t].rlen : jnl[t] + 1);

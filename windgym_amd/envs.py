@@ -60,11 +60,18 @@ def _resolve_turbulence(cfg: EnvConfig, turbulence_box=None):
     if cfg.turbtype == "MannLoad":
         from .mann import find_box_files, load_box
         pool, spacing = [], None
-        for f in find_box_files(getattr(cfg, "TurbBox", None))[:MAX_BOX_POOL]:
+        files = find_box_files(getattr(cfg, "TurbBox", None))
+        # The reference draws np_random.choice(self.TF_files) over ALL files (:614): a pool of a different size changes
+        # every later draw of the episode generator, so a pool that cannot be held as found is an error, not a silent
+        # truncation.
+        if len(files) > MAX_BOX_POOL:
+            raise ValueError(f"TurbBox: {len(files)} turbulence files found, the device pool holds at most {MAX_BOX_POOL}; "
+                             f"point TurbBox at a directory with fewer files (the reference draws one of ALL files per reset)")
+        for f in files:
             b, sp = load_box(f)
             if pool and (np.shape(b) != np.shape(pool[0]) or tuple(sp) != tuple(spacing)):
-                print(f"{f}: shape / spacing differs from the first box of the pool, skipped")
-                continue
+                raise ValueError(f"{f}: shape {np.shape(b)} / spacing {tuple(sp)} differs from the first box of the pool "
+                                 f"({np.shape(pool[0])} / {tuple(spacing)}); the device pool needs boxes of one shape")
             pool.append(b)
             spacing = sp
         if pool:
