@@ -172,6 +172,23 @@ __device__ inline T wg_tab_interp(const T* xs, const T* ys, int n, T x) {
     return ys[lo] + f * (ys[hi] - ys[lo]);
 }
 
+// the same interpolation done by a whole wave: every lane fetches one table node per pass and a ballot counts the nodes
+// <= x — ONE memory round trip instead of the binary search's chain of dependent loads (the episode set-up at the head
+// of k_flow sits on the launch's critical path).  Result valid in every lane; bit-identical to wg_tab_interp.
+template <class T>
+__device__ inline T wg_tab_interp_wave(const T* xs, const T* ys, int n, T x, int lane) {
+    int cnt = 0;                         // nodes with xs[i] <= x among i < n - 1
+    for (int i0 = 0; i0 < n - 1; i0 += 64) {
+        const int i = i0 + lane;
+        const bool le = (i < n - 1) && (xs[i] <= x);
+        cnt += __popcll(__ballot(le));
+    }
+    if (!(x >= xs[0]) || x > xs[n - 1]) return (T)0;
+    const int lo = cnt - 1, hi = lo + 1;         // xs ascending: the nodes <= x are a prefix; x >= xs[0] -> cnt >= 1
+    const T f = (x - xs[lo]) / (xs[hi] - xs[lo]);
+    return ys[lo] + f * (ys[hi] - ys[lo]);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // wave64 reductions
 // ---------------------------------------------------------------------------------------------------
@@ -269,7 +286,6 @@ __device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, c
             for (int f = f_lo; f < f_hi; ++f) d.yaw[(size_t)(ctx_id * F + f) * N + t] = y0;
         }
         cx.ws = ws; cx.ti = ti; cx.wd = wd; cx.turb_seed = tseed;
-        cx.rated_power = (float)wg_tab_interp<double>(d.tab_ws_d, d.tab_power_d, p.n_tab, ws);   // :700
         // the context-level counters have ONE writer each: n_pushed / pend_farm_n belong to farm 0's workgroup (it also
         // advances them in its epilogue), pend_base_n to the last farm's — a late initialising workgroup of the other
         // farm must not zero what the first one has already advanced (pipelined set-up at the head of k_flow)
@@ -278,6 +294,10 @@ __device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, c
         cx.episode_tag = episode_tag;
     }
     ws = __shfl(ws, 0, 64); ti = __shfl(ti, 0, 64); wd = __shfl(wd, 0, 64);
+    {
+        const double rp = wg_tab_interp_wave<double>(d.tab_ws_d, d.tab_power_d, p.n_tab, ws, lane);   // :700
+        if (lane == 0) cx.rated_power = (float)rp;
+    }
     // flow frame: rotate the layout by theta = 270 - wd about the farm centre
     const double th = (270.0 - wd) * (WG_PI_D / 180.0);
     const double cth = cos(th), sth = sin(th);
@@ -322,21 +342,17 @@ __device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, c
                 const int v = __shfl_up(incl, o, 64);
                 if (lane >= o) incl += v;
             }
-            if (t < N) ro[t] = base + incl - len;
+            if (t < N) {
+                ro[t] = base + incl - len;
+                // owner of every quad of ring slots: turbine t stamps its own quads (fire-and-forget byte stores; the
+                // earlier binary search per quad was a chain of dependent loads on the launch's critical path)
+                uint8_t* own = d.qown + (size_t)ctx_id * (p.NP >> 2);
+                const int q0 = (base + incl - len) >> 2, q1 = (base + incl) >> 2;
+                for (int q = q0; q < q1; ++q) own[q] = (uint8_t)t;
+            }
             base += __shfl(incl, WG_WAVE - 1, 64);
         }
         if (lane == 0) ro[N] = base;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own stores visible to own loads below
-        uint8_t* own = d.qown + (size_t)ctx_id * (p.NP >> 2);
-        for (int q = lane; q < (base >> 2); q += WG_WAVE) {
-            int lo = 0, hi = N;                    // ro[lo] <= 4 q < ro[hi]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (ro[mid] <= 4 * q) lo = mid; else hi = mid;
-            }
-            own[q] = (uint8_t)lo;
-        }
     }
     if (lane == 0) {
         cx.dist = xmax - xmin;                                                     // :723-724

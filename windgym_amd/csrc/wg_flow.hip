@@ -123,6 +123,20 @@ __shared__ long long wg_stamps[12];
 #define WG_STAMP(k) do { } while (0)
 #endif
 
+// Cold parameters.  k_flow's by-value parameter blocks are ~190 dwords; everything the hot loops do not touch used to
+// stay in SGPRs across them anyway (the compiler hoists every kernarg load to the top) and the overflow — ~90 values at
+// the main loop's head — went to VGPR lanes: v_writelane / v_readlane are VALU instructions, ~20 % of what a farm step
+// executed.  Code that runs once per step (measurement tail, epilogue) therefore re-reads its parameters from the
+// kernarg segment through a pointer the optimiser cannot see through: scalar loads that hit the constant cache, no
+// register held across the loops.
+struct KArgs { FlowP p; FlowPtrs d; };      // layout of the first two kernel arguments in the kernarg segment
+typedef const __attribute__((address_space(4))) KArgs* KArgsPtr;
+__device__ __forceinline__ KArgsPtr wg_cold_args() {
+    KArgsPtr k = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return k;
+}
+
 struct SlotRegs {
     double s_off, time;
     int head, n_valid;
@@ -1139,13 +1153,15 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     const size_t pbase = (size_t)slot_id * p.pstride;
 
     WG_STAMP(0);
+    if ((WG_ABLATE & 32) && mode == WG_MODE_STEP) return;      // profiling: cost of the dispatch alone
     // ---- prologue: issue every independent global load up front (ONE exposed memory round trip) -------
-    const WgEnv& env = d.env[e];
+    // (cold parameters: the pointers below are read from the kernarg segment where they are used and not kept — see
+    // wg_cold_args)
+    const KArgsPtr k0 = wg_cold_args();
+    const WgEnv& env = k0->d.env[e];
     const int env_live = env.live, env_done = env.done, env_shadow_iters = env.shadow_iters;
     const uint64_t noise_key = env.noise_key;
-    WgSlot& slot = d.slot[slot_id];
-    WgCtx& cx = d.ctx[ctx_id];
-    const int init_pending = cx.init_pending;
+    const int init_pending = k0->d.ctx[ctx_id].init_pending;
     const uint8_t masked_out = (mode == WG_MODE_RESET && mask) ? (uint8_t)(mask[e] == 0) : (uint8_t)0;
     const int t_own = tid < N ? tid : 0;
     int dev_rem, fill_rem, cursor, n_pushed, pend_farm_n, pend_base_n;
@@ -1159,10 +1175,13 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     float4 l_bnd = make_float4(0.f, 0.f, 0.f, 0.f);
     int l_jn = 0, l_roff = 0, l_rnext = 0, L_ring = 0;
     auto load_state = [&]() __attribute__((always_inline)) {
+        const KArgsPtr kl = wg_cold_args();
+        const WgSlot& slot = kl->d.slot[slot_id];
+        const WgCtx& cx = kl->d.ctx[ctx_id];
         dev_rem = slot.dev_remaining; fill_rem = slot.fill_remaining;
         sr = SlotRegs{slot.s_off, slot.time, slot.head, slot.n_valid, slot.istep, slot.n_emitted};
         if (RES) {
-            const int* ro = d.roff + (size_t)ctx_id * (N + 1);
+            const int* ro = kl->d.roff + (size_t)ctx_id * (N + 1);
             l_roff = ro[t_own]; l_rnext = ro[t_own + 1]; L_ring = ro[N];
         }
         cursor = slot.cursor;
@@ -1178,18 +1197,18 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         tc.sig = (float)(cx.ti * ws);
         tc.alpha = TURB == WG_TURB_NONE ? 0.f
                                         : (float)(1.0 - exp(-2.0 * WG_PI_D * (ws / (p.fc_scale * p.D_d)) * p.dt_d));
-        l_xr = d.xr[(size_t)ctx_id * N + t_own];
-        l_yr = d.yr[(size_t)ctx_id * N + t_own];
-        l_yaw = d.yaw[tb + t_own]; l_u = d.u[tb + t_own]; l_v = d.v[tb + t_own]; l_w = d.w[tb + t_own];
-        l_ti = d.ti_loc[tb + t_own]; l_pow = d.power[tb + t_own]; l_ct = d.ct[tb + t_own];
-        l_bnd = reinterpret_cast<const float4*>(d.bnd)[tb + t_own];
-        if (!RES) l_jn = d.jneed[(size_t)ctx_id * N + t_own];      // chain pruning by predicate: streaming variant only
+        l_xr = kl->d.xr[(size_t)ctx_id * N + t_own];
+        l_yr = kl->d.yr[(size_t)ctx_id * N + t_own];
+        l_yaw = kl->d.yaw[tb + t_own]; l_u = kl->d.u[tb + t_own]; l_v = kl->d.v[tb + t_own]; l_w = kl->d.w[tb + t_own];
+        l_ti = kl->d.ti_loc[tb + t_own]; l_pow = kl->d.power[tb + t_own]; l_ct = kl->d.ct[tb + t_own];
+        l_bnd = reinterpret_cast<const float4*>(kl->d.bnd)[tb + t_own];
+        if (!RES) l_jn = kl->d.jneed[(size_t)ctx_id * N + t_own];      // chain pruning by predicate: streaming variant only
     };
     load_state();
     // (first elements of the read-only tables: requested with the state loads — copied to LDS after the decision below, a
     // separate copy loop there costs every workgroup a second memory round trip)
-    const float pf_tp = tid < p.n_tab ? d.tab_power[tid] : 0.f, pf_tc = tid < p.n_tab ? d.tab_ct[tid] : 0.f;
-    const float pf_dy = tid < p.S ? d.rotor_dy[tid] : 0.f, pf_dz = tid < p.S ? d.rotor_dz[tid] : 0.f;
+    const float pf_tp = tid < p.n_tab ? k0->d.tab_power[tid] : 0.f, pf_tc = tid < p.n_tab ? k0->d.tab_ct[tid] : 0.f;
+    const float pf_dy = tid < p.S ? k0->d.rotor_dy[tid] : 0.f, pf_dz = tid < p.S ? k0->d.rotor_dz[tid] : 0.f;
     if (mode == WG_MODE_STEP && farm == 0) l_act = actions[(size_t)e * N + t_own];
 
     const bool is_live = (c == env_live);
@@ -1356,7 +1375,8 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         // per-turbine tail (thread t owns turbine t): power / thrust with the current yaw (model M0 step 5),
         // WindFarmEnv._take_measurements (Wind_Farm_Env.py:480-495) accumulated over the k sub-steps and, at
         // the end of the env step, farm_mes.add_measurements' ring push (MesClass.py:568-591)
-        float* __restrict__ rbase = d.ring + (size_t)ctx_id * p.ring_stride;
+        const KArgsPtr kc = wg_cold_args();
+        float* __restrict__ rbase = kc->d.ring + (size_t)ctx_id * kc->p.ring_stride;
         for (int t = tid; t < N; t += NT) {
             TurbLds& q = T[t];
             if (RES) q.head = q.head_n;          // the step's emissions are in the ring now
@@ -1370,8 +1390,8 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
                 const float wdm = atanf(q.v / q.u) * WG_RAD2DEG_F + wd_env;
                 float val[WG_N_CH] = {q.sws + wsm, q.swd + wdm, q.syaw + q.yaw, q.sp + q.pow};
                 if (unit_end) {
-                    d.cur_ws[(size_t)ctx_id * N + t] = wsm;
-                    d.cur_wd[(size_t)ctx_id * N + t] = wdm;
+                    kc->d.cur_ws[(size_t)ctx_id * N + t] = wsm;
+                    kc->d.cur_wd[(size_t)ctx_id * N + t] = wdm;
                     if (p.K != 1) {
 #pragma unroll
                         for (int ch = 0; ch < WG_N_CH; ++ch) val[ch] *= inv_k;
@@ -1379,14 +1399,14 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
                     if (NOISE) {
 #pragma unroll
                         for (int ch = 0; ch < WG_N_CH; ++ch)
-                            if (p.noise_sigma[ch] != 0.f)
-                                val[ch] += p.noise_sigma[ch] * wg_noise_normal(noise_key, (uint32_t)n_pushed, (uint32_t)t,
-                                                                               (uint32_t)ch, episode_tag);
+                            if (kc->p.noise_sigma[ch] != 0.f)
+                                val[ch] += kc->p.noise_sigma[ch] * wg_noise_normal(noise_key, (uint32_t)n_pushed, (uint32_t)t,
+                                                                                   (uint32_t)ch, episode_tag);
                     }
 #pragma unroll
                     for (int ch = 0; ch < WG_N_CH; ++ch) {
-                        const int H = p.hlen[ch];
-                        rbase[p.ring_off[ch] + t * H + fast_mod(n_pushed, H, p.inv_hlen[ch])] = val[ch];
+                        const int H = kc->p.hlen[ch];
+                        rbase[kc->p.ring_off[ch] + t * H + fast_mod(n_pushed, H, kc->p.inv_hlen[ch])] = val[ch];
                     }
                     // stage the pushed values for the farm-level mean / mean / sum
                     q.sws = val[0]; q.swd = val[1]; q.sp = val[3];
@@ -1404,12 +1424,13 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             if (tid < WG_WAVE) {
                 const float sws = WG_TURB_SUM(sws), swd = WG_TURB_SUM(swd), tot = WG_TURB_SUM(sp);
                 if (tid == 0) {
-                    float* fbase = d.fring + (size_t)ctx_id * p.fring_stride;
-                    fbase[p.fring_off[WG_CH_WS] + fast_mod(n_pushed, p.hlen[WG_CH_WS], p.inv_hlen[WG_CH_WS])] = sws * p.inv_N;
-                    fbase[p.fring_off[WG_CH_WD] + fast_mod(n_pushed, p.hlen[WG_CH_WD], p.inv_hlen[WG_CH_WD])] = swd * p.inv_N;
-                    fbase[p.fring_off[WG_CH_POWER] + fast_mod(n_pushed, p.hlen[WG_CH_POWER], p.inv_hlen[WG_CH_POWER])] = tot;
-                    if (live_step) d.step_farm_pow[e] = tot;
-                    else d.pend_farm[(size_t)ctx_id * p.power_avg + fast_mod(pend_farm_n, p.power_avg, p.inv_power_avg)] = tot;
+                    const FlowP __attribute__((address_space(4)))& pc = kc->p;
+                    float* fbase = kc->d.fring + (size_t)ctx_id * pc.fring_stride;
+                    fbase[pc.fring_off[WG_CH_WS] + fast_mod(n_pushed, pc.hlen[WG_CH_WS], pc.inv_hlen[WG_CH_WS])] = sws * pc.inv_N;
+                    fbase[pc.fring_off[WG_CH_WD] + fast_mod(n_pushed, pc.hlen[WG_CH_WD], pc.inv_hlen[WG_CH_WD])] = swd * pc.inv_N;
+                    fbase[pc.fring_off[WG_CH_POWER] + fast_mod(n_pushed, pc.hlen[WG_CH_POWER], pc.inv_hlen[WG_CH_POWER])] = tot;
+                    if (live_step) kc->d.step_farm_pow[e] = tot;
+                    else kc->d.pend_farm[(size_t)ctx_id * pc.power_avg + fast_mod(pend_farm_n, pc.power_avg, pc.inv_power_avg)] = tot;
                 }
             }
             ++n_pushed;
@@ -1419,8 +1440,8 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         } else {
             if (tid == 0) {
                 const float bp = p.K == 1 ? base_acc : base_acc * inv_k;
-                if (live_step) d.step_base_pow[e] = bp;
-                else d.pend_base[(size_t)ctx_id * p.power_avg + fast_mod(pend_base_n, p.power_avg, p.inv_power_avg)] = bp;
+                if (live_step) kc->d.step_base_pow[e] = bp;
+                else kc->d.pend_base[(size_t)ctx_id * kc->p.power_avg + fast_mod(pend_base_n, kc->p.power_avg, kc->p.inv_power_avg)] = bp;
             }
             if (!live_step) ++pend_base_n;
             base_acc = 0.f;
@@ -1431,13 +1452,16 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
 
     WG_STAMP(7);
     // epilogue: write the slot back (thread t owns turbine t; no barrier needed for its own T[t])
+    const KArgsPtr ke = wg_cold_args();
     for (int t = tid; t < N; t += NT) {
         const TurbLds& q = T[t];
-        d.yaw[tb + t] = q.yaw; d.u[tb + t] = q.u; d.v[tb + t] = q.v; d.w[tb + t] = q.w;
-        d.ti_loc[tb + t] = q.ti; d.power[tb + t] = q.pow; d.ct[tb + t] = q.ct;
-        reinterpret_cast<float4*>(d.bnd)[tb + t] = make_float4(q.bd, q.bk, q.be, __uint_as_float(q.mvl));
+        ke->d.yaw[tb + t] = q.yaw; ke->d.u[tb + t] = q.u; ke->d.v[tb + t] = q.v; ke->d.w[tb + t] = q.w;
+        ke->d.ti_loc[tb + t] = q.ti; ke->d.power[tb + t] = q.pow; ke->d.ct[tb + t] = q.ct;
+        reinterpret_cast<float4*>(ke->d.bnd)[tb + t] = make_float4(q.bd, q.bk, q.be, __uint_as_float(q.mvl));
     }
     if (tid == 0) {
+        WgSlot& slot = ke->d.slot[slot_id];
+        WgCtx& cx = ke->d.ctx[ctx_id];
         slot.part_count += (unsigned)jnl[N];
         slot.head = sr.head; slot.n_valid = sr.n_valid; slot.s_off = sr.s_off; slot.time = sr.time;
         slot.istep = sr.istep; slot.n_emitted = sr.n_emitted;
