@@ -371,6 +371,8 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         }
         if (f.res && !ql_fits) { f.res = 0; f.block = 256; }       // (after the env overrides too)
         f.ql_shift = ql_shift;
+        f.ql_lpt_shift = 0;
+        while (f.ql_lpt_shift < 3 && (p.N << (f.ql_lpt_shift + 1)) <= f.block) ++f.ql_lpt_shift;
         p.compact = f.res;
         // LDS carve.  The staging region of the deficit phases doubles as the quad list of the compact steady advection
         // pass (one 16-bit entry per quad of the farm's rings: at most NP / 2 bytes)
@@ -449,6 +451,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         f.dt = p.dt; f.D = p.D; f.inv_D = p.inv_D; f.hub = p.hub; f.dpart_f = (float)p.dpart; f.R_rot = 0.5f * p.D;
         f.inv_N = 1.0f / (float)p.N; f.inv_S = 1.0f / (float)p.S; f.inv_P = 1.0f / (float)p.P;
         f.inv_power_avg = 1.0f / (float)(p.power_avg > 0 ? p.power_avg : 1);
+        f.pavg_magic = (unsigned)((1ull << 32) / (unsigned long long)(p.power_avg > 0 ? p.power_avg : 1)) + 1u;
         f.dt_d = p.dt_d; f.dpart = p.dpart; f.inv_dpart = 1.0 / p.dpart;
         f.yaw_min = p.yaw_min; f.yaw_max = p.yaw_max; f.yaw_step = p.yaw_step;
         f.ka = p.ka; f.kb = p.kb; f.eps0 = p.eps0; f.hill = p.hill; f.tia = p.tia; f.tib = p.tib; f.tic = p.tic; f.tid = p.tid;
@@ -456,6 +459,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         for (int i = 0; i < WG_N_CH; ++i) {
             f.hlen[i] = p.ch[i].history_len; f.ring_off[i] = p.ring_off[i]; f.fring_off[i] = p.fring_off[i];
             f.inv_hlen[i] = 1.0f / (float)(p.ch[i].history_len > 0 ? p.ch[i].history_len : 1);
+            f.hmagic[i] = (unsigned)((1ull << 32) / (unsigned long long)(p.ch[i].history_len > 0 ? p.ch[i].history_len : 1)) + 1u;
             f.noise_sigma[i] = p.noise_sigma[i];
         }
         f.ring_stride = p.ring_stride; f.fring_stride = p.fring_stride;

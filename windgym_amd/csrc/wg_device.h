@@ -192,9 +192,28 @@ __device__ inline T wg_tab_interp_wave(const T* xs, const T* ys, int n, T x, int
 // ---------------------------------------------------------------------------------------------------
 // wave64 reductions
 // ---------------------------------------------------------------------------------------------------
+// Wave-wide sums with a FIXED tree (deterministic, the same in every kernel): four DPP steps inside each row of 16 lanes
+// (quad swaps, half-row mirror, row mirror: one VALU instruction each, no LDS traffic), then the rows are combined with
+// two lane permutes.  Result valid in every lane.
+template <int CTRL>
+__device__ __forceinline__ float wg_dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+#define WG_ROW_REDUCE(v, OP)                                                 \
+    v = OP(v, wg_dpp_f<0xB1>(v));  /* quad_perm [1,0,3,2] */               \
+    v = OP(v, wg_dpp_f<0x4E>(v));  /* quad_perm [2,3,0,1] */               \
+    v = OP(v, wg_dpp_f<0x141>(v)); /* row_half_mirror */                   \
+    v = OP(v, wg_dpp_f<0x140>(v)); /* row_mirror */
+__device__ __forceinline__ float wg_addf(float a, float b) { return a + b; }
+// sum over the 16 lanes of each row; valid in every lane of the row
+__device__ inline float wg_row_sum(float v) {
+    WG_ROW_REDUCE(v, wg_addf)
+    return v;
+}
 __device__ inline float wg_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    WG_ROW_REDUCE(v, wg_addf)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ inline int wg_wave_sum_i(int v) {

@@ -24,6 +24,7 @@ struct FlowP {
     int target_chunk;             // targets whose pair parameters are staged in LDS at once
     int lds_off_turb, lds_off_tab, lds_bytes;
     int ql_shift;                 // compact steady advection: quad-list entry = turbine << ql_shift | quad index in its ring (16 bits)
+    int ql_lpt_shift;             // ... and 2^ql_lpt_shift lanes share the listing of one turbine's quads (block / N, at most 8)
     int duo, duo_off_turb, duo_lds;   // k_flow_duo (both farms of a context in one wave): enabled, LDS carve (wg_flow_duo.inc)
     float dt, D, inv_D, hub, dpart_f, R_rot, inv_N, inv_S, inv_P;
     double dt_d, dpart, inv_dpart;
@@ -32,6 +33,7 @@ struct FlowP {
     float tab_x0, tab_inv_dx;     // uniform-grid turbine table
     int hlen[WG_N_CH], ring_off[WG_N_CH], fring_off[WG_N_CH];
     float inv_hlen[WG_N_CH], inv_power_avg;   // reciprocals for the division-free ring positions (fast_mod)
+    unsigned hmagic[WG_N_CH], pavg_magic;     // floor(2^32 / H) + 1: n mod H in three integer (scalar) operations, n * H < 2^32
     int ring_stride, fring_stride;
     float noise_sigma[WG_N_CH];
     // turbulent inflow (Random / frozen Mann box)

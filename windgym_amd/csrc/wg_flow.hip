@@ -103,6 +103,17 @@ __device__ __forceinline__ int fast_mod(int n, int H, float invH) {
     return r;
 }
 
+// n % H for a wave-uniform 0 <= n with n * H < 2^32 and magic = floor(2^32 / H) + 1 (host): integer-only, so the
+// compiler keeps it on the scalar unit (fast_mod's float reciprocal forces the vector ALU).  H = 1: magic wraps to 1,
+// the quotient estimate is 0 and the correction loop is not an option — handled explicitly.
+__device__ __forceinline__ int umod_small(int n, int H, unsigned magic) {
+    if (H == 1) return 0;
+    int r = n - (int)__umulhi((unsigned)n, magic) * H;
+    if (r >= H) r -= H;
+    if (r < 0) r += H;
+    return r;
+}
+
 // uniform-grid table lookup (linear interpolation, 0 outside)
 __device__ __forceinline__ float tab_lookup(const float* __restrict__ ys, const FlowP& p, float x) {
     const float fx = (x - p.tab_x0) * p.tab_inv_dx;
@@ -291,6 +302,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                                           const PartLds& pl, const bool first_step) {
     const int tid = threadIdx.x;
     const int N = p.N, P = p.P;
+    if (RES) __builtin_assume(N <= NT);
     const int TC = p.target_chunk;
 
     // travel of the chains over this step: particles released when the newest one is d_particle away
@@ -322,7 +334,11 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         q.bk = fmaxf(q.bk, q.rk + WG_K_MAX / 65535.0f);
         q.be = fmaxf(q.be, q.reps + 1.0f / 65535.0f);
         if (RES) {
-            q.head_n = (q.head + n_emit) % q.rlen;
+            {   // (q.head + n_emit) mod rlen without the integer division (n_emit is 0 or 1 in practice)
+                int hn = q.head + n_emit;
+                if (n_emit >= q.rlen) hn %= q.rlen; else if (hn >= q.rlen) hn -= q.rlen;
+                q.head_n = hn;
+            }
             if (n_emit > 0 && rec_moves(pack_b(q.reps, q.rhv))) q.mvl = sr.n_emitted + (unsigned)n_emit;
         }
     }
@@ -559,15 +575,21 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         int* nq = jnl + N + 1;              // (the same word serves as the candidate counter of the deficit phase)
         if (tid == 0) *nq = 0;
         lds_barrier<NT>();
-        for (int t = tid; t < ((WG_ABLATE & 1) ? 0 : N); t += NT) {
+        // (2^lsh adjacent lanes share a turbine: the listing loop of a moving chain — up to P / 4 entries — is split
+        // between them; the host chose lsh with N << lsh <= NT)
+        const int lsh = p.ql_lpt_shift, lpt = 1 << lsh;
+        const int t = tid >> lsh, kl = tid & (lpt - 1);
+        if (t < ((WG_ABLATE & 1) ? 0 : N)) {
             const TurbLds& tq = T[t];
             const int R = tq.rlen, nqd = R >> 2;
             const bool moving = tq.mvl != 0u && (int)(sr.n_emitted - tq.mvl) < R;
             const unsigned tag = (unsigned)t << qsh;
             if (moving || n_emit >= 4 || n_emit >= R) {
-                const int base = atomicAdd(nq, nqd);
-                for (int i = 0; i < nqd; ++i) ql[base + i] = (unsigned short)(tag | (unsigned)i);
-            } else if (n_emit > 0) {
+                int base = 0;
+                if (kl == 0) base = atomicAdd(nq, nqd);
+                base = __shfl(base, (tid & 63) & ~(lpt - 1), 64);
+                for (int i = kl; i < nqd; i += lpt) ql[base + i] = (unsigned short)(tag | (unsigned)i);
+            } else if (n_emit > 0 && kl == 0) {
                 int prev = -1;
                 for (int e = 0; e < n_emit; ++e) {
                     int r = tq.head + 1 + e; if (r >= R) r -= R;
@@ -1101,7 +1123,7 @@ __device__ __forceinline__ void script_step(const FlowP& p, const FlowPtrs& d, T
     ([&]() {                                                                                \
         float _s = 0.f;                                                                     \
         for (int _t = (int)(threadIdx.x & 63); _t < N; _t += WG_WAVE) _s += T[_t].field;    \
-        return wg_wave_sum(_s);                                                             \
+        return N <= 16 ? wg_row_sum(_s) : wg_wave_sum(_s);   /* (lanes >= N hold 0: row 0 alone is the sum) */ \
     }())
 
 // Rare path at the head of k_flow (WgCtx::init_pending): one wave sets up the episode a retired context will hold.
@@ -1124,6 +1146,9 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
        const uint8_t* __restrict__ mask, const int chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int F = p.F, N = p.N;
+    // (the host selects the compact variants only for farms with at most one turbine per thread: every
+    // `for (t = tid; t < N; t += NT)` below is a single trip, and the compiler may know it)
+    if (RES) __builtin_assume(N <= NT);
     const int bid = blockIdx.x;
     // Block order.  Inflow "None" / "Random": farm-major — all agent farms first; the lighter baseline farms (un-yawed
     // chains do not move) form the tail of the launch, where CUs drain (+1.6 % on cfg2).  Frozen box: env-major — the
@@ -1279,7 +1304,9 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             if (!RES) jnl[t] = l_jn;
             if (RES) {
                 q.roff = l_roff; q.rlen = l_rnext - l_roff;
-                q.head = sr.n_emitted == 0u ? q.rlen - 1 : (int)((sr.n_emitted - 1u) % (unsigned)q.rlen);
+                // ((n_emitted - 1) mod rlen: emission counts stay far below 2^24, fast_mod's range)
+                q.head = sr.n_emitted == 0u ? q.rlen - 1
+                                            : fast_mod((int)(sr.n_emitted - 1u), q.rlen, __builtin_amdgcn_rcpf((float)q.rlen));
                 q.head_n = q.head;
             }
         }
@@ -1332,7 +1359,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     // live:   one env step = K sub-steps with measurement (Wind_Farm_Env.py:932-979)
     // else:   background development of a not-yet-live episode: flow-development steps (fs.run), then
     //         window-fill env steps (Wind_Farm_Env.py:722-796)
-    int sub = 0, n_flow = 0;
+    int sub = 0, n_flow = 0, part_acc = 0;
     float base_acc = 0.f;
     const float inv_k = 1.0f / (float)p.K;
     for (;;) {
@@ -1360,12 +1387,8 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             script_step<NT>(p, d, T, e, farm, cursor, sr.time);
         } else {
             flow_step<NT, TURB, RES>(p, d, T, tabct, rdy, rdz, pair, tiap, tmask, jnl, pbase, ws, ti_f, ti_pow, tc, sr, pl, n_flow == 0);
-            if (tid < WG_WAVE) {   // roofline accounting: particles that can still reach a rotor
-                int cnt = 0;
-                for (int t = tid; t < N; t += WG_WAVE) cnt += min(sr.n_valid, RES ? T[t].rlen : jnl[t] + 1);
-                cnt = wg_wave_sum_i(cnt);
-                if (tid == 0) jnl[N] += cnt;          // only thread 0 ever touches this word
-            }
+            // roofline accounting: particles that can still reach a rotor (per lane; summed once in the epilogue)
+            for (int t = tid; t < N; t += NT) part_acc += min(sr.n_valid, RES ? T[t].rlen : jnl[t] + 1);
             ++n_flow;
         }
         --budget;
@@ -1406,7 +1429,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
 #pragma unroll
                     for (int ch = 0; ch < WG_N_CH; ++ch) {
                         const int H = kc->p.hlen[ch];
-                        rbase[kc->p.ring_off[ch] + t * H + fast_mod(n_pushed, H, kc->p.inv_hlen[ch])] = val[ch];
+                        rbase[kc->p.ring_off[ch] + t * H + umod_small(n_pushed, H, kc->p.hmagic[ch])] = val[ch];
                     }
                     // stage the pushed values for the farm-level mean / mean / sum
                     q.sws = val[0]; q.swd = val[1]; q.sp = val[3];
@@ -1426,11 +1449,11 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
                 if (tid == 0) {
                     const FlowP __attribute__((address_space(4)))& pc = kc->p;
                     float* fbase = kc->d.fring + (size_t)ctx_id * pc.fring_stride;
-                    fbase[pc.fring_off[WG_CH_WS] + fast_mod(n_pushed, pc.hlen[WG_CH_WS], pc.inv_hlen[WG_CH_WS])] = sws * pc.inv_N;
-                    fbase[pc.fring_off[WG_CH_WD] + fast_mod(n_pushed, pc.hlen[WG_CH_WD], pc.inv_hlen[WG_CH_WD])] = swd * pc.inv_N;
-                    fbase[pc.fring_off[WG_CH_POWER] + fast_mod(n_pushed, pc.hlen[WG_CH_POWER], pc.inv_hlen[WG_CH_POWER])] = tot;
+                    fbase[pc.fring_off[WG_CH_WS] + umod_small(n_pushed, pc.hlen[WG_CH_WS], pc.hmagic[WG_CH_WS])] = sws * pc.inv_N;
+                    fbase[pc.fring_off[WG_CH_WD] + umod_small(n_pushed, pc.hlen[WG_CH_WD], pc.hmagic[WG_CH_WD])] = swd * pc.inv_N;
+                    fbase[pc.fring_off[WG_CH_POWER] + umod_small(n_pushed, pc.hlen[WG_CH_POWER], pc.hmagic[WG_CH_POWER])] = tot;
                     if (live_step) kc->d.step_farm_pow[e] = tot;
-                    else kc->d.pend_farm[(size_t)ctx_id * pc.power_avg + fast_mod(pend_farm_n, pc.power_avg, pc.inv_power_avg)] = tot;
+                    else kc->d.pend_farm[(size_t)ctx_id * pc.power_avg + umod_small(pend_farm_n, pc.power_avg, pc.pavg_magic)] = tot;
                 }
             }
             ++n_pushed;
@@ -1441,7 +1464,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             if (tid == 0) {
                 const float bp = p.K == 1 ? base_acc : base_acc * inv_k;
                 if (live_step) kc->d.step_base_pow[e] = bp;
-                else kc->d.pend_base[(size_t)ctx_id * kc->p.power_avg + fast_mod(pend_base_n, kc->p.power_avg, kc->p.inv_power_avg)] = bp;
+                else kc->d.pend_base[(size_t)ctx_id * kc->p.power_avg + umod_small(pend_base_n, kc->p.power_avg, kc->p.pavg_magic)] = bp;
             }
             if (!live_step) ++pend_base_n;
             base_acc = 0.f;
@@ -1459,10 +1482,18 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         ke->d.ti_loc[tb + t] = q.ti; ke->d.power[tb + t] = q.pow; ke->d.ct[tb + t] = q.ct;
         reinterpret_cast<float4*>(ke->d.bnd)[tb + t] = make_float4(q.bd, q.bk, q.be, __uint_as_float(q.mvl));
     }
+    if (NT > WG_WAVE) {          // (multi-wave workgroups: per-wave partial sums meet in the LDS word)
+        part_acc = wg_wave_sum_i(part_acc);
+        if ((tid & 63) == 0) atomicAdd(&jnl[N], part_acc);
+        lds_barrier<NT>();
+        part_acc = jnl[N];
+    } else {
+        part_acc = wg_wave_sum_i(part_acc);
+    }
     if (tid == 0) {
         WgSlot& slot = ke->d.slot[slot_id];
         WgCtx& cx = ke->d.ctx[ctx_id];
-        slot.part_count += (unsigned)jnl[N];
+        slot.part_count += (unsigned)part_acc;
         slot.head = sr.head; slot.n_valid = sr.n_valid; slot.s_off = sr.s_off; slot.time = sr.time;
         slot.istep = sr.istep; slot.n_emitted = sr.n_emitted;
         slot.cursor = cursor;
