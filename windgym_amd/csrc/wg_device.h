@@ -410,12 +410,17 @@ __device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, c
 // ---------------------------------------------------------------------------------------------------
 // MesClass (WindGym/MesClass.py)
 // ---------------------------------------------------------------------------------------------------
+// A sensor deque.  The turbine-level rings of a channel are stored TIME-major, [H][N]: one push of all N turbines is one
+// contiguous store of N floats (turbine-major [N][H] made it N scattered 4-byte stores, i.e. N partial lines, per channel
+// and step), and turbine t's samples are `stride` = N floats apart.  Farm-level rings: stride 1.
 struct WgRing {
     const float* data;
     int n_pushed, hlen;
     int n_avail, start;      // start = physical slot of the oldest sample (one modulo per ring, not per element)
+    int stride;
     __device__ WgRing() {}
-    __device__ WgRing(const float* d_, int n_pushed_, int hlen_) : data(d_), n_pushed(n_pushed_), hlen(hlen_) {
+    __device__ WgRing(const float* d_, int n_pushed_, int hlen_, int stride_ = 1)
+        : data(d_), n_pushed(n_pushed_), hlen(hlen_), stride(stride_) {
         n_avail = n_pushed < hlen ? n_pushed : hlen;
         start = (n_pushed - n_avail) % hlen;
     }
@@ -423,7 +428,7 @@ struct WgRing {
     __device__ float at(int q) const {   // q = 0 oldest
         int phys = start + q;
         if (phys >= hlen) phys -= hlen;
-        return data[phys];
+        return data[phys * stride];
     }
 };
 
@@ -513,8 +518,8 @@ __device__ inline int wg_turb_block_b(const WgParams& p, const float* rbase, con
             bool ti_on = farm_level ? p.farm_ti : p.turb_ti;
             if (ti_on) {
                 const int H = p.ch[WG_CH_WS].history_len;
-                WgRing r{farm_level ? fbase + p.fring_off[WG_CH_WS] : rbase + p.ring_off[WG_CH_WS] + (size_t)t * H,
-                         n_pushed, H};
+                WgRing r = farm_level ? WgRing(fbase + p.fring_off[WG_CH_WS], n_pushed, H)
+                                      : WgRing(rbase + p.ring_off[WG_CH_WS] + t, n_pushed, H, p.N);
                 out[n++] = wg_scale(wg_calc_ti(r), p.ti_min_f, p.ti_rng_f);
             }
         }
@@ -526,7 +531,7 @@ __device__ inline int wg_turb_block_b(const WgParams& p, const float* rbase, con
             r = WgRing(fbase + p.fring_off[ch], (ch == WG_CH_YAW) ? 0 : n_pushed, H);
             if (ch == WG_CH_YAW) on = true;
         } else {
-            r = WgRing(rbase + p.ring_off[ch] + (size_t)t * H, n_pushed, H);
+            r = WgRing(rbase + p.ring_off[ch] + t, n_pushed, H, p.N);
         }
         float rng = (farm_level && ch == WG_CH_POWER) ? p.sc_rng_farm_power : p.sc_rng[ch];
         n += wg_mes_get(p.ch[ch], p.ch[ch].current && on, p.ch[ch].rolling_mean && on, r, p.sc_min[ch], rng,

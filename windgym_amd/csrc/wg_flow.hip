@@ -464,7 +464,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 const int jp0 = j - n_emit, jp1 = jp0 + 1;
                 int r0 = src.head - jp0; if (r0 < 0) r0 += Rs;
                 int r1 = src.head - jp1; if (r1 < 0) r1 += Rs;
-                const int i0 = src.roff + r0, i1 = src.roff + r1;
+                const int i0 = (WG_ABLATE & 128) ? src.roff : src.roff + r0, i1 = (WG_ABLATE & 128) ? src.roff + 1 : src.roff + r1;   // (profiling: gathers that hit one line per chain)
                 const bool g0 = jp0 >= 0, g1 = jp1 >= 0;
                 py0 = py1 = (float)src.yr; u0 = u1 = src.rue;
                 a0 = a1 = pack_a(src.rct, src.rk); b0_ = b1_ = pack_b(src.reps, src.rhv);
@@ -1183,10 +1183,10 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     // (cold parameters: the pointers below are read from the kernarg segment where they are used and not kept — see
     // wg_cold_args)
     const KArgsPtr k0 = wg_cold_args();
-    const WgEnv& env = k0->d.env[e];
+    const WgEnv& env = d.env[e];
     const int env_live = env.live, env_done = env.done, env_shadow_iters = env.shadow_iters;
     const uint64_t noise_key = env.noise_key;
-    const int init_pending = k0->d.ctx[ctx_id].init_pending;
+    const int init_pending = d.ctx[ctx_id].init_pending;
     const uint8_t masked_out = (mode == WG_MODE_RESET && mask) ? (uint8_t)(mask[e] == 0) : (uint8_t)0;
     const int t_own = tid < N ? tid : 0;
     int dev_rem, fill_rem, cursor, n_pushed, pend_farm_n, pend_base_n;
@@ -1201,8 +1201,11 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     int l_jn = 0, l_roff = 0, l_rnext = 0, L_ring = 0;
     auto load_state = [&]() __attribute__((always_inline)) {
         const KArgsPtr kl = wg_cold_args();
-        const WgSlot& slot = kl->d.slot[slot_id];
-        const WgCtx& cx = kl->d.ctx[ctx_id];
+        // (the slot / context headers through the plain kernel arguments: the compiler then knows the addresses are
+        // uniform and not written before, and fetches the fields with a few wide scalar loads instead of one vector
+        // load per field)
+        const WgSlot& slot = d.slot[slot_id];
+        const WgCtx& cx = d.ctx[ctx_id];
         dev_rem = slot.dev_remaining; fill_rem = slot.fill_remaining;
         sr = SlotRegs{slot.s_off, slot.time, slot.head, slot.n_valid, slot.istep, slot.n_emitted};
         if (RES) {
@@ -1429,7 +1432,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
 #pragma unroll
                     for (int ch = 0; ch < WG_N_CH; ++ch) {
                         const int H = kc->p.hlen[ch];
-                        rbase[kc->p.ring_off[ch] + t * H + umod_small(n_pushed, H, kc->p.hmagic[ch])] = val[ch];
+                        rbase[kc->p.ring_off[ch] + umod_small(n_pushed, H, kc->p.hmagic[ch]) * N + t] = val[ch];      // (time-major: WgRing)
                     }
                     // stage the pushed values for the farm-level mean / mean / sum
                     q.sws = val[0]; q.swd = val[1]; q.sp = val[3];

@@ -36,14 +36,13 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
         for (int ch = 0; ch < WG_N_CH; ++ch) {
             const int H = p.ch[ch].history_len;
             if (ch == WG_CH_POWER && p.turb_ti) {
-                WgRing r(rbase + p.ring_off[WG_CH_WS] + (size_t)t * p.ch[WG_CH_WS].history_len, n_pushed,
-                         p.ch[WG_CH_WS].history_len);
+                WgRing r(rbase + p.ring_off[WG_CH_WS] + t, n_pushed, p.ch[WG_CH_WS].history_len, N);
                 float v = WG_OBSV(wg_calc_ti(r), p.ti_min_f, p.ti_rng_f);
                 o[n] = v; if (obs2) obs2[(size_t)t * p.turb_obs + n] = v;
                 if (obs_m) obs_m[(size_t)t * p.obs_dim_multi + n] = v;
                 ++n;
             }
-            WgRing r(rbase + p.ring_off[ch] + (size_t)t * H, n_pushed, H);
+            WgRing r(rbase + p.ring_off[ch] + t, n_pushed, H, N);
             const bool on = p.turb_on[ch] != 0;
             const bool cur_on = p.ch[ch].current && on, rol_on = p.ch[ch].rolling_mean && on;
             // stream the values out one at a time (window count is unbounded: history_N up to 100s)
@@ -82,8 +81,7 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
             for (int k = 0; k < m; ++k) om[k] = wg_clip1(om[k]);
         }
         if (p.farm_ti) {   // farm TI = mean of the *scaled* turbine TIs (MesClass.py:670-673)
-            WgRing r(rbase + p.ring_off[WG_CH_WS] + (size_t)t * p.ch[WG_CH_WS].history_len, n_pushed,
-                     p.ch[WG_CH_WS].history_len);
+            WgRing r(rbase + p.ring_off[WG_CH_WS] + t, n_pushed, p.ch[WG_CH_WS].history_len, N);
             ti_sum += raw ? wg_calc_ti(r) : wg_scale(wg_calc_ti(r), p.ti_min_f, p.ti_rng_f);
         }
     }
@@ -172,7 +170,7 @@ __device__ inline void stage_rings(const WgParams& p, const WgPtrs& d, int ctx_i
             const int H = p.ch[ch].history_len;
             const int newest = (n_pushed - 1) % H;
             for (int t = lane; t < N; t += WG_WAVE) {
-                const int idx = p.ring_off[ch] + t * H + newest;
+                const int idx = p.ring_off[ch] + newest * N + t;
                 lds[idx] = gr[idx];
             }
         }
