@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WG_ABI_VERSION 1
+#define WG_ABI_VERSION 2
 
 typedef enum wg_status {
     WG_OK = 0,
@@ -140,6 +140,17 @@ typedef struct wg_config {
                                 * longer advected — it cannot reach a rotor any more, every output of step() is
                                 * unchanged; 1: advect all P slots of every chain (needed only if wg_get_windspeed
                                 * must be exact behind the last turbine row)                               */
+    /* ---- model options (ABI 2) ------------------------------------------------------------------- */
+    int32_t added_turbulence;  /* wake-added small-scale turbulence (reference: addedTurbulenceModel =
+                                * [Synchronized]AutoScalingIsotropicMannTurbulence(), Wind_Farm_Env.py:618, :638, :644,
+                                * :659).  0: none; 1: an isotropic unit-variance box (wg_set_added_turbulence_box) sampled
+                                * at the rotor points and scaled per source wake by k_mt = km1 |dU| + km2 |d dU / d(r/R)|
+                                * (Madsen et al. 2010), same advection offset as the ambient box ("Synchronized").
+                                * Ignored with turb_mode NONE (the reference has no model there, :664).              */
+    int32_t no_ti_fold;        /* 1: the Crespo-Hernandez added TI is NOT folded into the k of emitted particles     */
+    int32_t deficit_model;     /* 0: Gaussian (north_star); 1: super-Gaussian of Blondel & Cathelain (2020)          */
+    int32_t reserved0_;
+    double m0_km1, m0_km2;     /* DWM added-turbulence scaling constants (0.6, 0.35); 0 selects the default          */
 } wg_config;
 
 typedef struct wg_env_s* wg_handle;
@@ -203,6 +214,12 @@ int wg_hist_max(wg_handle h, int* hist_max);
  * released afterwards).  Must be called before wg_reset in the box modes.                               */
 int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, int ny, int nz,
                           double dx, double dy, double dz);
+
+/* Isotropic box of the wake-added turbulence (wg_config.added_turbulence = 1): 3 planes like above, unit variance;
+ * the reference's default is hipersim's L = 5 m, Gamma = 0, 128^3 cells of 3 m
+ * (examples/longer_steps_example.py:153).  The library keeps an interleaved copy.  Must be set before wg_reset.   */
+int wg_set_added_turbulence_box(wg_handle h, const float* box_dev, int nx, int ny, int nz,
+                                double dx, double dy, double dz);
 
 /* Pool of n_boxes frozen boxes of equal shape for turb_mode BOX_POOL (turbtype "MannLoad": one of the TF_* files per
  * reset, Wind_Farm_Env.py:611-618).  boxes_dev: HOST array of n_boxes DEVICE pointers, each 3 planes like above.  The

@@ -51,7 +51,7 @@ class Oracle:
         L = lib()
         pre = "wgo_" if precision == "f64" else "wgof_"
         self._f = {n: getattr(L, pre + n) for n in (
-            "create", "destroy", "obs_dim", "hist_max", "set_flow_script", "set_turbulence_box", "set_turbulence_boxes", "reset",
+            "create", "destroy", "obs_dim", "hist_max", "set_flow_script", "set_turbulence_box", "set_turbulence_boxes", "set_added_turbulence_box", "reset",
             "step", "obs_multi", "get_obs", "get_info", "metrics", "get_chain", "set_threads", "max_threads",
             "get_windspeed")}
         self._f["create"].restype = C.c_void_p
@@ -65,6 +65,7 @@ class Oracle:
         self.B, self.N = cfg.n_envs, cfg.n_turb
         self._script = None
         self._box = None
+        self._abox = None
 
     def close(self):
         if self._h:
@@ -102,6 +103,14 @@ class Oracle:
                                       C.c_int(box.shape[2]), C.c_int(box.shape[3]), C.c_double(spacing[0]),
                                       C.c_double(spacing[1]), C.c_double(spacing[2]))
 
+    def set_added_turbulence_box(self, box, spacing):
+        box = np.ascontiguousarray(box, dtype=np.float32)
+        assert box.ndim == 4 and box.shape[0] == 3
+        self._abox = box
+        self._f["set_added_turbulence_box"](self._h, box.ctypes.data_as(C.c_void_p), C.c_int(box.shape[1]),
+                                            C.c_int(box.shape[2]), C.c_int(box.shape[3]), C.c_double(spacing[0]),
+                                            C.c_double(spacing[1]), C.c_double(spacing[2]))
+
     def set_turbulence_boxes(self, boxes, spacing):
         bs = [np.ascontiguousarray(b, dtype=np.float32) for b in boxes]
         assert all(b.shape == bs[0].shape and b.ndim == 4 and b.shape[0] == 3 for b in bs)
@@ -125,6 +134,10 @@ class Oracle:
         return out
 
     def reset(self, seeds=None, mask=None):
+        if self._c.added_turbulence and self._abox is None:
+            # the default isotropic field of the wake-added turbulence: the same array the HIP batch installs
+            from windgym_amd.mann import default_added_box
+            self.set_added_turbulence_box(*default_added_box())
         obs = np.zeros((self.B, self.obs_dim))
         sp = None
         if seeds is not None:

@@ -132,6 +132,10 @@ typedef struct oracle_t {
      * only feel scales the DWM low-pass filter would keep anyway; the coarse box stays cache-resident) */
     float* cbox;
     int cnx, cny, cnz, coarse;
+    /* isotropic box of the wake-added turbulence (wg_config.added_turbulence), unit variance, host memory */
+    const float* abox;
+    int anx, any, anz;
+    double adx, ady, adz;
 } oracle_t;
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -207,6 +211,7 @@ void* WGO(create)(const wg_config* cfg) {
     c->m0_ti_a = defd(c->m0_ti_a, 0.73); c->m0_ti_b = defd(c->m0_ti_b, 0.8325);
     c->m0_ti_c = defd(c->m0_ti_c, 0.0325); c->m0_ti_d = defd(c->m0_ti_d, -0.32);
     c->m0_fc_scale = defd(c->m0_fc_scale, 2.0);
+    c->m0_km1 = defd(c->m0_km1, 0.6); c->m0_km2 = defd(c->m0_km2, 0.35);
     o->obs_dim = turb_obs_count(c) * o->N + farm_obs_count(c);
     /* per-agent vector of WindFarmEnvMulti._get_obs_multi (WindEnvMulti.py:79-103): own turbine block ++
      * farm_mes.farm_mes.get_measurements(); the farm object's yaw deque is never filled, so it contributes
@@ -301,6 +306,12 @@ int WGO(set_turbulence_boxes)(void* h, const float* const* boxes, int n_boxes, i
     }
     return 0;
 }
+/* isotropic box of the wake-added turbulence: [3][nx][ny][nz] float, z fastest, unit variance (borrowed) */
+void WGO(set_added_turbulence_box)(void* h, const float* box, int nx, int ny, int nz, double dx, double dy,
+                                   double dz) {
+    oracle_t* o = (oracle_t*)h;
+    o->abox = box; o->anx = nx; o->any = ny; o->anz = nz; o->adx = dx; o->ady = dy; o->adz = dz;
+}
 void WGO(set_turbulence_box)(void* h, const float* box, int nx, int ny, int nz, double dx, double dy,
                              double dz) {
     const float* one[1] = {box};
@@ -357,6 +368,27 @@ static inline real box_lookup(const oracle_t* o, int bid, int comp, double x, do
     long i1 = (i0 + 1) % o->bnx, j1 = (j0 + 1) % o->bny, k1 = (k0 + 1) % o->bnz;
     const float* p = o->box_pool[bid] + (size_t)comp * o->bnx * o->bny * o->bnz;
 #define BX(i, j, k) ((real)p[((size_t)(i) * o->bny + (j)) * o->bnz + (k)])
+    real c00 = BX(i0, j0, k0) + tx * (BX(i1, j0, k0) - BX(i0, j0, k0));
+    real c10 = BX(i0, j1, k0) + tx * (BX(i1, j1, k0) - BX(i0, j1, k0));
+    real c01 = BX(i0, j0, k1) + tx * (BX(i1, j0, k1) - BX(i0, j0, k1));
+    real c11 = BX(i0, j1, k1) + tx * (BX(i1, j1, k1) - BX(i0, j1, k1));
+#undef BX
+    real c0 = c00 + ty * (c10 - c00);
+    real c1 = c01 + ty * (c11 - c01);
+    return c0 + tz * (c1 - c0);
+}
+
+/* the same lookup in the added-turbulence box */
+static inline real abox_lookup(const oracle_t* o, int comp, double x, double y, double z) {
+    double fx = x / o->adx, fy = y / o->ady, fz = z / o->adz;
+    double ix = floor(fx), iy = floor(fy), iz = floor(fz);
+    real tx = (real)(fx - ix), ty = (real)(fy - iy), tz = (real)(fz - iz);
+    long i0 = (long)fmod(ix, (double)o->anx); if (i0 < 0) i0 += o->anx;
+    long j0 = (long)fmod(iy, (double)o->any); if (j0 < 0) j0 += o->any;
+    long k0 = (long)fmod(iz, (double)o->anz); if (k0 < 0) k0 += o->anz;
+    long i1 = (i0 + 1) % o->anx, j1 = (j0 + 1) % o->any, k1 = (k0 + 1) % o->anz;
+    const float* p = o->abox + (size_t)comp * o->anx * o->any * o->anz;
+#define BX(i, j, k) ((real)p[((size_t)(i) * o->any + (j)) * o->anz + (k)])
     real c00 = BX(i0, j0, k0) + tx * (BX(i1, j0, k0) - BX(i0, j0, k0));
     real c10 = BX(i0, j1, k0) + tx * (BX(i1, j1, k0) - BX(i0, j1, k0));
     real c01 = BX(i0, j0, k1) + tx * (BX(i1, j0, k1) - BX(i0, j0, k1));
@@ -480,10 +512,29 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
     }
     /* (4) rotor-averaged inflow of every turbine: ambient minus linearly superposed Gaussian deficits of
      * all upstream chains, wake centre / record interpolated between the two bracketing particles */
+    /* wake-added turbulence (reference: [Synchronized]AutoScalingIsotropicMannTurbulence, Wind_Farm_Env.py:618, :638,
+     * :644, :659; restated from the DWM literature — Madsen, Larsen G.C., Larsen T.J., Troldborg & Mikkelsen 2010,
+     * "Calibration and validation of the dynamic wake meandering model", J. Sol. Energy Eng. 132, eq. (11); IEC
+     * 61400-1 ed. 4 Annex E): a unit-variance ISOTROPIC small-scale field g, frozen and advected with the ambient
+     * field's clock and offset ("Synchronized"), is scaled inside every wake by
+     *     k_mt(r) = km1 |dU(r)| / U + km2 |d (dU / U) / d (r / R)| ,
+     * dU the wake's deficit at the point, r the distance from the wake centre, R the rotor radius.  At rotor point p of
+     * target t:  uvw_added = U sum_s k_mt,s(p) g(x_t - U t + o_x, y_p + o_y, z_p)  (per source wake, superposed
+     * linearly like the deficits); the rotor average enters (u, v, w)_t.  Gaussian wake: dU = A E, |d dU / dr| = A E r / sigma^2. */
+    const int added = c->added_turbulence && (box || rnd) && o->abox;
+    const real km1 = (real)c->m0_km1, km2 = (real)c->m0_km2;
     for (int t = 0; t < N; ++t) {
         real g = f->yaw[t] * (real)(PI_D / 180.0);
         real cg = R_COS(g);
         real dsum = 0, tiadd_max = 0;
+        real gadd[3][S > 0 ? S : 1], addsum[3] = {0, 0, 0};
+        if (added) {
+            for (int s = 0; s < S; ++s)
+                for (int cc = 0; cc < 3; ++cc)
+                    gadd[cc][s] = abox_lookup(o, cc, x->xr[t] - x->ws * f->time + x->box_ox,
+                                              x->yr[t] + (double)((real)o->rotor_dy[s] * cg) + x->box_oy,
+                                              c->hub_height + o->rotor_dz[s]);
+        }
         for (int s2 = 0; s2 < N; ++s2) {
             if (s2 == t) continue;
             double dx = x->xr[t] - x->xr[s2];
@@ -519,13 +570,20 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
                 real ys = (real)x->yr[t] + (real)o->rotor_dy[s] * cg;
                 real zs = hub + (real)o->rotor_dz[s];
                 real r2 = (ys - yc) * (ys - yc) + (zs - zc) * (zs - zc);
-                dsum += amp * R_EXP(-r2 * inv2s2);
+                real du = amp * R_EXP(-r2 * inv2s2);
+                dsum += du;
+                if (added) {
+                    /* U k_mt = km1 dU + km2 R |d dU / dr| = dU (km1 + km2 R r / sigma^2) */
+                    real wk = du * (km1 + km2 * R_rot * R_SQRT(r2) * ((real)2 * inv2s2));
+                    for (int cc = 0; cc < 3; ++cc) addsum[cc] += wk * gadd[cc][s];
+                }
             }
             /* wake-added turbulence (Crespo & Hernandez 1996), weighted by the Gaussian at the hub */
             real ind = (real)0.5 * ((real)1 - R_SQRT((real)1 - ctv));
             real xdc = xd < (real)1 ? (real)1 : xd;
             real tia = (real)c->m0_ti_a * R_POW(ind, (real)c->m0_ti_b) * R_POW((real)x->ti, (real)c->m0_ti_c) *
                        R_POW(xdc, (real)c->m0_ti_d) * R_EXP(-rc2 * inv2s2);
+            if (c->no_ti_fold) tia = 0;
             if (tia > tiadd_max) tiadd_max = tia;
         }
         real amb[3] = {0, 0, 0};
@@ -541,9 +599,9 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
             for (int cc = 0; cc < 3; ++cc)
                 amb[cc] = sc * (real)wgo_turb_normal(x->turb_seed, f->istep, (uint32_t)t, (uint32_t)cc, 0x52);
         }
-        f->u[t] = (real)x->ws + amb[0] - dsum / (real)S;
-        f->v[t] = amb[1];
-        f->w[t] = amb[2];
+        f->u[t] = (real)x->ws + amb[0] - dsum / (real)S + addsum[0] / (real)S;
+        f->v[t] = amb[1] + addsum[1] / (real)S;
+        f->w[t] = amb[2] + addsum[2] / (real)S;
         f->ti_loc[t] = R_SQRT((real)(x->ti * x->ti) + tiadd_max * tiadd_max);
     }
     /* (5) turbine power / thrust at the new inflow with the current yaw */

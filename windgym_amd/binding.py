@@ -31,7 +31,7 @@ UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 # every symbol include/windgym_hip.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = (
     "wg_last_error", "wg_abi_version", "wg_create", "wg_destroy", "wg_obs_dim", "wg_hist_max",
-    "wg_set_turbulence_box", "wg_set_turbulence_boxes", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_set_step_graph", "wg_check", "wg_obs_multi", "wg_set_obs_multi_buffer",
+    "wg_set_turbulence_box", "wg_set_turbulence_boxes", "wg_set_added_turbulence_box", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_set_step_graph", "wg_check", "wg_obs_multi", "wg_set_obs_multi_buffer",
     "wg_get_info", "wg_get_measurements", "wg_get_windspeed", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_algorithmic_bytes", "wg_flow_variant",
 )
 
@@ -63,6 +63,8 @@ def load_library():
     L.wg_hist_max.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.wg_set_turbulence_box.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
                                         C.c_double, C.c_double]
+    L.wg_set_added_turbulence_box.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                              C.c_double, C.c_double]
     L.wg_set_turbulence_boxes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_double, C.c_double, C.c_double]
     L.wg_set_flow_script.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -160,6 +162,9 @@ class HipBatch:
         if mask is not None:
             m = np.ascontiguousarray(np.asarray(mask, dtype=np.uint8).reshape(self.B))
             mp = m.ctypes.data_as(C.c_void_p)
+        if self._c.added_turbulence and not getattr(self, "_abox_set", False):
+            from .mann import default_added_box
+            self.set_added_turbulence_box(*default_added_box())
         _chk(self.L.wg_reset(self._h, mp, sp, C.c_void_p(self.obs.data_ptr()), self._stream()), "wg_reset")
         return self.obs
 
@@ -291,6 +296,18 @@ class HipBatch:
         _chk(self.L.wg_set_turbulence_box(self._h, C.c_void_p(b.data_ptr()), int(b.shape[1]), int(b.shape[2]),
                                           int(b.shape[3]), float(spacing[0]), float(spacing[1]),
                                           float(spacing[2])), "wg_set_turbulence_box")
+
+    def set_added_turbulence_box(self, box, spacing):
+        """Isotropic unit-variance box of the wake-added turbulence (wg_config.added_turbulence); default:
+        ``mann.default_added_box()`` installed at the first reset."""
+        t = self.torch
+        b = box if isinstance(box, t.Tensor) else t.as_tensor(np.ascontiguousarray(box, dtype=np.float32))
+        b = b.to(self.device, dtype=t.float32).contiguous()
+        assert b.ndim == 4 and b.shape[0] == 3
+        _chk(self.L.wg_set_added_turbulence_box(self._h, C.c_void_p(b.data_ptr()), int(b.shape[1]), int(b.shape[2]),
+                                                int(b.shape[3]), float(spacing[0]), float(spacing[1]),
+                                                float(spacing[2])), "wg_set_added_turbulence_box")
+        self._abox_set = True
 
     def set_turbulence_boxes(self, boxes, spacing):
         """Pool of K boxes of equal shape (turbtype "MannLoad": one TF_* file drawn per reset, :611-618)."""

@@ -18,7 +18,7 @@ import yaml
 
 from .turbine import as_tabular
 
-WG_ABI_VERSION = 1
+WG_ABI_VERSION = 2
 WG_N_CH = 4
 WG_N_METRICS = 8
 CH_NAMES = ("ws", "wd", "yaw", "power")
@@ -83,6 +83,9 @@ class CConfig(C.Structure):
         ("m0_ti_a", C.c_double), ("m0_ti_b", C.c_double), ("m0_ti_c", C.c_double), ("m0_ti_d", C.c_double),
         ("m0_fc_scale", C.c_double),
         ("full_chains", C.c_int32),
+        ("added_turbulence", C.c_int32), ("no_ti_fold", C.c_int32), ("deficit_model", C.c_int32),
+        ("reserved0_", C.c_int32),
+        ("m0_km1", C.c_double), ("m0_km2", C.c_double),
     ]
 
 
@@ -152,6 +155,12 @@ class EnvConfig:
     # constants of flow model M0, keys of wg_config without the m0_ prefix: ka, kb, eps, hill, ti_a ...
     # ti_d, fc_scale; missing keys keep the documented defaults (a calibrated M0 is configuration, not code)
     model_constants: Optional[dict] = None
+    # wake-added small-scale turbulence (reference: addedTurbulenceModel, Wind_Farm_Env.py:618-664): "auto" = the
+    # reference's choice (an isotropic Mann field scaled inside the wakes for every turbulent inflow, none for
+    # turbtype "None"), "iso" / "none" force it
+    added_turbulence: str = "auto"
+    wake_ti_fold: bool = True                    # Crespo-Hernandez added TI folded into the emitted particles' k (M0 §2.4)
+    deficit: str = "gaussian"                    # "gaussian" (north_star) | "super_gaussian" (Blondel & Cathelain 2020)
     _keep: list = field(default_factory=list, repr=False)
 
     def __post_init__(self):
@@ -353,6 +362,13 @@ class EnvConfig:
         c.extra_timestep_inc = int(bool(self.extra_timestep_inc))
         c.turb_mode = TURB[self.turbtype]
         c.full_chains = int(bool(self.advect_full_chains))
+        if self.added_turbulence not in ("auto", "iso", "none"):
+            raise ValueError("added_turbulence must be 'auto', 'iso' or 'none'")
+        c.added_turbulence = int(self.turbtype != "None" and self.added_turbulence in ("auto", "iso"))
+        c.no_ti_fold = int(not self.wake_ti_fold)
+        if self.deficit not in ("gaussian", "super_gaussian"):
+            raise ValueError("deficit must be 'gaussian' or 'super_gaussian'")
+        c.deficit_model = int(self.deficit == "super_gaussian")
         for k, v in (self.model_constants or {}).items():
             if not hasattr(c, "m0_" + k):
                 raise ValueError(f"unknown model constant {k!r}")

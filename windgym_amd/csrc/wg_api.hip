@@ -55,6 +55,9 @@ struct wg_env_s {
     long n_step_launches = 0;
     void* box4 = nullptr;            // interleaved copy of the caller's turbulence box (owned)
     void* box4c = nullptr;           // block-averaged copy for the particle lookups (owned)
+    void* abox4 = nullptr;           // interleaved isotropic box of the wake-added turbulence (owned)
+    int added = 0, no_ti_fold = 0, deficit_model = 0;   // wg_config model options
+    double km1 = 0.6, km2 = 0.35;
     double* wind_dev = nullptr;      // per-env wind override (wg_set_wind)
     int device;
     std::vector<Alloc> allocs;      // everything owned by the handle (state blob = allocs flagged `state`)
@@ -177,9 +180,14 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     for (int i = 0; i < WG_N_CH; ++i)
         if (c->ch[i].history_len < 1 || c->ch[i].window_len < 1 || c->ch[i].history_n < 1)
             return fail(WG_ERR_INVALID, "sensor history/window lengths must be >= 1");
+    if (c->deficit_model != 0)
+        return fail(WG_ERR_UNSUPPORTED, "deficit_model: only the Gaussian deficit (0) is built into the HIP kernels");
     HIPCHK(hipSetDevice(device));
     wg_env_s* h = new wg_env_s();
     h->device = device;
+    h->added = (c->added_turbulence != 0 && c->turb_mode != WG_TURB_NONE) ? 1 : 0;
+    h->no_ti_fold = c->no_ti_fold != 0; h->deficit_model = c->deficit_model;
+    h->km1 = defd(c->m0_km1, 0.6); h->km2 = defd(c->m0_km2, 0.35);
     WgParams& p = h->p;
     memset(&p, 0, sizeof(p));
     p.B = c->n_envs; p.N = c->n_turb; p.F = c->n_farms; p.K = c->k_sub; p.P = c->n_particles; p.S = c->n_rotor_pts;
@@ -388,16 +396,18 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
                 const size_t ql = ((size_t)p.NP / 2 + 15) & ~(size_t)15;
                 if (!small) {
                     const size_t budget = std::max(ql, off) + sizeof(float) * (size_t)tc * p.N;
-                    const int fit = (int)((budget - 16) / (10 * (size_t)p.N));
+                    const int fit = (int)((budget - 16) / ((h->added ? 22 : 10) * (size_t)p.N));
                     tc = std::max(tc, std::min(p.N, fit));
                     f.target_chunk = tc;
                 }
-                off = std::max(ql, ((size_t)10 * tc * p.N + 16 + 15) & ~(size_t)15);
+                // (+ 12 bytes per pair for the added-turbulence contributions when that model is on)
+                off = std::max(ql, ((size_t)(h->added ? 22 : 10) * tc * p.N + 16 + 15) & ~(size_t)15);
             }
             f.lds_off_turb = (int)off; off += (size_t)WG_TURB_LDS_BYTES * p.N;
             off = (off + 15) & ~(size_t)15;
             f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S) + sizeof(unsigned) * WG_MASK_WORDS * (size_t)tc + (f.res ? 0 : sizeof(float) * (size_t)tc * p.N);
             off += sizeof(int) * ((size_t)p.N + 2);      // chain-pruning ages + the particle counter + the candidate counter
+            if (h->added && f.res) off += sizeof(float) * 3 * ((size_t)p.N << f.S_shift) + sizeof(int) * (size_t)tc;   // gadd: isotropic field at the rotor points + per-target flags
             return (off + 15) & ~(size_t)15;
         };
         // The compact variant's quad list grows with N * P (NP / 2 bytes): a configuration whose carve exceeds what a
@@ -425,7 +435,8 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         // 43.6 -> 37.7 us) and not where the particle traffic does (cfg2 4x4 x P=128: 75 -> 78 us, cfg5 frozen box:
         // 157 -> 172 us): default for steady inflow up to 1024 ring slots per farm.  WG_FLOW_DUO=1 / 0 forces it on
         // (where eligible) / off (tests run both).
-        const bool duo_ok = f.res && small && f.block == 64 && p.F == 2 && 2 * p.N <= 64 && p.P <= 4096;
+        // (k_flow_duo does not carry the optional models: added turbulence, no TI folding)
+        const bool duo_ok = f.res && small && f.block == 64 && p.F == 2 && 2 * p.N <= 64 && p.P <= 4096 && !h->added && !h->no_ti_fold;
         f.duo = (duo_ok && p.NP <= 1024 && p.turb_mode == WG_TURB_NONE) ? 1 : 0;
         if (const char* ev = getenv("WG_FLOW_DUO")) f.duo = (duo_ok && atoi(ev) != 0) ? 1 : 0;
         bool duo_fits = true;
@@ -465,6 +476,8 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         f.ring_stride = p.ring_stride; f.fring_stride = p.fring_stride;
         f.turb_mode = p.turb_mode; f.fc_scale = p.fc_scale; f.D_d = p.D_d; f.hub_d = p.hub_d;
         f.inv_sqrt_S = 1.0f / std::sqrt((float)p.S);
+        f.added = h->added; f.no_ti_fold = h->no_ti_fold; f.deficit_model = h->deficit_model;
+        f.km1 = (float)h->km1; f.km2r = (float)(2.0 * h->km2 * 0.5 * p.D_d);
         FlowPtrs& g = h->fd;
         memset(&g, 0, sizeof(g));
         g.py = d.py; g.rec_a = d.rec_a; g.rec_b = d.rec_b; g.u_e = d.u_e; g.rec4 = d.rec4;
@@ -547,6 +560,7 @@ extern "C" int wg_destroy(wg_handle h) {
     for (auto& a : h->allocs) hipFree(a.ptr);
     if (h->box4) hipFree(h->box4);
     if (h->box4c) hipFree(h->box4c);
+    if (h->abox4) hipFree(h->abox4);
     delete h;
     return 0;
 }
@@ -604,6 +618,26 @@ extern "C" int wg_set_turbulence_boxes(wg_handle h, const float* const* boxes_de
     }
     h->fp.inv_bdx = 1.0 / dx; h->fp.inv_bdy = 1.0 / dy; h->fp.inv_bdz = 1.0 / dz;
     return sync_dev_params(h);
+}
+
+extern "C" int wg_set_added_turbulence_box(wg_handle h, const float* box_dev, int nx, int ny, int nz, double dx,
+                                           double dy, double dz) {
+    if (!h || !box_dev || nx < 2 || ny < 2 || nz < 2 || !(dx > 0) || !(dy > 0) || !(dz > 0))
+        return fail(WG_ERR_INVALID, "added-turbulence box: null pointer or bad dimensions");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    drop_step_graphs(h);
+    h->fd.abox4 = nullptr;
+    if (h->abox4) { void* q = h->abox4; h->abox4 = nullptr; HIPCHK(hipFree(q)); }
+    const size_t n_cells = (size_t)nx * ny * nz;
+    HIPCHK(hipMalloc(&h->abox4, n_cells * 16));
+    wg_launch_box_repack(box_dev, h->abox4, n_cells, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    h->fd.abox4 = (const float4*)h->abox4;
+    h->fp.anx = nx; h->fp.any = ny; h->fp.anz = nz;
+    h->fp.abox_pow2 = ((nx & (nx - 1)) == 0) && ((ny & (ny - 1)) == 0) && ((nz & (nz - 1)) == 0);
+    h->fp.inv_adx = 1.0 / dx; h->fp.inv_ady = 1.0 / dy; h->fp.inv_adz = 1.0 / dz;
+    return 0;
 }
 
 extern "C" int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, int ny, int nz, double dx,
@@ -671,6 +705,8 @@ extern "C" int wg_reset(wg_handle h, const uint8_t* env_mask_host, const uint64_
     HIPCHK(hipSetDevice(h->device));
     if (h->p.turb_mode >= WG_TURB_BOX && !h->d.box)
         return fail(WG_ERR_INVALID, "turbtype Mann*: call wg_set_turbulence_box before wg_reset");
+    if (h->added && !h->fd.abox4)
+        return fail(WG_ERR_INVALID, "added_turbulence: call wg_set_added_turbulence_box before wg_reset");
     const uint8_t* mask = nullptr;
     const uint64_t* seeds = nullptr;
     bool all = true;

@@ -42,6 +42,11 @@ struct FlowP {
     long long box_cells, cbox_cells;        // cells of one box of the pool (fine / block-averaged): box k starts at k * cells
     double inv_bdx, inv_bdy, inv_bdz, fc_scale, D_d, hub_d;
     float inv_sqrt_S;
+    // wake-added turbulence (wg_config.added_turbulence): isotropic box, k_mt constants (km2r = 2 km2 R_rot)
+    int added, anx, any, anz, abox_pow2;
+    int no_ti_fold, deficit_model;
+    float km1, km2r;
+    double inv_adx, inv_ady, inv_adz;
 };
 
 struct FlowPtrs {
@@ -50,6 +55,7 @@ struct FlowPtrs {
     unsigned *rec_a, *rec_b;      // packed emission record (see wg_flow.hip)
     const float4* box4;          // interleaved copy of the turbulence box: [Nx][Ny][Nz] x (u, v, w, 0)
     const float4* box4c;         // the same block-averaged over 4x4x4 cells
+    const float4* abox4;         // isotropic box of the wake-added turbulence, interleaved like box4
     float *yaw, *u, *v, *w, *ti_loc, *power, *ct;
     float* bnd;                   // [n_slots][N][4] conservative chain bounds (excursion, k, eps) + last moving emission (uint bits)
     WgSlot* slot;

@@ -182,10 +182,10 @@ struct TurbCtx {
 // loads per component.  Cell coordinates in double precision (x - U t reaches 1e5 m), weights in fp32 — as the
 // oracle does.  out[0..2] = (u, v, w).
 template <bool POW2>
-__device__ __forceinline__ void box_lookup(const float4* __restrict__ box, const FlowP& p, double x, double y,
-                                           double z, float* __restrict__ out) {
-    const double fx = x * p.inv_bdx, fy = y * p.inv_bdy, fz = z * p.inv_bdz;
-    const int bnx = p.bnx, bny = p.bny, bnz = p.bnz;
+__device__ __forceinline__ void box_lookup_dims(const float4* __restrict__ box, const int bnx, const int bny, const int bnz,
+                                                const double inv_dx, const double inv_dy, const double inv_dz, double x,
+                                                double y, double z, float* __restrict__ out) {
+    const double fx = x * inv_dx, fy = y * inv_dy, fz = z * inv_dz;
     const double ix = floor(fx), iy = floor(fy), iz = floor(fz);
     const float tx = (float)(fx - ix), ty = (float)(fy - iy), tz = (float)(fz - iz);
     // |cell index| < 2^31 for any realistic episode (x - U t < 1e6 m); power-of-two boxes wrap with a mask
@@ -215,6 +215,18 @@ __device__ __forceinline__ void box_lookup(const float4* __restrict__ box, const
     }())
     out[0] = WG_TRI(x); out[1] = WG_TRI(y); out[2] = WG_TRI(z);
 #undef WG_TRI
+}
+
+template <bool POW2>
+__device__ __forceinline__ void box_lookup(const float4* __restrict__ box, const FlowP& p, double x, double y,
+                                           double z, float* __restrict__ out) {
+    box_lookup_dims<POW2>(box, p.bnx, p.bny, p.bnz, p.inv_bdx, p.inv_bdy, p.inv_bdz, x, y, z, out);
+}
+// the isotropic box of the wake-added turbulence (FlowP::added)
+__device__ __forceinline__ void abox_lookup(const FlowP& p, const FlowPtrs& d, double x, double y, double z,
+                                            float* __restrict__ out) {
+    if (p.abox_pow2) box_lookup_dims<true>(d.abox4, p.anx, p.any, p.anz, p.inv_adx, p.inv_ady, p.inv_adz, x, y, z, out);
+    else box_lookup_dims<false>(d.abox4, p.anx, p.any, p.anz, p.inv_adx, p.inv_ady, p.inv_adz, x, y, z, out);
 }
 
 // The wake particles read the transverse components from the meandering box: the field block-averaged over
@@ -369,6 +381,11 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         float* def = reinterpret_cast<float*>(cl + ((TC * N + 7) & ~7));
         float* tiav = def + TC * N;
         int* ncand = jnl + N + 1;
+        // wake-added turbulence (wg_config.added_turbulence; turbulent inflow only): gadd[(t, sample)][3] =
+        // the isotropic field at every rotor point, addv[3][TC * N] = a candidate pair's rotor-summed contribution
+        const bool ADDED = TURB != WG_TURB_NONE && p.added != 0;
+        float* addv = tiav + TC * N;
+        float* gadd = reinterpret_cast<float*>(jnl + N + 2);
         // ambient inflow at the rotors (no wakes): thread t / the (t, sample) threads
         if (TURB == WG_TURB_BOX) {
             const int nitems = N << p.S_shift;
@@ -390,6 +407,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 }
             }
         } else {
+
             for (int t = tid; t < N; t += NT) {
                 float au = 0.f, av = 0.f, aw = 0.f;
                 if (TURB == WG_TURB_RANDOM) {
@@ -440,8 +458,30 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             }
         }
         lds_barrier<NT>();
-        // pass 2: exact evaluation of the candidates
         const int nc = *ncand;
+        if (ADDED && nc > 0) {
+            // the isotropic field at the rotor points of the chunk's targets that have a candidate source (a free-stream
+            // rotor needs none): "Synchronized" = the ambient field's clock and offset.  Flags: tmask word 3 is free in
+            // this phase for N <= 96; kept simple: one pass over the candidate list marks gflag[t]
+            int* gflag = reinterpret_cast<int*>(gadd + 3 * (N << p.S_shift));
+            for (int tl = tid; tl < nt; tl += NT) gflag[tl] = 0;
+            lds_barrier<NT>();
+            for (int c = tid; c < nc; c += NT) gflag[(int)(((float)cl[c] + 0.5f) * p.inv_N)] = 1;
+            lds_barrier<NT>();
+            const int nitems = nt << p.S_shift;
+            for (int it = tid; it < nitems; it += NT) {
+                const int tl = it >> p.S_shift, s = it & (p.S_pad - 1);
+                if (s >= p.S || !gflag[tl]) continue;
+                const int t = t0 + tl;
+                float g3[3];
+                abox_lookup(p, d, T[t].xr - tc.ws * sr.time + tc.ox, T[t].yr + (double)(rdy[s] * T[t].cg) + tc.oy,
+                            p.hub_d + (double)rdz[s], g3);
+                float* gp = gadd + ((t << p.S_shift) + s) * 3;
+                gp[0] = g3[0]; gp[1] = g3[1]; gp[2] = g3[2];
+            }
+            lds_barrier<NT>();
+        }
+        // pass 2: exact evaluation of the candidates
         for (int c = tid; c < nc; c += NT) {
             const int i = cl[c];
             const int tl = (int)(((float)i + 0.5f) * p.inv_N);
@@ -510,13 +550,30 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sig * sig);
             // wake-added turbulence (Crespo-Hernandez), Gaussian-weighted at the hub
             const float ind = 0.5f * (1.0f - __builtin_amdgcn_sqrtf(1.0f - ctv));
-            tiav[i] = p.tia * fast_pow(ind, p.tib) * ti_pow * fast_pow(fmaxf(xd, 1.0f), p.tid) * __expf(-rc2 * inv2s2);
+            tiav[i] = p.no_ti_fold ? 0.f
+                                   : p.tia * fast_pow(ind, p.tib) * ti_pow * fast_pow(fmaxf(xd, 1.0f), p.tid) * __expf(-rc2 * inv2s2);
             // Gaussian deficit at the S rotor points of the target (lateral offsets scaled by cos(yaw_t))
             const float cgt = T[t].cg, amp = uev * cf;
             float acc = 0.f;
-            for (int sI = 0; sI < p.S; ++sI) {
-                const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
-                acc += amp * __expf(-(dy * dy + dz * dz) * inv2s2);
+            if (ADDED) {
+                // + this wake's share of the added turbulence: U k_mt g = dU (km1 + km2 R r / sigma^2) g at every point
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+                const float kg = p.km2r * inv2s2;
+                const float* gt = gadd + (t << p.S_shift) * 3;
+                for (int sI = 0; sI < p.S; ++sI) {
+                    const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
+                    const float r2 = dy * dy + dz * dz;
+                    const float du = amp * __expf(-r2 * inv2s2);
+                    acc += du;
+                    const float wk = du * (p.km1 + kg * __builtin_amdgcn_sqrtf(r2));
+                    a0 += wk * gt[sI * 3]; a1 += wk * gt[sI * 3 + 1]; a2 += wk * gt[sI * 3 + 2];
+                }
+                addv[i] = a0 * p.inv_S; addv[TC * N + i] = a1 * p.inv_S; addv[2 * TC * N + i] = a2 * p.inv_S;
+            } else {
+                for (int sI = 0; sI < p.S; ++sI) {
+                    const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
+                    acc += amp * __expf(-(dy * dy + dz * dz) * inv2s2);
+                }
             }
             def[i] = acc * p.inv_S;
             atomicOr(&tmask[tl * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
@@ -524,7 +581,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         lds_barrier<NT>();
         // thread t: superposition in ascending source order
         for (int tl = tid; tl < nt; tl += NT) {
-            float dsum = 0.f, tia_max = 0.f;
+            float dsum = 0.f, tia_max = 0.f, au = 0.f, av = 0.f, aw = 0.f;
             for (int wd = 0; wd * 32 < N; ++wd) {
                 unsigned m = tmask[tl * WG_MASK_WORDS + wd];
                 while (m) {
@@ -532,8 +589,10 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     m &= m - 1;
                     dsum += def[tl * N + s2];
                     tia_max = fmaxf(tia_max, tiav[tl * N + s2]);
+                    if (ADDED) { au += addv[tl * N + s2]; av += addv[TC * N + tl * N + s2]; aw += addv[2 * TC * N + tl * N + s2]; }
                 }
             }
+            if (ADDED) { T[t0 + tl].u += au; T[t0 + tl].v += av; T[t0 + tl].w += aw; }
             T[t0 + tl].u -= dsum;
             T[t0 + tl].ti = __builtin_amdgcn_sqrtf(ti_f * ti_f + tia_max * tia_max);
         }
@@ -1026,8 +1085,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                         const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sig * sig);
                         // wake-added turbulence (Crespo-Hernandez), Gaussian-weighted at the hub
                         const float ind = 0.5f * (1.0f - __builtin_amdgcn_sqrtf(1.0f - ctv));
-                        const float tia = p.tia * fast_pow(ind, p.tib) * ti_pow * fast_pow(fmaxf(xd, 1.0f), p.tid) *
-                                          __expf(-rc2 * inv2s2);
+                        const float tia = p.no_ti_fold ? 0.f : p.tia * fast_pow(ind, p.tib) * ti_pow * fast_pow(fmaxf(xd, 1.0f), p.tid) *
+                                                               __expf(-rc2 * inv2s2);
                         pp = make_float4(yc, zc, inv2s2, uev * cf);
                         tiap[i] = tia;
                         atomicOr(&tmask[tl * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
@@ -1046,18 +1105,24 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             const bool live = (it < nitems) && (s < p.S);
             float acc = 0.f, tia_max = 0.f;
             float amb[3] = {0.f, 0.f, 0.f};
+            // wake-added turbulence (see the compact variant): this thread's rotor point, all source wakes
+            const bool ADDED = TURB != WG_TURB_NONE && p.added != 0;
+            float g3[3] = {0.f, 0.f, 0.f}, add3[3] = {0.f, 0.f, 0.f};
             if (live) {
                 const int t = t0 + tl;
                 const float4* __restrict__ pr = pair + tl * N;
                 const float ys = (float)T[t].yr + rdy[s] * T[t].cg;
                 const float zs = p.hub + rdz[s];
-                if (TURB == WG_TURB_BOX) {
+                if (TURB == WG_TURB_BOX || ADDED) {
                     // ambient fluctuation at this rotor point (8 corners x 3 components of the frozen box): requested
                     // first, the scattered HBM reads overlap the wake sum below
                     const double bx = T[t].xr - tc.ws * sr.time + tc.ox;
                     const double by = T[t].yr + (double)(rdy[s] * T[t].cg) + tc.oy, bz = p.hub_d + (double)rdz[s];
-                    if (p.box_pow2) box_lookup<true>(tc.box4, p, bx, by, bz, amb);
-                    else box_lookup<false>(tc.box4, p, bx, by, bz, amb);
+                    if (TURB == WG_TURB_BOX) {
+                        if (p.box_pow2) box_lookup<true>(tc.box4, p, bx, by, bz, amb);
+                        else box_lookup<false>(tc.box4, p, bx, by, bz, amb);
+                    }
+                    if (ADDED) abox_lookup(p, d, bx, by, bz, g3);
                 }
                 for (int wd = 0; wd * 32 < N; ++wd) {
                     unsigned m = tmask[tl * WG_MASK_WORDS + wd];
@@ -1067,11 +1132,22 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                         const float4 pp = pr[s2];
                         tia_max = fmaxf(tia_max, tiap[tl * N + s2]);
                         const float dy = ys - pp.x, dz = zs - pp.y;
-                        acc += pp.w * __expf(-(dy * dy + dz * dz) * pp.z);
+                        const float r2 = dy * dy + dz * dz;
+                        const float du = pp.w * __expf(-r2 * pp.z);
+                        acc += du;
+                        if (ADDED) {
+                            const float wk = du * (p.km1 + p.km2r * pp.z * __builtin_amdgcn_sqrtf(r2));
+                            add3[0] += wk * g3[0]; add3[1] += wk * g3[1]; add3[2] += wk * g3[2];
+                        }
                     }
                 }
             }
             for (int o = p.S_pad >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (ADDED) {
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+                    for (int o = p.S_pad >> 1; o > 0; o >>= 1) add3[cc] += __shfl_xor(add3[cc], o, 64);
+            }
             if (TURB == WG_TURB_BOX) {
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc)
@@ -1090,9 +1166,9 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     av = sc * wg_turb_normal(tc.seed, sr.istep, tt, 1u, 0x52u);
                     aw = sc * wg_turb_normal(tc.seed, sr.istep, tt, 2u, 0x52u);
                 }
-                q.u = ws_f + au - acc * p.inv_S;
-                q.v = av;
-                q.w = aw;
+                q.u = ws_f + au - acc * p.inv_S + add3[0] * p.inv_S;
+                q.v = av + add3[1] * p.inv_S;
+                q.w = aw + add3[2] * p.inv_S;
                 q.ti = __builtin_amdgcn_sqrtf(ti_f * ti_f + tia_max * tia_max);
             }
         }

@@ -18,6 +18,8 @@ import numpy as np
 
 
 def _eddy_lifetime_beta(kL, Gamma):
+    if Gamma == 0:                       # isotropic field: no shear distortion
+        return np.zeros_like(kL)
     from scipy.special import hyp2f1
     kL = np.maximum(kL, 1e-12)
     return Gamma * kL ** (-2.0 / 3.0) / np.sqrt(hyp2f1(1.0 / 3.0, 17.0 / 6.0, 4.0 / 3.0, -kL ** (-2.0)))
@@ -127,6 +129,24 @@ def generate_mann_box_torch(Nxyz=(2048, 512, 64), dxyz=(3.0, 3.0, 3.0), alphaeps
         dZ[c] = None
     out /= out[0].std()
     return out.contiguous()
+
+
+# Wake-added turbulence (row a7): the isotropic small-scale box the reference's addedTurbulenceModel =
+# [Synchronized]AutoScalingIsotropicMannTurbulence() scales inside the wakes (Wind_Farm_Env.py:618, :638, :644, :659).
+# Its default field is hipersim's "Hipersim_mann_l5.0_ae1.0000_g0.0_h0_128x128x128_3.000x3.00x3.00_s0001.nc"
+# (examples/longer_steps_example.py:153): L = 5 m, Gamma = 0 (isotropic), alpha-epsilon 1, 128^3 cells of 3 m, seed 1 —
+# regenerated here with the same parameters (hipersim's own random stream is not reproducible without hipersim), unit
+# variance.  One array per process, shared by the HIP batch and the oracle so that both see the same field.
+ADDED_BOX_SPEC = dict(Nxyz=(128, 128, 128), dxyz=(3.0, 3.0, 3.0), alphaepsilon=1.0, L=5.0, Gamma=0.0, seed=1)
+_ADDED_BOX = None
+
+
+def default_added_box():
+    """(box float32 [3, 128, 128, 128], spacing) of the wake-added isotropic turbulence."""
+    global _ADDED_BOX
+    if _ADDED_BOX is None:
+        _ADDED_BOX = generate_mann_box(**ADDED_BOX_SPEC)
+    return _ADDED_BOX, ADDED_BOX_SPEC["dxyz"]
 
 
 # the reference's box definitions per turbtype (Wind_Farm_Env.py:624-637, :649-658)
