@@ -44,7 +44,10 @@ typedef enum wg_status {
     WG_ERR_HIP = -3,          /* a HIP runtime call failed                                            */
     WG_ERR_NAN_POWER = -4,    /* reference: Exception("NaN Power"), Wind_Farm_Env.py:980-981           */
     WG_ERR_STATE = -5,        /* step() on a truncated env without autoreset (reference tears fs down)*/
-    WG_ERR_NOMEM = -6
+    WG_ERR_NOMEM = -6,
+    WG_ERR_RANGE = -7         /* a wake particle's emission record left the range of its 16-bit fixed-point storage
+                               * (wake-growth rate k > 0.25, i.e. local TI > 0.65, or deflection speed |hv| > 16 m/s,
+                               * i.e. rotor wind speed > 40 m/s): the value was saturated; reported by wg_check      */
 } wg_status;
 
 /* sensor channels, order fixed by MesClass.turb_mes.get_measurements (MesClass.py:328-351) */

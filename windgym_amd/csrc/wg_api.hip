@@ -180,6 +180,17 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     for (int i = 0; i < WG_N_CH; ++i)
         if (c->ch[i].history_len < 1 || c->ch[i].window_len < 1 || c->ch[i].history_n < 1)
             return fail(WG_ERR_INVALID, "sensor history/window lengths must be >= 1");
+    {
+        // the 16-bit emission record (wg_flow.hip): k = ka TI_loc + kb <= 0.25 and |hv| <= |hill| u <= 16 m/s must hold
+        // over the sampling ranges (TI_loc^2 <= ti_max^2 + 0.34^2, the Crespo-Hernandez bound at Ct = 0.96); the
+        // kernel also flags any violation at run time (wind overrides): WG_ERR_RANGE
+        const double ka = defd(c->m0_ka, 0.38), kb = defd(c->m0_kb, 0.004), hill = defd(c->m0_hill, 0.4);
+        const double tia = c->no_ti_fold ? 0.0 : 0.466 * defd(c->m0_ti_a, 0.73);
+        const double k_hi = ka * std::sqrt(c->ti_max * c->ti_max + tia * tia) + kb;
+        if (k_hi > 0.25 || std::fabs(hill) * c->ws_max > 16.0)
+            return fail(WG_ERR_INVALID, "wind ranges exceed the 16-bit emission record: need ka*sqrt(TI_max^2 + 0.34^2) + kb <= 0.25 "
+                                            "(TI_max <= 0.55 with the default constants) and |hill| * ws_max <= 16 m/s");
+    }
     if (c->deficit_model != 0)
         return fail(WG_ERR_UNSUPPORTED, "deficit_model: only the Gaussian deficit (0) is built into the HIP kernels");
     HIPCHK(hipSetDevice(device));
@@ -846,6 +857,9 @@ extern "C" int wg_check(wg_handle h, void* stream) {
     HIPCHK(hipGetLastError());
     if (status == WG_ERR_NAN_POWER) return fail(status, "NaN Power");
     if (status == WG_ERR_STATE) return fail(status, "step() on a truncated env without reset (or background episode not ready)");
+    if (status == WG_ERR_RANGE)
+        return fail(status, "a wake particle's emission record left its 16-bit range (k > 0.25: local TI > 0.65, or |hv| > 16 m/s: "
+                            "rotor wind speed > 40 m/s) and was saturated");
     return status;
 }
 

@@ -340,6 +340,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         q.rk = p.ka * q.ti + p.kb;
         q.reps = p.eps0 * __builtin_amdgcn_sqrtf(beta);
         q.rhv = -p.hill * sg * q.u;
+        // the packed record saturates outside [0, WG_K_MAX] x [-WG_HV_MAX, WG_HV_MAX]: never silently (wg_check reports it)
+        if (q.rk > WG_K_MAX || fabsf(q.rhv) > WG_HV_MAX) atomicMin(wg_cold_args()->d.status, (int)WG_ERR_RANGE);
         q.rue = q.u;
         q.cg = cg;
         q.sg = sg;
