@@ -87,3 +87,92 @@ def test_two_rank_gloo_matches_single_process(tmp_path, oracle_lib):
         for k in ("n_steps", "n_episodes", "ep_return_sum", "farm_power_sum", "mean_episode_power"):
             assert np.isclose(float(p[k]), ref[k], rtol=1e-12), k
     assert ref["n_steps"] == total * steps and ref["n_episodes"] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the HOST path of a sharded run: WindFarmVecEnv.shard() -> global seeds -> step -> ShardedMetrics over the process
+# group, with a HipBatch-shaped stand-in (same methods / tensor outputs as binding.HipBatch, backed by the oracle: there
+# is no GPU in this container).  What is exercised is everything a rank of `bench.py --gpus N` runs above the C ABI.
+# ---------------------------------------------------------------------------------------------------------------------
+class _StubHipBatch:
+    """Duck type of binding.HipBatch on CPU tensors."""
+
+    def __init__(self, cfg, device=None):
+        from oracle import oracle as om
+        self.torch = torch
+        self.device = torch.device("cpu")
+        self.orc = om.Oracle(cfg)
+        self.orc.set_threads(1)
+        self.B, self.N, self.obs_dim = cfg.n_envs, cfg.n_turb, self.orc.obs_dim
+
+    def reset(self, seeds=None, mask=None):
+        return torch.as_tensor(self.orc.reset(seeds=seeds, mask=mask), dtype=torch.float32)
+
+    def step(self, actions):
+        obs, rew, tr, fin = self.orc.step(actions.numpy())
+        return (torch.as_tensor(obs, dtype=torch.float32), torch.as_tensor(rew, dtype=torch.float32),
+                torch.as_tensor(tr), torch.as_tensor(fin, dtype=torch.float32))
+
+    def metrics(self, reset_after=False):
+        return torch.tensor(self.orc.metrics(reset_after), dtype=torch.float64)
+
+    def close(self):
+        pass
+
+
+def _run_rank_vecenv(rank, world, port, total, steps, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    from windgym_amd import envs, parallel
+    from windgym_amd.presets import env1_config
+    from windgym_amd.turbine import V80
+    envs.HipBatch = _StubHipBatch
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = parallel.shard_range(total, rank, world)
+    d = env1_config()
+    d["ActionMethod"] = "yaw"
+    venv = envs.WindFarmVecEnv(V80(), hi - lo, yaml_dict=d, turbtype="None", n_passthrough=1, n_rotor_pts=4,
+                               seed=100).shard(rank, world, total)
+    obs, _ = venv.reset()
+    rng = np.random.default_rng(5)
+    acts = rng.uniform(-1, 1, size=(steps, total, venv.n_turb)).astype(np.float32)
+    n_trunc = 0
+    for s in range(steps):
+        obs, rew, term, trunc, infos = venv.step(acts[s, lo:hi])
+        n_trunc += int(trunc.sum())
+    m = venv.metrics(reset_after=True)                       # all-reduce over gloo inside
+    np.savez(os.path.join(out_dir, f"v{rank}.npz"), obs=obs, n_trunc=n_trunc, **{k: v for k, v in m.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_vecenv_shard_matches_single_process(tmp_path, oracle_lib):
+    total, steps, world = 5, 120, 2             # (an uneven split: 3 + 2 envs)
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_run_rank_vecenv, args=(world, port, total, steps, str(tmp_path)), nprocs=world, join=True)
+    from windgym_amd import parallel
+    cfg = _cfg(total)
+    orc = oracle_lib.Oracle(cfg)
+    obs = orc.reset(seeds=100 + np.arange(total, dtype=np.uint64))
+    rng = np.random.default_rng(5)
+    acts = rng.uniform(-1, 1, size=(steps, total, cfg.n_turb)).astype(np.float32)
+    n_trunc = 0
+    for s in range(steps):
+        obs, _, tr, _ = orc.step(acts[s])
+        n_trunc += int(tr.sum())
+    ref = parallel.derive(orc.metrics())
+    parts = [np.load(tmp_path / f"v{r}.npz") for r in range(world)]
+    np.testing.assert_allclose(np.concatenate([p["obs"] for p in parts]), obs.astype(np.float32), rtol=0, atol=0)
+    assert sum(int(p["n_trunc"]) for p in parts) == n_trunc
+    for p in parts:
+        for k in ("n_steps", "n_episodes", "ep_return_sum", "farm_power_sum", "mean_episode_power"):
+            assert np.isclose(float(p[k]), ref[k], rtol=1e-12), k
+
+
+def test_bench_strong_scaling_split_is_the_global_env_axis():
+    """bench.py --scaling strong: rank g of N owns shard_range(total, g, N) and seeds 1234 + global index."""
+    from windgym_amd.parallel import shard_range
+    total = 4096
+    for world in (1, 2, 4, 8):
+        spans = [shard_range(total, r, world) for r in range(world)]
+        assert sum(hi - lo for lo, hi in spans) == total and all(hi - lo == total // world for lo, hi in spans)
