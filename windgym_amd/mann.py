@@ -173,6 +173,11 @@ def _dims_from_name(name):
     return tuple(int(m.group(i)) for i in (1, 2, 3)), tuple(float(m.group(i)) for i in (4, 5, 6))
 
 
+def _is_hdf5(path):
+    with open(path, "rb") as f:
+        return f.read(8) == b"\x89HDF\r\n\x1a\n"
+
+
 def load_box(path, dxyz=None, Nxyz=None):
     """Read a turbulence box from disk -> (float32 [3, Nx, Ny, Nz] normalised to unit std of u, (dx, dy, dz)).
 
@@ -180,8 +185,9 @@ def load_box(path, dxyz=None, Nxyz=None):
     * ``.npy`` [3, Nx, Ny, Nz] (spacing from ``dxyz`` or from a hipersim-style file name);
     * raw float32 binaries (HAWC2 / Mann-generator convention): one file holding u, v, w one after the other, or the
       ``*_u.bin`` of a ``_u / _v / _w`` triplet; grid from ``Nxyz`` / ``dxyz`` or from the file name;
-    * netCDF: only the classic (NetCDF3) container can be read here (``scipy.io.netcdf_file``); hipersim's NetCDF4/HDF5
-      files need netCDF4 or h5py, which this image does not have — convert them once with :func:`save_box`.
+    * netCDF: NetCDF-4 / HDF5 containers (hipersim's ``to_netcdf``: the reference's ``TF_*.nc`` files) through the
+      package's own minimal HDF5 reader (:mod:`windgym_amd.hdf5_min`: contiguous / chunked, deflate + shuffle), classic
+      NetCDF3 through ``scipy.io.netcdf_file``.
     """
     import os
     name = os.path.basename(path)
@@ -204,14 +210,15 @@ def load_box(path, dxyz=None, Nxyz=None):
                             for c in "uvw"])
         else:
             box = np.fromfile(path, dtype=np.float32, count=3 * n).reshape((3,) + tuple(Nxyz))
+    elif ext in (".nc", ".nc4", ".cdf", ".h5", ".hdf5") and _is_hdf5(path):
+        # NetCDF-4 = HDF5 container: what hipersim's MannTurbulenceField.to_netcdf writes and the reference loads
+        # (Wind_Farm_Env.py:616) — read with the package's own minimal HDF5 reader (hdf5_min.py)
+        from .hdf5_min import read_turbulence_box
+        box, sp = read_turbulence_box(path)
+        dxyz = sp or dxyz
     elif ext in (".nc", ".cdf"):
-        try:
-            from scipy.io import netcdf_file
-            f = netcdf_file(path, "r", mmap=False)
-        except Exception as e:                      # NetCDF4 / HDF5 container
-            raise NotImplementedError(
-                f"{name}: not a classic NetCDF3 file ({e}); NetCDF4/HDF5 needs netCDF4 or h5py, which are not installed "
-                "here — convert the box once with windgym_amd.mann.save_box") from e
+        from scipy.io import netcdf_file
+        f = netcdf_file(path, "r", mmap=False)
         keys = [k for k in ("uvw", "turb", "u") if k in f.variables]
         if "uvw" in f.variables or "turb" in f.variables:
             box = np.array(f.variables[keys[0]][:], dtype=np.float32)
