@@ -218,6 +218,11 @@ int wg_hist_max(wg_handle h, int* hist_max);
 int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, int ny, int nz,
                           double dx, double dy, double dz);
 
+/* Evaluation over several turbulence boxes (AgentEval.eval_multiple's `turbbox` loop, AgentEval.py:579-617, through
+ * FarmEval.update_tf(path): TF_files = [path], FarmEval.py:86-90): env e uses box ids_host[e] of the pool at every
+ * following reset instead of drawing one (a list of one consumes no random number); < 0 = draw; NULL removes the table. */
+int wg_set_box_ids(wg_handle h, const int32_t* ids_host);
+
 /* Isotropic box of the wake-added turbulence (wg_config.added_turbulence = 1): 3 planes like above, unit variance;
  * the reference's default is hipersim's L = 5 m, Gamma = 0, 128^3 cells of 3 m
  * (examples/longer_steps_example.py:153).  The library keeps an interleaved copy.  Must be set before wg_reset.   */

@@ -51,7 +51,7 @@ class Oracle:
         L = lib()
         pre = "wgo_" if precision == "f64" else "wgof_"
         self._f = {n: getattr(L, pre + n) for n in (
-            "create", "destroy", "obs_dim", "hist_max", "set_flow_script", "set_turbulence_box", "set_turbulence_boxes", "set_added_turbulence_box", "reset",
+            "create", "destroy", "obs_dim", "hist_max", "set_flow_script", "set_turbulence_box", "set_turbulence_boxes", "set_added_turbulence_box", "set_box_ids", "reset",
             "step", "obs_multi", "get_obs", "get_info", "metrics", "get_chain", "set_threads", "max_threads",
             "get_windspeed")}
         self._f["create"].restype = C.c_void_p
@@ -110,6 +110,10 @@ class Oracle:
         self._f["set_added_turbulence_box"](self._h, box.ctypes.data_as(C.c_void_p), C.c_int(box.shape[1]),
                                             C.c_int(box.shape[2]), C.c_int(box.shape[3]), C.c_double(spacing[0]),
                                             C.c_double(spacing[1]), C.c_double(spacing[2]))
+
+    def set_box_ids(self, ids):
+        self._box_ids = None if ids is None else np.ascontiguousarray(np.broadcast_to(np.asarray(ids, dtype=np.int32), (self.B,)))
+        self._f["set_box_ids"](self._h, None if ids is None else self._box_ids.ctypes.data_as(C.c_void_p))
 
     def set_turbulence_boxes(self, boxes, spacing):
         bs = [np.ascontiguousarray(b, dtype=np.float32) for b in boxes]

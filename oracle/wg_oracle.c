@@ -133,6 +133,7 @@ typedef struct oracle_t {
     float* cbox;
     int cnx, cny, cnz, coarse;
     /* isotropic box of the wake-added turbulence (wg_config.added_turbulence), unit variance, host memory */
+    const int* box_ids;                  /* [B] fixed box per env (FarmEval.update_tf) or NULL */
     const float* abox;
     int anx, any, anz;
     double adx, ady, adz;
@@ -306,6 +307,7 @@ int WGO(set_turbulence_boxes)(void* h, const float* const* boxes, int n_boxes, i
     }
     return 0;
 }
+void WGO(set_box_ids)(void* h, const int* ids) { ((oracle_t*)h)->box_ids = ids; }   /* borrowed */
 /* isotropic box of the wake-added turbulence: [3][nx][ny][nz] float, z fastest, unit variance (borrowed) */
 void WGO(set_added_turbulence_box)(void* h, const float* box, int nx, int ny, int nz, double dx, double dy,
                                    double dz) {
@@ -979,7 +981,12 @@ static void reset_env(oracle_t* o, int b, uint64_t seed, int reseed) {
     /* _def_site (:598-678): "Random" draws a turbulence seed; "None"/"MannFixed" draw nothing */
     x->turb_seed = 0; x->box_ox = 0; x->box_oy = 0; x->box_id = 0;
     if (c->turb_mode == WG_TURB_BOX_POOL)       /* tf_file = self.np_random.choice(self.TF_files) (:614) */
-        x->box_id = (int)wgo_pcg64_integers(&e->rng, (uint32_t)(o->n_boxes > 0 ? o->n_boxes : 1));
+    {
+        /* FarmEval.update_tf(path): TF_files = [path] -> np_random.choice of ONE file consumes no random number */
+        const int fixed = o->box_ids ? o->box_ids[b] : -1;
+        if (fixed >= 0) x->box_id = fixed < o->n_boxes ? fixed : 0;
+        else x->box_id = (int)wgo_pcg64_integers(&e->rng, (uint32_t)(o->n_boxes > 0 ? o->n_boxes : 1));
+    }
     if (c->turb_mode == WG_TURB_RANDOM || c->turb_mode == WG_TURB_BOX_SHIFT)
         x->turb_seed = wgo_pcg64_integers(&e->rng, 100000);
     if (c->turb_mode == WG_TURB_BOX_SHIFT && o->box) {

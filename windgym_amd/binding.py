@@ -31,7 +31,7 @@ UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 # every symbol include/windgym_hip.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = (
     "wg_last_error", "wg_abi_version", "wg_create", "wg_destroy", "wg_obs_dim", "wg_hist_max",
-    "wg_set_turbulence_box", "wg_set_turbulence_boxes", "wg_set_added_turbulence_box", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_set_step_graph", "wg_check", "wg_obs_multi", "wg_set_obs_multi_buffer",
+    "wg_set_turbulence_box", "wg_set_turbulence_boxes", "wg_set_added_turbulence_box", "wg_set_box_ids", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_set_step_graph", "wg_check", "wg_obs_multi", "wg_set_obs_multi_buffer",
     "wg_get_info", "wg_get_measurements", "wg_get_windspeed", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_algorithmic_bytes", "wg_flow_variant",
 )
 
@@ -63,6 +63,7 @@ def load_library():
     L.wg_hist_max.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.wg_set_turbulence_box.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
                                         C.c_double, C.c_double]
+    L.wg_set_box_ids.argtypes = [C.c_void_p, C.c_void_p]
     L.wg_set_added_turbulence_box.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
                                               C.c_double, C.c_double]
     L.wg_set_turbulence_boxes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int,
@@ -261,6 +262,14 @@ class HipBatch:
                 w[:, k] = np.broadcast_to(np.asarray(v, dtype=np.float64), (self.B,))
         w = np.ascontiguousarray(w)
         _chk(self.L.wg_set_wind(self._h, w.ctypes.data_as(C.c_void_p)), "wg_set_wind")
+
+    def set_box_ids(self, ids):
+        """Box of the pool each env uses from the next reset on (FarmEval.update_tf per env); None = draw again."""
+        if ids is None:
+            _chk(self.L.wg_set_box_ids(self._h, None), "wg_set_box_ids")
+            return
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(ids, dtype=np.int32), (self.B,)))
+        _chk(self.L.wg_set_box_ids(self._h, a.ctypes.data_as(C.c_void_p)), "wg_set_box_ids")
 
     def set_wind_device(self, wind):
         """Borrow a CUDA float64 tensor [B, 3] = (ws, wd, ti; NaN = keep the sampled value) as the per-env wind

@@ -55,6 +55,7 @@ struct wg_env_s {
     long n_step_launches = 0;
     void* box4 = nullptr;            // interleaved copy of the caller's turbulence box (owned)
     void* box4c = nullptr;           // block-averaged copy for the particle lookups (owned)
+    int* box_ids_dev = nullptr;      // wg_set_box_ids
     void* abox4 = nullptr;           // interleaved isotropic box of the wake-added turbulence (owned)
     int added = 0, no_ti_fold = 0, deficit_model = 0;   // wg_config model options
     double km1 = 0.6, km2 = 0.35;
@@ -672,6 +673,23 @@ extern "C" int wg_set_wind(wg_handle h, const double* wind_host) {
     }
     HIPCHK(hipMemcpy(h->wind_dev, wind_host, sizeof(double) * 3 * (size_t)h->p.B, hipMemcpyHostToDevice));
     h->d.wind_override = h->wind_dev;
+    return sync_dev_params(h);
+}
+
+extern "C" int wg_set_box_ids(wg_handle h, const int32_t* ids_host) {
+    if (!h) return fail(WG_ERR_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    drop_step_graphs(h);
+    if (!ids_host) { h->d.box_override = nullptr; return sync_dev_params(h); }
+    if (!h->box_ids_dev) {
+        int* w = nullptr;
+        int rc = dev_alloc(h, &w, (size_t)h->p.B, false);
+        if (rc) return rc;
+        h->box_ids_dev = w;
+    }
+    HIPCHK(hipMemcpy(h->box_ids_dev, ids_host, sizeof(int) * (size_t)h->p.B, hipMemcpyHostToDevice));
+    h->d.box_override = h->box_ids_dev;
     return sync_dev_params(h);
 }
 

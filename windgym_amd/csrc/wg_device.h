@@ -290,8 +290,12 @@ __device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, c
         if (p.turb_mode == WG_TURB_RANDOM || p.turb_mode == WG_TURB_BOX_SHIFT)
             tseed = wg_pcg_integers(rng, 100000);                                  // _def_site (:623, :642)
         cx.box_ox = 0.0; cx.box_oy = 0.0; cx.box_id = 0;
-        if (p.turb_mode == WG_TURB_BOX_POOL)       // tf_file = self.np_random.choice(self.TF_files) (:614)
-            cx.box_id = (int)wg_pcg_integers(rng, (uint32_t)(p.n_boxes > 0 ? p.n_boxes : 1));
+        if (p.turb_mode == WG_TURB_BOX_POOL) {     // tf_file = self.np_random.choice(self.TF_files) (:614)
+            // FarmEval.update_tf(path) makes TF_files a list of ONE: the choice then consumes no random number
+            const int fixed = d.box_override ? d.box_override[e] : -1;
+            if (fixed >= 0) cx.box_id = fixed < p.n_boxes ? fixed : 0;
+            else cx.box_id = (int)wg_pcg_integers(rng, (uint32_t)(p.n_boxes > 0 ? p.n_boxes : 1));
+        }
         if (p.turb_mode == WG_TURB_BOX_SHIFT && p.bnx > 0) {
             uint32_t a, b;
             wg_philox_turb(tseed, 0u, 0u, 0u, 0x4fu, a, b);

@@ -152,6 +152,7 @@ struct WgPtrs {
     float* metrics;           // [B][WG_N_METRICS] running per-env sums
     int* status;              // sticky error word
     const double* wind_override;   // [B][3] (ws, wd, ti) or null; NaN = keep the sampled value
+    const int* box_override;       // [B] box of the pool env e uses (FarmEval.update_tf: TF_files = [path]) or null; < 0 = draw
     // config tables
     const double *x_pos, *y_pos, *yaw_defined;
     const float *rotor_dy, *rotor_dz;

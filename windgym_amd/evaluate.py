@@ -18,16 +18,41 @@ from .envs import WindFarmVecEnv, _np
 
 def eval_sweep(turbine, yaml_path=None, model=None, *, winddirs=(270.0,), windspeeds=(10.0,),
                turbintensities=(0.05,), t_sim=100, turbtype="None", turbbox="Default", model_step=1,
-               Baseline_comp=True, yaw_init="Zeros", deterministic=True, seed=1, device=None, **env_kwargs):
+               Baseline_comp=True, yaw_init="Zeros", deterministic=True, seed=1, device=None, flow_script=None,
+               turbboxes=None, **env_kwargs):
     """Roll `model` (anything with predict(obs) -> (action, state)) for t_sim steps under every combination of
-    the given wind directions, speeds and turbulence intensities at once."""
-    conds = list(itertools.product(windspeeds, winddirs, turbintensities))
+    the given wind directions, speeds and turbulence intensities at once.  ``flow_script`` = (uvw [F,T,B,N,3],
+    power [F,T,B,N]): replay mode (test hook — the golden vectors recorded from the reference's eval_single_fast)."""
+    # `turbboxes`: the reference's eval_multiple loops over turbulence-box files too (AgentEval.py:579-617,
+    # FarmEval.update_tf).  Every entry — a TF_* file path or a (box [3, Nx, Ny, Nz], spacing) pair — becomes one box of
+    # the device-resident pool, and every (condition, box) pair one env pinned to its box (wg_set_box_ids).
+    box_names, box_ids = [turbbox], None
+    if turbboxes:
+        from .mann import load_box
+        pool, spacing, box_names = [], None, []
+        for k, tb in enumerate(turbboxes):
+            bx, sp = load_box(tb) if isinstance(tb, str) else (np.asarray(tb[0], dtype=np.float32), tuple(tb[1]))
+            if pool and (bx.shape != pool[0].shape or tuple(sp) != tuple(spacing)):
+                raise ValueError("turbboxes: all boxes of a sweep must share one shape and spacing")
+            pool.append(bx); spacing = sp
+            box_names.append(tb if isinstance(tb, str) else f"box{k}")
+        env_kwargs = dict(env_kwargs, turbulence_box=(pool, spacing))
+        turbtype = "MannLoad"
+    nb = len(box_names)
+    conds4 = list(itertools.product(windspeeds, winddirs, turbintensities, range(nb)))
+    conds = [c[:3] for c in conds4]
+    if turbboxes:
+        box_ids = np.array([c[3] for c in conds4], dtype=np.int32)
     B = len(conds)
     env = WindFarmVecEnv(turbine, B, yaml_path=yaml_path, turbtype=turbtype, Baseline_comp=Baseline_comp,
                          yaw_init=yaw_init, never_truncate=True, autoreset=False, seed=seed, device=device,
                          **env_kwargs)
     ws, wd, ti = (np.array(c, dtype=np.float64) for c in zip(*conds))
     env.batch.set_wind(ws=ws, wd=wd, ti=ti)                       # FarmEval.set_wind_vals for the whole batch
+    if box_ids is not None:
+        env.batch.set_box_ids(box_ids)
+    if flow_script is not None:
+        env.batch.set_flow_script(*flow_script)
     obs, _ = env.reset(seed=seed)
     if hasattr(model, "UseEnv"):                                   # AgentEval.py:126-129
         model.yaw_max, model.yaw_min, model.env = env.cfg.yaw_max, env.cfg.yaw_min, env
@@ -62,16 +87,18 @@ def eval_sweep(turbine, yaml_path=None, model=None, *, winddirs=(270.0,), windsp
     nws, nwd, nti = len(windspeeds), len(winddirs), len(turbintensities)
 
     def shape(a):      # [time, B, ...] -> [time, (turb,) ws, wd, TI, turbbox, model_step]
-        a = a.reshape((t_sim, nws, nwd, nti) + a.shape[2:])
-        if a.ndim == 5:
-            a = np.moveaxis(a, 4, 1)
-        return a[..., None, None]
+        a = a.reshape((t_sim, nws, nwd, nti, nb) + a.shape[2:])
+        if a.ndim == 6:
+            a = np.moveaxis(a, 5, 1)
+        return a[..., None]
 
-    data = {k: shape(v) for k, v in rec.items()}
+    # variable order of the reference's xr.Dataset (AgentEval.py:375-396 without, :410-455 with a baseline farm)
+    order = ["powerF_a", "powerT_a", "yaw_a", "ws_a"] + (["powerF_b", "powerT_b", "yaw_b", "ws_b"] if two else []) + ["reward"]
+    data = {k: shape(rec[k]) for k in order}
     if two:
         data["pct_inc"] = (data["powerF_a"] - data["powerF_b"]) / data["powerF_b"] * 100.0    # AgentEval.py:147, 209
     coords = dict(time=time, turb=np.arange(N), ws=np.asarray(windspeeds, float), wd=np.asarray(winddirs, float),
-                  TI=np.asarray(turbintensities, float), turbbox=[turbbox], model_step=[model_step])
+                  TI=np.asarray(turbintensities, float), turbbox=list(box_names), model_step=[model_step])
     dims4 = ("time", "ws", "wd", "TI", "turbbox", "model_step")
     dims5 = ("time", "turb", "ws", "wd", "TI", "turbbox", "model_step")
     try:
@@ -124,7 +151,8 @@ class AgentEval:
         kw = {k: v for k, v in self._env_kwargs.items() if v is not None}
         self.multiple_eval_ds = eval_sweep(self._turbine, self._yaml, self.model, winddirs=self.winddirs,
                                            windspeeds=self.windspeeds, turbintensities=self.turbintensities,
-                                           t_sim=self.t_sim, turbbox=self.turbboxes[0], **kw)
+                                           t_sim=self.t_sim, turbbox=self.turbboxes[0],
+                                           turbboxes=self.turbboxes if len(self.turbboxes) > 1 else None, **kw)
         self.multiple_eval = True
         return self.multiple_eval_ds
 
