@@ -154,6 +154,7 @@ typedef struct wg_config {
     int32_t deficit_model;     /* 0: Gaussian (north_star); 1: super-Gaussian of Blondel & Cathelain (2020)          */
     int32_t reserved0_;
     double m0_km1, m0_km2;     /* DWM added-turbulence scaling constants (0.6, 0.35); 0 selects the default          */
+    double m0_sg_af, m0_sg_bf, m0_sg_cf; /* super-Gaussian order n(x) = af exp(bf x/D) + cf (3.11, -0.68, 2.41)      */
 } wg_config;
 
 typedef struct wg_env_s* wg_handle;

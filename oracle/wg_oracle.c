@@ -213,6 +213,7 @@ void* WGO(create)(const wg_config* cfg) {
     c->m0_ti_c = defd(c->m0_ti_c, 0.0325); c->m0_ti_d = defd(c->m0_ti_d, -0.32);
     c->m0_fc_scale = defd(c->m0_fc_scale, 2.0);
     c->m0_km1 = defd(c->m0_km1, 0.6); c->m0_km2 = defd(c->m0_km2, 0.35);
+    c->m0_sg_af = defd(c->m0_sg_af, 3.11); c->m0_sg_bf = defd(c->m0_sg_bf, -0.68); c->m0_sg_cf = defd(c->m0_sg_cf, 2.41);
     o->obs_dim = turb_obs_count(c) * o->N + farm_obs_count(c);
     /* per-agent vector of WindFarmEnvMulti._get_obs_multi (WindEnvMulti.py:79-103): own turbine block ++
      * farm_mes.farm_mes.get_measurements(); the farm object's yaw deque is never filled, so it contributes
@@ -334,6 +335,20 @@ static inline real m0_cfrac(real ct, real sp) {
     real a = (real)1 - ct * m;
     if (a < (real)0) a = (real)0;
     return (real)1 - R_SQRT(a);
+}
+
+/* Super-Gaussian wake (wg_config.deficit_model = 1; Blondel & Cathelain 2020, "An alternative form of the
+ * super-Gaussian wind turbine wake model", Wind Energ. Sci. 5, eqs. 5-7 — the model behind the reference's PyWakeAgent):
+ *   dU / U = C exp(-(r/D)^n / (2 (sigma/D)^2)),  n = af exp(bf x/D) + cf,
+ *   C = 2^(2/n - 1) - sqrt(2^(4/n - 2) - n ct / (16 Gamma(2/n) (sigma/D)^(4/n)))   (mass + momentum conservation);
+ * n = 2 is the Gaussian wake.  sigma/D keeps M0's form k x/D + eps. */
+static inline real m0_sg_cfrac(real ct, real sp, real n) {
+    real a1 = R_POW((real)2, (real)2 / n - (real)1);
+    real a2 = R_POW((real)2, (real)4 / n - (real)2);
+    real g = (real)tgamma((double)((real)2 / n));
+    real a = a2 - n * ct / ((real)16 * g * R_POW(sp, (real)4 / n));
+    if (a < (real)0) a = (real)0;
+    return a1 - R_SQRT(a);
 }
 
 /* trilinear, periodic lookup of one component of the frozen box at (x,y,z) metres; cell coordinates are
@@ -559,7 +574,9 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
             real uev = w0 * f->u_e[i0] + w1 * f->u_e[i1];
             real xd = (real)dx * inv_D;
             real sp = m0_sigma_over_d(kv, epv, xd);
-            real cf = m0_cfrac(ctv, sp);
+            const int sg = c->deficit_model == 1;
+            const real nsg = sg ? (real)c->m0_sg_af * R_EXP((real)c->m0_sg_bf * xd) + (real)c->m0_sg_cf : (real)2;
+            real cf = sg ? m0_sg_cfrac(ctv, sp, nsg) : m0_cfrac(ctv, sp);
             real sig = sp * D;
             /* lateral cut-off: a wake whose centre is farther than R + 5 sigma from the rotor centre is
              * neglected (its Gaussian tail is < exp(-12.5) of the centreline deficit) */
@@ -572,11 +589,21 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
                 real ys = (real)x->yr[t] + (real)o->rotor_dy[s] * cg;
                 real zs = hub + (real)o->rotor_dz[s];
                 real r2 = (ys - yc) * (ys - yc) + (zs - zc) * (zs - zc);
-                real du = amp * R_EXP(-r2 * inv2s2);
+                real du, grad;            /* grad = |d dU / dr| / dU */
+                if (sg) {
+                    /* (r/D)^n / (2 (sigma/D)^2); d/dr: n (r/D)^n / (r 2 (sigma/D)^2) */
+                    real rn = r2 > (real)0 ? R_POW(r2 * inv_D * inv_D, (real)0.5 * nsg) : (real)0;
+                    real inv2sp2 = (real)1 / ((real)2 * sp * sp);
+                    du = amp * R_EXP(-rn * inv2sp2);
+                    grad = r2 > (real)0 ? nsg * rn * inv2sp2 / R_SQRT(r2) : (real)0;
+                } else {
+                    du = amp * R_EXP(-r2 * inv2s2);
+                    grad = R_SQRT(r2) * ((real)2 * inv2s2);
+                }
                 dsum += du;
                 if (added) {
-                    /* U k_mt = km1 dU + km2 R |d dU / dr| = dU (km1 + km2 R r / sigma^2) */
-                    real wk = du * (km1 + km2 * R_rot * R_SQRT(r2) * ((real)2 * inv2s2));
+                    /* U k_mt = km1 dU + km2 R |d dU / dr| = dU (km1 + km2 R r / sigma^2) for the Gaussian */
+                    real wk = du * (km1 + km2 * R_rot * grad);
                     for (int cc = 0; cc < 3; ++cc) addsum[cc] += wk * gadd[cc][s];
                 }
             }

@@ -86,6 +86,7 @@ class CConfig(C.Structure):
         ("added_turbulence", C.c_int32), ("no_ti_fold", C.c_int32), ("deficit_model", C.c_int32),
         ("reserved0_", C.c_int32),
         ("m0_km1", C.c_double), ("m0_km2", C.c_double),
+        ("m0_sg_af", C.c_double), ("m0_sg_bf", C.c_double), ("m0_sg_cf", C.c_double),
     ]
 
 
@@ -369,6 +370,10 @@ class EnvConfig:
         if self.deficit not in ("gaussian", "super_gaussian"):
             raise ValueError("deficit must be 'gaussian' or 'super_gaussian'")
         c.deficit_model = int(self.deficit == "super_gaussian")
+        if c.deficit_model:
+            # Blondel & Cathelain (2020), Table 2 (py_wake BlondelSuperGaussianDeficit2020 — the model of the reference's
+            # PyWakeAgent): characteristic width sigma/D = (0.17 TI + 0.005) x/D + 0.2 sqrt(beta); model_constants override
+            c.m0_ka, c.m0_kb, c.m0_eps = 0.17, 0.005, 0.2
         for k, v in (self.model_constants or {}).items():
             if not hasattr(c, "m0_" + k):
                 raise ValueError(f"unknown model constant {k!r}")

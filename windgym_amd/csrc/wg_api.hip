@@ -58,7 +58,7 @@ struct wg_env_s {
     int* box_ids_dev = nullptr;      // wg_set_box_ids
     void* abox4 = nullptr;           // interleaved isotropic box of the wake-added turbulence (owned)
     int added = 0, no_ti_fold = 0, deficit_model = 0;   // wg_config model options
-    double km1 = 0.6, km2 = 0.35;
+    double km1 = 0.6, km2 = 0.35, sg_af = 3.11, sg_bf = -0.68, sg_cf = 2.41;
     double* wind_dev = nullptr;      // per-env wind override (wg_set_wind)
     int device;
     std::vector<Alloc> allocs;      // everything owned by the handle (state blob = allocs flagged `state`)
@@ -192,14 +192,14 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             return fail(WG_ERR_INVALID, "wind ranges exceed the 16-bit emission record: need ka*sqrt(TI_max^2 + 0.34^2) + kb <= 0.25 "
                                             "(TI_max <= 0.55 with the default constants) and |hill| * ws_max <= 16 m/s");
     }
-    if (c->deficit_model != 0)
-        return fail(WG_ERR_UNSUPPORTED, "deficit_model: only the Gaussian deficit (0) is built into the HIP kernels");
+    if (c->deficit_model != 0 && c->deficit_model != 1) return fail(WG_ERR_INVALID, "deficit_model must be 0 (Gaussian) or 1 (super-Gaussian)");
     HIPCHK(hipSetDevice(device));
     wg_env_s* h = new wg_env_s();
     h->device = device;
     h->added = (c->added_turbulence != 0 && c->turb_mode != WG_TURB_NONE) ? 1 : 0;
     h->no_ti_fold = c->no_ti_fold != 0; h->deficit_model = c->deficit_model;
     h->km1 = defd(c->m0_km1, 0.6); h->km2 = defd(c->m0_km2, 0.35);
+    h->sg_af = defd(c->m0_sg_af, 3.11); h->sg_bf = defd(c->m0_sg_bf, -0.68); h->sg_cf = defd(c->m0_sg_cf, 2.41);
     WgParams& p = h->p;
     memset(&p, 0, sizeof(p));
     p.B = c->n_envs; p.N = c->n_turb; p.F = c->n_farms; p.K = c->k_sub; p.P = c->n_particles; p.S = c->n_rotor_pts;
@@ -448,7 +448,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         // 157 -> 172 us): default for steady inflow up to 1024 ring slots per farm.  WG_FLOW_DUO=1 / 0 forces it on
         // (where eligible) / off (tests run both).
         // (k_flow_duo does not carry the optional models: added turbulence, no TI folding)
-        const bool duo_ok = f.res && small && f.block == 64 && p.F == 2 && 2 * p.N <= 64 && p.P <= 4096 && !h->added && !h->no_ti_fold;
+        const bool duo_ok = f.res && small && f.block == 64 && p.F == 2 && 2 * p.N <= 64 && p.P <= 4096 && !h->added && !h->no_ti_fold && h->deficit_model == 0;
         f.duo = (duo_ok && p.NP <= 1024 && p.turb_mode == WG_TURB_NONE) ? 1 : 0;
         if (const char* ev = getenv("WG_FLOW_DUO")) f.duo = (duo_ok && atoi(ev) != 0) ? 1 : 0;
         bool duo_fits = true;
@@ -490,6 +490,12 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         f.inv_sqrt_S = 1.0f / std::sqrt((float)p.S);
         f.added = h->added; f.no_ti_fold = h->no_ti_fold; f.deficit_model = h->deficit_model;
         f.km1 = (float)h->km1; f.km2r = (float)(2.0 * h->km2 * 0.5 * p.D_d);
+        f.sg_af = (float)h->sg_af; f.sg_bf = (float)h->sg_bf; f.sg_cf = (float)h->sg_cf;
+        if (h->deficit_model == 1 && !f.res) {
+            wg_destroy(h);
+            return fail(WG_ERR_UNSUPPORTED, "deficit_model 1 (super-Gaussian) is built into the compact k_flow variants only "
+                                            "(farms of up to 32 turbines, larger ones with steady inflow)");
+        }
         FlowPtrs& g = h->fd;
         memset(&g, 0, sizeof(g));
         g.py = d.py; g.rec_a = d.rec_a; g.rec_b = d.rec_b; g.u_e = d.u_e; g.rec4 = d.rec4;

@@ -46,6 +46,7 @@ struct FlowP {
     int added, anx, any, anz, abox_pow2;
     int no_ti_fold, deficit_model;
     float km1, km2r;
+    float sg_af, sg_bf, sg_cf;    // super-Gaussian order n(x) = af exp(bf x/D) + cf (deficit_model = 1)
     double inv_adx, inv_ady, inv_adz;
 };
 

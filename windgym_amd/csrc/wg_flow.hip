@@ -300,7 +300,8 @@ __device__ __forceinline__ void full_barrier() {
 
 // One DWMFlowSimulation.step() of model M0 up to the new rotor inflow (T[t].u/v/w/ti); power and the
 // measurement are done by the caller's per-turbine tail.
-template <int NT, int TURB, bool RES>
+template <int NT, int TURB, bool RES, bool SGM>
+// (SGM: super-Gaussian deficit compiled in — a run-time switch in the pair loop cost the Gaussian default 5 us on cfg2)
 // (the LDS arrays that lanes exchange data through — T, pair, tiap, tmask, jnl — are deliberately NOT __restrict__: for a
 // noalias pointer the compiler may carry a value this lane loaded earlier across lds_barrier()'s memory clobber and miss
 // what another lane stored in between; the read-only tables may be)
@@ -548,8 +549,19 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             if (rc2 > rcut * rcut) continue;
             const float ctv = w0 * rec_ct(a0) + w1 * rec_ct(a1);
             const float uev = w0 * u0 + w1 * u1;
-            const float cf = m0_cfrac(ctv, sp);
             const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sig * sig);
+            // super-Gaussian option (Blondel & Cathelain 2020): order n(x), centre-line deficit from
+            // mass + momentum conservation; n = 2 is the Gaussian wake
+            constexpr bool SG = SGM;
+            float nsg = 2.0f, cf;
+            if (SG) {
+                nsg = p.sg_af * __expf(p.sg_bf * xd) + p.sg_cf;
+                const float in2 = 2.0f * __builtin_amdgcn_rcpf(nsg);
+                const float rad = exp2f(2.0f * in2 - 2.0f) - nsg * ctv * __builtin_amdgcn_rcpf(16.0f * tgammaf(in2) * fast_pow(sp, 2.0f * in2));
+                cf = exp2f(in2 - 1.0f) - __builtin_amdgcn_sqrtf(fmaxf(rad, 0.0f));
+            } else {
+                cf = m0_cfrac(ctv, sp);
+            }
             // wake-added turbulence (Crespo-Hernandez), Gaussian-weighted at the hub
             const float ind = 0.5f * (1.0f - __builtin_amdgcn_sqrtf(1.0f - ctv));
             tiav[i] = p.no_ti_fold ? 0.f
@@ -562,15 +574,32 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f;
                 const float kg = p.km2r * inv2s2;
                 const float* gt = gadd + (t << p.S_shift) * 3;
+                const float inv2sp2 = __builtin_amdgcn_rcpf(2.0f * sp * sp), iD2 = p.inv_D * p.inv_D;
                 for (int sI = 0; sI < p.S; ++sI) {
                     const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
                     const float r2 = dy * dy + dz * dz;
-                    const float du = amp * __expf(-r2 * inv2s2);
+                    float du, grad2r;         // grad2r = km2 2R |d dU / dr| / dU
+                    if (SG) {
+                        const float rn = r2 > 0.f ? fast_pow(r2 * iD2, 0.5f * nsg) : 0.f;
+                        du = amp * __expf(-rn * inv2sp2);
+                        grad2r = r2 > 0.f ? 0.5f * p.km2r * nsg * rn * inv2sp2 * __builtin_amdgcn_rsqf(r2) : 0.f;
+                    } else {
+                        du = amp * __expf(-r2 * inv2s2);
+                        grad2r = kg * __builtin_amdgcn_sqrtf(r2);
+                    }
                     acc += du;
-                    const float wk = du * (p.km1 + kg * __builtin_amdgcn_sqrtf(r2));
+                    const float wk = du * (p.km1 + grad2r);
                     a0 += wk * gt[sI * 3]; a1 += wk * gt[sI * 3 + 1]; a2 += wk * gt[sI * 3 + 2];
                 }
                 addv[i] = a0 * p.inv_S; addv[TC * N + i] = a1 * p.inv_S; addv[2 * TC * N + i] = a2 * p.inv_S;
+            } else if (SG) {
+                const float inv2sp2 = __builtin_amdgcn_rcpf(2.0f * sp * sp), iD2 = p.inv_D * p.inv_D;
+                for (int sI = 0; sI < p.S; ++sI) {
+                    const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
+                    const float r2 = dy * dy + dz * dz;
+                    const float rn = r2 > 0.f ? fast_pow(r2 * iD2, 0.5f * nsg) : 0.f;
+                    acc += amp * __expf(-rn * inv2sp2);
+                }
             } else {
                 for (int sI = 0; sI < p.S; ++sI) {
                     const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
@@ -1218,7 +1247,7 @@ __device__ __attribute__((noinline)) void flow_init_episode(const WgParams* gp, 
     }
 }
 
-template <int NT, int TURB, bool REPLAY, bool NOISE, bool RES>
+template <int NT, int TURB, bool REPLAY, bool NOISE, bool RES, bool SGM = false>
 __global__ void __launch_bounds__(NT, TURB != WG_TURB_NONE ? WG_BOX_WAVES : (RES ? WG_FLOW_WAVES_CG : WG_FLOW_WAVES))
 k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict__ actions,
        const uint8_t* __restrict__ mask, const int chunk) {
@@ -1467,7 +1496,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             // sin/cos are not needed in replay mode: power comes from the script
             script_step<NT>(p, d, T, e, farm, cursor, sr.time);
         } else {
-            flow_step<NT, TURB, RES>(p, d, T, tabct, rdy, rdz, pair, tiap, tmask, jnl, pbase, ws, ti_f, ti_pow, tc, sr, pl, n_flow == 0);
+            flow_step<NT, TURB, RES, SGM>(p, d, T, tabct, rdy, rdz, pair, tiap, tmask, jnl, pbase, ws, ti_f, ti_pow, tc, sr, pl, n_flow == 0);
             // roofline accounting: particles that can still reach a rotor (per lane; summed once in the epilogue)
             for (int t = tid; t < N; t += NT) part_acc += min(sr.n_valid, RES ? T[t].rlen : jnl[t] + 1);
             ++n_flow;
@@ -1602,6 +1631,17 @@ static void launch_nt(const FlowP* p, const FlowPtrs* d, int mode, const float* 
 #define WG_LAUNCH(TURB, REPLAY, NOISE) \
     hipLaunchKernelGGL((k_flow<NT, TURB, REPLAY, NOISE, RES>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk)
     const int turb = (p->turb_mode >= WG_TURB_BOX) ? WG_TURB_BOX : p->turb_mode;
+    if constexpr (RES) {
+        if (p->deficit_model == 1 && !replay) {      // super-Gaussian instantiations (compact variants only)
+#define WG_LAUNCH_SG(TURB, NOISE) \
+    hipLaunchKernelGGL((k_flow<NT, TURB, false, NOISE, true, true>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk)
+            if (turb == WG_TURB_NONE) { if (noise) WG_LAUNCH_SG(WG_TURB_NONE, true); else WG_LAUNCH_SG(WG_TURB_NONE, false); }
+            else if (turb == WG_TURB_RANDOM) { if (noise) WG_LAUNCH_SG(WG_TURB_RANDOM, true); else WG_LAUNCH_SG(WG_TURB_RANDOM, false); }
+            else { if (noise) WG_LAUNCH_SG(WG_TURB_BOX, true); else WG_LAUNCH_SG(WG_TURB_BOX, false); }
+#undef WG_LAUNCH_SG
+            return;
+        }
+    }
     if (replay) {                       // replay mode ignores the physics
         if (noise) WG_LAUNCH(WG_TURB_NONE, true, true); else WG_LAUNCH(WG_TURB_NONE, true, false);
     } else if (turb == WG_TURB_NONE) {
