@@ -87,3 +87,34 @@ def test_sb3_housekeeping_methods():
             pass
     env.close()
     assert v.closed
+
+
+def test_vec_env_subclasses_gymnasium_vectorenv_when_gymnasium_is_installed(monkeypatch):
+    """The reference's RecordEpisodeVals extends gymnasium.wrappers.vector.RecordEpisodeStatistics
+    (wrappers/recordEpisodeVals.py:8), which only accepts a gymnasium VectorEnv: with gymnasium importable,
+    WindFarmVecEnv must be one (same-step autoreset declared in its metadata)."""
+    import importlib
+    import sys
+    import types
+    gym = types.ModuleType("gymnasium")
+    vec = types.ModuleType("gymnasium.vector")
+
+    class VectorEnv:
+        pass
+
+    class AutoresetMode:
+        SAME_STEP = "same_step_enum"
+
+    vec.VectorEnv, vec.AutoresetMode = VectorEnv, AutoresetMode
+    gym.vector = vec
+    monkeypatch.setitem(sys.modules, "gymnasium", gym)
+    monkeypatch.setitem(sys.modules, "gymnasium.vector", vec)
+    import windgym_amd.envs as envs
+    try:
+        mod = importlib.reload(envs)
+        assert issubclass(mod.WindFarmVecEnv, VectorEnv)
+        assert mod._gym_autoreset_mode() == "same_step_enum"
+    finally:
+        monkeypatch.undo()
+        importlib.reload(envs)
+    assert envs.WindFarmVecEnv.__mro__[1] is object

@@ -150,7 +150,26 @@ class _FlowProxy:
 
 
 # ======================================================================================================
-class WindFarmVecEnv:
+def _gym_vector_base():
+    """gymnasium's ``VectorEnv`` when gymnasium is installed — isinstance checks of vector wrappers and of training
+    libraries then pass (the reference's RecordEpisodeVals extends gymnasium.wrappers.vector.RecordEpisodeStatistics,
+    wrappers/recordEpisodeVals.py:8, which requires a VectorEnv) — a plain object otherwise."""
+    try:
+        from gymnasium.vector import VectorEnv
+        return VectorEnv
+    except Exception:
+        return object
+
+
+def _gym_autoreset_mode():
+    try:
+        from gymnasium.vector import AutoresetMode
+        return AutoresetMode.SAME_STEP
+    except Exception:
+        return "SameStep"
+
+
+class WindFarmVecEnv(_gym_vector_base()):
     """``n_envs`` independent farms on one GPU behind one handle.
 
     ``step(actions)`` takes a float32 array / CUDA tensor ``[n_envs, n_turb]`` in [-1, 1] and returns
@@ -183,6 +202,11 @@ class WindFarmVecEnv:
         self.observation_space = Box(-1.0, 1.0, (self.num_envs, self.batch.obs_dim), np.float32)
         self.action_space = Box(-1.0, 1.0, (self.num_envs, self.n_turb), np.float32)
         self._base_seed = seed
+        # gymnasium >= 1.0 vector API: truncated envs are reset in the SAME step (final_obs in the info dict)
+        self.metadata = {"autoreset_mode": _gym_autoreset_mode(), "render_modes": []}
+        self.render_mode = None
+        self.spec = None
+        self.closed = False
         self._global_offset = 0          # first global env index of this shard (set by shard())
         self._actions = self.torch.zeros((self.num_envs, self.n_turb), dtype=self.torch.float32,
                                          device=self.batch.device)
