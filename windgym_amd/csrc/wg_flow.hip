@@ -1289,12 +1289,24 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     // ---- prologue: issue every independent global load up front (ONE exposed memory round trip) -------
     // (cold parameters: the pointers below are read from the kernarg segment where they are used and not kept — see
     // wg_cold_args)
+    // Per-workgroup timeline (tools/timeline2.sh, cfg2): a memory round trip costs ~5-7 k cycles under load and the
+    // prologue was THREE in sequence (kernarg -> env header, waited for before the mask branch -> headers + state).  So:
+    //  * the env / slot / context headers are wave-uniform and not written by this workgroup before it reads them: they
+    //    are fetched through the constant address space = scalar loads (K$ is invalidated at every kernel start), which do
+    //    not queue behind, nor hold up, the vector loads of the turbine state;
+    //  * no control flow between the loads (the mask byte is read unconditionally from a valid address).
     const KArgsPtr k0 = wg_cold_args();
+    typedef const __attribute__((address_space(4))) WgEnv* CEnvPtr;
+    typedef const __attribute__((address_space(4))) WgSlot* CSlotPtr;
+    typedef const __attribute__((address_space(4))) WgCtx* CCtxPtr;
     const WgEnv& env = d.env[e];
-    const int env_live = env.live, env_done = env.done, env_shadow_iters = env.shadow_iters;
-    const uint64_t noise_key = env.noise_key;
-    const int init_pending = d.ctx[ctx_id].init_pending;
-    const uint8_t masked_out = (mode == WG_MODE_RESET && mask) ? (uint8_t)(mask[e] == 0) : (uint8_t)0;
+    const CEnvPtr envc = (CEnvPtr)(d.env + e);
+    const int env_live = envc->live, env_done = envc->done, env_shadow_iters = envc->shadow_iters;
+    const uint64_t noise_key = envc->noise_key;
+    const int init_pending = ((CCtxPtr)(d.ctx + ctx_id))->init_pending;
+    const bool use_mask = mode == WG_MODE_RESET && mask != nullptr;
+    const uint8_t mask_byte = *(use_mask ? mask + e : reinterpret_cast<const uint8_t*>(d.env + e));
+    const uint8_t masked_out = use_mask ? (uint8_t)(mask_byte == 0) : (uint8_t)0;
     const int t_own = tid < N ? tid : 0;
     int dev_rem, fill_rem, cursor, n_pushed, pend_farm_n, pend_base_n;
     SlotRegs sr;
@@ -1306,19 +1318,9 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     float l_yaw = 0, l_u = 0, l_v = 0, l_w = 0, l_ti = 0, l_pow = 0, l_ct = 0, l_act = 0;
     float4 l_bnd = make_float4(0.f, 0.f, 0.f, 0.f);
     int l_jn = 0, l_roff = 0, l_rnext = 0, L_ring = 0;
-    auto load_state = [&]() __attribute__((always_inline)) {
-        const KArgsPtr kl = wg_cold_args();
-        // (the slot / context headers through the plain kernel arguments: the compiler then knows the addresses are
-        // uniform and not written before, and fetches the fields with a few wide scalar loads instead of one vector
-        // load per field)
-        const WgSlot& slot = d.slot[slot_id];
-        const WgCtx& cx = d.ctx[ctx_id];
+    auto load_headers = [&](const auto& slot, const auto& cx) __attribute__((always_inline)) {
         dev_rem = slot.dev_remaining; fill_rem = slot.fill_remaining;
         sr = SlotRegs{slot.s_off, slot.time, slot.head, slot.n_valid, slot.istep, slot.n_emitted};
-        if (RES) {
-            const int* ro = kl->d.roff + (size_t)ctx_id * (N + 1);
-            l_roff = ro[t_own]; l_rnext = ro[t_own + 1]; L_ring = ro[N];
-        }
         cursor = slot.cursor;
         ws = cx.ws;
         ti_f = (float)cx.ti;
@@ -1332,6 +1334,17 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         tc.sig = (float)(cx.ti * ws);
         tc.alpha = TURB == WG_TURB_NONE ? 0.f
                                         : (float)(1.0 - exp(-2.0 * WG_PI_D * (ws / (p.fc_scale * p.D_d)) * p.dt_d));
+    };
+    // `fresh`: after the in-kernel episode set-up the headers were just rewritten by this workgroup -> plain (vector)
+    // loads, not the scalar cache
+    auto load_state = [&](const bool fresh) __attribute__((always_inline)) {
+        const KArgsPtr kl = wg_cold_args();
+        if (fresh) load_headers(d.slot[slot_id], d.ctx[ctx_id]);
+        else load_headers(*(CSlotPtr)(d.slot + slot_id), *(CCtxPtr)(d.ctx + ctx_id));
+        if (RES) {
+            const int* ro = kl->d.roff + (size_t)ctx_id * (N + 1);
+            l_roff = ro[t_own]; l_rnext = ro[t_own + 1]; L_ring = ro[N];
+        }
         l_xr = kl->d.xr[(size_t)ctx_id * N + t_own];
         l_yr = kl->d.yr[(size_t)ctx_id * N + t_own];
         l_yaw = kl->d.yaw[tb + t_own]; l_u = kl->d.u[tb + t_own]; l_v = kl->d.v[tb + t_own]; l_w = kl->d.w[tb + t_own];
@@ -1339,12 +1352,18 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         l_bnd = reinterpret_cast<const float4*>(kl->d.bnd)[tb + t_own];
         if (!RES) l_jn = kl->d.jneed[(size_t)ctx_id * N + t_own];      // chain pruning by predicate: streaming variant only
     };
-    load_state();
+    load_state(false);
     // (first elements of the read-only tables: requested with the state loads — copied to LDS after the decision below, a
     // separate copy loop there costs every workgroup a second memory round trip)
-    const float pf_tp = tid < p.n_tab ? k0->d.tab_power[tid] : 0.f, pf_tc = tid < p.n_tab ? k0->d.tab_ct[tid] : 0.f;
-    const float pf_dy = tid < p.S ? k0->d.rotor_dy[tid] : 0.f, pf_dz = tid < p.S ? k0->d.rotor_dz[tid] : 0.f;
-    if (mode == WG_MODE_STEP && farm == 0) l_act = actions[(size_t)e * N + t_own];
+    // (clamped indices instead of predicated loads: no branches, every request above and below is in flight together)
+    const int i_tab = min(tid, p.n_tab - 1), i_s = min(tid, p.S - 1);
+    const float pf_tp = k0->d.tab_power[i_tab], pf_tc = k0->d.tab_ct[i_tab];
+    const float pf_dy = k0->d.rotor_dy[i_s], pf_dz = k0->d.rotor_dz[i_s];
+    {
+        const bool has_act = mode == WG_MODE_STEP && farm == 0;
+        const float a = *(has_act ? actions + (size_t)e * N + t_own : k0->d.tab_ct);
+        l_act = has_act ? a : 0.f;
+    }
 
     const bool is_live = (c == env_live);
     int budget = 0;
@@ -1367,7 +1386,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
                 const WgParams& gp = *d.gp;
                 if (tid < WG_WAVE) flow_init_episode(d.gp, d.gd, d.env_rw + e, e, c, farm, tid);
                 full_barrier<NT>();
-                load_state();
+                load_state(true);
                 // first share of the background work, planned here because k_glue could not know it yet
                 const int fill_max = F == 2 ? max(gp.fill_a, gp.fill_b) : gp.fill_a;
                 const int inc = 1 + (gp.extra_inc ? 1 : 0);
