@@ -635,6 +635,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         // advection pass stored)
         if (!first_step) full_barrier<NT>();
         res_pair_phase(std::true_type{});
+        WG_STAMP(9);
     }
 
     // (2) pass over the particle SoA: advect over dt, release the new particles
@@ -690,6 +691,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             }
         }
         lds_barrier<NT>();
+        WG_STAMP(10);
         const int nlist = *nq;
         for (int c = tid; c < nlist; c += NT) {
             const unsigned ent = ql[c];
@@ -1633,7 +1635,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
 #ifdef WG_TIMELINE
         if (d.dbg && n_flow == 1) {
             wg_stamps[8] = clock64();
-            for (int k = 0; k < 9; ++k) d.dbg[(size_t)blockIdx.x * 12 + k] = wg_stamps[k];
+            for (int k = 0; k < 12; ++k) d.dbg[(size_t)blockIdx.x * 12 + k] = wg_stamps[k];
         }
 #endif
     }
