@@ -7,11 +7,12 @@ cp /tmp/lib_keep.so windgym_amd/libwindgym_hip.so
 python - <<'PY'
 import numpy as np
 raw = np.fromfile('gpurun_out/timeline.bin', dtype=np.int64).reshape(-1, 12)
-ok = (raw[:, 8] > raw[:, 0]) & (raw[:, 0] > 0) & (raw[:, 9] > raw[:, 2])
+ok = (raw[:, 8] > raw[:, 0]) & (raw[:, 0] > 0) & (raw[:, 9] > raw[:, 2]) & (raw[:, 11] > raw[:, 1])
 a = raw[ok]
 print('blocks with one full step:', len(a), 'of', len(raw))
-seq = [(0, 1, 'prologue: kernarg + state loads + LDS set-up'), (1, 2, 'records'), (2, 9, 'pair phase (candidates, gathers, deficits, sums)'),
-       (9, 10, 'quad list'), (10, 3, 'advection pass (loads, compute, stores issued)'), (3, 6, 'clock update'), (6, 7, 'tail (power, measurement, ring push)'),
+seq = [(0, 1, 'prologue: kernarg + state loads + LDS set-up'), (1, 5, 'candidate pass'), (5, 11, 'brackets + LDS-DMA gathers issued'), (11, 2, 'records'),
+       (2, 10, 'quad list'), (10, 9, 'deficits from the landed gathers + sums'),
+       (9, 3, 'advection pass (loads, compute, stores issued)'), (3, 6, 'clock update'), (6, 7, 'tail (power, measurement, ring push)'),
        (7, 8, 'epilogue (state stores, accounting)')]
 tot = a[:, 8] - a[:, 0]
 print('total: mean %.0f median %.0f p90 %.0f' % (tot.mean(), np.median(tot), np.percentile(tot, 90)))

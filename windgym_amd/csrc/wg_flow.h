@@ -23,6 +23,8 @@ struct FlowP {
     int pstride;                  // floats between the particle blocks of consecutive farm slots (>= NP, see wg_create)
     int target_chunk;             // targets whose pair parameters are staged in LDS at once
     int lds_off_turb, lds_off_tab, lds_bytes;
+    int lds_off_ql, lds_off_gat;  // single-wave steady compact variant: quad list of its own (0 = aliases the pair staging) and the
+                                  // landing zone of the deficit phase's LDS-DMA gathers (WG_GAT_BYTES)
     int ql_shift;                 // compact steady advection: quad-list entry = turbine << ql_shift | quad index in its ring (16 bits)
     int ql_lpt_shift;             // ... and 2^ql_lpt_shift lanes share the listing of one turbine's quads (block / N, at most 8)
     int duo, duo_off_turb, duo_lds;   // k_flow_duo (both farms of a context in one wave): enabled, LDS carve (wg_flow_duo.inc)
@@ -80,5 +82,8 @@ struct FlowPtrs {
 
 // sizeof(TurbLds) in wg_flow.hip; kept here so the host can size the dynamic LDS
 #define WG_TURB_LDS_BYTES 120
+// landing zone of the LDS-DMA gathers: 8 words (py, rec_a, rec_b, u_e of the two bracketing particles) x 64 candidates, + the
+// quad-list counter
+#define WG_GAT_BYTES (8 * 64 * 4 + 16)
 // per-target bit mask of contributing sources: 32-bit words per target (N <= 32 * WG_MASK_WORDS)
 #define WG_MASK_WORDS 4

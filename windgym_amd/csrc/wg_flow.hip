@@ -85,6 +85,9 @@ __device__ __forceinline__ float m0_advect(float py, unsigned ra, unsigned rb, i
     return __builtin_fmaf(rec_hv(rb) * m0_cfrac(rec_ct(ra), sp), dt, py);
 }
 
+#ifndef WG_GLDS
+#define WG_GLDS 1         // single-wave steady compact variant: deficit-phase gathers as early LDS-DMA requests (0 = register gathers, for A/B builds)
+#endif
 #ifndef WG_PAIR_FIRST
 #define WG_PAIR_FIRST 1   // steady compact variant: deficit phase BEFORE the advection pass (0 = round-2 order, for A/B builds)
 #endif
@@ -282,7 +285,22 @@ __device__ __forceinline__ void lds_barrier() {
 template <int NT>
 __device__ __forceinline__ void full_barrier() {
     if (NT > WG_WAVE) __syncthreads();
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else {
+        // (the builtin, not inline asm: the compiler's wait-count pass sees that nothing is outstanding afterwards — with an
+        // opaque wait it keeps "possibly pending" loads of skipped branches alive around the flow-step loop and orders
+        // later register writes behind them with waits of its own, see wg_wait_vmem)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0)
+        asm volatile("" ::: "memory");
+    }
+}
+
+// s_waitcnt vmcnt(0) that the compiler's own wait-count pass sees (expcnt / lgkmcnt fields at their maxima = no wait), and
+// that no memory access is moved across
+__device__ __forceinline__ void wg_wait_vmem() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
 }
 
 // streamed particle state of the turbulent pass: touched once per launch -> non-temporal, so that it does not evict
@@ -328,6 +346,105 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     int new_valid = n_valid + n_emit; if (new_valid > P) new_valid = P;
     const float s_off_f = (float)sr.s_off;
 
+    // staging of the compact variants' deficit phases (the `pair` region, per chunk of TC targets):
+    // cl[TC*N] u16 candidate list | def[TC*N] rotor-mean deficit | tiav[TC*N] added TI
+    unsigned short* cl = reinterpret_cast<unsigned short*>(pair);
+    float* def = reinterpret_cast<float*>(cl + ((TC * N + 7) & ~7));
+    float* tiav = def + TC * N;
+    int* ncand = jnl + N + 1;
+    // wake-added turbulence (wg_config.added_turbulence; turbulent inflow only): gadd[(t, sample)][3] =
+    // the isotropic field at every rotor point, addv[3][TC * N] = a candidate pair's rotor-summed contribution
+    const bool ADDED = TURB != WG_TURB_NONE && p.added != 0;
+    float* addv = tiav + TC * N;
+    float* gadd = reinterpret_cast<float*>(jnl + N + 4);
+
+    // ---- single-wave steady compact variant (GL): the deficit phase's memory round trip is taken off the workgroup's
+    // latency chain.  Candidate pairs and the ring slots that bracket them depend on the layout, the chain clocks and the
+    // chains' running bounds only — all known before this step's records.  So: candidate pass -> the 8 gathers per
+    // candidate are issued as LDS-DMA requests (global_load_lds: no result registers, the wave does not wait) -> records
+    // and quad list (LDS / ALU work, ~5 k cycles = one loaded round trip) -> the deficit evaluation reads the landed
+    // words from LDS.  (The bounds are those BEFORE this step's records: they cover every particle already in the
+    // rings; a pair close enough to be bracketed by a particle released in this step is a candidate unconditionally.)
+    constexpr bool PRE = RES && TURB == WG_TURB_NONE && (WG_PAIR_FIRST != 0);
+    constexpr bool GL = PRE && NT == WG_WAVE && (WG_GLDS != 0);
+    const float ws_f = (float)ws;
+    float* gat = reinterpret_cast<float*>(reinterpret_cast<char*>(pair) + p.lds_off_gat);
+    typedef const __attribute__((address_space(1))) void* GPtr;
+    typedef __attribute__((address_space(3))) void* LPtr;
+    int gl_nc = 0;
+    // bracket of candidate c (list entry cl[c]): target, source, distance, age j of the older... of the two particles AFTER the
+    // step, interpolation weight; false if the chain has not reached the target yet
+    auto gl_bracket = [&](const int c, int& i, int& tl, int& s2, double& dx, int& j, float& wgt) __attribute__((always_inline)) -> bool {
+        i = cl[c];
+        tl = (int)(((float)i + 0.5f) * p.inv_N);
+        s2 = i - tl * N;
+        dx = T[tl].xr - T[s2].xr;
+        const double xi = (dx - s_new) * p.inv_dpart;
+        const double jf = floor(xi);
+        wgt = (float)(xi - jf);
+        j = (int)jf;
+        if (j < 0) { j = 0; wgt = 0.f; }
+        return j + 1 <= new_valid - 1;
+    };
+    // LDS-DMA gathers of candidate c: word k of lane l lands at gat[k * 64 + l]; k = 0..7: py, u_e, rec_a, rec_b of the
+    // particle of pre-step age jp0 = j - n_emit, then of jp0 + 1.  Lanes without a candidate / particles released in this
+    // step (negative pre-step age: the turbine's record, not in memory yet) request a valid dummy address.
+    auto gl_issue = [&](const int c, const int nc) __attribute__((always_inline)) {
+        int i, tl, s2, j; double dx; float wgt;
+        int i0 = 0, i1 = 0;
+        if (c < nc && gl_bracket(c, i, tl, s2, dx, j, wgt)) {
+            const TurbLds& src = T[s2];
+            const int Rs = src.rlen;
+            const int jp0 = j - n_emit, jp1 = jp0 + 1;
+            int r0 = src.head - jp0; if (r0 < 0) r0 += Rs;
+            int r1 = src.head - jp1; if (r1 < 0) r1 += Rs;
+            if (jp0 >= 0) i0 = src.roff + r0;
+            if (jp1 >= 0) i1 = src.roff + r1;
+        }
+        __builtin_amdgcn_global_load_lds((GPtr)(pl.py + i0), (LPtr)(gat + 0 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(pl.ue + i0), (LPtr)(gat + 1 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(pl.ra + i0), (LPtr)(gat + 2 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(pl.rb + i0), (LPtr)(gat + 3 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(pl.py + i1), (LPtr)(gat + 4 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(pl.ue + i1), (LPtr)(gat + 5 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(pl.ra + i1), (LPtr)(gat + 6 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(pl.rb + i1), (LPtr)(gat + 7 * 64), 4, 0, 0);
+    };
+    if (GL) {
+        // (a further flow step of the same launch gathers what the previous step's advection pass stored)
+        if (!first_step) full_barrier<NT>();
+        const float move_max = fabsf(p.hill) * ws_f * p.dt;
+        // a target closer than this is bracketed by a particle released in this step
+        const double near = sr.s_off + ws * p.dt_d + p.dpart;
+        const int npairs = N * N;
+        for (int i0 = 0; i0 < ((WG_ABLATE & 2) ? 0 : npairs); i0 += NT) {
+            const int i = i0 + tid;
+            bool cand = false;
+            if (i < npairs) {
+                const int tg = (int)(((float)i + 0.5f) * p.inv_N);
+                const int s2 = i - tg * N;
+                const double dx = T[tg].xr - T[s2].xr;
+                cand = (s2 != tg) && (dx > 0.0);
+                if (cand && !(dx < near)) {
+                    const TurbLds& src = T[s2];
+                    const float sig_max = (src.bk * ((float)dx * p.inv_D) + src.be) * p.D;
+                    const float bd = src.bd + (src.mvl != 0u ? move_max : 0.f);
+                    const float gap = fabsf((float)(T[tg].yr - src.yr)) - (p.R_rot + 5.0f * sig_max + bd);
+                    cand = gap <= 1.0e-3f * p.D;
+                }
+            }
+            // (single wave: the list position is a running count in a register — and an LDS atomic would be ordered behind
+            // every outstanding memory operation by the compiler once LDS-DMA requests exist in the kernel)
+            const unsigned long long bal = __ballot(cand);
+            if (cand) cl[gl_nc + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)i;
+            gl_nc += __popcll(bal);
+        }
+        lds_barrier<NT>();
+        WG_STAMP(5);
+        if (gl_nc > 0) gl_issue(tid, gl_nc);
+        WG_STAMP(11);
+    }
+
     // (1) emission records of this step, sin/cos of the yaw; clear the source masks
     for (int t = tid; t < N; t += NT) {
         TurbLds& q = T[t];
@@ -361,6 +478,86 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     lds_barrier<NT>();
     WG_STAMP(2);
 
+    // exact evaluation of one (target t, source s2) candidate from its two bracketing particles: interpolation, lateral
+    // cut-off, deficit at the S rotor points -> def[i], tiav[i] (, addv) and the source's bit in the target's mask
+    auto eval_pair = [&](const int i, const int tl, const int s2, const int t, const double dx, const float wgt,
+                         const float py0, const float py1, const float pz0, const float pz1, const unsigned a0, const unsigned a1,
+                         const unsigned b0_, const unsigned b1_, const float u0, const float u1) __attribute__((always_inline)) {
+            const float w0 = 1.0f - wgt, w1 = wgt;
+            const float yc = w0 * py0 + w1 * py1;
+            float zc = p.hub;
+            if (TURB != WG_TURB_NONE) zc = w0 * pz0 + w1 * pz1;
+            const float kv = w0 * rec_k(a0) + w1 * rec_k(a1);
+            const float epv = w0 * rec_eps(b0_) + w1 * rec_eps(b1_);
+            const float xd = (float)dx * p.inv_D;
+            const float sp = kv * xd + epv;
+            const float sig = sp * p.D;
+            const float yt = (float)T[t].yr;
+            const float rc2 = (yt - yc) * (yt - yc) + (p.hub - zc) * (p.hub - zc);
+            const float rcut = p.R_rot + 5.0f * sig;
+            if (rc2 > rcut * rcut) return;
+            const float ctv = w0 * rec_ct(a0) + w1 * rec_ct(a1);
+            const float uev = w0 * u0 + w1 * u1;
+            const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sig * sig);
+            // super-Gaussian option (Blondel & Cathelain 2020; DESIGN.md §2.8): order n(x), centre-line deficit from
+            // mass + momentum conservation; n = 2 is the Gaussian wake
+            constexpr bool SG = SGM;
+            float nsg = 2.0f, cf;
+            if (SG) {
+                nsg = p.sg_af * __expf(p.sg_bf * xd) + p.sg_cf;
+                const float in2 = 2.0f * __builtin_amdgcn_rcpf(nsg);
+                const float rad = exp2f(2.0f * in2 - 2.0f) - nsg * ctv * __builtin_amdgcn_rcpf(16.0f * tgammaf(in2) * fast_pow(sp, 2.0f * in2));
+                cf = exp2f(in2 - 1.0f) - __builtin_amdgcn_sqrtf(fmaxf(rad, 0.0f));
+            } else {
+                cf = m0_cfrac(ctv, sp);
+            }
+            // wake-added turbulence (Crespo-Hernandez), Gaussian-weighted at the hub
+            const float ind = 0.5f * (1.0f - __builtin_amdgcn_sqrtf(1.0f - ctv));
+            tiav[i] = p.no_ti_fold ? 0.f
+                                   : p.tia * fast_pow(ind, p.tib) * ti_pow * fast_pow(fmaxf(xd, 1.0f), p.tid) * __expf(-rc2 * inv2s2);
+            // Gaussian deficit at the S rotor points of the target (lateral offsets scaled by cos(yaw_t))
+            const float cgt = T[t].cg, amp = uev * cf;
+            float acc = 0.f;
+            if (ADDED) {
+                // + this wake's share of the added turbulence: U k_mt g = dU (km1 + km2 R r / sigma^2) g at every point
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+                const float kg = p.km2r * inv2s2;
+                const float* gt = gadd + (t << p.S_shift) * 3;
+                const float inv2sp2 = __builtin_amdgcn_rcpf(2.0f * sp * sp), iD2 = p.inv_D * p.inv_D;
+                for (int sI = 0; sI < p.S; ++sI) {
+                    const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
+                    const float r2 = dy * dy + dz * dz;
+                    float du, grad2r;         // grad2r = km2 2R |d dU / dr| / dU
+                    if (SG) {
+                        const float rn = r2 > 0.f ? fast_pow(r2 * iD2, 0.5f * nsg) : 0.f;
+                        du = amp * __expf(-rn * inv2sp2);
+                        grad2r = r2 > 0.f ? 0.5f * p.km2r * nsg * rn * inv2sp2 * __builtin_amdgcn_rsqf(r2) : 0.f;
+                    } else {
+                        du = amp * __expf(-r2 * inv2s2);
+                        grad2r = kg * __builtin_amdgcn_sqrtf(r2);
+                    }
+                    acc += du;
+                    const float wk = du * (p.km1 + grad2r);
+                    a0 += wk * gt[sI * 3]; a1 += wk * gt[sI * 3 + 1]; a2 += wk * gt[sI * 3 + 2];
+                }
+                addv[i] = a0 * p.inv_S; addv[TC * N + i] = a1 * p.inv_S; addv[2 * TC * N + i] = a2 * p.inv_S;
+            } else if (SG) {
+                const float inv2sp2 = __builtin_amdgcn_rcpf(2.0f * sp * sp), iD2 = p.inv_D * p.inv_D;
+                for (int sI = 0; sI < p.S; ++sI) {
+                    const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
+                    const float r2 = dy * dy + dz * dz;
+                    const float rn = r2 > 0.f ? fast_pow(r2 * iD2, 0.5f * nsg) : 0.f;
+                    acc += amp * __expf(-rn * inv2sp2);
+                }
+            } else {
+                for (int sI = 0; sI < p.S; ++sI) {
+                    const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
+                    acc += amp * __expf(-(dy * dy + dz * dz) * inv2s2);
+                }
+            }
+            def[i] = acc * p.inv_S;
+            atomicOr(&tmask[tl * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
+    };
     // (3)+(4) rotor-averaged inflow of the compact variants, as a closure: the steady variant runs it BEFORE the advection
     // pass (PRE), the turbulent ones after it.
     // PRE (steady inflow): the bracketing particles are gathered in their PRE-step state and advanced by the same
@@ -369,8 +566,6 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     // no wait for the pass's stores, the gathers are in flight before the streaming loads of the same lines (which then
     // hit in L2 instead of the other way round, after L2 has lost them), and a live workgroup's latency chain is three
     // memory round trips (state, gathers, stream) instead of five.
-    constexpr bool PRE = RES && TURB == WG_TURB_NONE && (WG_PAIR_FIRST != 0);
-    const float ws_f = (float)ws;
     auto res_pair_phase = [&](auto pre_tag) __attribute__((always_inline)) {
         constexpr bool PREV = decltype(pre_tag)::value;
         const float move_max = fabsf(p.hill) * ws_f * p.dt;
@@ -380,15 +575,6 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         // (L2 hits: this workgroup just streamed them), interpolation, lateral cut-off, then the Gaussian deficit at all S rotor points summed in the thread.
         // Thread t finally subtracts its sources' contributions in ascending source order (deterministic).
         // Staging (the `pair` region, per chunk of TC targets): cl[TC*N] u16 candidate list | def[TC*N] rotor-mean deficit | tiav[TC*N] added TI.
-        unsigned short* cl = reinterpret_cast<unsigned short*>(pair);
-        float* def = reinterpret_cast<float*>(cl + ((TC * N + 7) & ~7));
-        float* tiav = def + TC * N;
-        int* ncand = jnl + N + 1;
-        // wake-added turbulence (wg_config.added_turbulence; turbulent inflow only): gadd[(t, sample)][3] =
-        // the isotropic field at every rotor point, addv[3][TC * N] = a candidate pair's rotor-summed contribution
-        const bool ADDED = TURB != WG_TURB_NONE && p.added != 0;
-        float* addv = tiav + TC * N;
-        float* gadd = reinterpret_cast<float*>(jnl + N + 2);
         // ambient inflow at the rotors (no wakes): thread t / the (t, sample) threads
         if (TURB == WG_TURB_BOX) {
             const int nitems = N << p.S_shift;
@@ -534,80 +720,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     a0 = pl.ra[i0]; a1 = pl.ra[i1]; b0_ = pl.rb[i0]; b1_ = pl.rb[i1];
                 }
             }
-            const float w0 = 1.0f - wgt, w1 = wgt;
-            const float yc = w0 * py0 + w1 * py1;
-            float zc = p.hub;
-            if (TURB != WG_TURB_NONE) zc = w0 * pz0 + w1 * pz1;
-            const float kv = w0 * rec_k(a0) + w1 * rec_k(a1);
-            const float epv = w0 * rec_eps(b0_) + w1 * rec_eps(b1_);
-            const float xd = (float)dx * p.inv_D;
-            const float sp = kv * xd + epv;
-            const float sig = sp * p.D;
-            const float yt = (float)T[t].yr;
-            const float rc2 = (yt - yc) * (yt - yc) + (p.hub - zc) * (p.hub - zc);
-            const float rcut = p.R_rot + 5.0f * sig;
-            if (rc2 > rcut * rcut) continue;
-            const float ctv = w0 * rec_ct(a0) + w1 * rec_ct(a1);
-            const float uev = w0 * u0 + w1 * u1;
-            const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sig * sig);
-            // super-Gaussian option (Blondel & Cathelain 2020; DESIGN.md §2.8): order n(x), centre-line deficit from
-            // mass + momentum conservation; n = 2 is the Gaussian wake
-            constexpr bool SG = SGM;
-            float nsg = 2.0f, cf;
-            if (SG) {
-                nsg = p.sg_af * __expf(p.sg_bf * xd) + p.sg_cf;
-                const float in2 = 2.0f * __builtin_amdgcn_rcpf(nsg);
-                const float rad = exp2f(2.0f * in2 - 2.0f) - nsg * ctv * __builtin_amdgcn_rcpf(16.0f * tgammaf(in2) * fast_pow(sp, 2.0f * in2));
-                cf = exp2f(in2 - 1.0f) - __builtin_amdgcn_sqrtf(fmaxf(rad, 0.0f));
-            } else {
-                cf = m0_cfrac(ctv, sp);
-            }
-            // wake-added turbulence (Crespo-Hernandez), Gaussian-weighted at the hub
-            const float ind = 0.5f * (1.0f - __builtin_amdgcn_sqrtf(1.0f - ctv));
-            tiav[i] = p.no_ti_fold ? 0.f
-                                   : p.tia * fast_pow(ind, p.tib) * ti_pow * fast_pow(fmaxf(xd, 1.0f), p.tid) * __expf(-rc2 * inv2s2);
-            // Gaussian deficit at the S rotor points of the target (lateral offsets scaled by cos(yaw_t))
-            const float cgt = T[t].cg, amp = uev * cf;
-            float acc = 0.f;
-            if (ADDED) {
-                // + this wake's share of the added turbulence: U k_mt g = dU (km1 + km2 R r / sigma^2) g at every point
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-                const float kg = p.km2r * inv2s2;
-                const float* gt = gadd + (t << p.S_shift) * 3;
-                const float inv2sp2 = __builtin_amdgcn_rcpf(2.0f * sp * sp), iD2 = p.inv_D * p.inv_D;
-                for (int sI = 0; sI < p.S; ++sI) {
-                    const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
-                    const float r2 = dy * dy + dz * dz;
-                    float du, grad2r;         // grad2r = km2 2R |d dU / dr| / dU
-                    if (SG) {
-                        const float rn = r2 > 0.f ? fast_pow(r2 * iD2, 0.5f * nsg) : 0.f;
-                        du = amp * __expf(-rn * inv2sp2);
-                        grad2r = r2 > 0.f ? 0.5f * p.km2r * nsg * rn * inv2sp2 * __builtin_amdgcn_rsqf(r2) : 0.f;
-                    } else {
-                        du = amp * __expf(-r2 * inv2s2);
-                        grad2r = kg * __builtin_amdgcn_sqrtf(r2);
-                    }
-                    acc += du;
-                    const float wk = du * (p.km1 + grad2r);
-                    a0 += wk * gt[sI * 3]; a1 += wk * gt[sI * 3 + 1]; a2 += wk * gt[sI * 3 + 2];
-                }
-                addv[i] = a0 * p.inv_S; addv[TC * N + i] = a1 * p.inv_S; addv[2 * TC * N + i] = a2 * p.inv_S;
-            } else if (SG) {
-                const float inv2sp2 = __builtin_amdgcn_rcpf(2.0f * sp * sp), iD2 = p.inv_D * p.inv_D;
-                for (int sI = 0; sI < p.S; ++sI) {
-                    const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
-                    const float r2 = dy * dy + dz * dz;
-                    const float rn = r2 > 0.f ? fast_pow(r2 * iD2, 0.5f * nsg) : 0.f;
-                    acc += amp * __expf(-rn * inv2sp2);
-                }
-            } else {
-                for (int sI = 0; sI < p.S; ++sI) {
-                    const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
-                    acc += amp * __expf(-(dy * dy + dz * dz) * inv2s2);
-                }
-            }
-            def[i] = acc * p.inv_S;
-            atomicOr(&tmask[tl * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
+            eval_pair(i, tl, s2, t, dx, wgt, py0, py1, pz0, pz1, a0, a1, b0_, b1_, u0, u1);
         }
         lds_barrier<NT>();
         // thread t: superposition in ascending source order
@@ -630,7 +743,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         }   // target chunks
         lds_barrier<NT>();
     };
-    if (PRE) {
+    if (PRE && !GL) {
         // (a further flow step of the same launch — background development, reset — gathers what the previous step's
         // advection pass stored)
         if (!first_step) full_barrier<NT>();
@@ -661,15 +774,59 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         // (py, rec_a, rec_b) requested together — one memory round trip per 64 quads, none for a resting chain.
         // (16-bit list entries: turbine << ql_shift | quad index inside the turbine's ring; the host selects this variant
         // only where both fit)
-        unsigned short* ql = reinterpret_cast<unsigned short*>(pair);
+        unsigned short* ql = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(pair) + (GL ? p.lds_off_ql : 0));
         const int qsh = p.ql_shift;
-        int* nq = jnl + N + 1;              // (the same word serves as the candidate counter of the deficit phase)
-        if (tid == 0) *nq = 0;
-        lds_barrier<NT>();
+        // (not GL: the same word serves as the candidate counter of the deficit phase, the list aliases its staging)
+        int* nq = jnl + N + 1;
         // (2^lsh adjacent lanes share a turbine: the listing loop of a moving chain — up to P / 4 entries — is split
         // between them; the host chose lsh with N << lsh <= NT)
         const int lsh = p.ql_lpt_shift, lpt = 1 << lsh;
         const int t = tid >> lsh, kl = tid & (lpt - 1);
+        int gl_nlist = 0;
+        if (GL) {
+            // single wave: list positions from a wave-level prefix sum, no LDS atomics — the compiler orders an LDS
+            // atomic behind every pending LDS-DMA request (s_waitcnt vmcnt(0)), which would put the gathers' round trip
+            // back on the chain right here
+            int cnt = 0, nqd = 0, q0 = 0, q1 = 0, q2 = 0;
+            bool full = false;
+            unsigned tag = 0u;
+            if (t < ((WG_ABLATE & 1) ? 0 : N)) {
+                const TurbLds& tq = T[t];
+                const int R = tq.rlen;
+                nqd = R >> 2;
+                const bool moving = tq.mvl != 0u && (int)(sr.n_emitted - tq.mvl) < R;
+                tag = (unsigned)t << qsh;
+                full = moving || n_emit >= 4 || n_emit >= R;
+                if (full) cnt = nqd;
+                else {
+                    int prev = -1;
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        if (e < n_emit) {
+                            int r = tq.head + 1 + e; if (r >= R) r -= R;
+                            const int qd = r >> 2;
+                            if (qd != prev) { if (cnt == 0) q0 = qd; else if (cnt == 1) q1 = qd; else q2 = qd; ++cnt; }
+                            prev = qd;
+                        }
+                    }
+                }
+            }
+            const int mine = kl == 0 ? cnt : 0;
+            int inc = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if ((tid & 63) >= o) inc += v; }
+            gl_nlist = __shfl(inc, 63, 64);
+            const int base = __shfl(inc - mine, (tid & 63) & ~(lpt - 1), 64);
+            if (full) {
+                for (int i = kl; i < nqd; i += lpt) ql[base + i] = (unsigned short)(tag | (unsigned)i);
+            } else if (kl == 0) {
+                if (cnt > 0) ql[base] = (unsigned short)(tag | (unsigned)q0);
+                if (cnt > 1) ql[base + 1] = (unsigned short)(tag | (unsigned)q1);
+                if (cnt > 2) ql[base + 2] = (unsigned short)(tag | (unsigned)q2);
+            }
+        } else {
+        if (tid == 0) *nq = 0;
+        lds_barrier<NT>();
         if (t < ((WG_ABLATE & 1) ? 0 : N)) {
             const TurbLds& tq = T[t];
             const int R = tq.rlen, nqd = R >> 2;
@@ -690,9 +847,66 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 }
             }
         }
+        }
         lds_barrier<NT>();
         WG_STAMP(10);
-        const int nlist = *nq;
+        if (GL) {
+            // deficit phase, part 2: the gathers issued before the records have landed (or do so now)
+            for (int t = tid; t < N; t += NT) { T[t].u = ws_f; T[t].v = 0.f; T[t].w = 0.f; }
+            // (the wait is the s_waitcnt BUILTIN, not inline asm: the compiler's wait-count bookkeeping sees it and stops
+            // treating the LDS-DMA requests as pending — otherwise every later wait for an ordinary load degrades to
+            // vmcnt(0), which drains the advection pass's stores once per 64 quads, and every LDS atomic gets one too.  It
+            // does NOT order plain LDS reads of the landing zone behind the requests by itself; the empty asm keeps the
+            // reads below the wait)
+            const int l = tid & 63;
+            wg_wait_vmem();
+            float g_py0 = gat[0 * 64 + l], g_u0 = gat[1 * 64 + l], g_py1 = gat[4 * 64 + l], g_u1 = gat[5 * 64 + l];
+            unsigned g_a0 = __float_as_uint(gat[2 * 64 + l]), g_b0 = __float_as_uint(gat[3 * 64 + l]);
+            unsigned g_a1 = __float_as_uint(gat[6 * 64 + l]), g_b1 = __float_as_uint(gat[7 * 64 + l]);
+            for (int c0 = 0; c0 < gl_nc; c0 += NT) {
+                const int c = c0 + tid;
+                if (c0 > 0) {      // (more than 64 candidates: not the common case) the next batch lands in the same words
+                    lds_barrier<NT>();
+                    gl_issue(c, gl_nc);
+                    wg_wait_vmem();
+                    g_py0 = gat[0 * 64 + l]; g_u0 = gat[1 * 64 + l]; g_py1 = gat[4 * 64 + l]; g_u1 = gat[5 * 64 + l];
+                    g_a0 = __float_as_uint(gat[2 * 64 + l]); g_b0 = __float_as_uint(gat[3 * 64 + l]);
+                    g_a1 = __float_as_uint(gat[6 * 64 + l]); g_b1 = __float_as_uint(gat[7 * 64 + l]);
+                }
+                int i, tl, s2, j; double dx; float wgt;
+                if (c < gl_nc && gl_bracket(c, i, tl, s2, dx, j, wgt)) {
+                    const TurbLds& src = T[s2];
+                    const int jp0 = j - n_emit, jp1 = jp0 + 1;
+                    float py0 = g_py0, u0 = g_u0, py1 = g_py1, u1 = g_u1;
+                    unsigned a0 = g_a0, b0_ = g_b0, a1 = g_a1, b1_ = g_b1;
+                    // released in this step: the turbine's record, at the turbine
+                    if (jp0 < 0) { py0 = (float)src.yr; u0 = src.rue; a0 = pack_a(src.rct, src.rk); b0_ = pack_b(src.reps, src.rhv); }
+                    if (jp1 < 0) { py1 = (float)src.yr; u1 = src.rue; a1 = pack_a(src.rct, src.rk); b1_ = pack_b(src.reps, src.rhv); }
+                    if (jp0 >= 0 && jp0 < n_valid) py0 = m0_advect(py0, a0, b0_, jp0, s_off_f, p.dpart_f, p.inv_D, p.dt);
+                    if (jp1 >= 0 && jp1 < n_valid) py1 = m0_advect(py1, a1, b1_, jp1, s_off_f, p.dpart_f, p.inv_D, p.dt);
+                    eval_pair(i, tl, s2, tl, dx, wgt, py0, py1, 0.f, 0.f, a0, a1, b0_, b1_, u0, u1);
+                }
+            }
+            lds_barrier<NT>();
+            // thread t: superposition in ascending source order
+            for (int tl = tid; tl < N; tl += NT) {
+                float dsum = 0.f, tia_max = 0.f;
+                for (int wd = 0; wd * 32 < N; ++wd) {
+                    unsigned m = tmask[tl * WG_MASK_WORDS + wd];
+                    while (m) {
+                        const int s2 = wd * 32 + __builtin_ctz(m);
+                        m &= m - 1;
+                        dsum += def[tl * N + s2];
+                        tia_max = fmaxf(tia_max, tiav[tl * N + s2]);
+                    }
+                }
+                T[tl].u -= dsum;
+                T[tl].ti = __builtin_amdgcn_sqrtf(ti_f * ti_f + tia_max * tia_max);
+            }
+            lds_barrier<NT>();
+            WG_STAMP(9);
+        }
+        const int nlist = GL ? gl_nlist : *nq;
         for (int c = tid; c < nlist; c += NT) {
             const unsigned ent = ql[c];
             const int t = (int)(ent >> qsh), kq = (int)(ent & ((1u << qsh) - 1u));
@@ -1464,6 +1678,10 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
 
     const float ti_pow = fast_pow(ti_f, p.tic);
 
+    // (every prologue load has been consumed by now: a wait the compiler's bookkeeping sees costs nothing here and keeps it
+    // from ordering later register writes behind "possibly pending" prologue loads — in the GL variant such a wait
+    // would sit between the LDS-DMA gathers and their use and drain them)
+    if (RES && TURB == WG_TURB_NONE && NT == WG_WAVE) wg_wait_vmem();
     // WindFarmEnv._adjust_yaws (Wind_Farm_Env.py:822-864), float32 like numpy evaluates it on a float32 action
     if (live_step && farm == 0) {
         for (int t = tid; t < N; t += NT) {
