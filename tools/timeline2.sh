@@ -10,7 +10,7 @@ raw = np.fromfile('gpurun_out/timeline.bin', dtype=np.int64).reshape(-1, 12)
 ok = (raw[:, 8] > raw[:, 0]) & (raw[:, 0] > 0) & (raw[:, 9] > raw[:, 2]) & (raw[:, 11] > raw[:, 1])
 a = raw[ok]
 print('blocks with one full step:', len(a), 'of', len(raw))
-seq = [(0, 1, 'prologue: kernarg + state loads + LDS set-up'), (1, 5, 'candidate pass'), (5, 11, 'brackets + LDS-DMA gathers issued'), (11, 2, 'records'),
+seq = [(0, 1, 'prologue: kernarg + state loads + LDS set-up'), (1, 4, 'step set-up (controller, clocks, parameters)'), (4, 5, 'candidate pass'), (5, 11, 'brackets + LDS-DMA gathers issued'), (11, 2, 'records'),
        (2, 10, 'quad list'), (10, 9, 'deficits from the landed gathers + sums'),
        (9, 3, 'advection pass (loads, compute, stores issued)'), (3, 6, 'clock update'), (6, 7, 'tail (power, measurement, ring push)'),
        (7, 8, 'epilogue (state stores, accounting)')]

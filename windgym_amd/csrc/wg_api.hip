@@ -417,8 +417,9 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
                 // single-wave steady variant: the deficit phase's gathers are LDS-DMA requests issued before the record /
                 // quad-list phases, so the candidate list and the quad list are alive together (no aliasing) and the
                 // gathers need a landing zone
-                f.lds_off_ql = 0; f.lds_off_gat = 0;
-                if (f.block == 64 && p.turb_mode == WG_TURB_NONE) {
+                f.lds_off_ql = 0; f.lds_off_gat = 0; f.gl = 0;
+                if ((WG_GLDS != 0) && (WG_PAIR_FIRST != 0) && f.block == 64 && p.turb_mode == WG_TURB_NONE) {
+                    f.gl = 1;
                     off = ((size_t)10 * tc * p.N + 16 + 15) & ~(size_t)15;
                     f.lds_off_ql = (int)off; off += ql;
                     f.lds_off_gat = (int)off; off += WG_GAT_BYTES;
@@ -426,8 +427,8 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             }
             f.lds_off_turb = (int)off; off += (size_t)WG_TURB_LDS_BYTES * p.N;
             off = (off + 15) & ~(size_t)15;
-            f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S) + sizeof(unsigned) * WG_MASK_WORDS * (size_t)tc + (f.res ? 0 : sizeof(float) * (size_t)tc * p.N);
-            off += sizeof(int) * ((size_t)p.N + 4);      // chain-pruning ages + the particle counter + the candidate counter + the quad counter (+ pad)
+            f.lds_off_tab = (int)off; off += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S) + (f.gl ? 0 : sizeof(unsigned) * WG_MASK_WORDS * (size_t)tc) + (f.res ? 0 : sizeof(float) * (size_t)tc * p.N);
+            off += sizeof(int) * (4 * (size_t)p.N + 4);      // chain-pruning ages + the particle counter + the candidate counter + the quad counter (+ pad) + the yaws before the action + float positions
             if (h->added && f.res) off += sizeof(float) * 3 * ((size_t)p.N << f.S_shift) + sizeof(int) * (size_t)tc;   // gadd: isotropic field at the rotor points + per-target flags
             return (off + 15) & ~(size_t)15;
         };

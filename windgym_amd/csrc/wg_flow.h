@@ -15,6 +15,13 @@
 #define WG_FLOW_WAVES 5   // min waves/SIMD the register allocator must leave room for (5 -> <= 96 VGPRs; measured best)
 #endif
 
+#ifndef WG_GLDS
+#define WG_GLDS 1         // single-wave steady compact variant: deficit-phase gathers as early LDS-DMA requests (0 = register gathers, for A/B builds)
+#endif
+#ifndef WG_PAIR_FIRST
+#define WG_PAIR_FIRST 1   // steady compact variant: deficit phase BEFORE the advection pass (0 = round-2 order, for A/B builds)
+#endif
+
 struct FlowP {
     int B, N, F, K, P, S, S_pad, S_shift, NP, n_tab;
     int autoreset, action_method, base_controller, power_avg, script_rows, noise;
@@ -23,6 +30,7 @@ struct FlowP {
     int pstride;                  // floats between the particle blocks of consecutive farm slots (>= NP, see wg_create)
     int target_chunk;             // targets whose pair parameters are staged in LDS at once
     int lds_off_turb, lds_off_tab, lds_bytes;
+    int gl;                       // the launch runs the GL variant of k_flow (LDS-DMA gathers; no per-target source masks in LDS)
     int lds_off_ql, lds_off_gat;  // single-wave steady compact variant: quad list of its own (0 = aliases the pair staging) and the
                                   // landing zone of the deficit phase's LDS-DMA gathers (WG_GAT_BYTES)
     int ql_shift;                 // compact steady advection: quad-list entry = turbine << ql_shift | quad index in its ring (16 bits)
@@ -82,8 +90,7 @@ struct FlowPtrs {
 
 // sizeof(TurbLds) in wg_flow.hip; kept here so the host can size the dynamic LDS
 #define WG_TURB_LDS_BYTES 120
-// landing zone of the LDS-DMA gathers: 8 words (py, rec_a, rec_b, u_e of the two bracketing particles) x 64 candidates, + the
-// quad-list counter
-#define WG_GAT_BYTES (8 * 64 * 4 + 16)
+// landing zone of the LDS-DMA gathers: 8 words (py, rec_a, rec_b, u_e of the two bracketing particles) x 64 candidates
+#define WG_GAT_BYTES (8 * 64 * 4)
 // per-target bit mask of contributing sources: 32-bit words per target (N <= 32 * WG_MASK_WORDS)
 #define WG_MASK_WORDS 4

@@ -85,13 +85,6 @@ __device__ __forceinline__ float m0_advect(float py, unsigned ra, unsigned rb, i
     return __builtin_fmaf(rec_hv(rb) * m0_cfrac(rec_ct(ra), sp), dt, py);
 }
 
-#ifndef WG_GLDS
-#define WG_GLDS 1         // single-wave steady compact variant: deficit-phase gathers as early LDS-DMA requests (0 = register gathers, for A/B builds)
-#endif
-#ifndef WG_PAIR_FIRST
-#define WG_PAIR_FIRST 1   // steady compact variant: deficit phase BEFORE the advection pass (0 = round-2 order, for A/B builds)
-#endif
-
 // x^y for x >= 0 via v_log_f32 / v_exp_f32 (HIP's __powf expands to the full-precision routine)
 __device__ __forceinline__ float fast_pow(float x, float y) {
     return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
@@ -312,6 +305,9 @@ __device__ __forceinline__ void wg_wait_vmem() {
 #define WG_LDS(p) __builtin_nontemporal_load(p)
 #define WG_STS(p, v) __builtin_nontemporal_store((v), (p))
 #endif
+#ifndef WG_NT_PY
+#define WG_NT_PY 0
+#endif
 #ifndef WG_ABLATE
 #define WG_ABLATE 0   // profiling only: 1 = no advection pass, 2 = no deficit phases
 #endif
@@ -356,7 +352,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     // the isotropic field at every rotor point, addv[3][TC * N] = a candidate pair's rotor-summed contribution
     const bool ADDED = TURB != WG_TURB_NONE && p.added != 0;
     float* addv = tiav + TC * N;
-    float* gadd = reinterpret_cast<float*>(jnl + N + 4);
+    float* gadd = reinterpret_cast<float*>(jnl + 4 * N + 4);
 
     // ---- single-wave steady compact variant (GL): the deficit phase's memory round trip is taken off the workgroup's
     // latency chain.  Candidate pairs and the ring slots that bracket them depend on the layout, the chain clocks and the
@@ -372,6 +368,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     typedef const __attribute__((address_space(1))) void* GPtr;
     typedef __attribute__((address_space(3))) void* LPtr;
     int gl_nc = 0;
+    unsigned gl_mask = 0u;        // thread t < N: candidate sources of target t
     // bracket of candidate c (list entry cl[c]): target, source, distance, age j of the older... of the two particles AFTER the
     // step, interpolation weight; false if the chain has not reached the target yet
     auto gl_bracket = [&](const int c, int& i, int& tl, int& s2, double& dx, int& j, float& wgt) __attribute__((always_inline)) -> bool {
@@ -384,64 +381,99 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         wgt = (float)(xi - jf);
         j = (int)jf;
         if (j < 0) { j = 0; wgt = 0.f; }
-        return j + 1 <= new_valid - 1;
+        return dx > 0.0 && j + 1 <= new_valid - 1;
+    };
+    // no particle in the chain's ring was released by a yawed turbine (pre-records state: this step's release is not in the
+    // ring yet): every one of them still sits at the turbine's lateral position
+    auto gl_resting = [&](const TurbLds& src) __attribute__((always_inline)) -> bool {
+        return !(src.mvl != 0u && (int)(sr.n_emitted - src.mvl) < src.rlen);
     };
     // LDS-DMA gathers of candidate c: word k of lane l lands at gat[k * 64 + l]; k = 0..7: py, u_e, rec_a, rec_b of the
     // particle of pre-step age jp0 = j - n_emit, then of jp0 + 1.  Lanes without a candidate / particles released in this
     // step (negative pre-step age: the turbine's record, not in memory yet) request a valid dummy address.
-    auto gl_issue = [&](const int c, const int nc) __attribute__((always_inline)) {
+    auto gl_issue = [&](const int c, const int nc) __attribute__((always_inline)) -> bool {
         int i, tl, s2, j; double dx; float wgt;
         int i0 = 0, i1 = 0;
+        bool rest = false;
         if (c < nc && gl_bracket(c, i, tl, s2, dx, j, wgt)) {
             const TurbLds& src = T[s2];
             const int Rs = src.rlen;
+            rest = gl_resting(src);
             const int jp0 = j - n_emit, jp1 = jp0 + 1;
             int r0 = src.head - jp0; if (r0 < 0) r0 += Rs;
             int r1 = src.head - jp1; if (r1 < 0) r1 += Rs;
             if (jp0 >= 0) i0 = src.roff + r0;
             if (jp1 >= 0) i1 = src.roff + r1;
         }
-        __builtin_amdgcn_global_load_lds((GPtr)(pl.py + i0), (LPtr)(gat + 0 * 64), 4, 0, 0);
+        // (a resting chain's particles sit where they were released — at the turbine: their py is not fetched; the request
+        // points into the rec_a line the lane fetches anyway and the consumer substitutes y_t)
+        __builtin_amdgcn_global_load_lds((GPtr)(rest ? (const float*)(pl.ra + i0) : pl.py + i0), (LPtr)(gat + 0 * 64), 4, 0, 0);
         __builtin_amdgcn_global_load_lds((GPtr)(pl.ue + i0), (LPtr)(gat + 1 * 64), 4, 0, 0);
         __builtin_amdgcn_global_load_lds((GPtr)(pl.ra + i0), (LPtr)(gat + 2 * 64), 4, 0, 0);
         __builtin_amdgcn_global_load_lds((GPtr)(pl.rb + i0), (LPtr)(gat + 3 * 64), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((GPtr)(pl.py + i1), (LPtr)(gat + 4 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(rest ? (const float*)(pl.ra + i1) : pl.py + i1), (LPtr)(gat + 4 * 64), 4, 0, 0);
         __builtin_amdgcn_global_load_lds((GPtr)(pl.ue + i1), (LPtr)(gat + 5 * 64), 4, 0, 0);
         __builtin_amdgcn_global_load_lds((GPtr)(pl.ra + i1), (LPtr)(gat + 6 * 64), 4, 0, 0);
         __builtin_amdgcn_global_load_lds((GPtr)(pl.rb + i1), (LPtr)(gat + 7 * 64), 4, 0, 0);
+        return rest;
     };
+    bool gl_rest = false;
     if (GL) {
-        // (a further flow step of the same launch gathers what the previous step's advection pass stored)
-        if (!first_step) full_barrier<NT>();
+        // (a further flow step of the same launch gathers what the previous step's advection pass stored: the caller's loop
+        // waits for the stores on its back edge)
         const float move_max = fabsf(p.hill) * ws_f * p.dt;
         // a target closer than this is bracketed by a particle released in this step
-        const double near = sr.s_off + ws * p.dt_d + p.dpart;
+        const float near_f = (float)(sr.s_off + ws * p.dt_d + p.dpart) + 0.01f;
+        const float* xf = reinterpret_cast<const float*>(jnl + 2 * N + 4);
+        const float* yf = xf + N;
+        WG_STAMP(4);
         const int npairs = N * N;
-        for (int i0 = 0; i0 < ((WG_ABLATE & 2) ? 0 : npairs); i0 += NT) {
-            const int i = i0 + tid;
-            bool cand = false;
-            if (i < npairs) {
-                const int tg = (int)(((float)i + 0.5f) * p.inv_N);
-                const int s2 = i - tg * N;
-                const double dx = T[tg].xr - T[s2].xr;
-                cand = (s2 != tg) && (dx > 0.0);
-                if (cand && !(dx < near)) {
-                    const TurbLds& src = T[s2];
-                    const float sig_max = (src.bk * ((float)dx * p.inv_D) + src.be) * p.D;
-                    const float bd = src.bd + (src.mvl != 0u ? move_max : 0.f);
-                    const float gap = fabsf((float)(T[tg].yr - src.yr)) - (p.R_rot + 5.0f * sig_max + bd);
-                    cand = gap <= 1.0e-3f * p.D;
+        const unsigned maskN = N >= 32 ? 0xffffffffu : (1u << N) - 1u;
+        // four pairs per lane and trip: their tests are independent, so the LDS round trips of the four overlap (one pair
+        // per trip was a chain of 3 dependent LDS reads per 64 pairs: 4.9 k cycles for cfg2's 256 pairs)
+        for (int i0 = 0; i0 < ((WG_ABLATE & 2) ? 0 : npairs); i0 += 4 * NT) {
+            bool cand[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * NT + tid;
+                cand[u] = false;
+                if (i < npairs) {
+                    const int tg = (int)(((float)i + 0.5f) * p.inv_N);
+                    const int s2 = i - tg * N;
+                    // (float copies of the positions: their rounding, ~1e-3 m, is far inside the test's margin; the exact
+                    // sign of dx is checked in double where the bracket is computed)
+                    const float dxf = xf[tg] - xf[s2];
+                    bool cd = (s2 != tg) && (dxf >= 0.f);
+                    if (cd && !(dxf < near_f)) {
+                        const TurbLds& src = T[s2];
+                        const float sig_max = (src.bk * (dxf * p.inv_D) + src.be) * p.D;
+                        const float bd = src.bd + (src.mvl != 0u ? move_max : 0.f);
+                        const float gap = fabsf(yf[tg] - yf[s2]) - (p.R_rot + 5.0f * sig_max + bd);
+                        cd = gap <= 1.0e-3f * p.D;
+                    }
+                    cand[u] = cd;
                 }
             }
-            // (single wave: the list position is a running count in a register — and an LDS atomic would be ordered behind
-            // every outstanding memory operation by the compiler once LDS-DMA requests exist in the kernel)
-            const unsigned long long bal = __ballot(cand);
-            if (cand) cl[gl_nc + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)i;
-            gl_nc += __popcll(bal);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ib = i0 + u * NT, i = ib + tid;
+                // (single wave: the list position is a running count in a register — and an LDS atomic would be ordered behind
+                // every outstanding memory operation by the compiler once LDS-DMA requests exist in the kernel)
+                const unsigned long long bal = __ballot(cand[u]);
+                if (cand[u]) {
+                    cl[gl_nc + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)i;
+                    def[i] = 0.f; tiav[i] = 0.f;      // a candidate the exact evaluation drops contributes zero
+                }
+                gl_nc += __popcll(bal);
+                // thread t keeps the candidate sources of target t: its N bits of the ballots, no LDS masks
+                const int lo = tid * N - ib;
+                if (tid < N && lo < 64 && lo + N > 0)
+                    gl_mask |= (unsigned)(lo >= 0 ? (bal >> lo) : (bal << -lo)) & maskN;
+            }
         }
         lds_barrier<NT>();
         WG_STAMP(5);
-        if (gl_nc > 0) gl_issue(tid, gl_nc);
+        if (gl_nc > 0) gl_rest = gl_issue(tid, gl_nc);
         WG_STAMP(11);
     }
 
@@ -474,7 +506,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             if (n_emit > 0 && rec_moves(pack_b(q.reps, q.rhv))) q.mvl = sr.n_emitted + (unsigned)n_emit;
         }
     }
-    for (int i = tid; i < TC * WG_MASK_WORDS; i += NT) tmask[i] = 0u;
+    if (!GL) for (int i = tid; i < TC * WG_MASK_WORDS; i += NT) tmask[i] = 0u;
     lds_barrier<NT>();
     WG_STAMP(2);
 
@@ -556,7 +588,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 }
             }
             def[i] = acc * p.inv_S;
-            atomicOr(&tmask[tl * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
+            if (!GL) atomicOr(&tmask[tl * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
     };
     // (3)+(4) rotor-averaged inflow of the compact variants, as a closure: the steady variant runs it BEFORE the advection
     // pass (PRE), the turbulent ones after it.
@@ -867,7 +899,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 const int c = c0 + tid;
                 if (c0 > 0) {      // (more than 64 candidates: not the common case) the next batch lands in the same words
                     lds_barrier<NT>();
-                    gl_issue(c, gl_nc);
+                    gl_rest = gl_issue(c, gl_nc);
                     wg_wait_vmem();
                     g_py0 = gat[0 * 64 + l]; g_u0 = gat[1 * 64 + l]; g_py1 = gat[4 * 64 + l]; g_u1 = gat[5 * 64 + l];
                     g_a0 = __float_as_uint(gat[2 * 64 + l]); g_b0 = __float_as_uint(gat[3 * 64 + l]);
@@ -878,6 +910,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     const TurbLds& src = T[s2];
                     const int jp0 = j - n_emit, jp1 = jp0 + 1;
                     float py0 = g_py0, u0 = g_u0, py1 = g_py1, u1 = g_u1;
+                    if (gl_rest) { py0 = (float)src.yr; py1 = py0; }      // (not fetched: see gl_issue)
                     unsigned a0 = g_a0, b0_ = g_b0, a1 = g_a1, b1_ = g_b1;
                     // released in this step: the turbine's record, at the turbine
                     if (jp0 < 0) { py0 = (float)src.yr; u0 = src.rue; a0 = pack_a(src.rct, src.rk); b0_ = pack_b(src.reps, src.rhv); }
@@ -888,20 +921,18 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 }
             }
             lds_barrier<NT>();
-            // thread t: superposition in ascending source order
-            for (int tl = tid; tl < N; tl += NT) {
+            // thread t: superposition in ascending source order over its candidate mask
+            if (tid < N) {
                 float dsum = 0.f, tia_max = 0.f;
-                for (int wd = 0; wd * 32 < N; ++wd) {
-                    unsigned m = tmask[tl * WG_MASK_WORDS + wd];
-                    while (m) {
-                        const int s2 = wd * 32 + __builtin_ctz(m);
-                        m &= m - 1;
-                        dsum += def[tl * N + s2];
-                        tia_max = fmaxf(tia_max, tiav[tl * N + s2]);
-                    }
+                unsigned m = gl_mask;
+                while (m) {
+                    const int s2 = __builtin_ctz(m);
+                    m &= m - 1;
+                    dsum += def[tid * N + s2];
+                    tia_max = fmaxf(tia_max, tiav[tid * N + s2]);
                 }
-                T[tl].u -= dsum;
-                T[tl].ti = __builtin_amdgcn_sqrtf(ti_f * ti_f + tia_max * tia_max);
+                T[tid].u -= dsum;
+                T[tid].ti = __builtin_amdgcn_sqrtf(ti_f * ti_f + tia_max * tia_max);
             }
             lds_barrier<NT>();
             WG_STAMP(9);
@@ -942,7 +973,16 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 reinterpret_cast<uint4*>(pl.ra)[q] = make_uint4(rav[0], rav[1], rav[2], rav[3]);
                 reinterpret_cast<uint4*>(pl.rb)[q] = make_uint4(rbv[0], rbv[1], rbv[2], rbv[3]);
             }
+#if WG_NT_PY
+            {   // (streamed once per launch and not read again before the next launch: non-temporal, so that the lines do not
+                // sit dirty in L2 until the end-of-kernel write-back)
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                f4v pv = {pyv[0], pyv[1], pyv[2], pyv[3]};
+                __builtin_nontemporal_store(pv, reinterpret_cast<f4v*>(pl.py) + q);
+            }
+#else
             reinterpret_cast<float4*>(pl.py)[q] = make_float4(pyv[0], pyv[1], pyv[2], pyv[3]);
+#endif
             // (excursion bound over the VALID particles of the quad only: a slot that holds no particle yet keeps whatever
             // an earlier episode left there, and one such value would loosen the chain's bound for the whole episode)
             float ex = 0.f;
@@ -1248,8 +1288,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     sr.head = new_head; sr.n_valid = new_valid; sr.s_off = s_new; sr.time += p.dt_d; sr.istep += 1u;
     sr.n_emitted += (unsigned)n_emit;
     WG_STAMP(3);
-    full_barrier<NT>();
-    WG_STAMP(4);   // this workgroup's particle stores are visible to its own gathers below
+    if (!GL) { full_barrier<NT>(); WG_STAMP(4); }      // (GL: the caller's loop waits on its back edge only — a single live step ends without it)   // this workgroup's particle stores are visible to its own gathers below
 
     // (3)+(4) rotor-averaged inflow
     if (RES) {
@@ -1525,6 +1564,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     const uint8_t masked_out = use_mask ? (uint8_t)(mask_byte == 0) : (uint8_t)0;
     const int t_own = tid < N ? tid : 0;
     int dev_rem, fill_rem, cursor, n_pushed, pend_farm_n, pend_base_n;
+    unsigned part0, flow0;       // accounting counters: read with the headers, so that the epilogue only stores
     SlotRegs sr;
     double ws;
     float ti_f, wd_env;
@@ -1538,6 +1578,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         dev_rem = slot.dev_remaining; fill_rem = slot.fill_remaining;
         sr = SlotRegs{slot.s_off, slot.time, slot.head, slot.n_valid, slot.istep, slot.n_emitted};
         cursor = slot.cursor;
+        part0 = slot.part_count; flow0 = slot.flow_count;
         ws = cx.ws;
         ti_f = (float)cx.ti;
         wd_env = (float)cx.wd;
@@ -1629,8 +1670,11 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     float* rdy = tabct + p.n_tab;
     float* rdz = rdy + p.S;
     unsigned* tmask = reinterpret_cast<unsigned*>(rdz + p.S);
-    float* tiap = reinterpret_cast<float*>(tmask + p.target_chunk * WG_MASK_WORDS);
+    float* tiap = reinterpret_cast<float*>(tmask + (p.gl ? 0 : p.target_chunk * WG_MASK_WORDS));
     int* jnl = reinterpret_cast<int*>(tiap + (RES ? 0 : p.target_chunk * N));   // [N] chain pruning ages (tiap: sample-major phases only)
+    float* xyf = reinterpret_cast<float*>(jnl + 2 * N + 4);   // [2][N] float copies of the rotated positions (GL candidate pass)
+    float* oyaw = reinterpret_cast<float*>(jnl + N + 4);      // [N] yaw before this step's action (a separate array: TurbLds at 120 bytes
+                                                             // keeps its fields of consecutive turbines in different LDS banks; 128 does not)
     PartLds pl;
     if (RES) {
         pl.py = d.py + pbase; pl.ra = d.rec_a + pbase; pl.rb = d.rec_b + pbase;
@@ -1644,6 +1688,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     for (int t = tid; t < N; t += NT) {
         TurbLds& q = T[t];
         if (t == tid && tid < N) {
+            xyf[t] = (float)l_xr; xyf[N + t] = (float)l_yr;
             q.xr = l_xr; q.yr = l_yr; q.yaw = l_yaw; q.u = l_u; q.v = l_v; q.w = l_w; q.ti = l_ti; q.pow = l_pow; q.ct = l_ct;
             q.bd = l_bnd.x; q.bk = l_bnd.y; q.be = l_bnd.z; q.mvl = __float_as_uint(l_bnd.w);
             if (!RES) jnl[t] = l_jn;
@@ -1686,7 +1731,8 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     if (live_step && farm == 0) {
         for (int t = tid; t < N; t += NT) {
             float yaw = t < NT ? l_yaw : d.yaw[tb + t];
-            d.old_yaw[(size_t)e * N + t] = yaw;          // :932
+            oyaw[t] = yaw;            // :932 (written to d.old_yaw in the epilogue: a store here is the oldest outstanding memory
+                                      // operation when the step's first phases run, and the compiler's waits order behind it)
             const float a = t < NT ? l_act : actions[(size_t)e * N + t];
             if (p.action_method == WG_ACT_YAW) {
                 yaw = fminf(fmaxf(yaw + a * p.yaw_step, p.yaw_min), p.yaw_max);
@@ -1711,7 +1757,12 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     int sub = 0, n_flow = 0, part_acc = 0;
     float base_acc = 0.f;
     const float inv_k = 1.0f / (float)p.K;
-    for (;;) {
+    // (GL variant: a further flow step of the launch gathers what this step's advection pass stored — the wait sits on the
+    // loop's back edge, where the compiler's wait-count pass sees it on every path around the loop; a live step with K = 1
+    // leaves the loop without it)
+    constexpr bool GLK = RES && TURB == WG_TURB_NONE && NT == WG_WAVE && (WG_GLDS != 0) && (WG_PAIR_FIRST != 0);
+    auto back_edge = [&]() __attribute__((always_inline)) { if (GLK) full_barrier<NT>(); };
+    for (;; back_edge()) {
         if (!live_step && sub == 0 && (budget <= 0 || (dev_rem == 0 && fill_rem == 0))) break;
         const bool is_dev = !live_step && dev_rem > 0;
         if (live_step && farm == 1) {
@@ -1830,6 +1881,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         ke->d.yaw[tb + t] = q.yaw; ke->d.u[tb + t] = q.u; ke->d.v[tb + t] = q.v; ke->d.w[tb + t] = q.w;
         ke->d.ti_loc[tb + t] = q.ti; ke->d.power[tb + t] = q.pow; ke->d.ct[tb + t] = q.ct;
         reinterpret_cast<float4*>(ke->d.bnd)[tb + t] = make_float4(q.bd, q.bk, q.be, __uint_as_float(q.mvl));
+        if (live_step && farm == 0) ke->d.old_yaw[(size_t)e * N + t] = oyaw[t];
     }
     if (NT > WG_WAVE) {          // (multi-wave workgroups: per-wave partial sums meet in the LDS word)
         part_acc = wg_wave_sum_i(part_acc);
@@ -1842,14 +1894,14 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     if (tid == 0) {
         WgSlot& slot = ke->d.slot[slot_id];
         WgCtx& cx = ke->d.ctx[ctx_id];
-        slot.part_count += (unsigned)part_acc;
+        slot.part_count = part0 + (unsigned)part_acc;
         slot.head = sr.head; slot.n_valid = sr.n_valid; slot.s_off = sr.s_off; slot.time = sr.time;
         slot.istep = sr.istep; slot.n_emitted = sr.n_emitted;
         slot.cursor = cursor;
         slot.dev_remaining = dev_rem; slot.fill_remaining = fill_rem;
         if (farm == 0) { cx.n_pushed = n_pushed; cx.pend_farm_n = pend_farm_n; }
         else cx.pend_base_n = pend_base_n;
-        slot.flow_count += (unsigned)n_flow;   // NOT a global atomic: one hot word serialises the whole grid
+        slot.flow_count = flow0 + (unsigned)n_flow;   // NOT a global atomic: one hot word serialises the whole grid
 #ifdef WG_TIMELINE
         if (d.dbg && n_flow == 1) {
             wg_stamps[8] = clock64();
