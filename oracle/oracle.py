@@ -28,10 +28,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
-        if not os.path.exists(so):
-            build()
-        _LIB = C.CDLL(so)
+        _LIB = C.CDLL(build())      # (rebuilds when a source or include/windgym_hip.h — the ABI version — is newer than the library)
     return _LIB
 
 

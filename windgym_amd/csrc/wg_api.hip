@@ -279,7 +279,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     pstride *= 64;
     if (const char* ev = getenv("WG_PSTRIDE_PAD")) pstride = (size_t)p.NP + (size_t)atoi(ev);
     h->fp.pstride = (int)pstride;
-    A(py, n_slots * pstride, true); A(rec_a, n_slots * pstride, true); A(rec_b, n_slots * pstride, true);
+    A(py, n_slots * pstride, true);     // (rec_a / rec_b: allocated with the kernel variant below — one interleaved array for GL handles)
 
     if (p.turb_mode != WG_TURB_NONE) {
         A(pz, n_slots * pstride, true); A(vlp, n_slots * pstride, true); A(wlp, n_slots * pstride, true);
@@ -476,6 +476,15 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             duo_fits = f.duo_lds <= lds_limit;
         }
         if (!duo_fits) f.duo = 0;
+        // packed emission record: two arrays, or one interleaved (ct|k, eps|hv) array for the GL variant
+        f.rec_il = (f.gl && !f.duo) ? 1 : 0;
+        if (f.rec_il) {
+            if (!rc) rc = dev_alloc(h, &d.rec_a, 2 * n_slots * pstride_keep, true);
+            d.rec_b = d.rec_a ? d.rec_a + 1 : nullptr;
+        } else {
+            if (!rc) rc = dev_alloc(h, &d.rec_a, n_slots * pstride_keep, true);
+            if (!rc) rc = dev_alloc(h, &d.rec_b, n_slots * pstride_keep, true);
+        }
         // frozen-record layout for the deficit gathers of the large-farm variant: 16-byte AoS copy (rec4)
         if (!f.res || !small) { if (!rc) rc = dev_alloc(h, &d.rec4, n_slots * pstride_keep, true); }
         else { if (!rc) rc = dev_alloc(h, &d.u_e, n_slots * pstride_keep, true); }

@@ -18,6 +18,9 @@
 #ifndef WG_GLDS
 #define WG_GLDS 1         // single-wave steady compact variant: deficit-phase gathers as early LDS-DMA requests (0 = register gathers, for A/B builds)
 #endif
+#ifndef WG_ADV_PIPE
+#define WG_ADV_PIPE 0      // GL variant: software-pipelined advection pass (first quad requested before the deficit phase)
+#endif
 #ifndef WG_PAIR_FIRST
 #define WG_PAIR_FIRST 1   // steady compact variant: deficit phase BEFORE the advection pass (0 = round-2 order, for A/B builds)
 #endif
@@ -30,6 +33,8 @@ struct FlowP {
     int pstride;                  // floats between the particle blocks of consecutive farm slots (>= NP, see wg_create)
     int target_chunk;             // targets whose pair parameters are staged in LDS at once
     int lds_off_turb, lds_off_tab, lds_bytes;
+    int rec_il;                   // the packed emission record is ONE interleaved array (rec_a[2 i] = ct|k, rec_a[2 i + 1] = eps|hv; rec_b = rec_a + 1):
+                                  // GL handles — a pair's gathers touch one record line instead of two, an emission writes one sector
     int gl;                       // the launch runs the GL variant of k_flow (LDS-DMA gathers; no per-target source masks in LDS)
     int lds_off_ql, lds_off_gat;  // single-wave steady compact variant: quad list of its own (0 = aliases the pair staging) and the
                                   // landing zone of the deficit phase's LDS-DMA gathers (WG_GAT_BYTES)

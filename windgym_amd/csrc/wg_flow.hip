@@ -295,6 +295,12 @@ __device__ __forceinline__ void wg_wait_vmem() {
     __builtin_amdgcn_s_waitcnt(0x0F70);
     asm volatile("" ::: "memory");
 }
+// ... all but the three youngest vector-memory requests (vmcnt(3): the counter retires in order)
+__device__ __forceinline__ void wg_wait_vmem_but3() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F73);
+    asm volatile("" ::: "memory");
+}
 
 // streamed particle state of the turbulent pass: touched once per launch -> non-temporal, so that it does not evict
 // the meandering box from L2
@@ -407,14 +413,17 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         }
         // (a resting chain's particles sit where they were released — at the turbine: their py is not fetched; the request
         // points into the rec_a line the lane fetches anyway and the consumer substitutes y_t)
-        __builtin_amdgcn_global_load_lds((GPtr)(rest ? (const float*)(pl.ra + i0) : pl.py + i0), (LPtr)(gat + 0 * 64), 4, 0, 0);
+        // (interleaved record: ct|k and eps|hv of a particle are adjacent words — both requests hit one line)
+        const unsigned* r0p = pl.ra + 2 * i0;
+        const unsigned* r1p = pl.ra + 2 * i1;
+        __builtin_amdgcn_global_load_lds((GPtr)(rest ? (const float*)r0p : pl.py + i0), (LPtr)(gat + 0 * 64), 4, 0, 0);
         __builtin_amdgcn_global_load_lds((GPtr)(pl.ue + i0), (LPtr)(gat + 1 * 64), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((GPtr)(pl.ra + i0), (LPtr)(gat + 2 * 64), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((GPtr)(pl.rb + i0), (LPtr)(gat + 3 * 64), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((GPtr)(rest ? (const float*)(pl.ra + i1) : pl.py + i1), (LPtr)(gat + 4 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(r0p), (LPtr)(gat + 2 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(r0p + 1), (LPtr)(gat + 3 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(rest ? (const float*)r1p : pl.py + i1), (LPtr)(gat + 4 * 64), 4, 0, 0);
         __builtin_amdgcn_global_load_lds((GPtr)(pl.ue + i1), (LPtr)(gat + 5 * 64), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((GPtr)(pl.ra + i1), (LPtr)(gat + 6 * 64), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((GPtr)(pl.rb + i1), (LPtr)(gat + 7 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(r1p), (LPtr)(gat + 6 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(r1p + 1), (LPtr)(gat + 7 * 64), 4, 0, 0);
         return rest;
     };
     bool gl_rest = false;
@@ -882,6 +891,25 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         }
         lds_barrier<NT>();
         WG_STAMP(10);
+        // pipelined advection (GLP): the loads of a lane's first listed quad are requested HERE, before the deficit phase
+        // (its ~5 k cycles of LDS / ALU work hide their round trip), and inside the pass every lane requests its next quad
+        // before it computes the current one.  Costs 12 + 12 registers: this variant is built at 4 waves per SIMD.
+        constexpr bool GLP = GL && (WG_ADV_PIPE != 0);
+        const int nlist_pre = GL ? gl_nlist : 0;
+        float4 n_py = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint4 n_ra = make_uint4(0u, 0u, 0u, 0u), n_rb = n_ra;
+        int n_t = 0, n_kq = 0, n_q = 0;
+        auto adv_request = [&](const int c, const bool valid) __attribute__((always_inline)) {
+            const unsigned ent = valid ? ql[c] : 0u;
+            n_t = (int)(ent >> qsh); n_kq = (int)(ent & ((1u << qsh) - 1u));
+            n_q = valid ? (T[n_t].roff >> 2) + n_kq : 0;
+            n_py = reinterpret_cast<const float4*>(pl.py)[n_q];
+            n_ra = reinterpret_cast<const uint4*>(pl.ra)[GL ? 2 * n_q : n_q];
+            n_rb = GL ? reinterpret_cast<const uint4*>(pl.ra)[2 * n_q + 1] : reinterpret_cast<const uint4*>(pl.rb)[n_q];
+        };
+        // (requested by every lane, a lane without a quad reads quad 0: exactly three more requests are outstanding behind
+        // the gathers, which is what the counted wait below relies on)
+        if (GLP) adv_request(tid, tid < nlist_pre);
         if (GL) {
             // deficit phase, part 2: the gathers issued before the records have landed (or do so now)
             for (int t = tid; t < N; t += NT) { T[t].u = ws_f; T[t].v = 0.f; T[t].w = 0.f; }
@@ -891,7 +919,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             // does NOT order plain LDS reads of the landing zone behind the requests by itself; the empty asm keeps the
             // reads below the wait)
             const int l = tid & 63;
-            wg_wait_vmem();
+            if (GLP) wg_wait_vmem_but3(); else wg_wait_vmem();
             float g_py0 = gat[0 * 64 + l], g_u0 = gat[1 * 64 + l], g_py1 = gat[4 * 64 + l], g_u1 = gat[5 * 64 + l];
             unsigned g_a0 = __float_as_uint(gat[2 * 64 + l]), g_b0 = __float_as_uint(gat[3 * 64 + l]);
             unsigned g_a1 = __float_as_uint(gat[6 * 64 + l]), g_b1 = __float_as_uint(gat[7 * 64 + l]);
@@ -939,21 +967,29 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         }
         const int nlist = GL ? gl_nlist : *nq;
         for (int c = tid; c < nlist; c += NT) {
-            const unsigned ent = ql[c];
-            const int t = (int)(ent >> qsh), kq = (int)(ent & ((1u << qsh) - 1u));
+            int t, kq, q;
+            float4 py; uint4 ra, rb;
+            if (GLP) {
+                t = n_t; kq = n_kq; q = n_q; py = n_py; ra = n_ra; rb = n_rb;
+                if (c + NT < nlist) adv_request(c + NT, true);
+            } else {
+                const unsigned ent = ql[c];
+                t = (int)(ent >> qsh); kq = (int)(ent & ((1u << qsh) - 1u));
+                q = (T[t].roff >> 2) + kq;
+                py = reinterpret_cast<const float4*>(pl.py)[q];
+                ra = reinterpret_cast<const uint4*>(pl.ra)[GL ? 2 * q : q];
+                rb = GL ? reinterpret_cast<const uint4*>(pl.ra)[2 * q + 1] : reinterpret_cast<const uint4*>(pl.rb)[q];
+            }
             TurbLds& tq = T[t];
-            const int q = (tq.roff >> 2) + kq;
-            const float4 py = reinterpret_cast<const float4*>(pl.py)[q];
-            const uint4 ra = reinterpret_cast<const uint4*>(pl.ra)[q];
-            const uint4 rb = reinterpret_cast<const uint4*>(pl.rb)[q];
             const int R = tq.rlen, hd = tq.head;
             const int r0 = 4 * kq;
             int j0 = hd - r0; if (j0 < 0) j0 += R;             // age of ring slot r0 (slot r0+i: j0-i)
             int e0 = r0 - hd - 1; if (e0 < 0) e0 += R;         // emission index of slot r0 (r0+i: e0+i)
             const bool emits = (e0 < n_emit) || (n_emit > 0 && e0 + 3 >= R);   // wraps past R-1 -> 0
             float pyv[4] = {py.x, py.y, py.z, py.w};
-            unsigned rav[4] = {ra.x, ra.y, ra.z, ra.w};
-            unsigned rbv[4] = {rb.x, rb.y, rb.z, rb.w};
+            // (GL: `ra` / `rb` hold the quad's interleaved records (a0 b0 a1 b1) (a2 b2 a3 b3))
+            unsigned rav[4] = {ra.x, GL ? ra.z : ra.y, GL ? rb.x : ra.z, GL ? rb.z : ra.w};
+            unsigned rbv[4] = {GL ? ra.y : rb.x, GL ? ra.w : rb.y, GL ? rb.y : rb.z, rb.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int j = j0 - i; if (j < 0) j += R;
@@ -970,8 +1006,13 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                         else pl.ue[4 * q + i] = tq.rue;
                     }
                 }
-                reinterpret_cast<uint4*>(pl.ra)[q] = make_uint4(rav[0], rav[1], rav[2], rav[3]);
-                reinterpret_cast<uint4*>(pl.rb)[q] = make_uint4(rbv[0], rbv[1], rbv[2], rbv[3]);
+                if (GL) {
+                    reinterpret_cast<uint4*>(pl.ra)[2 * q] = make_uint4(rav[0], rbv[0], rav[1], rbv[1]);
+                    reinterpret_cast<uint4*>(pl.ra)[2 * q + 1] = make_uint4(rav[2], rbv[2], rav[3], rbv[3]);
+                } else {
+                    reinterpret_cast<uint4*>(pl.ra)[q] = make_uint4(rav[0], rav[1], rav[2], rav[3]);
+                    reinterpret_cast<uint4*>(pl.rb)[q] = make_uint4(rbv[0], rbv[1], rbv[2], rbv[3]);
+                }
             }
 #if WG_NT_PY
             {   // (streamed once per launch and not read again before the next launch: non-temporal, so that the lines do not
@@ -1285,6 +1326,10 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             }
         }
     }
+    // (GLP: a wait the compiler's bookkeeping sees, right after the pipelined pass — the last trip's conditional request
+    // otherwise stays "possibly pending" in its view around the flow-step loop and it orders the next step's register
+    // writes behind it with vmcnt(0) waits that drain the LDS-DMA gathers)
+    if (RES && TURB == WG_TURB_NONE && NT == WG_WAVE && (WG_GLDS != 0) && (WG_PAIR_FIRST != 0) && (WG_ADV_PIPE != 0)) wg_wait_vmem();
     sr.head = new_head; sr.n_valid = new_valid; sr.s_off = s_new; sr.time += p.dt_d; sr.istep += 1u;
     sr.n_emitted += (unsigned)n_emit;
     WG_STAMP(3);
@@ -1677,7 +1722,9 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
                                                              // keeps its fields of consecutive turbines in different LDS banks; 128 does not)
     PartLds pl;
     if (RES) {
-        pl.py = d.py + pbase; pl.ra = d.rec_a + pbase; pl.rb = d.rec_b + pbase;
+        pl.py = d.py + pbase;
+        if (p.rec_il) { pl.ra = d.rec_a + 2 * pbase; pl.rb = pl.ra + 1; }      // interleaved record (GL handles)
+        else { pl.ra = d.rec_a + pbase; pl.rb = d.rec_b + pbase; }
         pl.ue = d.u_e ? d.u_e + pbase : nullptr; pl.r4 = d.rec4 ? d.rec4 + pbase : nullptr;
         pl.pz = TURB != WG_TURB_NONE ? d.pz + pbase : nullptr;
         pl.vl = TURB != WG_TURB_NONE ? d.vlp + pbase : nullptr;
@@ -2039,7 +2086,8 @@ k_windspeed(const FlowP p, const FlowPtrs d, const int e, const int farm, const 
             const uint4 q0 = d.rec4[i0], q1 = d.rec4[i1];
             a0 = q0.x; a1 = q1.x; b0 = q0.y; b1 = q1.y; ue0 = __uint_as_float(q0.z); ue1 = __uint_as_float(q1.z);
         } else {
-            a0 = d.rec_a[i0]; a1 = d.rec_a[i1]; b0 = d.rec_b[i0]; b1 = d.rec_b[i1]; ue0 = d.u_e[i0]; ue1 = d.u_e[i1];
+            const size_t rs = p.rec_il ? 2 : 1;      // (interleaved record: rec_b = rec_a + 1)
+            a0 = d.rec_a[i0 * rs]; a1 = d.rec_a[i1 * rs]; b0 = d.rec_b[i0 * rs]; b1 = d.rec_b[i1 * rs]; ue0 = d.u_e[i0]; ue1 = d.u_e[i1];
         }
         const float w0 = 1.0f - wgt, w1 = wgt;
         const float yc = w0 * d.py[i0] + w1 * d.py[i1];
