@@ -11,6 +11,10 @@
 #ifndef WG_FLOW_WAVES_CG
 #define WG_FLOW_WAVES_CG 5    // small-farm variants (compact rings, 64 / 128 threads): 96 VGPRs; measured 4 / 5 / 6 waves: 104 / 93.5 / 96 us on cfg2
 #endif
+#ifndef WG_FLOW_WAVES_GL
+#define WG_FLOW_WAVES_GL 4    // single-wave steady variant (GL): 128 VGPRs, no spills — room for the pipelined advection pass's second quad;
+                              // 4 vs 5 waves per SIMD measured equal without the pipeline (the launch is not occupancy-bound), -4.5 % with it
+#endif
 #ifndef WG_FLOW_WAVES
 #define WG_FLOW_WAVES 5   // min waves/SIMD the register allocator must leave room for (5 -> <= 96 VGPRs; measured best)
 #endif
@@ -19,7 +23,8 @@
 #define WG_GLDS 1         // single-wave steady compact variant: deficit-phase gathers as early LDS-DMA requests (0 = register gathers, for A/B builds)
 #endif
 #ifndef WG_ADV_PIPE
-#define WG_ADV_PIPE 0      // GL variant: software-pipelined advection pass (first quad requested before the deficit phase)
+#define WG_ADV_PIPE 1      // GL variant: software-pipelined advection pass (first quad requested before the deficit evaluation, the next
+                           // quad before the current one is computed): cfg2 k_flow 61.5 -> 58.8 us same box (0 = plain loop, for A/B builds)
 #endif
 #ifndef WG_PAIR_FIRST
 #define WG_PAIR_FIRST 1   // steady compact variant: deficit phase BEFORE the advection pass (0 = round-2 order, for A/B builds)

@@ -295,13 +295,6 @@ __device__ __forceinline__ void wg_wait_vmem() {
     __builtin_amdgcn_s_waitcnt(0x0F70);
     asm volatile("" ::: "memory");
 }
-// ... all but the three youngest vector-memory requests (vmcnt(3): the counter retires in order)
-__device__ __forceinline__ void wg_wait_vmem_but3() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0x0F73);
-    asm volatile("" ::: "memory");
-}
-
 // streamed particle state of the turbulent pass: touched once per launch -> non-temporal, so that it does not evict
 // the meandering box from L2
 #ifdef WG_NO_NT
@@ -891,8 +884,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         }
         lds_barrier<NT>();
         WG_STAMP(10);
-        // pipelined advection (GLP): the loads of a lane's first listed quad are requested HERE, before the deficit phase
-        // (its ~5 k cycles of LDS / ALU work hide their round trip), and inside the pass every lane requests its next quad
+        // pipelined advection (GLP): the loads of a lane's first listed quad are requested before the deficit evaluation
+        // (its ~4 k cycles of ALU work hide their round trip), and inside the pass every lane requests its next quad
         // before it computes the current one.  Costs 12 + 12 registers: this variant is built at 4 waves per SIMD.
         constexpr bool GLP = GL && (WG_ADV_PIPE != 0);
         const int nlist_pre = GL ? gl_nlist : 0;
@@ -907,9 +900,6 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             n_ra = reinterpret_cast<const uint4*>(pl.ra)[GL ? 2 * n_q : n_q];
             n_rb = GL ? reinterpret_cast<const uint4*>(pl.ra)[2 * n_q + 1] : reinterpret_cast<const uint4*>(pl.rb)[n_q];
         };
-        // (requested by every lane, a lane without a quad reads quad 0: exactly three more requests are outstanding behind
-        // the gathers, which is what the counted wait below relies on)
-        if (GLP) adv_request(tid, tid < nlist_pre);
         if (GL) {
             // deficit phase, part 2: the gathers issued before the records have landed (or do so now)
             for (int t = tid; t < N; t += NT) { T[t].u = ws_f; T[t].v = 0.f; T[t].w = 0.f; }
@@ -919,10 +909,13 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             // does NOT order plain LDS reads of the landing zone behind the requests by itself; the empty asm keeps the
             // reads below the wait)
             const int l = tid & 63;
-            if (GLP) wg_wait_vmem_but3(); else wg_wait_vmem();
+            wg_wait_vmem();
             float g_py0 = gat[0 * 64 + l], g_u0 = gat[1 * 64 + l], g_py1 = gat[4 * 64 + l], g_u1 = gat[5 * 64 + l];
             unsigned g_a0 = __float_as_uint(gat[2 * 64 + l]), g_b0 = __float_as_uint(gat[3 * 64 + l]);
             unsigned g_a1 = __float_as_uint(gat[6 * 64 + l]), g_b1 = __float_as_uint(gat[7 * 64 + l]);
+            // (GLP: the first quad of the advection pass is requested now — its round trip runs under the deficit
+            // evaluation below)
+            if (GLP) adv_request(tid, tid < nlist_pre);
             for (int c0 = 0; c0 < gl_nc; c0 += NT) {
                 const int c = c0 + tid;
                 if (c0 > 0) {      // (more than 64 candidates: not the common case) the next batch lands in the same words
@@ -1548,7 +1541,7 @@ __device__ __attribute__((noinline)) void flow_init_episode(const WgParams* gp, 
 }
 
 template <int NT, int TURB, bool REPLAY, bool NOISE, bool RES, bool SGM = false>
-__global__ void __launch_bounds__(NT, TURB != WG_TURB_NONE ? WG_BOX_WAVES : (RES ? WG_FLOW_WAVES_CG : WG_FLOW_WAVES))
+__global__ void __launch_bounds__(NT, TURB != WG_TURB_NONE ? WG_BOX_WAVES : (RES ? (NT == WG_WAVE ? WG_FLOW_WAVES_GL : WG_FLOW_WAVES_CG) : WG_FLOW_WAVES))
 k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict__ actions,
        const uint8_t* __restrict__ mask, const int chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
