@@ -486,7 +486,8 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             if (!rc) rc = dev_alloc(h, &d.rec_b, n_slots * pstride_keep, true);
         }
         // frozen-record layout for the deficit gathers of the large-farm variant: 16-byte AoS copy (rec4)
-        if (!f.res || !small) { if (!rc) rc = dev_alloc(h, &d.rec4, n_slots * pstride_keep, true); }
+        // (GL handles too: their gathers read the 16-byte copy — one line per pair instead of record line + u_e line)
+        if (!f.res || !small || f.rec_il) { if (!rc) rc = dev_alloc(h, &d.rec4, n_slots * pstride_keep, true); }
         else { if (!rc) rc = dev_alloc(h, &d.u_e, n_slots * pstride_keep, true); }
         if (rc) { wg_destroy(h); return rc; }
         f.lds_bytes = (int)((off + 15) & ~(size_t)15);

@@ -100,7 +100,8 @@ struct FlowPtrs {
 
 // sizeof(TurbLds) in wg_flow.hip; kept here so the host can size the dynamic LDS
 #define WG_TURB_LDS_BYTES 120
-// landing zone of the LDS-DMA gathers: 8 words (py, rec_a, rec_b, u_e of the two bracketing particles) x 64 candidates
-#define WG_GAT_BYTES (8 * 64 * 4)
+// landing zone of the LDS-DMA gathers, per candidate lane: the 16-byte record copy (rec_a, rec_b, u_e, 0) of the two
+// bracketing particles + their py
+#define WG_GAT_BYTES (2 * 64 * 16 + 2 * 64 * 4)
 // per-target bit mask of contributing sources: 32-bit words per target (N <= 32 * WG_MASK_WORDS)
 #define WG_MASK_WORDS 4

@@ -387,8 +387,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     auto gl_resting = [&](const TurbLds& src) __attribute__((always_inline)) -> bool {
         return !(src.mvl != 0u && (int)(sr.n_emitted - src.mvl) < src.rlen);
     };
-    // LDS-DMA gathers of candidate c: word k of lane l lands at gat[k * 64 + l]; k = 0..7: py, u_e, rec_a, rec_b of the
-    // particle of pre-step age jp0 = j - n_emit, then of jp0 + 1.  Lanes without a candidate / particles released in this
+    // LDS-DMA gathers of candidate c: the record copies of the particles of pre-step age jp0 = j - n_emit and jp0 + 1 land at
+    // gat4[l] and gat4[64 + l] (16 bytes per lane), their py at gat[512 + l] and gat[576 + l].  Lanes without a candidate / particles released in this
     // step (negative pre-step age: the turbine's record, not in memory yet) request a valid dummy address.
     auto gl_issue = [&](const int c, const int nc) __attribute__((always_inline)) -> bool {
         int i, tl, s2, j; double dx; float wgt;
@@ -406,17 +406,15 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         }
         // (a resting chain's particles sit where they were released — at the turbine: their py is not fetched; the request
         // points into the rec_a line the lane fetches anyway and the consumer substitutes y_t)
-        // (interleaved record: ct|k and eps|hv of a particle are adjacent words — both requests hit one line)
-        const unsigned* r0p = pl.ra + 2 * i0;
-        const unsigned* r1p = pl.ra + 2 * i1;
-        __builtin_amdgcn_global_load_lds((GPtr)(rest ? (const float*)r0p : pl.py + i0), (LPtr)(gat + 0 * 64), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((GPtr)(pl.ue + i0), (LPtr)(gat + 1 * 64), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((GPtr)(r0p), (LPtr)(gat + 2 * 64), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((GPtr)(r0p + 1), (LPtr)(gat + 3 * 64), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((GPtr)(rest ? (const float*)r1p : pl.py + i1), (LPtr)(gat + 4 * 64), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((GPtr)(pl.ue + i1), (LPtr)(gat + 5 * 64), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((GPtr)(r1p), (LPtr)(gat + 6 * 64), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((GPtr)(r1p + 1), (LPtr)(gat + 7 * 64), 4, 0, 0);
+        // (the 16-byte record copy rec4 = (rec_a, rec_b, u_e, 0), written once at emission: one request and — for the two
+        // adjacent bracketing particles — one line per pair; the interleaved rec_a / rec_b array is what the advection
+        // pass streams)
+        const uint4* q0p = pl.r4 + i0;
+        const uint4* q1p = pl.r4 + i1;
+        __builtin_amdgcn_global_load_lds((GPtr)q0p, (LPtr)(gat + 0 * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)q1p, (LPtr)(gat + 1 * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(rest ? (const float*)q0p : pl.py + i0), (LPtr)(gat + 512), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(rest ? (const float*)q1p : pl.py + i1), (LPtr)(gat + 512 + 64), 4, 0, 0);
         return rest;
     };
     bool gl_rest = false;
@@ -889,17 +887,21 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         // before it computes the current one.  Costs 12 + 12 registers: this variant is built at 4 waves per SIMD.
         constexpr bool GLP = GL && (WG_ADV_PIPE != 0);
         const int nlist_pre = GL ? gl_nlist : 0;
-        float4 n_py = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint4 n_ra = make_uint4(0u, 0u, 0u, 0u), n_rb = n_ra;
-        int n_t = 0, n_kq = 0, n_q = 0;
-        auto adv_request = [&](const int c, const bool valid) __attribute__((always_inline)) {
+        // (two quads ahead when WG_ADV_PIPE = 2: `n_*` is the lane's next quad, `m_*` the one after it)
+        struct QuadReq { float4 py; uint4 ra, rb; int t, kq, q; };
+        QuadReq nq_, mq_;
+        nq_.py = mq_.py = make_float4(0.f, 0.f, 0.f, 0.f);
+        nq_.ra = nq_.rb = mq_.ra = mq_.rb = make_uint4(0u, 0u, 0u, 0u);
+        nq_.t = nq_.kq = nq_.q = mq_.t = mq_.kq = mq_.q = 0;
+        auto adv_request_to = [&](QuadReq& r, const int c, const bool valid) __attribute__((always_inline)) {
             const unsigned ent = valid ? ql[c] : 0u;
-            n_t = (int)(ent >> qsh); n_kq = (int)(ent & ((1u << qsh) - 1u));
-            n_q = valid ? (T[n_t].roff >> 2) + n_kq : 0;
-            n_py = reinterpret_cast<const float4*>(pl.py)[n_q];
-            n_ra = reinterpret_cast<const uint4*>(pl.ra)[GL ? 2 * n_q : n_q];
-            n_rb = GL ? reinterpret_cast<const uint4*>(pl.ra)[2 * n_q + 1] : reinterpret_cast<const uint4*>(pl.rb)[n_q];
+            r.t = (int)(ent >> qsh); r.kq = (int)(ent & ((1u << qsh) - 1u));
+            r.q = valid ? (T[r.t].roff >> 2) + r.kq : 0;
+            r.py = reinterpret_cast<const float4*>(pl.py)[r.q];
+            r.ra = reinterpret_cast<const uint4*>(pl.ra)[GL ? 2 * r.q : r.q];
+            r.rb = GL ? reinterpret_cast<const uint4*>(pl.ra)[2 * r.q + 1] : reinterpret_cast<const uint4*>(pl.rb)[r.q];
         };
+        constexpr bool GLP2 = GLP && (WG_ADV_PIPE >= 2);
         if (GL) {
             // deficit phase, part 2: the gathers issued before the records have landed (or do so now)
             for (int t = tid; t < N; t += NT) { T[t].u = ws_f; T[t].v = 0.f; T[t].w = 0.f; }
@@ -910,29 +912,29 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             // reads below the wait)
             const int l = tid & 63;
             wg_wait_vmem();
-            float g_py0 = gat[0 * 64 + l], g_u0 = gat[1 * 64 + l], g_py1 = gat[4 * 64 + l], g_u1 = gat[5 * 64 + l];
-            unsigned g_a0 = __float_as_uint(gat[2 * 64 + l]), g_b0 = __float_as_uint(gat[3 * 64 + l]);
-            unsigned g_a1 = __float_as_uint(gat[6 * 64 + l]), g_b1 = __float_as_uint(gat[7 * 64 + l]);
+            const uint4* gat4 = reinterpret_cast<const uint4*>(gat);
+            uint4 g_q0 = gat4[l], g_q1 = gat4[64 + l];
+            float g_py0 = gat[512 + l], g_py1 = gat[512 + 64 + l];
             // (GLP: the first quad of the advection pass is requested now — its round trip runs under the deficit
             // evaluation below)
-            if (GLP) adv_request(tid, tid < nlist_pre);
+            if (GLP) adv_request_to(nq_, tid, tid < nlist_pre);
+            if (GLP2) adv_request_to(mq_, tid + NT, tid + NT < nlist_pre);
             for (int c0 = 0; c0 < gl_nc; c0 += NT) {
                 const int c = c0 + tid;
                 if (c0 > 0) {      // (more than 64 candidates: not the common case) the next batch lands in the same words
                     lds_barrier<NT>();
                     gl_rest = gl_issue(c, gl_nc);
                     wg_wait_vmem();
-                    g_py0 = gat[0 * 64 + l]; g_u0 = gat[1 * 64 + l]; g_py1 = gat[4 * 64 + l]; g_u1 = gat[5 * 64 + l];
-                    g_a0 = __float_as_uint(gat[2 * 64 + l]); g_b0 = __float_as_uint(gat[3 * 64 + l]);
-                    g_a1 = __float_as_uint(gat[6 * 64 + l]); g_b1 = __float_as_uint(gat[7 * 64 + l]);
+                    g_q0 = gat4[l]; g_q1 = gat4[64 + l];
+                    g_py0 = gat[512 + l]; g_py1 = gat[512 + 64 + l];
                 }
                 int i, tl, s2, j; double dx; float wgt;
                 if (c < gl_nc && gl_bracket(c, i, tl, s2, dx, j, wgt)) {
                     const TurbLds& src = T[s2];
                     const int jp0 = j - n_emit, jp1 = jp0 + 1;
-                    float py0 = g_py0, u0 = g_u0, py1 = g_py1, u1 = g_u1;
+                    float py0 = g_py0, u0 = __uint_as_float(g_q0.z), py1 = g_py1, u1 = __uint_as_float(g_q1.z);
                     if (gl_rest) { py0 = (float)src.yr; py1 = py0; }      // (not fetched: see gl_issue)
-                    unsigned a0 = g_a0, b0_ = g_b0, a1 = g_a1, b1_ = g_b1;
+                    unsigned a0 = g_q0.x, b0_ = g_q0.y, a1 = g_q1.x, b1_ = g_q1.y;
                     // released in this step: the turbine's record, at the turbine
                     if (jp0 < 0) { py0 = (float)src.yr; u0 = src.rue; a0 = pack_a(src.rct, src.rk); b0_ = pack_b(src.reps, src.rhv); }
                     if (jp1 < 0) { py1 = (float)src.yr; u1 = src.rue; a1 = pack_a(src.rct, src.rk); b1_ = pack_b(src.reps, src.rhv); }
@@ -963,8 +965,11 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             int t, kq, q;
             float4 py; uint4 ra, rb;
             if (GLP) {
-                t = n_t; kq = n_kq; q = n_q; py = n_py; ra = n_ra; rb = n_rb;
-                if (c + NT < nlist) adv_request(c + NT, true);
+                t = nq_.t; kq = nq_.kq; q = nq_.q; py = nq_.py; ra = nq_.ra; rb = nq_.rb;
+                if (GLP2) {
+                    nq_ = mq_;
+                    if (c + 2 * NT < nlist) adv_request_to(mq_, c + 2 * NT, true);
+                } else if (c + NT < nlist) adv_request_to(nq_, c + NT, true);
             } else {
                 const unsigned ent = ql[c];
                 t = (int)(ent >> qsh); kq = (int)(ent & ((1u << qsh) - 1u));
