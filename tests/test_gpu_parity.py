@@ -120,7 +120,7 @@ def _physics_cfg(n_envs, autoreset, n_passthrough, nx=4, ny=4, n_particles=None,
                      n_passthrough=n_passthrough, n_particles=n_particles, n_rotor_pts=16)
 
 
-def _compare_step(env, orc, a, step, check_flow=True):
+def _compare_step(env, orc, a, step, check_flow=True, power_rtol=2e-4):
     import torch
     obs, rew, tr, fin = env.step(torch.as_tensor(a, device="cuda"))
     o_obs, o_rew, o_tr, o_fin = orc.step(a)
@@ -133,7 +133,7 @@ def _compare_step(env, orc, a, step, check_flow=True):
         np.testing.assert_allclose(env.info("rotor_uvw_agent").cpu().numpy(), orc.info("rotor_uvw_agent"),
                                    rtol=1e-4, atol=1e-4, err_msg=f"rotor wind step {step}")
         np.testing.assert_allclose(env.info("power_turb_agent").cpu().numpy(), orc.info("power_turb_agent"),
-                                   rtol=2e-4, atol=20.0, err_msg=f"power step {step}")
+                                   rtol=power_rtol, atol=20.0, err_msg=f"power step {step}")
         np.testing.assert_allclose(env.info("rotor_uvw_base").cpu().numpy(), orc.info("rotor_uvw_base"),
                                    rtol=1e-4, atol=1e-4)
 
@@ -179,6 +179,13 @@ EDGE_CASES = {
     "short_ring_P16": (2, 2, dict(n_rotor_pts=16, n_particles=16), {}),          # chain shorter than the farm
     "substeps_dt3": (3, 2, dict(n_rotor_pts=16, dt_sim=1, dt_env=3), {}),        # K = 3 sub-steps per env step
     "half_second_dt": (2, 2, dict(n_rotor_pts=16, dt_sim=0.5, dt_env=1), {}),    # dt_sim = 0.5 s, K = 2
+    # single-wave GL variant of k_flow (LDS-DMA gathers): 30 turbines in 5 rows of 6 -> 75 in-row pairs alone, i.e. more
+    # than one batch of 64 candidates (the second batch lands in the same LDS words)
+    "dense_6x5_two_candidate_batches": (6, 5, dict(n_rotor_pts=16), {"farm": dict(xDist=3, yDist=2)}),
+    # turbines 0.1 D apart along the wind: closer than the particle spacing (0.2 D), so the bracketing particles of the pair
+    # are released in the very step that evaluates them (the turbine's record in LDS, not in memory yet) and the pair is
+    # a candidate before the chain's bounds know the new record
+    "near_pair_released_this_step": (3, 1, dict(n_rotor_pts=16), {"farm": dict(xDist=0.1, yDist=3)}),
 }
 
 
@@ -192,6 +199,8 @@ def test_edge_shapes_match_oracle(hip, oracle_lib, case):
     d["farm"].update(nx=nx, ny=ny)
     d["ActionMethod"] = "yaw"
     d["mes_level"].update(turb_wd=True, turb_power=True, farm_ws=True, farm_power=True)
+    for k, v in over.items():
+        d[k].update(v)
     B = 4
     cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_envs=B, autoreset=True, n_passthrough=1, **kw)
     env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
@@ -202,7 +211,9 @@ def test_edge_shapes_match_oracle(hip, oracle_lib, case):
     steps = 60 if case == "max_128_turbines" else 160
     for step in range(steps):
         a = rng.uniform(-1, 1, size=(B, cfg.n_turb)).astype(np.float32)
-        _compare_step(env, orc, a, step)
+        # (6 x 5 at 3 D spacing: rotors sit in up to five superposed wakes at ~60 % of the free stream; the rotor wind speed
+        # holds its 1e-4 bar, the power is its cube on the steep part of the curve -> 4e-4, in every kernel variant alike)
+        _compare_step(env, orc, a, step, power_rtol=4e-4 if case.startswith("dense_6x5") else 2e-4)
         n_tr += int(orc.info("timestep").min() == 0)
     env.check()
     if case == "single_turbine":
