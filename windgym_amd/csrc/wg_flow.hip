@@ -390,11 +390,17 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     // LDS-DMA gathers of candidate c: the record copies of the particles of pre-step age jp0 = j - n_emit and jp0 + 1 land at
     // gat4[l] and gat4[64 + l] (16 bytes per lane), their py at gat[512 + l] and gat[576 + l].  Lanes without a candidate / particles released in this
     // step (negative pre-step age: the turbine's record, not in memory yet) request a valid dummy address.
+    // (the bracket — pair index, target, source, distance, age, weight, valid — stays in registers for the evaluation)
+    int b_i = 0, b_tl = 0, b_s2 = 0, b_j = 0;
+    double b_dx = 0.0;
+    float b_wgt = 0.f;
+    bool b_ok = false;
     auto gl_issue = [&](const int c, const int nc) __attribute__((always_inline)) -> bool {
-        int i, tl, s2, j; double dx; float wgt;
         int i0 = 0, i1 = 0;
         bool rest = false;
-        if (c < nc && gl_bracket(c, i, tl, s2, dx, j, wgt)) {
+        b_ok = c < nc && gl_bracket(c, b_i, b_tl, b_s2, b_dx, b_j, b_wgt);
+        if (b_ok) {
+            const int s2 = b_s2, j = b_j;
             const TurbLds& src = T[s2];
             const int Rs = src.rlen;
             rest = gl_resting(src);
@@ -819,7 +825,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             // single wave: list positions from a wave-level prefix sum, no LDS atomics — the compiler orders an LDS
             // atomic behind every pending LDS-DMA request (s_waitcnt vmcnt(0)), which would put the gathers' round trip
             // back on the chain right here
-            int cnt = 0, nqd = 0, q0 = 0, q1 = 0, q2 = 0;
+            int cnt = 0, nqd = 0;
             bool full = false;
             unsigned tag = 0u;
             if (t < ((WG_ABLATE & 1) ? 0 : N)) {
@@ -830,15 +836,22 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 tag = (unsigned)t << qsh;
                 full = moving || n_emit >= 4 || n_emit >= R;
                 if (full) cnt = nqd;
-                else {
-                    int prev = -1;
+                else if (kl == 0) {
+                    // A resting chain only receives this step's new particles (at most 3 here).  They are written straight to
+                    // their ring slots — py, the interleaved record, the record copy: three small stores per particle, no load —
+                    // instead of listing their quads for the advection pass, which read-modify-writes whole quads (two or three
+                    // lines fetched to change 28 bytes).  The slots hold the chain's oldest particles (pre-step ages >= R -
+                    // n_emit), which no bracket of this step can touch, so the stores need not wait for the gathers in flight.
+                    const float y0 = (float)tq.yr;
+                    const unsigned na = pack_a(tq.rct, tq.rk), nb = pack_b(tq.reps, tq.rhv);
 #pragma unroll
                     for (int e = 0; e < 3; ++e) {
                         if (e < n_emit) {
                             int r = tq.head + 1 + e; if (r >= R) r -= R;
-                            const int qd = r >> 2;
-                            if (qd != prev) { if (cnt == 0) q0 = qd; else if (cnt == 1) q1 = qd; else q2 = qd; ++cnt; }
-                            prev = qd;
+                            const int ix = tq.roff + r;
+                            pl.py[ix] = y0;
+                            reinterpret_cast<uint2*>(pl.ra)[ix] = make_uint2(na, nb);
+                            pl.r4[ix] = make_uint4(na, nb, __float_as_uint(tq.rue), 0u);
                         }
                     }
                 }
@@ -851,10 +864,6 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             const int base = __shfl(inc - mine, (tid & 63) & ~(lpt - 1), 64);
             if (full) {
                 for (int i = kl; i < nqd; i += lpt) ql[base + i] = (unsigned short)(tag | (unsigned)i);
-            } else if (kl == 0) {
-                if (cnt > 0) ql[base] = (unsigned short)(tag | (unsigned)q0);
-                if (cnt > 1) ql[base + 1] = (unsigned short)(tag | (unsigned)q1);
-                if (cnt > 2) ql[base + 2] = (unsigned short)(tag | (unsigned)q2);
             }
         } else {
         if (tid == 0) *nq = 0;
@@ -928,8 +937,10 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     g_q0 = gat4[l]; g_q1 = gat4[64 + l];
                     g_py0 = gat[512 + l]; g_py1 = gat[512 + 64 + l];
                 }
-                int i, tl, s2, j; double dx; float wgt;
-                if (c < gl_nc && gl_bracket(c, i, tl, s2, dx, j, wgt)) {
+                if (b_ok) {
+                    const int i = b_i, tl = b_tl, s2 = b_s2, j = b_j;
+                    const double dx = b_dx;
+                    const float wgt = b_wgt;
                     const TurbLds& src = T[s2];
                     const int jp0 = j - n_emit, jp1 = jp0 + 1;
                     float py0 = g_py0, u0 = __uint_as_float(g_q0.z), py1 = g_py1, u1 = __uint_as_float(g_q1.z);
