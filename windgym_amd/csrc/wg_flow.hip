@@ -1831,7 +1831,9 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             for (int t = tid; t < N; t += NT) {
                 float yaw = T[t].yaw;
                 if (p.base_controller == WG_CTRL_LOCAL) {
-                    const float wdir = atanf(T[t].v / T[t].u) * WG_RAD2DEG_F;
+                    // (steady inflow: v == 0 exactly — the deficits only act on u — so atan(v / u) = +-0; the IEEE division + atanf
+                    // are ~60 VALU instructions a baseline-farm step need not execute.  Replay mode scripts (u, v, w) freely.)
+                    const float wdir = (TURB == WG_TURB_NONE && !REPLAY) ? 0.f : atanf(T[t].v / T[t].u) * WG_RAD2DEG_F;
                     const float off = wdir - yaw;
                     const float sgn = (float)((off > 0.f) - (off < 0.f));
                     yaw = yaw + sgn * fminf(fabsf(off), p.yaw_step);
@@ -1871,7 +1873,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             }
             if (measuring && farm == 0) {
                 const float wsm = __builtin_amdgcn_sqrtf(q.u * q.u + q.v * q.v + q.w * q.w);
-                const float wdm = atanf(q.v / q.u) * WG_RAD2DEG_F + wd_env;
+                const float wdm = ((TURB == WG_TURB_NONE && !REPLAY) ? 0.f : atanf(q.v / q.u) * WG_RAD2DEG_F) + wd_env;
                 float val[WG_N_CH] = {q.sws + wsm, q.swd + wdm, q.syaw + q.yaw, q.sp + q.pow};
                 if (unit_end) {
                     kc->d.cur_ws[(size_t)ctx_id * N + t] = wsm;
