@@ -220,6 +220,24 @@ def test_edge_shapes_match_oracle(hip, oracle_lib, case):
         assert n_tr == steps                         # x_max - x_min = 0 -> time_max = 0 (Wind_Farm_Env.py:723-732)
 
 
+def test_lds_fallback_to_uniform_rings_matches_oracle(hip, oracle_lib):
+    """A small farm whose compact-variant LDS carve does not fit a workgroup (N = 32, P = 4096: the 16-bit quad list alone
+    is 64 KB) must fall back to the uniform-ring variant at wg_create — not fail at the first launch — and still match
+    the oracle (the fallback also has to drop the single-wave variant's LDS-DMA layout flags)."""
+    B = 2
+    cfg = _physics_cfg(B, autoreset=True, n_passthrough=0.1, nx=8, ny=4, n_particles=4096)
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    block, compact, duo = env.flow_variant()
+    assert (block, compact, duo) == (256, False, False)
+    seeds = 5 + np.arange(B)
+    np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=OBS_ATOL)
+    rng = np.random.default_rng(3)
+    for step in range(12):
+        a = rng.uniform(-1, 1, size=(B, cfg.n_turb)).astype(np.float32)
+        _compare_step(env, orc, a, step)
+    env.check()
+
+
 def test_nonuniform_turbine_table_matches_oracle(hip, oracle_lib):
     """A power/Ct table on a non-uniform wind-speed grid (the kernel resamples it on 1024 uniform points)."""
     from windgym_amd.config import EnvConfig

@@ -403,6 +403,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         auto carve = [&]() -> size_t {
             tc = tc0;
             f.target_chunk = tc;
+            f.lds_off_ql = 0; f.lds_off_gat = 0; f.gl = 0;      // (re-decided below: the fallback carve runs with res = 0)
             size_t off = sizeof(float) * 4 * (size_t)tc * p.N;
             if (f.res) {
                 const size_t ql = ((size_t)p.NP / 2 + 15) & ~(size_t)15;
@@ -417,7 +418,6 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
                 // single-wave steady variant: the deficit phase's gathers are LDS-DMA requests issued before the record /
                 // quad-list phases, so the candidate list and the quad list are alive together (no aliasing) and the
                 // gathers need a landing zone
-                f.lds_off_ql = 0; f.lds_off_gat = 0; f.gl = 0;
                 if ((WG_GLDS != 0) && (WG_PAIR_FIRST != 0) && f.block == 64 && p.turb_mode == WG_TURB_NONE) {
                     f.gl = 1;
                     off = ((size_t)10 * tc * p.N + 16 + 15) & ~(size_t)15;
