@@ -172,6 +172,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--timing-period", type=int, default=16, help="HIP events bracket the kernels of every n-th step() "
+                    "of the timed region (roofline.kernel_ms)")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step timed region; the median is reported")
     ap.add_argument("--preroll", type=int, default=None,
                     help="untimed steps before the warm-up that take the batch out of its synchronised start "
@@ -301,7 +303,7 @@ def main():
         step(acts[it % n_act]); it += 1
     env.check()
     for rep in range(args.reps):
-        env.kernel_timing(4)             # HIP events around every 4th step() of the timed region
+        env.kernel_timing(args.timing_period)   # HIP events around every n-th step() of the timed region
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -319,8 +321,8 @@ def main():
     if n_launch:
         flow_ms /= n_launch; glue_ms /= n_launch
     flow_steps /= args.reps; particles /= args.reps
-    if multi_out is not None:          # the fused buffer holds what an explicit wg_obs_multi returns
-        assert torch.equal(multi_out, env.obs_multi())
+    if multi_out is not None:          # the fused buffer holds what an explicit wg_obs_multi returns (to summation order)
+        assert (multi_out - env.obs_multi()).abs().max().item() <= 2e-6
     m = metrics.all_reduce()            # the only collective on the path: 8 floats
 
     el_med = sorted(rep_s)[len(rep_s) // 2]

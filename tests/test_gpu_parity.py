@@ -411,8 +411,9 @@ def test_multi_agent_3x3_batched_matches_oracle(hip, oracle_lib):
 
 
 def test_fused_per_agent_observations_equal_the_explicit_packing(hip, oracle_lib):
-    """wg_set_obs_multi_buffer: the per-agent observations written by the step's own glue kernel are bit-identical to
-    what wg_obs_multi returns after the step (and to the oracle's packing), across resets and episode rollovers."""
+    """wg_set_obs_multi_buffer: the per-agent observations written by the step's own glue kernel equal what wg_obs_multi
+    returns after the step (to float rounding: the glue sums a window on several lanes, wg_obs_multi sequentially) and
+    the oracle's packing, across resets and episode rollovers."""
     import torch
     from windgym_amd import presets
     from windgym_amd.config import EnvConfig
@@ -424,7 +425,7 @@ def test_fused_per_agent_observations_equal_the_explicit_packing(hip, oracle_lib
     buf = env.fuse_obs_multi()
     seeds = 31 + np.arange(B)
     env.reset(seeds=seeds), orc.reset(seeds=seeds)
-    assert torch.equal(buf, env.obs_multi())
+    assert (buf - env.obs_multi()).abs().max().item() <= 2e-6
     np.testing.assert_allclose(buf.cpu().numpy(), orc.obs_multi(), rtol=0, atol=OBS_ATOL)
     rng = np.random.default_rng(2)
     n_tr = 0
@@ -432,7 +433,7 @@ def test_fused_per_agent_observations_equal_the_explicit_packing(hip, oracle_lib
         a = rng.uniform(-1, 1, size=(B, cfg.n_turb)).astype(np.float32)
         _, _, tr, _ = env.step(torch.as_tensor(a, device="cuda"))
         orc.step(a)
-        assert torch.equal(buf, env.obs_multi()), step
+        assert (buf - env.obs_multi()).abs().max().item() <= 2e-6, step
         if step % 13 == 0:
             np.testing.assert_allclose(buf.cpu().numpy(), orc.obs_multi(), rtol=0, atol=OBS_ATOL, err_msg=f"step {step}")
         n_tr += int(tr.sum().item())

