@@ -215,47 +215,34 @@ __device__ inline void stage_rings(const WgParams& p, const WgPtrs& d, int ctx_i
     const float* gf = d.fring + (size_t)ctx_id * p.fring_stride;
     if (!RL) { rbase = gr; fbase = gf; return; }
     const int N = p.N;
-    // compact index space over the fully staged channels
-    const int l0 = p.stage_ch[0] == 2 ? N * p.ch[0].history_len : 0, l1 = p.stage_ch[1] == 2 ? N * p.ch[1].history_len : 0;
-    const int l2 = p.stage_ch[2] == 2 ? N * p.ch[2].history_len : 0, l3 = p.stage_ch[3] == 2 ? N * p.ch[3].history_len : 0;
-    const int c1 = l0, c2 = c1 + l1, c3 = c2 + l2, total = c3 + l3;
-    const int d0 = p.ring_off[0], d1 = p.ring_off[1] - c1, d2 = p.ring_off[2] - c2, d3 = p.ring_off[3] - c3;
-    // 16 loads in flight per lane (a plain copy loop waits for every load before its LDS store)
-    constexpr int U = 16;
-    for (int b0 = lane; b0 < total; b0 += WG_WAVE * U) {
-        float v[U];
-        int gi[U];
+    // LDS-DMA (global_load_lds): lane i of a request reads one float at its own global address and the 64 results land
+    // at consecutive LDS words from a wave-uniform base — the LDS copy keeps the global layout, so a run of 64 ring
+    // floats is one request, with no result registers, no LDS store instructions and nothing waited for until every
+    // request of the turbine AND the farm rings is in flight.  (The register-staged copy held 32 VGPRs, and the farm
+    // rings' requests went out only after the turbine rings had landed: a second memory round trip where they are read.)
+    typedef const __attribute__((address_space(1))) void* GPtr;
+    typedef __attribute__((address_space(3))) void* LPtr;
 #pragma unroll
-        for (int k = 0; k < U; ++k) {
-            const int i = b0 + k * WG_WAVE;
-            gi[k] = i + (i >= c3 ? d3 : (i >= c2 ? d2 : (i >= c1 ? d1 : d0)));
-            v[k] = i < total ? gr[gi[k]] : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < U; ++k) { const int i = b0 + k * WG_WAVE; if (i < total) lds[gi[k]] = v[k]; }
-    }
-    if (n_pushed > 0) {
-#pragma unroll
-        for (int ch = 0; ch < WG_N_CH; ++ch) {
-            if (p.stage_ch[ch] != 1) continue;
-            const int H = p.ch[ch].history_len;
-            const int newest = (n_pushed - 1) % H;
-            for (int t = lane; t < N; t += WG_WAVE) {
-                const int idx = p.ring_off[ch] + newest * N + t;
-                lds[idx] = gr[idx];
-            }
+    for (int ch = 0; ch < WG_N_CH; ++ch) {
+        const int off = p.ring_off[ch];
+        if (p.stage_ch[ch] == 2) {
+            const int len = N * p.ch[ch].history_len;
+#pragma nounroll
+            for (int s0 = 0; s0 < len; s0 += WG_WAVE)
+                if (s0 + lane < len) __builtin_amdgcn_global_load_lds((GPtr)(gr + off + s0 + lane), (LPtr)(lds + off + s0), 4, 0, 0);
+        } else if (p.stage_ch[ch] == 1 && n_pushed > 0) {
+            const int row = off + ((n_pushed - 1) % p.ch[ch].history_len) * N;
+#pragma nounroll
+            for (int s0 = 0; s0 < N; s0 += WG_WAVE)
+                if (s0 + lane < N) __builtin_amdgcn_global_load_lds((GPtr)(gr + row + s0 + lane), (LPtr)(lds + row + s0), 4, 0, 0);
         }
     }
     // (the farm rings are staged only if something reads them: farm-level observations, the per-agent blocks of the
-    // PettingZoo facade — Env1.yaml observes turbines only, and the copy is a memory round trip of its own)
+    // PettingZoo facade — Env1.yaml observes turbines only)
     const int n_farm = (p.farm_obs > 0 || d.multi_out != nullptr) ? p.fring_stride : 0;
-    for (int b0 = lane; b0 < n_farm; b0 += WG_WAVE * U) {
-        float v[U];
-#pragma unroll
-        for (int k = 0; k < U; ++k) { const int i = b0 + k * WG_WAVE; v[k] = i < p.fring_stride ? gf[i] : 0.f; }
-#pragma unroll
-        for (int k = 0; k < U; ++k) { const int i = b0 + k * WG_WAVE; if (i < p.fring_stride) lds[p.ring_stride + i] = v[k]; }
-    }
+#pragma nounroll
+    for (int s0 = 0; s0 < n_farm; s0 += WG_WAVE)
+        if (s0 + lane < n_farm) __builtin_amdgcn_global_load_lds((GPtr)(gf + s0 + lane), (LPtr)(lds + p.ring_stride + s0), 4, 0, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // single wave: program order suffices
     rbase = lds; fbase = lds + p.ring_stride;
 }
@@ -393,6 +380,16 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
 #ifndef WG_GLUE_ABLATE
 #define WG_GLUE_ABLATE 0
 #endif
+    // debug build (-DWG_GLUE_TL, tools/glue_timeline.py): shader-clock stamps at the phase boundaries of this wave, left in
+    // the env's final_obs row (which the build therefore destroys) — how the truncating waves' share of the kernel
+    // was measured
+#ifdef WG_GLUE_TL
+    unsigned tl[8];
+#define WG_GSTAMP(k) tl[k] = (unsigned)clock64()
+#else
+#define WG_GSTAMP(k) do { } while (0)
+#endif
+    WG_GSTAMP(0);
     if (WG_GLUE_ABLATE == 1) return;
     EnvHot ev = env_load(env);
     const int live = ev.live;
@@ -476,6 +473,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     // An env that truncates with same-step autoreset returns the NEXT episode's first observation (built below,
     // after the swap); the finished episode's last observation is only wanted as final_obs.  (Building it into `obs`
     // first and overwriting it made the truncating waves — about 9 per launch of 4096 — the kernel's tail.)
+    WG_GSTAMP(1);
     const int truncated = ev.timestep >= time_max;                                    // :1003
     const bool swap_obs = truncated && p.autoreset && obs != nullptr;
     if (!swap_obs || fin) {
@@ -486,6 +484,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
                        MULTI ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr, n_pushed_live, mscr);
     }
     if (WG_GLUE_ABLATE == 4) return;
+    WG_GSTAMP(2);
 
     // action penalty sums (:804-820) and current farm powers ("Power agent", :539)
     float pen_s = 0.f, pnow = 0.f, pbase = 0.f;
@@ -538,6 +537,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         met[lane] = l_met + add;
     }
     if (WG_GLUE_ABLATE == 6) return;
+    WG_GSTAMP(3);
     if (truncated) {
         ev.ep_return = 0.f; ev.ep_power_sum = 0.f; ev.ep_len = 0;
         ev.episode += 1;
@@ -584,6 +584,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         }
     }
     if (WG_GLUE_ABLATE == 7) return;
+    WG_GSTAMP(4);
     if (!p.autoreset) {
         ev.shadow_iters = 0;
     } else if (truncated) {
@@ -601,6 +602,13 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     }
     if (WG_GLUE_ABLATE == 8) return;
     env_writeback(env, ev, lane);
+#ifdef WG_GLUE_TL
+    WG_GSTAMP(5);
+    if (lane == 0 && fin) {
+        for (int k = 0; k < 6; ++k) fin[k] = __uint_as_float(tl[k]);
+        fin[6] = __uint_as_float((unsigned)truncated);
+    }
+#endif
 }
 
 // ===================================================================================================
