@@ -26,11 +26,11 @@ kern = []
 for i in range(200):
     _, _, tr, fin = env.step(acts[i % 8])
     torch.cuda.synchronize()
-    st = fin[:, :7].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
-    t0 = st[:, 0].min()
+    st = fin[:, :9].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    t0 = st[:, 7].min()                          # device-wide 100 MHz clock: 10 ns units
     d = (st[:, 1:6] - st[:, 0:5]) & 0xFFFFFFFF
-    end = (st[:, 5] - t0) & 0xFFFFFFFF
-    start = (st[:, 0] - t0) & 0xFFFFFFFF
+    end = (st[:, 8] - t0) & 0xFFFFFFFF
+    start = (st[:, 7] - t0) & 0xFFFFFFFF
     trn = st[:, 6] != 0
     kern.append(end.max())
     for k in (0, 1):
@@ -39,7 +39,9 @@ for i in range(200):
             rows[k].append(np.concatenate([start[m, None], d[m], end[m, None]], axis=1))
 for k, label in ((0, "waves that do not truncate"), (1, "truncating waves")):
     a = np.concatenate(rows[k])
-    print(f"{label}: {len(a)} samples; start after the first wave: mean {a[:, 0].mean():.0f} cycles; end: mean {a[:, -1].mean():.0f} p99 {np.percentile(a[:, -1], 99):.0f} max {a[:, -1].max():.0f}")
+    print(f"{label}: {len(a)} samples; start after the first wave's start: mean {a[:, 0].mean() / 100:.2f} us p99 {np.percentile(a[:, 0], 99) / 100:.2f}; end: mean {a[:, -1].mean() / 100:.2f} us p99 {np.percentile(a[:, -1], 99) / 100:.2f} max {a[:, -1].max() / 100:.2f}")
     for j, nm in enumerate(names[:5]):
         print(f"   {nm:45s} mean {a[:, 1 + j].mean():8.0f}  p90 {np.percentile(a[:, 1 + j], 90):8.0f}")
-print(f"last wave's end after the first wave's start, per launch: mean {np.mean(kern):.0f} cycles")
+print(f"last wave's end after the first wave's start, per launch: mean {np.mean(kern) / 100:.2f} us")
+ends_nt = [r[:, -1].max() for r in rows[0]]
+print(f"last NON-truncating wave's end, per launch: mean {np.mean(ends_nt) / 100:.2f} us")

@@ -385,6 +385,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     // was measured
 #ifdef WG_GLUE_TL
     unsigned tl[8];
+    const unsigned tl_w0 = (unsigned)wall_clock64();       // (100 MHz, one counter for the whole device)
 #define WG_GSTAMP(k) tl[k] = (unsigned)clock64()
 #else
 #define WG_GSTAMP(k) do { } while (0)
@@ -476,6 +477,11 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     WG_GSTAMP(1);
     const int truncated = ev.timestep >= time_max;                                    // :1003
     const bool swap_obs = truncated && p.autoreset && obs != nullptr;
+    // (A truncating wave builds two observations — final_obs of the finished episode, the first one of the next — and
+    // swaps the contexts: it ends ~5 us after the others and IS the end of the kernel, tools/glue_timeline.py.  Measured
+    // and not kept: requesting the next context's header, deferred deque entries and rings with the first staging
+    // (swap block 12.7 k -> 7.7 k cycles, but the common path slowed by as much as the tail gained); s_setprio(3) for
+    // the truncating wave: no effect.)
     if (!swap_obs || fin) {
         stage_rings<RL>(p, d, ctx_id, lane, my_lds, rbase, fbase, n_pushed_live);
         if (WG_GLUE_ABLATE == 3) return;
@@ -607,6 +613,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     if (lane == 0 && fin) {
         for (int k = 0; k < 6; ++k) fin[k] = __uint_as_float(tl[k]);
         fin[6] = __uint_as_float((unsigned)truncated);
+        fin[7] = __uint_as_float(tl_w0); fin[8] = __uint_as_float((unsigned)wall_clock64());
     }
 #endif
 }
