@@ -820,3 +820,60 @@ def test_box_pool_draws_like_np_random_choice_and_matches_oracle(hip, oracle_lib
     g = np.random.default_rng(int(seeds[0]))
     ws = g.uniform(cfg.ws_min, cfg.ws_max)
     assert env1.info("wind_f64").cpu().numpy()[0, 0] == ws
+
+
+@pytest.mark.parametrize("case", ["rings_in_global", "current_only_and_farm", "ti_and_windows_l2"])
+def test_glue_instantiations_match_oracle(hip, oracle_lib, case):
+    """k_glue is instantiated per <per-agent buffer, rings staged in LDS, lanes per turbine>; the observation's window
+    sums run on 64/N lanes per turbine and the rings are staged by LDS-DMA requests.  Cases the benchmark configs do not
+    reach: rings too large for the wave's LDS region (80 turbines x 100-sample histories: read from global memory, one
+    lane per turbine), channels observed through their newest sample only together with farm-level observations and
+    TI (partial staging, farm rings), and a 5 x 4 farm (two lanes per turbine) with several windows per channel —
+    observations, final observations and rewards against the oracle across an autoreset."""
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.presets import horns_rev1_layout, horns_rev_config, env1_config
+    from windgym_amd.turbine import V80
+    import copy
+    kw = {}
+    if case == "rings_in_global":
+        d = horns_rev_config()
+        d["ws_mes"].update(ws_current=True, ws_history_N=3, ws_history_length=100, ws_window_length=20)
+        d["yaw_mes"].update(yaw_history_N=2, yaw_history_length=60, yaw_window_length=10)
+        d["mes_level"].update(turb_TI=True)
+        x, y = horns_rev1_layout()
+        kw = dict(x_pos=x, y_pos=y)
+        B, steps, npt = 2, 40, 0.15
+    elif case == "current_only_and_farm":
+        d = copy.deepcopy(env1_config())
+        d["ActionMethod"] = "yaw"
+        d["farm"].update(nx=3, ny=2)
+        d["mes_level"].update(turb_ws=True, turb_wd=True, turb_TI=True, turb_power=True, farm_ws=True, farm_wd=True,
+                              farm_TI=True, farm_power=True)
+        d["ws_mes"].update(ws_current=True, ws_rolling_mean=True, ws_history_N=2, ws_history_length=12, ws_window_length=5)
+        d["wd_mes"].update(wd_current=True, wd_rolling_mean=False)
+        d["power_mes"].update(power_current=True, power_rolling_mean=False)
+        d["yaw_mes"].update(yaw_current=True, yaw_rolling_mean=False)
+        B, steps, npt = 5, 120, 0.3
+    else:
+        d = copy.deepcopy(env1_config())
+        d["ActionMethod"] = "yaw"
+        d["farm"].update(nx=5, ny=4)
+        d["mes_level"].update(turb_TI=True, farm_TI=True)
+        d["ws_mes"].update(ws_current=True, ws_history_N=4, ws_history_length=30, ws_window_length=7)
+        d["yaw_mes"].update(yaw_history_N=3, yaw_history_length=9, yaw_window_length=4)
+        B, steps, npt = 3, 120, 0.3
+    cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_envs=B, autoreset=True, n_passthrough=npt,
+                    n_rotor_pts=16, **kw)
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    seeds = 400 + np.arange(B)
+    np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=OBS_ATOL)
+    rng = np.random.default_rng(11)
+    n_tr = 0
+    for step in range(steps):
+        a = rng.uniform(-1, 1, size=(B, cfg.n_turb)).astype(np.float32)
+        _compare_step(env, orc, a, step, check_flow=False)
+        n_tr += int(env.truncated.sum().item())
+    if case != "rings_in_global":
+        assert n_tr >= 1
+    env.check()
+    env.close()
