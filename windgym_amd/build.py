@@ -20,16 +20,32 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the three translation units in parallel (wg_flow.hip and wg_kernels.hip take about a minute each: they
+    hold all the kernel instantiations) and link them; objects go to a temporary directory, only the .so stays in-tree."""
     if not force and not needs_build():
         return LIB
+    import tempfile
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("WG_HIPCC_FLAGS", "").split()
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra + [
-           "-Wno-unused-result", "-Wno-unused-value", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + extra + ["-Wno-unused-result", "-Wno-unused-value"]
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+        flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
+    with tempfile.TemporaryDirectory(prefix="wg_build_") as tmp:
+        objs, procs = [], []
+        for src in SOURCES:
+            obj = os.path.join(tmp, src.replace(".hip", ".o"))
+            cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+            objs.append(obj)
+        for cmd, pr in procs:
+            if pr.wait() != 0:
+                for _, other in procs:
+                    if other.poll() is None:
+                        other.kill()
+                raise subprocess.CalledProcessError(pr.returncode, cmd)
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, check=True)
     return LIB
 
 
