@@ -298,6 +298,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     A(step_farm_pow, (size_t)p.B, true); A(step_base_pow, (size_t)p.B, true);
     A(last_pow_agent, (size_t)p.B, true); A(last_pow_base, (size_t)p.B, true);
     A(metrics, (size_t)p.B * WG_N_METRICS, true);
+    A(next_obs, n_ctx * (size_t)p.obs_dim, false); A(next_obs_ok, n_ctx, false);
     A(status, 1, true);
 #undef A
     if (!rc) rc = dev_alloc(h, &h->mask_dev, (size_t)p.B, false);
@@ -561,6 +562,10 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
                                  (double)p.N * (7 * 4 * 2 + 16) + (boxm ? (double)p.N * p.S * 96 : 0.0);
     h->alg_bytes = (double)p.B * ((double)p.K * p.F * per_farm_step + 20.0 * p.N + 12.0 * p.obs_dim + 20.0);
 
+    // The first observation of a background episode is built inside k_flow only by the single-wave steady variant (small
+    // farms: one wave reads 35 floats per turbine; measured on the multi-wave variants — cfg3, cfg5 — the building
+    // workgroup became the flow kernel's tail: -5 % / -1.3 %).  Other handles keep the glue's own second build.
+    if (!(h->fp.gl && !h->fp.duo)) { d.next_obs = nullptr; d.next_obs_ok = nullptr; }
     wg_launch_create(&p, &d, nullptr);
     if (sync_dev_params(h)) { wg_destroy(h); return WG_ERR_HIP; }
     {
@@ -1010,6 +1015,7 @@ extern "C" int wg_set_state(wg_handle h, const void* blob_host, size_t size) {
     if (int rc = use_device(h)) return rc;
     HIPCHK(hipDeviceSynchronize());
     const char* o = (const char*)blob_host + sizeof(StateHeader);
+    if (h->d.next_obs_ok) HIPCHK(hipMemset(h->d.next_obs_ok, 0, sizeof(int) * (size_t)h->p.B * 2));      // (derived data, not in the blob)
     for (size_t i : h->state_idx) {
         HIPCHK(hipMemcpy(h->allocs[i].ptr, o, h->allocs[i].bytes, hipMemcpyHostToDevice));
         o += h->allocs[i].bytes;

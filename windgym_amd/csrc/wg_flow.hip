@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include "wg_device.h"
+#include "wg_obs.h"
 #include "wg_flow.h"
 #include <type_traits>
 
@@ -1561,6 +1562,20 @@ __device__ __attribute__((noinline)) void flow_init_episode(const WgParams* gp, 
     }
 }
 
+// First observation of a background episode, built by the workgroup of its agent farm when the episode's development
+// completes (its last window-fill push): the glue wave of the env's truncation then copies obs_dim floats instead of
+// staging the rings and building a second observation — the truncating waves are the tail of k_glue.
+// Out of line and rare (once per episode and env); reads the rings this workgroup just completed from global memory.
+__device__ __attribute__((noinline)) void wg_first_obs(const WgParams* gp, const WgPtrs* gd, const int ctx_id,
+                                                       const int n_pushed, const int lane) {
+    const WgParams& p = *gp;
+    const WgPtrs& d = *gd;
+    if (d.next_obs == nullptr) return;
+    build_obs<1>(p, d, ctx_id, lane, d.next_obs + (size_t)ctx_id * p.obs_dim, nullptr,
+                 d.ring + (size_t)ctx_id * p.ring_stride, d.fring + (size_t)ctx_id * p.fring_stride, false, nullptr, n_pushed);
+    if (lane == 0) d.next_obs_ok[ctx_id] = 1;
+}
+
 template <int NT, int TURB, bool REPLAY, bool NOISE, bool RES, bool SGM = false>
 __global__ void __launch_bounds__(NT, TURB != WG_TURB_NONE ? WG_BOX_WAVES : (RES ? (NT == WG_WAVE ? WG_FLOW_WAVES_GL : WG_FLOW_WAVES_CG) : WG_FLOW_WAVES))
 k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict__ actions,
@@ -1971,6 +1986,14 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             for (int k = 0; k < 12; ++k) d.dbg[(size_t)blockIdx.x * 12 + k] = wg_stamps[k];
         }
 #endif
+    }
+    // a background episode's development ends with this launch: its first observation (wg_first_obs)
+    // (single-wave steady variant only: wg_create leaves next_obs null for every other handle)
+    if (RES && TURB == WG_TURB_NONE && NT == WG_WAVE) {
+        if (mode == WG_MODE_STEP && !live_step && farm == 0 && dev_rem == 0 && fill_rem == 0) {
+            full_barrier<NT>();                  // the ring pushes have left the wave
+            wg_first_obs(ke->d.gp, ke->d.gd, ctx_id, n_pushed, tid);
+        }
     }
 }
 

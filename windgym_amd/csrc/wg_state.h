@@ -150,6 +150,13 @@ struct WgPtrs {
     float *step_farm_pow, *step_base_pow;   // [B] produced by the flow kernel, consumed by the glue kernel
     float *last_pow_agent, *last_pow_base;  // [B] farm power of the step just taken (before an autoreset swap)
     float* metrics;           // [B][WG_N_METRICS] running per-env sums
+    // First observation of a background episode, built by the k_flow workgroup that completes its development
+    // (wg_first_obs) so that the truncating glue wave copies it instead of staging and building a second observation;
+    // next_obs_ok[ctx] = 1 while next_obs[ctx] holds the context's current episode (cleared when the context
+    // is retired — k_glue — or reset — k_init; not part of the state blob: without it the glue builds the observation
+    // itself).  Null unless the handle runs the single-wave steady flow kernel (wg_create).
+    float* next_obs;          // [B*2][obs_dim]
+    int* next_obs_ok;         // [B*2]
     int* status;              // sticky error word
     const double* wind_override;   // [B][3] (ws, wd, ti) or null; NaN = keep the sampled value
     const int* box_override;       // [B] box of the pool env e uses (FarmEval.update_tf: TF_files = [path]) or null; < 0 = draw
