@@ -877,3 +877,35 @@ def test_glue_instantiations_match_oracle(hip, oracle_lib, case):
         assert n_tr >= 1
     env.check()
     env.close()
+
+
+def test_prepared_first_observation_survives_buffer_switches(hip, oracle_lib):
+    """On a handle whose flow kernel prepares the next episode's first observation (single-wave steady variant, 4 x 4
+    farm) the glue copies it at truncation; with a per-agent buffer registered the glue builds it itself.  Switching the
+    buffer on and off across rollovers (and restoring a state blob, which does not carry the prepared rows) must never
+    hand out the first observation of an episode that has since been replaced: every step against the oracle."""
+    import torch
+    B = 6
+    cfg = _physics_cfg(B, autoreset=True, n_passthrough=0.25)
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    assert env.flow_variant()[0] == 64 and not env.flow_variant()[2]
+    seeds = 900 + np.arange(B)
+    np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=OBS_ATOL)
+    rng = np.random.default_rng(5)
+    n_tr = [0, 0, 0, 0]
+    step = 0
+    for phase in range(4):
+        if phase == 1:
+            env.fuse_obs_multi()
+        elif phase == 2:
+            env.fuse_obs_multi(False)
+        elif phase == 3:
+            env.set_state(env.get_state())
+        for _ in range(130):
+            a = rng.uniform(-1, 1, size=(B, cfg.n_turb)).astype(np.float32)
+            _compare_step(env, orc, a, step, check_flow=False)
+            n_tr[phase] += int(env.truncated.sum().item())
+            step += 1
+    assert min(n_tr) >= 1, n_tr
+    env.check()
+    env.close()

@@ -917,6 +917,12 @@ extern "C" int wg_set_obs_multi_buffer(wg_handle h, float* obs_multi_dev) {
     if (h->d.multi_out != obs_multi_dev) drop_step_graphs(h);
     h->d.multi_out = obs_multi_dev;     // borrowed; written by k_glue in every following wg_step / wg_reset
     if (int rc = use_device(h)) return rc;
+    // (the per-agent instantiation of k_glue neither consumes nor retires the prepared first observations of
+    // WgPtrs::next_obs: switching between the two must not leave a flag of an episode that has since been replaced)
+    if (h->d.next_obs_ok) {
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemset(h->d.next_obs_ok, 0, sizeof(int) * (size_t)h->p.B * 2));
+    }
     return sync_dev_params(h);
 }
 
