@@ -13,8 +13,10 @@ visible GPUs than ranks, is an error — the line never reports a GPU count it d
 
 Timed region: after `--preroll` untimed steps (the batch leaves its synchronised start: episodes truncate and reset at
 their own times, background episodes are in their steady-state schedule) and W warm-up steps, EXACTLY K steps are timed
-between barrier + synchronize; that is repeated `--reps` times and the MEDIAN repetition is reported (all of them are
-listed in `ms_per_step_reps`), so that one descheduled host thread does not decide the number.
+between barrier + synchronize; that is repeated `--reps` times and the MEDIAN repetition is reported (with its
+inter-quartile range `ms_per_step_iqr`; the repetitions are listed in `ms_per_step_reps`), so that one descheduled host
+thread does not decide the number.  When K is small the repetition count is raised until the timed regions add up to
+`--min-timed-seconds` (0.25 s): repetitions are free, a 1.5 ms sample is not a measurement.
 """
 from __future__ import annotations
 
@@ -175,6 +177,8 @@ def parse():
     ap.add_argument("--timing-period", type=int, default=16, help="HIP events bracket the kernels of every n-th step() "
                     "of the timed region (roofline.kernel_ms)")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step timed region; the median is reported")
+    ap.add_argument("--min-timed-seconds", type=float, default=0.25,
+                    help="raise the repetition count until the timed regions add up to this much (0 = exactly --reps)")
     ap.add_argument("--preroll", type=int, default=None,
                     help="untimed steps before the warm-up that take the batch out of its synchronised start "
                          "(default: 600 for cfg2/cfg4/cfg5, 100 for cfg3)")
@@ -298,11 +302,12 @@ def main():
     rep_s = []
     flow_ms = glue_ms = 0.0
     n_launch = 0
-    flow_steps = particles = 0.0
+    flow_steps = particles = added = 0.0
     for _ in range(args.warmup):
         step(acts[it % n_act]); it += 1
     env.check()
-    for rep in range(args.reps):
+    n_reps, rep = args.reps, 0
+    while rep < n_reps:
         env.kernel_timing(args.timing_period)   # HIP events around every n-th step() of the timed region
         barrier()
         t0 = time.perf_counter()
@@ -316,16 +321,22 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)        # slowest rank
         rep_s.append(float(t.item()))
         flow_ms += f * n; glue_ms += g * n; n_launch += n
-        flow_steps += fs; particles += pt
+        flow_steps += fs; particles += pt; added += env.added_lookups()
+        rep += 1
+        if rep == 1 and args.min_timed_seconds > 0:
+            # (decided from the slowest rank's first repetition, so every rank runs the same count)
+            n_reps = max(args.reps, min(2000, int(args.min_timed_seconds / max(rep_s[0], 1e-6)) + 1))
     env.check()
     if n_launch:
         flow_ms /= n_launch; glue_ms /= n_launch
-    flow_steps /= args.reps; particles /= args.reps
+    flow_steps /= n_reps; particles /= n_reps; added /= n_reps
     if multi_out is not None:          # the fused buffer holds what an explicit wg_obs_multi returns (to summation order)
         assert (multi_out - env.obs_multi()).abs().max().item() <= 2e-6
     m = metrics.all_reduce()            # the only collective on the path: 8 floats
 
-    el_med = sorted(rep_s)[len(rep_s) // 2]
+    rs = sorted(rep_s)
+    el_med = rs[len(rs) // 2]
+    el_iqr = rs[(3 * len(rs)) // 4] - rs[len(rs) // 4]
     total_envs = B_flag if args.scaling == "strong" else B * world
     value = total_envs * args.steps / el_med
 
@@ -336,10 +347,11 @@ def main():
         # and the farm flow-steps executed (live farms + background development of the next episodes).
         # per particle: py read+write (8) + packed record ct|k, eps|hv read (8); per turbine: state r/w + positions;
         # box: + pz,vlp,wlp r/w (24) + 8 corners x (v, w) of the meandering box per particle (64), 8 corners x
-        # (u, v, w) of the fine box per rotor point (96)
+        # (u, v, w) of the fine box per rotor point (96); wake-added turbulence (row a7): 8 corners x (u, v, w) of the
+        # isotropic box at the rotor points of every target with a candidate source wake (96 each), counted on the device
         per_particle = 16.0 + (24.0 + 64.0 if args.workload == "cfg5" else 0.0)
         per_farm_step = cfg.n_turb * 72.0 + (cfg.n_turb * cfg.n_rotor_pts * 96.0 if args.workload == "cfg5" else 0.0)
-        alg_bytes_flow = particles * per_particle + flow_steps * per_farm_step
+        alg_bytes_flow = particles * per_particle + flow_steps * per_farm_step + added * 96.0
         bytes_per_flow_step = alg_bytes_flow / flow_steps if flow_steps > 0 else 0.0
         achieved = alg_bytes_flow / (flow_ms * 1e-3) / 1e9 if flow_ms > 0 else 0.0
         # HBM bytes per k_flow launch: NOT measured in this run — read from the committed summary of the rocprofv3 PMC
@@ -347,7 +359,7 @@ def main():
         # profiles/r03_<cfgN>_kflow_traffic.json); `traffic_source` names the file.  Only quoted for the profiled
         # workloads at their profiled size (the workload's default env count, baseline farm on, one GPU).
         traffic = traffic_source = None
-        for rnd in ("r03", "r02"):
+        for rnd in ("r04", "r03", "r02"):
             tf = os.path.join(ROOT, "profiles", f"{rnd}_kflow_traffic.json" if args.workload == "cfg2" and rnd == "r02"
                               else f"{rnd}_{args.workload}_kflow_traffic.json")
             if os.path.exists(tf) and args.envs is None and F == 2 and world == 1:
@@ -372,8 +384,10 @@ def main():
                                    f"S={cfg.n_rotor_pts}, same-step autoreset on; f32 arithmetic, u16 emission record",
                        "envs_per_gpu": B, "n_turb": cfg.n_turb, "farms_per_env": F,
                        "parallelism": f"env-axis shard x{world}"},
-            "reps": args.reps, "preroll": preroll,
-            "ms_per_step_reps": [r / args.steps * 1e3 for r in rep_s],
+            "reps": n_reps, "preroll": preroll,
+            "ms_per_step_iqr": el_iqr / args.steps * 1e3,
+            "timed_seconds": sum(rep_s),
+            "ms_per_step_reps": [round(r / args.steps * 1e3, 6) for r in (rep_s if len(rep_s) <= 32 else rs[::max(1, len(rs) // 32)])],
             "gpu_ms_per_step": flow_ms + glue_ms,
             "rccl": rccl,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -382,6 +396,7 @@ def main():
                          "kernel_ms": flow_ms, "glue_kernel_ms": glue_ms, "launches_timed": n_launch,
                          "algorithmic_bytes_per_launch": alg_bytes_flow, "farm_flow_steps_per_launch": flow_steps,
                          "particles_needed_per_launch": particles,
+                         "added_turbulence_rotor_points_per_launch": added,
                          "particle_slots_per_launch": flow_steps * cfg.n_turb * cfg.n_particles,
                          "bytes_per_farm_flow_step": bytes_per_flow_step},
             "episode_metrics": {k: float(v) for k, v in m.items()},

@@ -285,7 +285,8 @@ int wg_set_step_graph(wg_handle h, int enable);
 
 /* step() is asynchronous, so the errors the reference raises inside step() (Exception("NaN Power"), stepping
  * a torn-down env) are latched in a sticky device word.  wg_check synchronises `stream` and returns it
- * (0, WG_ERR_NAN_POWER or WG_ERR_STATE); a wg_reset of the whole batch clears it.                                           */
+ * (0, WG_ERR_NAN_POWER, WG_ERR_STATE or WG_ERR_RANGE — the conditions are latched independently and the most serious one
+ * is reported, in that order); a wg_reset of the whole batch clears it.                                                     */
 int wg_check(wg_handle h, void* stream);
 
 /* Per-agent observations of the PettingZoo facade for the current state: f32[B,N,obs_dim_multi].      */
@@ -328,6 +329,11 @@ int wg_set_state(wg_handle h, const void* blob_host, size_t size);
  * wg_step (an event pair per launch costs a few percent of a ~200 us step).                            */
 int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, double* glue_ms_avg, int* n_launches,
                      double* flow_steps_per_launch, double* particles_per_launch);
+
+/* Rotor points at which one flow launch looked the wake-added turbulence box up (8 corners x (u, v, w) = 96 bytes each:
+ * only the rotors of targets with a candidate source wake do), averaged over the window the LAST wg_kernel_timing call
+ * closed — the a7 term of bench.py's algorithmic bytes.  0 without wg_config.added_turbulence.                              */
+int wg_added_lookups(wg_handle h, double* rotor_points_per_launch);
 
 /* Algorithmic HBM bytes one wg_step() moves (the figure bench.py's roofline uses).       */
 int wg_algorithmic_bytes(wg_handle h, double* bytes_per_step);

@@ -42,6 +42,24 @@ def _soak(env, cfg, B, steps, min_roll, check_every=500):
     return u, n_trunc
 
 
+def test_soak_cfg2_headline_batch_4096_envs(hip):
+    """The batch the headline metric is quoted on: bench.py's cfg2 configuration, 4096 envs x 16 turbines x
+    2 farms on one GPU, default n_passthrough, 1200 steps (time_max <= 1121: every env rolls over at least once) — same
+    assertions as the 1024-env soak of test_gpu_parity.py."""
+    import bench
+    B = 4096
+    cfg = bench.make_cfg(B, workload="cfg2")
+    env = hip.HipBatch(cfg)
+    assert env.flow_variant() == (64, True, False)          # the GL kernel the bench line times
+    env.reset(seeds=1234 + np.arange(B))
+    u, n_trunc = _soak(env, cfg, B, 1200, 1, check_every=200)
+    assert int(n_trunc.max()) <= 3
+    tm = env.info("time_max").cpu().numpy()
+    assert tm.min() >= 426 and tm.max() <= 1121              # int(5 * dist / ws), ws in [7, 15], 1280 m <= dist <= 1568 m
+    ws = env.info("ws_global").cpu().numpy()
+    assert (u.max(axis=1) <= ws * (1 + 1e-5)).all() and (u.min(axis=1) < ws - 0.02).all()   # every farm is waked
+
+
 def test_soak_cfg3_horns_rev_512_envs(hip):
     """cfg3 at its per-GPU bench size: Horns Rev 1 (80 turbines) x 512 envs x 2 farms, compact / pair-major variant at
     256 threads with chunked targets, >= 2 rollovers per env (n_passthrough 1.5 keeps the run short: ~620-1330 steps per

@@ -32,7 +32,7 @@ UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 ABI_SYMBOLS = (
     "wg_last_error", "wg_abi_version", "wg_create", "wg_destroy", "wg_obs_dim", "wg_hist_max",
     "wg_set_turbulence_box", "wg_set_turbulence_boxes", "wg_set_added_turbulence_box", "wg_set_box_ids", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_set_step_graph", "wg_check", "wg_obs_multi", "wg_set_obs_multi_buffer",
-    "wg_get_info", "wg_get_measurements", "wg_get_windspeed", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_algorithmic_bytes", "wg_flow_variant",
+    "wg_get_info", "wg_get_measurements", "wg_get_windspeed", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_added_lookups", "wg_algorithmic_bytes", "wg_flow_variant",
 )
 
 _lib = None
@@ -86,6 +86,7 @@ def load_library():
     L.wg_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.wg_kernel_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.wg_added_lookups.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.wg_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.wg_flow_variant.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _lib = L
@@ -350,6 +351,13 @@ class HipBatch:
         _chk(self.L.wg_kernel_timing(self._h, int(enable), C.byref(f), C.byref(g), C.byref(n), C.byref(fs),
                                      C.byref(pt)), "wg_kernel_timing")
         return f.value, g.value, n.value, fs.value, pt.value
+
+    def added_lookups(self):
+        """Rotor points per flow launch at which the wake-added turbulence box was looked up (window of the last
+        kernel_timing call)."""
+        v = C.c_double()
+        _chk(self.L.wg_added_lookups(self._h, C.byref(v)), "wg_added_lookups")
+        return v.value
 
     def algorithmic_bytes(self):
         v = C.c_double()

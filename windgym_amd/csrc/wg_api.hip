@@ -51,7 +51,8 @@ struct wg_env_s {
     WgPtrs d;
     FlowP fp;
     FlowPtrs fd;
-    unsigned long long flow_steps_mark = 0, particles_mark = 0;
+    unsigned long long flow_steps_mark = 0, particles_mark = 0, added_mark = 0;
+    double added_per_launch = 0.0;  // window closed by the last wg_kernel_timing
     long n_step_launches = 0;
     void* box4 = nullptr;            // interleaved copy of the caller's turbulence box (owned)
     void* box4c = nullptr;           // block-averaged copy for the particle lookups (owned)
@@ -713,6 +714,14 @@ extern "C" int wg_set_box_ids(wg_handle h, const int32_t* ids_host) {
     HIPCHK(hipDeviceSynchronize());
     drop_step_graphs(h);
     if (!ids_host) { h->d.box_override = nullptr; return sync_dev_params(h); }
+    // (a caller error must not produce results labelled with the wrong box: wg_ctx_init would fold a bad id to box 0 and
+    // ignores the table without a pool)
+    if (h->p.turb_mode != WG_TURB_BOX_POOL || h->p.n_boxes < 1)
+        return fail(WG_ERR_INVALID, "wg_set_box_ids: the handle has no box pool (turb_mode WG_TURB_BOX_POOL + wg_set_turbulence_boxes first)");
+    for (int b = 0; b < h->p.B; ++b)
+        if (ids_host[b] >= h->p.n_boxes)
+            return fail(WG_ERR_INVALID, "wg_set_box_ids: env " + std::to_string(b) + " asks for box " + std::to_string(ids_host[b]) +
+                                            " of a pool of " + std::to_string(h->p.n_boxes));
     if (!h->box_ids_dev) {
         int* w = nullptr;
         int rc = dev_alloc(h, &w, (size_t)h->p.B, false);
@@ -904,16 +913,23 @@ extern "C" int wg_check(wg_handle h, void* stream) {
     HIPCHK(hipMemcpyAsync(&status, h->d.status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     HIPCHK(hipGetLastError());
-    if (status == WG_ERR_NAN_POWER) return fail(status, "NaN Power");
-    if (status == WG_ERR_STATE) return fail(status, "step() on a truncated env without reset (or background episode not ready)");
-    if (status == WG_ERR_RANGE)
-        return fail(status, "a wake particle's emission record left its 16-bit range (k > 0.25: local TI > 0.65, or |hv| > 16 m/s: "
+    // (a bit mask: reported by priority — the reference treats the first two as fatal exceptions)
+    if (status & WG_STATUS_BIT_NAN_POWER) return fail(WG_ERR_NAN_POWER, "NaN Power");
+    if (status & WG_STATUS_BIT_STATE)
+        return fail(WG_ERR_STATE, "step() on a truncated env without reset (or background episode not ready)");
+    if (status & WG_STATUS_BIT_RANGE)
+        return fail(WG_ERR_RANGE, "a wake particle's emission record left its 16-bit range (k > 0.25: local TI > 0.65, or |hv| > 16 m/s: "
                             "rotor wind speed > 40 m/s) and was saturated");
-    return status;
+    return 0;
 }
 
 extern "C" int wg_set_obs_multi_buffer(wg_handle h, float* obs_multi_dev) {
     if (!h) return fail(WG_ERR_INVALID, "null handle");
+    // k_glue keeps one farm block per wave in LDS for the per-agent packing (wg_launch_glue): it must fit a workgroup's
+    // 64 KB by itself (the staged rings give way first)
+    if (obs_multi_dev && (size_t)h->p.farm_obs * 4 * WG_NWAVES > 65536)
+        return fail(WG_ERR_UNSUPPORTED, "wg_set_obs_multi_buffer: the farm-level observation block is too long for the fused "
+                                        "per-agent packing (use wg_obs_multi)");
     if (h->d.multi_out != obs_multi_dev) drop_step_graphs(h);
     h->d.multi_out = obs_multi_dev;     // borrowed; written by k_glue in every following wg_step / wg_reset
     if (int rc = use_device(h)) return rc;
@@ -1033,12 +1049,12 @@ extern "C" int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, do
                                 double* flow_steps_per_launch, double* particles_per_launch) {
     if (!h) return fail(WG_ERR_INVALID, "null handle");
     HIPCHK(hipDeviceSynchronize());
-    unsigned long long fs_now = 0, pt_now = 0;
+    unsigned long long fs_now = 0, pt_now = 0, ad_now = 0;
     {
         const size_t n_slots = (size_t)h->p.B * 2 * h->p.F;
         std::vector<WgSlot> slots(n_slots);
         HIPCHK(hipMemcpy(slots.data(), h->d.slot, sizeof(WgSlot) * n_slots, hipMemcpyDeviceToHost));
-        for (const WgSlot& s : slots) { fs_now += s.flow_count; pt_now += s.part_count; }
+        for (const WgSlot& s : slots) { fs_now += s.flow_count; pt_now += s.part_count; ad_now += s.add_count; }
     }
     double fsum = 0, gsum = 0;
     int nf = 0, ng = 0;
@@ -1062,6 +1078,8 @@ extern "C" int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, do
         const double per_launch = h->n_step_launches ? 1.0 / h->n_step_launches : 0.0;
         *particles_per_launch = (double)(pt_now - h->particles_mark) * per_launch;
     }
+    h->added_per_launch = h->n_step_launches ? (double)(ad_now - h->added_mark) / h->n_step_launches : 0.0;
+    h->added_mark = ad_now;
     h->n_step_launches = 0;
     h->flow_steps_mark = fs_now;
     h->particles_mark = pt_now;
@@ -1077,6 +1095,12 @@ extern "C" int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, do
         }
         h->ev_kind.assign(WG_MAX_TIMING_EVENTS / 2, 0);
     }
+    return 0;
+}
+
+extern "C" int wg_added_lookups(wg_handle h, double* rotor_points_per_launch) {
+    if (!h || !rotor_points_per_launch) return fail(WG_ERR_INVALID, "null argument");
+    *rotor_points_per_launch = h->added_per_launch;
     return 0;
 }
 

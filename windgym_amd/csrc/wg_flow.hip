@@ -326,7 +326,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                                           unsigned* tmask, int* jnl,
                                           const size_t pbase, const double ws,
                                           const float ti_f, const float ti_pow, const TurbCtx& tc, SlotRegs& sr,
-                                          const PartLds& pl, const bool first_step) {
+                                          const PartLds& pl, const bool first_step, int& add_acc) {
     const int tid = threadIdx.x;
     const int N = p.N, P = p.P;
     if (RES) __builtin_assume(N <= NT);
@@ -498,7 +498,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         q.reps = p.eps0 * __builtin_amdgcn_sqrtf(beta);
         q.rhv = -p.hill * sg * q.u;
         // the packed record saturates outside [0, WG_K_MAX] x [-WG_HV_MAX, WG_HV_MAX]: never silently (wg_check reports it)
-        if (q.rk > WG_K_MAX || fabsf(q.rhv) > WG_HV_MAX) atomicMin(wg_cold_args()->d.status, (int)WG_ERR_RANGE);
+        if (q.rk > WG_K_MAX || fabsf(q.rhv) > WG_HV_MAX) atomicOr(wg_cold_args()->d.status, WG_STATUS_BIT_RANGE);
         q.rue = q.u;
         q.cg = cg;
         q.sg = sg;
@@ -705,6 +705,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 const int tl = it >> p.S_shift, s = it & (p.S_pad - 1);
                 if (s >= p.S || !gflag[tl]) continue;
                 const int t = t0 + tl;
+                ++add_acc;                    // (roofline accounting: one 8-corner lookup of the isotropic box)
                 float g3[3];
                 abox_lookup(p, d, T[t].xr - tc.ws * sr.time + tc.ox, T[t].yr + (double)(rdy[s] * T[t].cg) + tc.oy,
                             p.hub_d + (double)rdz[s], g3);
@@ -1468,7 +1469,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                         if (p.box_pow2) box_lookup<true>(tc.box4, p, bx, by, bz, amb);
                         else box_lookup<false>(tc.box4, p, bx, by, bz, amb);
                     }
-                    if (ADDED) abox_lookup(p, d, bx, by, bz, g3);
+                    if (ADDED) { abox_lookup(p, d, bx, by, bz, g3); ++add_acc; }
                 }
                 for (int wd = 0; wd * 32 < N; ++wd) {
                     unsigned m = tmask[tl * WG_MASK_WORDS + wd];
@@ -1791,7 +1792,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         }
         q.sws = 0.f; q.swd = 0.f; q.syaw = 0.f; q.sp = 0.f;
     }
-    if (tid == 0) jnl[N] = 0;
+    if (tid == 0) { jnl[N] = 0; jnl[N + 3] = 0; }
     if (tid < p.n_tab) { tabp[tid] = pf_tp; tabct[tid] = pf_tc; }
     if (tid < p.S) { rdy[tid] = pf_dy; rdz[tid] = pf_dz; }
     for (int i = tid + NT; i < p.n_tab; i += NT) { tabp[i] = d.tab_power[i]; tabct[i] = d.tab_ct[i]; }
@@ -1830,7 +1831,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     // live:   one env step = K sub-steps with measurement (Wind_Farm_Env.py:932-979)
     // else:   background development of a not-yet-live episode: flow-development steps (fs.run), then
     //         window-fill env steps (Wind_Farm_Env.py:722-796)
-    int sub = 0, n_flow = 0, part_acc = 0;
+    int sub = 0, n_flow = 0, part_acc = 0, add_acc = 0;
     float base_acc = 0.f;
     const float inv_k = 1.0f / (float)p.K;
     // (GL variant: a further flow step of the launch gathers what this step's advection pass stored — the wait sits on the
@@ -1864,7 +1865,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
             // sin/cos are not needed in replay mode: power comes from the script
             script_step<NT>(p, d, T, e, farm, cursor, sr.time);
         } else {
-            flow_step<NT, TURB, RES, SGM>(p, d, T, tabct, rdy, rdz, pair, tiap, tmask, jnl, pbase, ws, ti_f, ti_pow, tc, sr, pl, n_flow == 0);
+            flow_step<NT, TURB, RES, SGM>(p, d, T, tabct, rdy, rdz, pair, tiap, tmask, jnl, pbase, ws, ti_f, ti_pow, tc, sr, pl, n_flow == 0, add_acc);
             // roofline accounting: particles that can still reach a rotor (per lane; summed once in the epilogue)
             for (int t = tid; t < N; t += NT) part_acc += min(sr.n_valid, RES ? T[t].rlen : jnl[t] + 1);
             ++n_flow;
@@ -1964,15 +1965,19 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     if (NT > WG_WAVE) {          // (multi-wave workgroups: per-wave partial sums meet in the LDS word)
         part_acc = wg_wave_sum_i(part_acc);
         if ((tid & 63) == 0) atomicAdd(&jnl[N], part_acc);
+        if (TURB != WG_TURB_NONE) { add_acc = wg_wave_sum_i(add_acc); if ((tid & 63) == 0) atomicAdd(&jnl[N + 3], add_acc); }
         lds_barrier<NT>();
         part_acc = jnl[N];
+        if (TURB != WG_TURB_NONE) add_acc = jnl[N + 3];
     } else {
         part_acc = wg_wave_sum_i(part_acc);
+        if (TURB != WG_TURB_NONE) add_acc = wg_wave_sum_i(add_acc);
     }
     if (tid == 0) {
         WgSlot& slot = ke->d.slot[slot_id];
         WgCtx& cx = ke->d.ctx[ctx_id];
         slot.part_count = part0 + (unsigned)part_acc;
+        if (TURB != WG_TURB_NONE && add_acc != 0) slot.add_count += (unsigned)add_acc;
         slot.head = sr.head; slot.n_valid = sr.n_valid; slot.s_off = sr.s_off; slot.time = sr.time;
         slot.istep = sr.istep; slot.n_emitted = sr.n_emitted;
         slot.cursor = cursor;

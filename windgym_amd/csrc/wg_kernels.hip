@@ -156,7 +156,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         WgCtx& cx = d.ctx[ctx_id];
         if (lane < p.F) {     // wg_reset develops until every slot is ready; anything else is a bug
             const WgSlot& sl = d.slot[ctx_id * p.F + lane];
-            if (sl.dev_remaining != 0 || sl.fill_remaining != 0) atomicMin(d.status, (int)WG_ERR_STATE);
+            if (sl.dev_remaining != 0 || sl.fill_remaining != 0) atomicOr(d.status, WG_STATUS_BIT_STATE);
         }
         if (lane == 0) {
             const int nf = cx.pend_farm_n < p.power_avg ? cx.pend_farm_n : p.power_avg;
@@ -186,7 +186,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     }
 
     if (env.done) {
-        if (lane == 0) atomicMin(d.status, (int)WG_ERR_STATE);
+        if (lane == 0) atomicOr(d.status, WG_STATUS_BIT_STATE);
         return;
     }
     // Work on a register copy of the env header: through the reference every field access is a dependent
@@ -281,7 +281,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     if (lane == 0) {
         fq[fslot] = fp;
         if (p.F == 2) bq[bslot] = bp;
-        if (fp != fp) atomicMin(d.status, (int)WG_ERR_NAN_POWER);
+        if (fp != fp) atomicOr(d.status, WG_STATUS_BIT_NAN_POWER);
     }
     // observation (:983)
     float* fin = final_obs_out ? final_obs_out + (size_t)e * p.obs_dim : nullptr;
@@ -378,7 +378,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         // fill (:766, :796; lane q moves entry q): independent loads, one round trip
         if (lane < p.F) {
             const WgSlot& sl = d.slot[nctx * p.F + lane];
-            if (sl.dev_remaining != 0 || sl.fill_remaining != 0) atomicMin(d.status, (int)WG_ERR_STATE);
+            if (sl.dev_remaining != 0 || sl.fill_remaining != 0) atomicOr(d.status, WG_STATUS_BIT_STATE);
         }
         for (int q = lane; q < nf; q += WG_WAVE)
             fq[(ev.farm_pow_n + q) % p.power_avg] = deque_at(d.pend_farm + (size_t)nctx * p.power_avg, pfn, p.power_avg, q);
@@ -657,9 +657,12 @@ extern "C" void wg_launch_glue(const WgParams* p, const WgPtrs* d, int phase, co
                                float* reward, uint8_t* trunc, float* final_obs, hipStream_t st) {
     const int grid = (p->B + WG_NWAVES - 1) / WG_NWAVES;
     // rings of one env staged in LDS when they fit (<= 16 KiB per wave); otherwise read from global memory
+    // (the per-agent buffer's farm-block scratch shares the wave's region: the fit is decided on the sum, so that the
+    // workgroup's request never exceeds the 64 KB no kernel opts in beyond — ADVICE r3)
     int ring_floats = p->ring_stride + p->fring_stride;
-    if (ring_floats * 4 > 16384) ring_floats = 0;
-    const int per_wave = ring_floats + (d->multi_out ? p->farm_obs : 0);
+    const int scratch = d->multi_out ? p->farm_obs : 0;
+    if ((size_t)(ring_floats + scratch) * 4 > 16384) ring_floats = 0;
+    const int per_wave = ring_floats + scratch;
     const size_t lds = (size_t)per_wave * 4 * WG_NWAVES;
     // lanes per turbine in the observation's window sums: the largest power of two with N * L <= 64 (16 turbines: 4,
     // 9: 4, 80: 1)

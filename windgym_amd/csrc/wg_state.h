@@ -26,6 +26,10 @@ typedef unsigned __int128 wg_u128;
 
 enum { WG_MODE_STEP = 0, WG_MODE_RESET = 1 };
 
+// Sticky device status word (WgPtrs::status): one bit per condition, latched with atomicOr, so that a saturated emission
+// record cannot hide a NaN power or a step on a finished env; wg_check reports the most serious one set.
+enum { WG_STATUS_BIT_NAN_POWER = 1, WG_STATUS_BIT_STATE = 2, WG_STATUS_BIT_RANGE = 4 };
+
 struct WgParams {
     int B, N, F, K, P, S, NP;
     float dt, D, inv_D, hub;
@@ -81,7 +85,7 @@ struct WgSlot {
     unsigned istep;      // flow steps since the farm was built (counter of the inflow random stream)
     unsigned part_count; // particles the advection passes streamed (roofline accounting, like flow_count)
     unsigned n_emitted;  // compact rings: particles each chain has emitted so far (ring head of turbine t = (n_emitted - 1) mod R_t)
-    unsigned pad_;
+    unsigned add_count;  // rotor points at which the wake-added turbulence box was looked up (roofline accounting: 96 B each)
 };
 
 // per episode context

@@ -239,7 +239,8 @@ class WindFarmVecEnv(_gym_vector_base()):
     def step(self, actions):
         t = self.torch
         if not isinstance(actions, t.Tensor):
-            self._actions.copy_(t.as_tensor(np.ascontiguousarray(actions, dtype=np.float32)).reshape(self.num_envs, self.n_turb))
+            # (np.array copies: a read-only view — np.broadcast_to in eval_sweep — must not be wrapped as a writable tensor)
+            self._actions.copy_(t.from_numpy(np.array(actions, dtype=np.float32, order="C")).reshape(self.num_envs, self.n_turb))
             actions = self._actions
         elif not (actions.is_cuda and actions.dtype == t.float32 and actions.is_contiguous()):
             self._actions.copy_(actions.reshape(self.num_envs, self.n_turb))
@@ -249,8 +250,13 @@ class WindFarmVecEnv(_gym_vector_base()):
         obs, rew, trunc, fin = self.batch.step(actions)
         term = t.zeros_like(trunc, dtype=t.bool)                         # terminated is always False (:1029)
         infos = self.infos(step=True)
+        trunc_b = self._out(trunc.bool())
+        # gymnasium's vector info convention: a value array plus a "_key" mask of the envs it is valid for.  final_obs stays
+        # a dense [B, obs_dim] array (rows of envs that did not truncate are unspecified) instead of gymnasium's per-env
+        # object array: no per-env host objects on the step path
         infos["final_obs"] = self._out(fin)
-        return self._out(obs), self._out(rew), self._out(term), self._out(trunc.bool()), infos
+        infos["_final_obs"] = trunc_b
+        return self._out(obs), self._out(rew), self._out(term), trunc_b, infos
 
     def infos(self, step=False):
         """Lazy info dict: values are fetched from the device on first access (keys of _get_info).  After a step(),
@@ -265,6 +271,7 @@ class WindFarmVecEnv(_gym_vector_base()):
 
     def close(self):
         self.batch.close()
+        self.closed = True          # gymnasium.vector.VectorEnv's flag (its own close() sets it after close_extras)
 
     def as_sb3(self):
         """The same batch behind stable-baselines3's ``VecEnv`` protocol (see :class:`SB3VecEnv`)."""

@@ -152,7 +152,10 @@ class AgentEval:
         self.multiple_eval_ds = eval_sweep(self._turbine, self._yaml, self.model, winddirs=self.winddirs,
                                            windspeeds=self.windspeeds, turbintensities=self.turbintensities,
                                            t_sim=self.t_sim, turbbox=self.turbboxes[0],
-                                           turbboxes=self.turbboxes if len(self.turbboxes) > 1 else None, **kw)
+                                           # (the reference calls set_condition(turbbox=box) for EVERY entry, also a single one: a real path is
+                                           # loaded and pinned, only the placeholder "Default" means the env's own inflow)
+                                           turbboxes=self.turbboxes if any(not (isinstance(tb, str) and tb == "Default")
+                                                                           for tb in self.turbboxes) else None, **kw)
         self.multiple_eval = True
         return self.multiple_eval_ds
 
