@@ -330,6 +330,21 @@ int wg_set_state(wg_handle h, const void* blob_host, size_t size);
 int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, double* glue_ms_avg, int* n_launches,
                      double* flow_steps_per_launch, double* particles_per_launch);
 
+/* Mann spectral-tensor turbulence box generated on the device — MannTurbulenceField.generate(alphaepsilon, L, Gamma, Nxyz,
+ * dxyz, seed) of hipersim / dynamiks behind turbtype "MannFixed" / "MannGenerate" (Wind_Farm_Env.py:624-637, :649-658;
+ * tests/test_basics.py:38-45).  box_dev: f32[3][nx][ny][nz] (z fastest: what wg_set_turbulence_box takes), normalised to
+ * unit standard deviation of u (the reference rescales with scale_TI(TI, U); the kernels multiply by TI * U per env).
+ * noise_dev: optional complex white noise f32[3][nx][ny][nz][2] (E|n|^2 = 1) to use instead of the built-in Philox stream
+ * keyed by `seed` — lets a test feed the identical noise to a CPU restatement.  Sheared von Karman tensor per wave-number
+ * cell in a HIP kernel, three in-place inverse C2C transforms in hipFFT, synchronous on `stream`.  No handle needed.   */
+int wg_generate_mann_box(int device, float* box_dev, int nx, int ny, int nz, double dx, double dy, double dz,
+                         double alphaepsilon, double L, double Gamma, uint64_t seed, const float* noise_dev, void* stream);
+
+/* Host only: the eddy-lifetime factor beta(kL) = Gamma (kL)^(-2/3) / sqrt(2F1(1/3, 17/6; 4/3; -(kL)^-2)) (Mann 1998) on n
+ * log-spaced points kL = 10^[log10_lo, log10_hi] — the table wg_generate_mann_box interpolates (4096 points over
+ * [1e-6, 1e6]); exported so that tests pin it against an independent 2F1.                                               */
+int wg_mann_beta_table(double Gamma, int n, double log10_lo, double log10_hi, double* beta_out);
+
 /* Rotor points at which one flow launch looked the wake-added turbulence box up (8 corners x (u, v, w) = 96 bytes each:
  * only the rotors of targets with a candidate source wake do), averaged over the window the LAST wg_kernel_timing call
  * closed — the a7 term of bench.py's algorithmic bytes.  0 without wg_config.added_turbulence.                              */

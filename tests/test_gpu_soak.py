@@ -57,7 +57,9 @@ def test_soak_cfg2_headline_batch_4096_envs(hip):
     tm = env.info("time_max").cpu().numpy()
     assert tm.min() >= 426 and tm.max() <= 1121              # int(5 * dist / ws), ws in [7, 15], 1280 m <= dist <= 1568 m
     ws = env.info("ws_global").cpu().numpy()
-    assert (u.max(axis=1) <= ws * (1 + 1e-5)).all() and (u.min(axis=1) < ws - 0.02).all()   # every farm is waked
+    # (among 4096 sampled wind directions a few leave every rotor of the 5.33 D grid outside the 5-sigma cut-off of the
+    # upstream wakes: "waked" holds for the batch, not for every single env)
+    assert (u.max(axis=1) <= ws * (1 + 1e-5)).all() and (u.min(axis=1) < ws - 0.02).mean() > 0.98
 
 
 def test_soak_cfg3_horns_rev_512_envs(hip):

@@ -32,7 +32,7 @@ UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 ABI_SYMBOLS = (
     "wg_last_error", "wg_abi_version", "wg_create", "wg_destroy", "wg_obs_dim", "wg_hist_max",
     "wg_set_turbulence_box", "wg_set_turbulence_boxes", "wg_set_added_turbulence_box", "wg_set_box_ids", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_set_step_graph", "wg_check", "wg_obs_multi", "wg_set_obs_multi_buffer",
-    "wg_get_info", "wg_get_measurements", "wg_get_windspeed", "wg_metrics", "wg_get_state", "wg_set_state", "wg_kernel_timing", "wg_added_lookups", "wg_algorithmic_bytes", "wg_flow_variant",
+    "wg_get_info", "wg_get_measurements", "wg_get_windspeed", "wg_metrics", "wg_get_state", "wg_set_state", "wg_generate_mann_box", "wg_mann_beta_table", "wg_kernel_timing", "wg_added_lookups", "wg_algorithmic_bytes", "wg_flow_variant",
 )
 
 _lib = None
@@ -87,6 +87,9 @@ def load_library():
     L.wg_kernel_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.wg_added_lookups.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.wg_generate_mann_box.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                       C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.wg_mann_beta_table.argtypes = [C.c_double, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]
     L.wg_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.wg_flow_variant.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _lib = L

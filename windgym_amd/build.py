@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwindgym_hip.so")
-SOURCES = ["wg_flow.hip", "wg_kernels.hip", "wg_api.hip"]
+SOURCES = ["wg_flow.hip", "wg_kernels.hip", "wg_api.hip", "wg_mann.hip"]
 HEADERS = ["wg_state.h", "wg_device.h", "wg_obs.h", "wg_flow.h", "wg_flow_duo.inc", os.path.join("..", "..", "include", "windgym_hip.h")]
 
 
@@ -45,7 +45,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
                     if other.poll() is None:
                         other.kill()
                 raise subprocess.CalledProcessError(pr.returncode, cmd)
-        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, check=True)
+        # (hipFFT: the one library call on the box-generation path, wg_mann.hip)
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lhipfft"], check=True)
     return LIB
 
 

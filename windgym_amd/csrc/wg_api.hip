@@ -34,6 +34,8 @@ static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+// (other translation units of the library report through the same thread-local message: wg_mann.hip)
+extern "C" int wg_set_last_error_(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 #define HIPCHK(x)                                                                                   \
     do {                                                                                            \
         hipError_t _e = (x);                                                                        \
@@ -266,6 +268,35 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         p.stage_ch[i] = st;
     }
 
+    // Sums mode: every rolling mean the observation reads has history_N = 1, i.e. it is the mean of the newest
+    // min(window, history, pushed) samples (Mes.get_measurements' first window, MesClass.py:85-91) — a window that
+    // slides by exactly one sample per push.  The flow kernels then keep the window sums (and the ws deque's sum / sum of
+    // squares for calc_TI) up to date at every push, and the glue kernel reads those instead of staging the rings
+    // (Env1.yaml: 2 doubles per turbine instead of 35 ring floats behind two dependent round trips).  Configurations with
+    // several windows per channel (2turb.yaml: history_N = 100) keep the ring-staging path.  WG_SUMS=0 forces that path
+    // (tests compare the two).
+    {
+        bool ok = true;
+        for (int i = 0; i < WG_N_CH; ++i) {
+            const bool used = p.turb_on[i] || (i != WG_CH_YAW && p.farm_on[i]);
+            if (used && c->ch[i].rolling_mean && c->ch[i].history_n != 1) ok = false;
+        }
+        if (const char* ev = getenv("WG_SUMS")) if (atoi(ev) == 0) ok = false;
+        p.sums_mode = ok ? 1 : 0;
+        if (ok) {
+            for (int i = 0; i < WG_N_CH; ++i) {
+                p.sum_w[i] = std::min(c->ch[i].window_len, c->ch[i].history_len);
+                if (p.turb_on[i] && c->ch[i].rolling_mean) p.sum_mask_t |= 1u << i;
+                if (p.turb_on[i] && c->ch[i].current) p.cur_mask_t |= 1u << i;
+                if (i != WG_CH_YAW && p.farm_on[i] && c->ch[i].rolling_mean) p.sum_mask_f |= 1u << i;
+                if (i != WG_CH_YAW && p.farm_on[i] && c->ch[i].current) p.cur_mask_f |= 1u << i;
+            }
+            p.sum_w[WG_SUM_TI1] = p.sum_w[WG_SUM_TI2] = c->ch[WG_CH_WS].history_len;
+            if (c->turb_ti || c->farm_ti) p.sum_mask_t |= (1u << WG_SUM_TI1) | (1u << WG_SUM_TI2);
+            if (c->farm_ti) p.sum_mask_f |= (1u << WG_SUM_TI1) | (1u << WG_SUM_TI2);
+        }
+    }
+
     WgPtrs& d = h->d;
     memset(&d, 0, sizeof(d));
     const size_t n_slots = (size_t)p.B * 2 * p.F, n_ctx = (size_t)p.B * 2;
@@ -300,6 +331,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     A(last_pow_agent, (size_t)p.B, true); A(last_pow_base, (size_t)p.B, true);
     A(metrics, (size_t)p.B * WG_N_METRICS, true);
     A(next_obs, n_ctx * (size_t)p.obs_dim, false); A(next_obs_ok, n_ctx, false);
+    if (p.sums_mode) { A(wsum, n_ctx * WG_N_SUMS * (size_t)(p.N + 1), true); A(wcur, n_ctx * WG_N_CH * (size_t)(p.N + 1), true); }
     A(status, 1, true);
 #undef A
     if (!rc) rc = dev_alloc(h, &h->mask_dev, (size_t)p.B, false);
@@ -536,6 +568,10 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         g.rotor_dy = d.rotor_dy; g.rotor_dz = d.rotor_dz; g.tab_power = tpu; g.tab_ct = tcu;
         g.gp = h->p_dev; g.gd = h->d_dev; g.env_rw = d.env;
         g.roff = d.roff; g.qown = d.qown; g.status = d.status;
+        g.wsum = d.wsum; g.wcur = d.wcur;
+        f.sums_mode = p.sums_mode; f.sum_mask_t = p.sum_mask_t; f.sum_mask_f = p.sum_mask_f;
+        f.cur_mask_t = p.cur_mask_t; f.cur_mask_f = p.cur_mask_f;
+        for (int i = 0; i < WG_N_SUMS; ++i) f.sum_w[i] = p.sum_w[i];
     }
 
     // how many RESET-mode launches develop the slowest possible episode: the chain needs
@@ -566,7 +602,8 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     // The first observation of a background episode is built inside k_flow only by the single-wave steady variant (small
     // farms: one wave reads 35 floats per turbine; measured on the multi-wave variants — cfg3, cfg5 — the building
     // workgroup became the flow kernel's tail: -5 % / -1.3 %).  Other handles keep the glue's own second build.
-    if (!(h->fp.gl && !h->fp.duo)) { d.next_obs = nullptr; d.next_obs_ok = nullptr; }
+    // (sums mode: the glue reads the next episode's window sums directly — nothing to prepare)
+    if (!(h->fp.gl && !h->fp.duo) || p.sums_mode) { d.next_obs = nullptr; d.next_obs_ok = nullptr; }
     wg_launch_create(&p, &d, nullptr);
     if (sync_dev_params(h)) { wg_destroy(h); return WG_ERR_HIP; }
     {

@@ -317,6 +317,11 @@ __device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, c
         cx.episode_tag = episode_tag;
     }
     ws = __shfl(ws, 0, 64); ti = __shfl(ti, 0, 64); wd = __shfl(wd, 0, 64);
+    // sums mode: the new episode's deques are empty (one writer, like n_pushed: farm 0's set-up)
+    if (f_lo == 0 && d.wsum) {
+        double* wsm = d.wsum + (size_t)ctx_id * WG_N_SUMS * (N + 1);
+        for (int i = lane; i < WG_N_SUMS * (N + 1); i += WG_WAVE) wsm[i] = 0.0;
+    }
     {
         const double rp = wg_tab_interp_wave<double>(d.tab_ws_d, d.tab_power_d, p.n_tab, ws, lane);   // :700
         if (lane == 0) cx.rated_power = (float)rp;

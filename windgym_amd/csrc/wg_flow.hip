@@ -111,6 +111,46 @@ __device__ __forceinline__ int umod_small(int n, int H, unsigned magic) {
     return r;
 }
 
+// Sums mode (WgParams::sums_mode): one sensor push of entity `ent` (turbine t, or N = the farm-level deques) updates the
+// running window sums the glue kernel reads — S += new - leaving, where `leaving` is the sample that drops out of the
+// window: pushed min(window, history) pushes ago, still in the ring (when the window spans the whole history it sits in
+// the very slot this push overwrites: call this BEFORE the ring stores, with the same ring pointer, so the accesses stay
+// ordered).  `val` = the values being pushed (after noise), ring element of channel ch, row r = ring[off[ch] + r * stride +
+// idx] with off = FlowP::fring_off (farm_level) or ring_off.  P / D: the by-value parameter blocks or their kernarg-segment (address space 4) views.
+template <typename P, typename D>
+__device__ __forceinline__ void wg_sums_push(const P& p, const D& d, const int ctx_id, const int ent, const unsigned smask,
+                                             const unsigned cmask, const float* val, const int n_pushed,
+                                             const float* ring, const bool farm_level, const int stride, const int idx) {
+    const int NS = p.N + 1;
+    double* ws_ = d.wsum + (size_t)ctx_id * WG_N_SUMS * NS + ent;
+    float* wc_ = d.wcur + (size_t)ctx_id * WG_N_CH * NS + ent;
+    double S[WG_N_SUMS];
+    float lv[WG_N_SUMS];
+    // (all loads first: one memory round trip for the push, not one per slot)
+#pragma unroll
+    for (int s = 0; s < WG_N_SUMS; ++s) {
+        S[s] = 0.0; lv[s] = 0.f;
+        if ((smask >> s) & 1u) {
+            const int ch = s < WG_N_CH ? s : WG_CH_WS;
+            const int Wc = p.sum_w[s];
+            S[s] = ws_[(size_t)s * NS];
+            if (n_pushed >= Wc) lv[s] = ring[(farm_level ? p.fring_off[ch] : p.ring_off[ch]) + umod_small(n_pushed - Wc, p.hlen[ch], p.hmagic[ch]) * stride + idx];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < WG_N_SUMS; ++s) {
+        if ((smask >> s) & 1u) {
+            const int ch = s < WG_N_CH ? s : WG_CH_WS;
+            double v = (double)val[ch], l = (double)lv[s];
+            if (s == WG_SUM_TI2) { v = v * v; l = l * l; }
+            ws_[(size_t)s * NS] = (S[s] - l) + v;
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < WG_N_CH; ++ch)
+        if ((cmask >> ch) & 1u) wc_[(size_t)ch * NS] = val[ch];
+}
+
 // uniform-grid table lookup (linear interpolation, 0 outside)
 __device__ __forceinline__ float tab_lookup(const float* __restrict__ ys, const FlowP& p, float x) {
     const float fx = (x - p.tab_x0) * p.tab_inv_dx;
@@ -1905,6 +1945,8 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
                                 val[ch] += kc->p.noise_sigma[ch] * wg_noise_normal(noise_key, (uint32_t)n_pushed, (uint32_t)t,
                                                                                    (uint32_t)ch, episode_tag);
                     }
+                    if (kc->p.sums_mode)
+                        wg_sums_push(kc->p, kc->d, ctx_id, t, kc->p.sum_mask_t, kc->p.cur_mask_t, val, n_pushed, rbase, false, N, t);
 #pragma unroll
                     for (int ch = 0; ch < WG_N_CH; ++ch) {
                         const int H = kc->p.hlen[ch];
@@ -1928,6 +1970,10 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
                 if (tid == 0) {
                     const FlowP __attribute__((address_space(4)))& pc = kc->p;
                     float* fbase = kc->d.fring + (size_t)ctx_id * pc.fring_stride;
+                    if (pc.sums_mode && (pc.sum_mask_f | pc.cur_mask_f)) {
+                        const float fval[WG_N_CH] = {sws * pc.inv_N, swd * pc.inv_N, 0.f, tot};
+                        wg_sums_push(pc, kc->d, ctx_id, N, pc.sum_mask_f, pc.cur_mask_f, fval, n_pushed, fbase, true, 1, 0);
+                    }
                     fbase[pc.fring_off[WG_CH_WS] + umod_small(n_pushed, pc.hlen[WG_CH_WS], pc.hmagic[WG_CH_WS])] = sws * pc.inv_N;
                     fbase[pc.fring_off[WG_CH_WD] + umod_small(n_pushed, pc.hlen[WG_CH_WD], pc.hmagic[WG_CH_WD])] = swd * pc.inv_N;
                     fbase[pc.fring_off[WG_CH_POWER] + umod_small(n_pushed, pc.hlen[WG_CH_POWER], pc.hmagic[WG_CH_POWER])] = tot;

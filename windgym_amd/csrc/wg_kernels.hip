@@ -131,7 +131,9 @@ __device__ inline void env_writeback(WgEnv& env, const EnvHot& ev, const int lan
 // PRE: the handle's flow kernel builds a background episode's first observation when its development completes
 // (WgPtrs::next_obs, single-wave steady variant): the swap copies it.  A template parameter so that the other
 // handles' instantiations are the code they were.
-template <bool MULTI, bool RL, int L, bool PRE>
+// SUMS: sums mode (WgParams::sums_mode) — the observation comes from the running window sums the flow kernels maintain;
+// no ring staging (RL = false, L = 1, PRE = false in these instantiations).
+template <bool MULTI, bool RL, int L, bool PRE, bool SUMS = false>
 __global__ void __launch_bounds__(WG_BLOCK, 4)
 k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restrict__ mask,
        float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out,
@@ -178,9 +180,15 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         }
         if (obs) {
             const int np1 = cx.n_pushed;
-            stage_rings<RL>(p, d, ctx_id, lane, my_lds, rbase, fbase, np1);
-            build_obs<L>(p, d, ctx_id, lane, obs, nullptr, rbase, fbase, false,
-                      MULTI ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr, np1, mscr);
+            if (SUMS) {
+                const ObsIn oi = wg_obs_load(p, d, ctx_id, lane < N ? lane : 0);
+                build_obs_sums<MULTI>(p, d, ctx_id, lane, obs, nullptr, MULTI ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr,
+                                      np1, mscr, oi);
+            } else {
+                stage_rings<RL>(p, d, ctx_id, lane, my_lds, rbase, fbase, np1);
+                build_obs<L>(p, d, ctx_id, lane, obs, nullptr, rbase, fbase, false,
+                          MULTI ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr, np1, mscr);
+            }
         }
         return;
     }
@@ -227,6 +235,9 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         l_yaw = d.yaw[tb_a + lane]; l_old = d.old_yaw[(size_t)e * N + lane]; l_pow = d.power[tb_a + lane];
         if (p.F == 2) l_powb = d.power[tb_a + N + lane];
     }
+    // (sums mode: this lane's turbine — a few doubles at addresses that depend on the context only)
+    ObsIn oi{};
+    if (SUMS) oi = wg_obs_load(p, d, ctx_id, lane < N ? lane : 0);
     float* met = d.metrics + (size_t)e * WG_N_METRICS;
     float l_met = lane < WG_N_METRICS ? met[lane] : 0.f;
     // (first 64 elements of the power deques: requested with the loads above, consumed by the deque loop below)
@@ -297,7 +308,11 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     // and not kept: requesting the next context's header, deferred deque entries and rings with the first staging
     // (swap block 12.7 k -> 7.7 k cycles, but the common path slowed by as much as the tail gained); s_setprio(3) for
     // the truncating wave: no effect.)
-    if (!swap_obs || fin) {
+    if (SUMS) {
+        if (swap_obs) { if (fin) build_obs_sums<false>(p, d, ctx_id, lane, fin, nullptr, nullptr, n_pushed_live, nullptr, oi); }
+        else if (obs) build_obs_sums<MULTI>(p, d, ctx_id, lane, obs, fin, MULTI ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr,
+                                            n_pushed_live, mscr, oi);
+    } else if (!swap_obs || fin) {
         stage_rings<RL>(p, d, ctx_id, lane, my_lds, rbase, fbase, n_pushed_live);
         if (WG_GLUE_ABLATE == 3) return;
         if (swap_obs) build_obs<L>(p, d, ctx_id, lane, fin, nullptr, rbase, fbase, false, nullptr, n_pushed_live);
@@ -403,7 +418,11 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
             // the next episode's first observation: built by the k_flow workgroup that completed its development
             // (wg_first_obs) — copied; otherwise (per-agent buffer, duo flow kernel, restored state) built here
             const bool pre = PRE && d.next_obs_ok[nctx] != 0;
-            if (pre) {
+            if (SUMS) {
+                const ObsIn on = wg_obs_load(p, d, nctx, lane < N ? lane : 0);
+                build_obs_sums<MULTI>(p, d, nctx, lane, obs, nullptr, MULTI ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr,
+                                      nnp, mscr, on);
+            } else if (pre) {
                 const float* no = d.next_obs + (size_t)nctx * p.obs_dim;
                 for (int i = lane; i < p.obs_dim; i += WG_WAVE) obs[i] = no[i];
             } else {
@@ -662,6 +681,7 @@ extern "C" void wg_launch_glue(const WgParams* p, const WgPtrs* d, int phase, co
     int ring_floats = p->ring_stride + p->fring_stride;
     const int scratch = d->multi_out ? p->farm_obs : 0;
     if ((size_t)(ring_floats + scratch) * 4 > 16384) ring_floats = 0;
+    if (p->sums_mode) ring_floats = 0;        // nothing is staged
     const int per_wave = ring_floats + scratch;
     const size_t lds = (size_t)per_wave * 4 * WG_NWAVES;
     // lanes per turbine in the observation's window sums: the largest power of two with N * L <= 64 (16 turbines: 4,
@@ -673,7 +693,12 @@ extern "C" void wg_launch_glue(const WgParams* p, const WgPtrs* d, int phase, co
 #define WG_GLUE_L(M, R, P) do { if (L == 1) WG_GLUE_LAUNCH(M, R, 1, P); else if (L == 2) WG_GLUE_LAUNCH(M, R, 2, P); \
                                 else if (L == 4) WG_GLUE_LAUNCH(M, R, 4, P); else WG_GLUE_LAUNCH(M, R, 8, P); } while (0)
     const bool pre = d->next_obs_ok != nullptr && !d->multi_out;
-    if (d->multi_out) { if (ring_floats > 0) WG_GLUE_L(true, true, false); else WG_GLUE_L(true, false, false); }
+    if (p->sums_mode) {
+        if (d->multi_out) hipLaunchKernelGGL((k_glue<true, false, 1, false, true>), dim3(grid), dim3(WG_BLOCK), lds, st, *p, *d, phase,
+                                             mask, obs, reward, trunc, final_obs, per_wave, ring_floats);
+        else hipLaunchKernelGGL((k_glue<false, false, 1, false, true>), dim3(grid), dim3(WG_BLOCK), lds, st, *p, *d, phase,
+                                mask, obs, reward, trunc, final_obs, per_wave, ring_floats);
+    } else if (d->multi_out) { if (ring_floats > 0) WG_GLUE_L(true, true, false); else WG_GLUE_L(true, false, false); }
     else if (pre) { if (ring_floats > 0) WG_GLUE_L(false, true, true); else WG_GLUE_L(false, false, true); }
     else { if (ring_floats > 0) WG_GLUE_L(false, true, false); else WG_GLUE_L(false, false, false); }
 #undef WG_GLUE_L

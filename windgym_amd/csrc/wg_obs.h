@@ -193,3 +193,122 @@ __device__ inline void build_obs(const WgParams& p, const WgPtrs& d, int ctx_id,
     }
 }
 
+// ===================================================================================================
+// Sums mode (WgParams::sums_mode): the same observation from the running window sums the flow kernels maintain
+// (WgPtrs::wsum / wcur) — per turbine a handful of values at addresses that depend on the context only, so the glue
+// kernel requests them together with the context header instead of staging the rings behind it.
+// ===================================================================================================
+struct ObsIn {
+    double S[WG_N_SUMS];
+    float cur[WG_N_CH];
+};
+// entity `ent`: turbine t, or N = the farm-level deques
+__device__ inline ObsIn wg_obs_load(const WgParams& p, const WgPtrs& d, const int ctx_id, const int ent) {
+    ObsIn o;
+    const int NS = p.N + 1;
+    const double* ws_ = d.wsum + (size_t)ctx_id * WG_N_SUMS * NS + ent;
+    const float* wc_ = d.wcur + (size_t)ctx_id * WG_N_CH * NS + ent;
+    const unsigned sm = ent == p.N ? p.sum_mask_f : p.sum_mask_t, cm = ent == p.N ? p.cur_mask_f : p.cur_mask_t;
+#pragma unroll
+    for (int s = 0; s < WG_N_SUMS; ++s) o.S[s] = ((sm >> s) & 1u) ? ws_[(size_t)s * NS] : 0.0;
+#pragma unroll
+    for (int ch = 0; ch < WG_N_CH; ++ch) o.cur[ch] = ((cm >> ch) & 1u) ? wc_[(size_t)ch * NS] : 0.f;
+    return o;
+}
+// mean of the newest min(window, available) samples: Mes.get_measurements' window 0 (MesClass.py:85-91)
+__device__ inline float wg_sums_mean(const WgParams& p, const ObsIn& o, const int ch, const int n_pushed) {
+    const int H = p.ch[ch].history_len, W = p.ch[ch].window_len;
+    const int avail = n_pushed < H ? n_pushed : H;
+    const int cnt = W < avail ? W : avail;
+    return (float)o.S[ch] / (float)cnt;
+}
+// turb_mes.calc_TI (MesClass.py:220-237) from the deque's sum and sum of squares
+__device__ inline float wg_sums_ti(const WgParams& p, const ObsIn& o, const int n_pushed) {
+    const int H = p.ch[WG_CH_WS].history_len;
+    const double n = (double)(n_pushed < H ? n_pushed : H);
+    const double U = o.S[WG_SUM_TI1] / n;
+    double var = o.S[WG_SUM_TI2] / n - U * U;
+    if (!(var > 0.0)) var = 0.0;
+    return (float)(sqrt(var) / U);
+}
+
+// `first`: wg_obs_load(ctx, lane) requested early by the caller (entity = this lane's first turbine; ignored for lanes >= N)
+template <bool MULTI>
+__device__ inline void build_obs_sums(const WgParams& p, const WgPtrs& d, const int ctx_id, const int lane,
+                                      float* __restrict__ obs, float* __restrict__ obs2, float* __restrict__ obs_m,
+                                      const int n_pushed, float* mscratch, const ObsIn& first) {
+    const int N = p.N;
+    float ti_sum = 0.f;
+    int n_turb_vals = 0;
+#define WG_EMIT(v_)                                                         \
+    do {                                                                    \
+        const float _v = (v_);                                              \
+        o[n] = _v;                                                          \
+        if (obs2) obs2[(size_t)t * p.turb_obs + n] = _v;                    \
+        if (MULTI && obs_m) obs_m[(size_t)t * p.obs_dim_multi + n] = _v;    \
+        ++n;                                                                \
+    } while (0)
+    for (int t = lane; t < N; t += WG_WAVE) {
+        const ObsIn oi = t == lane ? first : wg_obs_load(p, d, ctx_id, t);
+        float* o = obs + (size_t)t * p.turb_obs;
+        int n = 0;
+        const float ti = (p.turb_ti || p.farm_ti) ? wg_sums_ti(p, oi, n_pushed) : 0.f;
+#pragma unroll
+        for (int ch = 0; ch < WG_N_CH; ++ch) {
+            if (ch == WG_CH_POWER && p.turb_ti) WG_EMIT(wg_clip1(wg_scale(ti, p.ti_min_f, p.ti_rng_f)));
+            const bool on = p.turb_on[ch] != 0;
+            if (n_pushed == 0) continue;
+            if (p.ch[ch].current && on) WG_EMIT(wg_clip1(wg_scale(oi.cur[ch], p.sc_min[ch], p.sc_rng[ch])));
+            if (p.ch[ch].rolling_mean && on) WG_EMIT(wg_clip1(wg_scale(wg_sums_mean(p, oi, ch, n_pushed), p.sc_min[ch], p.sc_rng[ch])));
+        }
+        n_turb_vals = n;
+        if (p.farm_ti) ti_sum += wg_scale(ti, p.ti_min_f, p.ti_rng_f);   // mean of the *scaled* turbine TIs (MesClass.py:670-673)
+    }
+#undef WG_EMIT
+    const bool farm_any = p.farm_obs > 0 || (MULTI && obs_m != nullptr);
+    if (!farm_any) return;
+    if (p.farm_ti) ti_sum = wg_wave_sum(ti_sum);
+    // farm-level entity (lane 0): the farm deques' sums
+    ObsIn of{};
+    if (lane == 0 && (p.sum_mask_f | p.cur_mask_f)) of = wg_obs_load(p, d, ctx_id, N);
+    if (MULTI && obs_m) {
+        // the agents' farm_mes.farm_mes block (WindEnvMulti.py:90-92; wg_turb_block_b with farm_level): same for every
+        // agent — computed once into the wave's LDS scratch, clipped and copied behind each agent's turbine block
+        const int nt = __shfl(n_turb_vals, 0, 64);
+        int m = 0;
+        if (lane == 0) {
+#pragma unroll
+            for (int ch = 0; ch < WG_N_CH; ++ch) {
+                if (ch == WG_CH_POWER && p.farm_ti) mscratch[m++] = wg_scale(wg_sums_ti(p, of, n_pushed), p.ti_min_f, p.ti_rng_f);
+                if (ch == WG_CH_YAW || !p.farm_on[ch] || n_pushed == 0) continue;     // (the farm object's yaw deque is never filled)
+                const float rng = ch == WG_CH_POWER ? p.sc_rng_farm_power : p.sc_rng[ch];
+                if (p.ch[ch].current) mscratch[m++] = wg_scale(of.cur[ch], p.sc_min[ch], rng);
+                if (p.ch[ch].rolling_mean) mscratch[m++] = wg_scale(wg_sums_mean(p, of, ch, n_pushed), p.sc_min[ch], rng);
+            }
+        }
+        m = __shfl(m, 0, 64);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // single wave: program order suffices
+        for (int i = lane; i < N * m; i += WG_WAVE) {
+            const int t = i / m, k = i - t * m;
+            obs_m[(size_t)t * p.obs_dim_multi + nt + k] = wg_clip1(mscratch[k]);
+        }
+    }
+    if (lane == 0 && p.farm_obs > 0) {
+        float* o = obs + (size_t)N * p.turb_obs;
+        float* o2 = obs2 ? obs2 + (size_t)N * p.turb_obs : nullptr;
+        int n = 0;
+        const int chs[3] = {WG_CH_WS, WG_CH_WD, WG_CH_POWER};
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+            const int ch = chs[ci];
+            if (ch == WG_CH_POWER && p.farm_ti) { const float v = wg_clip1(ti_sum / (float)N); o[n] = v; if (o2) o2[n] = v; ++n; }
+            if (!p.farm_on[ch] || n_pushed == 0) continue;
+            const float rng = ch == WG_CH_POWER ? p.sc_rng_farm_power : p.sc_rng[ch];
+            if (p.ch[ch].current) { const float v = wg_clip1(wg_scale(of.cur[ch], p.sc_min[ch], rng)); o[n] = v; if (o2) o2[n] = v; ++n; }
+            if (p.ch[ch].rolling_mean) {
+                const float v = wg_clip1(wg_scale(wg_sums_mean(p, of, ch, n_pushed), p.sc_min[ch], rng));
+                o[n] = v; if (o2) o2[n] = v; ++n;
+            }
+        }
+    }
+}

@@ -26,6 +26,14 @@ typedef unsigned __int128 wg_u128;
 
 enum { WG_MODE_STEP = 0, WG_MODE_RESET = 1 };
 
+// Running window sums of the sensor deques (WgPtrs::wsum), maintained by the flow kernels at every push so that the glue
+// kernel reads a handful of values per turbine instead of staging the rings ("sums mode", wg_create).  Slot s < WG_N_CH: sum
+// of the newest min(window_len, history_len, pushed) samples of channel s — the one window a rolling mean with history_N
+// = 1 reads (MesClass.py:85-91); slots 4 / 5: sum of v and of v^2 over the whole ws deque (calc_TI, MesClass.py:220-237).
+// Double accumulators: adding and later subtracting the same float is exact, the sums do not drift.
+#define WG_N_SUMS 6
+enum { WG_SUM_TI1 = 4, WG_SUM_TI2 = 5 };
+
 // Sticky device status word (WgPtrs::status): one bit per condition, latched with atomicOr, so that a saturated emission
 // record cannot hide a NaN power or a step on a finished env; wg_check reports the most serious one set.
 enum { WG_STATUS_BIT_NAN_POWER = 1, WG_STATUS_BIT_STATE = 2, WG_STATUS_BIT_RANGE = 4 };
@@ -70,6 +78,11 @@ struct WgParams {
     int compact;         // 1: per-turbine ring lengths (small-farm k_flow variant), see WgPtrs::roff
     int stage_ch[WG_N_CH];   // k_glue ring staging per channel: 0 = not observed, 1 = newest sample only, 2 = whole ring
     double cx0, cy0;     // farm centre (mean of the layout), the pivot of the flow-frame rotation
+    // sums mode (every observed rolling mean has history_N = 1): which slots of WgPtrs::wsum / channels of WgPtrs::wcur
+    // are maintained at turbine level (_t) and for the farm-level deques (_f); sum_w[s] = min(window, history) of slot s
+    int sums_mode;
+    unsigned sum_mask_t, sum_mask_f, cur_mask_t, cur_mask_f;
+    int sum_w[WG_N_SUMS];
 };
 
 // per farm slot
@@ -161,6 +174,10 @@ struct WgPtrs {
     // itself).  Null unless the handle runs the single-wave steady flow kernel (wg_create).
     float* next_obs;          // [B*2][obs_dim]
     int* next_obs_ok;         // [B*2]
+    // sums mode: wsum[ctx][WG_N_SUMS][N + 1] running window sums (entity N = the farm-level deques), wcur[ctx][WG_N_CH][N + 1]
+    // the newest sample of every channel observed through `current`; null otherwise
+    double* wsum;
+    float* wcur;
     int* status;              // sticky error word
     const double* wind_override;   // [B][3] (ws, wd, ti) or null; NaN = keep the sampled value
     const int* box_override;       // [B] box of the pool env e uses (FarmEval.update_tf: TF_files = [path]) or null; < 0 = draw
