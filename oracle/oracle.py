@@ -203,3 +203,15 @@ class Oracle:
         n = self._f["get_chain"](self._h, C.c_int(b), C.c_int(farm), C.c_int(t), _d(py), _d(ue), _d(ct),
                                  C.byref(s))
         return py[:n], ue[:n], ct[:n], s.value
+
+
+def mann_noise(seed, Nxyz):
+    """The complex white noise wg_generate_mann_box draws for ``seed`` (Philox stream of wg_mann.hip, restated in
+    rng_api.c): complex64 [3, Nx, Ny, Nz], E|n|^2 = 1."""
+    L = lib()
+    cells = int(np.prod(Nxyz))
+    out = np.empty((3, cells, 2), dtype=np.float32)
+    L.wgo_mann_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
+    L.wgo_mann_noise.restype = None
+    L.wgo_mann_noise(C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_uint64(cells), out.ctypes.data_as(C.c_void_p))
+    return (out[..., 0] + 1j * out[..., 1]).reshape((3,) + tuple(int(n) for n in Nxyz))

@@ -24,3 +24,20 @@ void wgo_rng_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4
 double wgo_rng_noise(uint64_t key, uint32_t push_idx, uint32_t turbine, uint32_t channel, uint32_t episode) {
     return wgo_noise_normal(key, push_idx, turbine, channel, episode);
 }
+
+/* the Philox stream of wg_generate_mann_box (windgym_amd/csrc/wg_mann.hip: mann_noise): complex standard normal of
+ * (component c, cell idx), E|n|^2 = 1 — out[(c * cells + idx) * 2 + {0, 1}] = (re, im); float arithmetic like the kernel's */
+void wgo_mann_noise(uint64_t seed, uint64_t cells, float* out) {
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (uint32_t c = 0; c < 3; ++c)
+        for (uint64_t idx = 0; idx < cells; ++idx) {
+            const uint32_t ctr[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), c, 0x4d414e4eu};
+            uint32_t o[4];
+            wgo_philox4x32_10(ctr, key, o);
+            const float u1 = ((float)(o[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+            const float u2 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
+            const float r = sqrtf(-logf(u1));
+            out[(c * cells + idx) * 2] = r * cosf(6.2831853071795864f * u2);
+            out[(c * cells + idx) * 2 + 1] = r * sinf(6.2831853071795864f * u2);
+        }
+}

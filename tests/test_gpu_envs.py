@@ -396,7 +396,8 @@ def test_mannload_reads_the_turbbox_file_or_falls_back(wg, tmp_path, capsys):
         a = env.action_space.sample()
         o1, r1, *_ = env.step(a)
         o2, r2, *_ = ref.step(a)
-        np.testing.assert_array_equal(o1, o2)                 # the file round-trips to the same field
+        # the file round-trips to the same field (load_box renormalises to unit std: one float rounding of the box values)
+        np.testing.assert_allclose(o1, o2, rtol=0, atol=1e-6)
     v = env.fs.windTurbines.rotor_avg_windspeed[:, 1]
     assert np.abs(v).max() > 1e-3                             # turbulent inflow is on
     env.close(), ref.close()

@@ -16,7 +16,7 @@
 
 extern "C" {
 void wg_launch_flow(const FlowP*, const FlowPtrs*, int, const float*, const uint8_t*, int, hipStream_t);
-void wg_launch_glue(const WgParams*, const WgPtrs*, int, const uint8_t*, float*, float*, uint8_t*, float*, hipStream_t);
+void wg_launch_glue(const WgParams*, const WgPtrs*, int, const uint8_t*, float*, float*, uint8_t*, float*, hipStream_t, const WgParams*, const WgPtrs*);
 void wg_launch_init(const WgParams*, const WgPtrs*, const uint8_t*, const uint64_t*, hipStream_t);
 void wg_launch_create(const WgParams*, const WgPtrs*, hipStream_t);
 void wg_launch_obs_multi(const WgParams*, const WgPtrs*, float*, hipStream_t);
@@ -249,12 +249,6 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     p.obs_dim = p.turb_obs * p.N + p.farm_obs;
     p.obs_dim_multi = p.turb_obs + p.farm_obs;
     p.hist_max = std::max(c->ch[WG_CH_WS].history_len, std::max(c->ch[WG_CH_WD].history_len, c->ch[WG_CH_YAW].history_len));
-    int off = 0, foff = 0;
-    for (int i = 0; i < WG_N_CH; ++i) {
-        p.ring_off[i] = off; off += p.N * c->ch[i].history_len;
-        p.fring_off[i] = foff; foff += c->ch[i].history_len;
-    }
-    p.ring_stride = off; p.fring_stride = foff;
     // what k_glue stages of the turbine rings (the farm rings are tiny and always staged): a channel read through
     // windows (rolling means) or through the TI of its whole deque needs the whole ring, a channel read through its
     // `current` value only needs the newest sample, anything else is not part of the observation.  The per-agent
@@ -270,10 +264,12 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
 
     // Sums mode: every rolling mean the observation reads has history_N = 1, i.e. it is the mean of the newest
     // min(window, history, pushed) samples (Mes.get_measurements' first window, MesClass.py:85-91) — a window that
-    // slides by exactly one sample per push.  The flow kernels then keep the window sums (and the ws deque's sum / sum of
-    // squares for calc_TI) up to date at every push, and the glue kernel reads those instead of staging the rings
-    // (Env1.yaml: 2 doubles per turbine instead of 35 ring floats behind two dependent round trips).  Configurations with
-    // several windows per channel (2turb.yaml: history_N = 100) keep the ring-staging path.  WG_SUMS=0 forces that path
+    // slides by exactly one sample per push.  The lean glue kernel (k_glue_lean) then keeps the window sums of the live
+    // episode (and the ws deque's sum / sum of squares for calc_TI) as running sums, S += newest - leaving in exact double
+    // arithmetic, instead of staging and re-summing the rings every step (Env1.yaml: 4 ring samples per turbine instead of
+    // 35).  The flow kernels are untouched: they push into rings that hold ONE sample more than the deque (ring_cap = H +
+    // 1), so that the sample leaving a window as long as the deque is still there when the glue runs.  Configurations with
+    // several windows per channel (2turb.yaml: history_N = 100) keep the ring-staging kernel.  WG_SUMS=0 forces that path
     // (tests compare the two).
     {
         bool ok = true;
@@ -283,6 +279,10 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         }
         if (const char* ev = getenv("WG_SUMS")) if (atoi(ev) == 0) ok = false;
         p.sums_mode = ok ? 1 : 0;
+        for (int i = 0; i < WG_N_CH; ++i) {
+            p.ring_cap[i] = c->ch[i].history_len + (ok ? 1 : 0);
+            p.ring_magic[i] = (unsigned)((1ull << 32) / (unsigned long long)p.ring_cap[i]) + 1u;
+        }
         if (ok) {
             for (int i = 0; i < WG_N_CH; ++i) {
                 p.sum_w[i] = std::min(c->ch[i].window_len, c->ch[i].history_len);
@@ -295,6 +295,24 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             if (c->turb_ti || c->farm_ti) p.sum_mask_t |= (1u << WG_SUM_TI1) | (1u << WG_SUM_TI2);
             if (c->farm_ti) p.sum_mask_f |= (1u << WG_SUM_TI1) | (1u << WG_SUM_TI2);
         }
+        // one turbine's block of the observation (wg_obs_turbine)
+        WgObsCfg& oc = p.oc;
+        oc.cur_mask = p.cur_mask_t; oc.rol_mask = p.sum_mask_t & 0xfu;
+        oc.turb_ti = c->turb_ti; oc.turb_obs = p.turb_obs; oc.obs_dim = p.obs_dim; oc.obs_dim_multi = p.obs_dim_multi;
+        for (int i = 0; i < WG_N_CH; ++i) {
+            oc.hlen[i] = c->ch[i].history_len; oc.wlen[i] = c->ch[i].window_len;
+            oc.mn[i] = p.sc_min[i]; oc.inv_rng[i] = 1.0f / p.sc_rng[i];
+            oc.inv_w[i] = 1.0 / (double)std::min(c->ch[i].window_len, c->ch[i].history_len);
+        }
+        oc.ti_mn = p.ti_min_f; oc.inv_ti_rng = 1.0f / p.ti_rng_f;
+    }
+    {
+        int off = 0, foff = 0;
+        for (int i = 0; i < WG_N_CH; ++i) {
+            p.ring_off[i] = off; off += p.N * p.ring_cap[i];
+            p.fring_off[i] = foff; foff += p.ring_cap[i];
+        }
+        p.ring_stride = off; p.fring_stride = foff;
     }
 
     WgPtrs& d = h->d;
@@ -331,7 +349,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     A(last_pow_agent, (size_t)p.B, true); A(last_pow_base, (size_t)p.B, true);
     A(metrics, (size_t)p.B * WG_N_METRICS, true);
     A(next_obs, n_ctx * (size_t)p.obs_dim, false); A(next_obs_ok, n_ctx, false);
-    if (p.sums_mode) { A(wsum, n_ctx * WG_N_SUMS * (size_t)(p.N + 1), true); A(wcur, n_ctx * WG_N_CH * (size_t)(p.N + 1), true); }
+    if (p.sums_mode) A(wsum, n_ctx * WG_N_SUMS * (size_t)(p.N + 1), true);
     A(status, 1, true);
 #undef A
     if (!rc) rc = dev_alloc(h, &h->mask_dev, (size_t)p.B, false);
@@ -534,9 +552,10 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         f.ka = p.ka; f.kb = p.kb; f.eps0 = p.eps0; f.hill = p.hill; f.tia = p.tia; f.tib = p.tib; f.tic = p.tic; f.tid = p.tid;
         f.tab_x0 = (float)x0; f.tab_inv_dx = (float)(1.0 / dxu);
         for (int i = 0; i < WG_N_CH; ++i) {
-            f.hlen[i] = p.ch[i].history_len; f.ring_off[i] = p.ring_off[i]; f.fring_off[i] = p.fring_off[i];
-            f.inv_hlen[i] = 1.0f / (float)(p.ch[i].history_len > 0 ? p.ch[i].history_len : 1);
-            f.hmagic[i] = (unsigned)((1ull << 32) / (unsigned long long)(p.ch[i].history_len > 0 ? p.ch[i].history_len : 1)) + 1u;
+            // (the flow kernels only push: what they call the history length is the rings' physical capacity)
+            f.hlen[i] = p.ring_cap[i]; f.ring_off[i] = p.ring_off[i]; f.fring_off[i] = p.fring_off[i];
+            f.inv_hlen[i] = 1.0f / (float)p.ring_cap[i];
+            f.hmagic[i] = (unsigned)((1ull << 32) / (unsigned long long)p.ring_cap[i]) + 1u;
             f.noise_sigma[i] = p.noise_sigma[i];
         }
         f.ring_stride = p.ring_stride; f.fring_stride = p.fring_stride;
@@ -568,10 +587,6 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         g.rotor_dy = d.rotor_dy; g.rotor_dz = d.rotor_dz; g.tab_power = tpu; g.tab_ct = tcu;
         g.gp = h->p_dev; g.gd = h->d_dev; g.env_rw = d.env;
         g.roff = d.roff; g.qown = d.qown; g.status = d.status;
-        g.wsum = d.wsum; g.wcur = d.wcur;
-        f.sums_mode = p.sums_mode; f.sum_mask_t = p.sum_mask_t; f.sum_mask_f = p.sum_mask_f;
-        f.cur_mask_t = p.cur_mask_t; f.cur_mask_f = p.cur_mask_f;
-        for (int i = 0; i < WG_N_SUMS; ++i) f.sum_w[i] = p.sum_w[i];
     }
 
     // how many RESET-mode launches develop the slowest possible episode: the chain needs
@@ -602,8 +617,8 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     // The first observation of a background episode is built inside k_flow only by the single-wave steady variant (small
     // farms: one wave reads 35 floats per turbine; measured on the multi-wave variants — cfg3, cfg5 — the building
     // workgroup became the flow kernel's tail: -5 % / -1.3 %).  Other handles keep the glue's own second build.
-    // (sums mode: the glue reads the next episode's window sums directly — nothing to prepare)
-    if (!(h->fp.gl && !h->fp.duo) || p.sums_mode) { d.next_obs = nullptr; d.next_obs_ok = nullptr; }
+    // (sums mode: wg_first_obs prepares the episode's window sums as well, in WgPtrs::wsum)
+    if (!(h->fp.gl && !h->fp.duo)) { d.next_obs = nullptr; d.next_obs_ok = nullptr; }
     wg_launch_create(&p, &d, nullptr);
     if (sync_dev_params(h)) { wg_destroy(h); return WG_ERR_HIP; }
     {
@@ -854,7 +869,7 @@ extern "C" int wg_reset(wg_handle h, const uint8_t* env_mask_host, const uint64_
             return fail(WG_ERR_STATE, "wg_reset: episode development does not terminate (wind speed override ~ 0?)");
         batch = std::max(8, n_plan / 4);
     }
-    wg_launch_glue(&h->p, &h->d, 1, mask, obs_dev, nullptr, nullptr, nullptr, st);
+    wg_launch_glue(&h->p, &h->d, 1, mask, obs_dev, nullptr, nullptr, nullptr, st, h->p_dev, h->d_dev);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -865,7 +880,7 @@ static void launch_step(wg_env_s* h, const float* actions_dev, float* obs_dev, f
     if (sample) sample = time_begin(h, 0, st);
     wg_launch_flow(&h->fp, &h->fd, WG_MODE_STEP, actions_dev, nullptr, 0, st);
     if (sample) { time_end(h, st); sample = time_begin(h, 1, st); }
-    wg_launch_glue(&h->p, &h->d, 0, nullptr, obs_dev, reward_dev, truncated_dev, final_obs_dev, st);
+    wg_launch_glue(&h->p, &h->d, 0, nullptr, obs_dev, reward_dev, truncated_dev, final_obs_dev, st, h->p_dev, h->d_dev);
     if (sample) time_end(h, st);
 }
 

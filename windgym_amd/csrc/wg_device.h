@@ -317,11 +317,6 @@ __device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, c
         cx.episode_tag = episode_tag;
     }
     ws = __shfl(ws, 0, 64); ti = __shfl(ti, 0, 64); wd = __shfl(wd, 0, 64);
-    // sums mode: the new episode's deques are empty (one writer, like n_pushed: farm 0's set-up)
-    if (f_lo == 0 && d.wsum) {
-        double* wsm = d.wsum + (size_t)ctx_id * WG_N_SUMS * (N + 1);
-        for (int i = lane; i < WG_N_SUMS * (N + 1); i += WG_WAVE) wsm[i] = 0.0;
-    }
     {
         const double rp = wg_tab_interp_wave<double>(d.tab_ws_d, d.tab_power_d, p.n_tab, ws, lane);   // :700
         if (lane == 0) cx.rated_power = (float)rp;
@@ -426,17 +421,17 @@ struct WgRing {
     const float* data;
     int n_pushed, hlen;
     int n_avail, start;      // start = physical slot of the oldest sample (one modulo per ring, not per element)
-    int stride;
+    int stride, cap;         // cap = physical slots of the ring (WgParams::ring_cap: the deque length, + 1 in sums mode)
     __device__ WgRing() {}
-    __device__ WgRing(const float* d_, int n_pushed_, int hlen_, int stride_ = 1)
-        : data(d_), n_pushed(n_pushed_), hlen(hlen_), stride(stride_) {
+    __device__ WgRing(const float* d_, int n_pushed_, int hlen_, int stride_, int cap_)
+        : data(d_), n_pushed(n_pushed_), hlen(hlen_), stride(stride_), cap(cap_) {
         n_avail = n_pushed < hlen ? n_pushed : hlen;
-        start = (n_pushed - n_avail) % hlen;
+        start = (n_pushed - n_avail) % cap;
     }
     __device__ int avail() const { return n_avail; }
     __device__ float at(int q) const {   // q = 0 oldest
         int phys = start + q;
-        if (phys >= hlen) phys -= hlen;
+        if (phys >= cap) phys -= cap;
         return data[phys * stride];
     }
 };
@@ -527,8 +522,8 @@ __device__ inline int wg_turb_block_b(const WgParams& p, const float* rbase, con
             bool ti_on = farm_level ? p.farm_ti : p.turb_ti;
             if (ti_on) {
                 const int H = p.ch[WG_CH_WS].history_len;
-                WgRing r = farm_level ? WgRing(fbase + p.fring_off[WG_CH_WS], n_pushed, H)
-                                      : WgRing(rbase + p.ring_off[WG_CH_WS] + t, n_pushed, H, p.N);
+                WgRing r = farm_level ? WgRing(fbase + p.fring_off[WG_CH_WS], n_pushed, H, 1, p.ring_cap[WG_CH_WS])
+                                      : WgRing(rbase + p.ring_off[WG_CH_WS] + t, n_pushed, H, p.N, p.ring_cap[WG_CH_WS]);
                 out[n++] = wg_scale(wg_calc_ti(r), p.ti_min_f, p.ti_rng_f);
             }
         }
@@ -537,10 +532,10 @@ __device__ inline int wg_turb_block_b(const WgParams& p, const float* rbase, con
         WgRing r;
         if (farm_level) {
             // the farm object's yaw deque is never filled: the flags would allow it, the empty deque yields []
-            r = WgRing(fbase + p.fring_off[ch], (ch == WG_CH_YAW) ? 0 : n_pushed, H);
+            r = WgRing(fbase + p.fring_off[ch], (ch == WG_CH_YAW) ? 0 : n_pushed, H, 1, p.ring_cap[ch]);
             if (ch == WG_CH_YAW) on = true;
         } else {
-            r = WgRing(rbase + p.ring_off[ch] + t, n_pushed, H, p.N);
+            r = WgRing(rbase + p.ring_off[ch] + t, n_pushed, H, p.N, p.ring_cap[ch]);
         }
         float rng = (farm_level && ch == WG_CH_POWER) ? p.sc_rng_farm_power : p.sc_rng[ch];
         n += wg_mes_get(p.ch[ch], p.ch[ch].current && on, p.ch[ch].rolling_mean && on, r, p.sc_min[ch], rng,

@@ -68,10 +68,6 @@ struct FlowP {
     float km1, km2r;
     float sg_af, sg_bf, sg_cf;    // super-Gaussian order n(x) = af exp(bf x/D) + cf (deficit_model = 1)
     double inv_adx, inv_ady, inv_adz;
-    // sums mode (WgParams::sums_mode): read through the cold kernarg pointer by the push code only
-    int sums_mode;
-    unsigned sum_mask_t, sum_mask_f, cur_mask_t, cur_mask_f;
-    int sum_w[WG_N_SUMS];
 };
 
 struct FlowPtrs {
@@ -100,8 +96,6 @@ struct FlowPtrs {
     const WgParams* gp;
     const WgPtrs* gd;
     WgEnv* env_rw;                // == env; the initialising workgroup of farm 0 commits the advanced generator
-    double* wsum;                 // sums mode: see WgPtrs
-    float* wcur;
 };
 
 // sizeof(TurbLds) in wg_flow.hip; kept here so the host can size the dynamic LDS

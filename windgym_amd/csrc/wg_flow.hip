@@ -111,46 +111,6 @@ __device__ __forceinline__ int umod_small(int n, int H, unsigned magic) {
     return r;
 }
 
-// Sums mode (WgParams::sums_mode): one sensor push of entity `ent` (turbine t, or N = the farm-level deques) updates the
-// running window sums the glue kernel reads — S += new - leaving, where `leaving` is the sample that drops out of the
-// window: pushed min(window, history) pushes ago, still in the ring (when the window spans the whole history it sits in
-// the very slot this push overwrites: call this BEFORE the ring stores, with the same ring pointer, so the accesses stay
-// ordered).  `val` = the values being pushed (after noise), ring element of channel ch, row r = ring[off[ch] + r * stride +
-// idx] with off = FlowP::fring_off (farm_level) or ring_off.  P / D: the by-value parameter blocks or their kernarg-segment (address space 4) views.
-template <typename P, typename D>
-__device__ __forceinline__ void wg_sums_push(const P& p, const D& d, const int ctx_id, const int ent, const unsigned smask,
-                                             const unsigned cmask, const float* val, const int n_pushed,
-                                             const float* ring, const bool farm_level, const int stride, const int idx) {
-    const int NS = p.N + 1;
-    double* ws_ = d.wsum + (size_t)ctx_id * WG_N_SUMS * NS + ent;
-    float* wc_ = d.wcur + (size_t)ctx_id * WG_N_CH * NS + ent;
-    double S[WG_N_SUMS];
-    float lv[WG_N_SUMS];
-    // (all loads first: one memory round trip for the push, not one per slot)
-#pragma unroll
-    for (int s = 0; s < WG_N_SUMS; ++s) {
-        S[s] = 0.0; lv[s] = 0.f;
-        if ((smask >> s) & 1u) {
-            const int ch = s < WG_N_CH ? s : WG_CH_WS;
-            const int Wc = p.sum_w[s];
-            S[s] = ws_[(size_t)s * NS];
-            if (n_pushed >= Wc) lv[s] = ring[(farm_level ? p.fring_off[ch] : p.ring_off[ch]) + umod_small(n_pushed - Wc, p.hlen[ch], p.hmagic[ch]) * stride + idx];
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < WG_N_SUMS; ++s) {
-        if ((smask >> s) & 1u) {
-            const int ch = s < WG_N_CH ? s : WG_CH_WS;
-            double v = (double)val[ch], l = (double)lv[s];
-            if (s == WG_SUM_TI2) { v = v * v; l = l * l; }
-            ws_[(size_t)s * NS] = (S[s] - l) + v;
-        }
-    }
-#pragma unroll
-    for (int ch = 0; ch < WG_N_CH; ++ch)
-        if ((cmask >> ch) & 1u) wc_[(size_t)ch * NS] = val[ch];
-}
-
 // uniform-grid table lookup (linear interpolation, 0 outside)
 __device__ __forceinline__ float tab_lookup(const float* __restrict__ ys, const FlowP& p, float x) {
     const float fx = (x - p.tab_x0) * p.tab_inv_dx;
@@ -1614,6 +1574,49 @@ __device__ __attribute__((noinline)) void wg_first_obs(const WgParams* gp, const
     if (d.next_obs == nullptr) return;
     build_obs<1>(p, d, ctx_id, lane, d.next_obs + (size_t)ctx_id * p.obs_dim, nullptr,
                  d.ring + (size_t)ctx_id * p.ring_stride, d.fring + (size_t)ctx_id * p.fring_stride, false, nullptr, n_pushed);
+    if (p.sums_mode) {
+        // sums mode (k_glue_lean): the episode's window sums, summed afresh from its rings into WgPtrs::wsum — the swap then
+        // finds them ready.  Lg = 2^k lanes share an entity (turbine t, or N = the farm-level deques); lane `sub` of a group
+        // takes the window's samples sub, sub + Lg, ... eight at a time; double sums of floats are exact, so the partial sums
+        // combine to THE sum in any order.
+        const int N = p.N, NS = N + 1;
+        int Lg = 1;
+        while (Lg < 8 && N * (Lg * 2) <= WG_WAVE) Lg *= 2;
+        const int sub = lane & (Lg - 1), per_pass = WG_WAVE / Lg;
+        const bool farm_ent = p.sum_mask_f != 0u;
+        for (int t0 = 0; t0 < N + (farm_ent ? 1 : 0); t0 += per_pass) {
+            const int ent = t0 + lane / Lg;
+            const bool have = ent < N || (ent == N && farm_ent);
+            const SumsEnt q = wg_sums_ent(p, d, ctx_id, have ? ent : 0);
+            double* ws_ = d.wsum + (size_t)ctx_id * WG_N_SUMS * NS + (have ? ent : 0);
+#pragma nounroll
+            for (int sl = 0; sl < WG_N_SUMS; ++sl) {
+                const bool on = have && ((q.sm >> sl) & 1u);
+                const int ch = sl < WG_N_CH ? sl : WG_CH_WS;
+                const int off = q.farm ? p.fring_off[ch] : p.ring_off[ch];
+                const int cap = p.ring_cap[ch];
+                const int cnt = p.sum_w[sl] < n_pushed ? p.sum_w[sl] : n_pushed;
+                const int r0 = (n_pushed - cnt) % cap;
+                double acc = 0.0;
+                if (on) {
+#pragma nounroll
+                    for (int k = sub; k < cnt; k += 8 * Lg) {
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            int row = r0 + min(k + u * Lg, cnt - 1); if (row >= cap) row -= cap;
+                            v[u] = q.rb[off + row * q.stride];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (k + u * Lg < cnt) acc += sl == WG_SUM_TI2 ? (double)v[u] * (double)v[u] : (double)v[u];
+                    }
+                }
+                for (int s2 = 1; s2 < Lg; s2 <<= 1) acc += __shfl_xor(acc, s2, 64);
+                if (on && sub == 0) ws_[(size_t)sl * NS] = acc;
+            }
+        }
+    }
     if (lane == 0) d.next_obs_ok[ctx_id] = 1;
 }
 
@@ -1945,8 +1948,6 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
                                 val[ch] += kc->p.noise_sigma[ch] * wg_noise_normal(noise_key, (uint32_t)n_pushed, (uint32_t)t,
                                                                                    (uint32_t)ch, episode_tag);
                     }
-                    if (kc->p.sums_mode)
-                        wg_sums_push(kc->p, kc->d, ctx_id, t, kc->p.sum_mask_t, kc->p.cur_mask_t, val, n_pushed, rbase, false, N, t);
 #pragma unroll
                     for (int ch = 0; ch < WG_N_CH; ++ch) {
                         const int H = kc->p.hlen[ch];
@@ -1970,10 +1971,6 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
                 if (tid == 0) {
                     const FlowP __attribute__((address_space(4)))& pc = kc->p;
                     float* fbase = kc->d.fring + (size_t)ctx_id * pc.fring_stride;
-                    if (pc.sums_mode && (pc.sum_mask_f | pc.cur_mask_f)) {
-                        const float fval[WG_N_CH] = {sws * pc.inv_N, swd * pc.inv_N, 0.f, tot};
-                        wg_sums_push(pc, kc->d, ctx_id, N, pc.sum_mask_f, pc.cur_mask_f, fval, n_pushed, fbase, true, 1, 0);
-                    }
                     fbase[pc.fring_off[WG_CH_WS] + umod_small(n_pushed, pc.hlen[WG_CH_WS], pc.hmagic[WG_CH_WS])] = sws * pc.inv_N;
                     fbase[pc.fring_off[WG_CH_WD] + umod_small(n_pushed, pc.hlen[WG_CH_WD], pc.hmagic[WG_CH_WD])] = swd * pc.inv_N;
                     fbase[pc.fring_off[WG_CH_POWER] + umod_small(n_pushed, pc.hlen[WG_CH_POWER], pc.hmagic[WG_CH_POWER])] = tot;

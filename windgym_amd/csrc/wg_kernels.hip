@@ -38,12 +38,12 @@ __device__ inline void stage_rings(const WgParams& p, const WgPtrs& d, int ctx_i
     for (int ch = 0; ch < WG_N_CH; ++ch) {
         const int off = p.ring_off[ch];
         if (p.stage_ch[ch] == 2) {
-            const int len = N * p.ch[ch].history_len;
+            const int len = N * p.ring_cap[ch];
 #pragma nounroll
             for (int s0 = 0; s0 < len; s0 += WG_WAVE)
                 if (s0 + lane < len) __builtin_amdgcn_global_load_lds((GPtr)(gr + off + s0 + lane), (LPtr)(lds + off + s0), 4, 0, 0);
         } else if (p.stage_ch[ch] == 1 && n_pushed > 0) {
-            const int row = off + ((n_pushed - 1) % p.ch[ch].history_len) * N;
+            const int row = off + ((n_pushed - 1) % p.ring_cap[ch]) * N;
 #pragma nounroll
             for (int s0 = 0; s0 < N; s0 += WG_WAVE)
                 if (s0 + lane < N) __builtin_amdgcn_global_load_lds((GPtr)(gr + row + s0 + lane), (LPtr)(lds + row + s0), 4, 0, 0);
@@ -131,9 +131,7 @@ __device__ inline void env_writeback(WgEnv& env, const EnvHot& ev, const int lan
 // PRE: the handle's flow kernel builds a background episode's first observation when its development completes
 // (WgPtrs::next_obs, single-wave steady variant): the swap copies it.  A template parameter so that the other
 // handles' instantiations are the code they were.
-// SUMS: sums mode (WgParams::sums_mode) — the observation comes from the running window sums the flow kernels maintain;
-// no ring staging (RL = false, L = 1, PRE = false in these instantiations).
-template <bool MULTI, bool RL, int L, bool PRE, bool SUMS = false>
+template <bool MULTI, bool RL, int L, bool PRE>
 __global__ void __launch_bounds__(WG_BLOCK, 4)
 k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restrict__ mask,
        float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out,
@@ -180,15 +178,9 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         }
         if (obs) {
             const int np1 = cx.n_pushed;
-            if (SUMS) {
-                const ObsIn oi = wg_obs_load(p, d, ctx_id, lane < N ? lane : 0);
-                build_obs_sums<MULTI>(p, d, ctx_id, lane, obs, nullptr, MULTI ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr,
-                                      np1, mscr, oi);
-            } else {
-                stage_rings<RL>(p, d, ctx_id, lane, my_lds, rbase, fbase, np1);
-                build_obs<L>(p, d, ctx_id, lane, obs, nullptr, rbase, fbase, false,
-                          MULTI ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr, np1, mscr);
-            }
+            stage_rings<RL>(p, d, ctx_id, lane, my_lds, rbase, fbase, np1);
+            build_obs<L>(p, d, ctx_id, lane, obs, nullptr, rbase, fbase, false,
+                      MULTI ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr, np1, mscr);
         }
         return;
     }
@@ -235,9 +227,6 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         l_yaw = d.yaw[tb_a + lane]; l_old = d.old_yaw[(size_t)e * N + lane]; l_pow = d.power[tb_a + lane];
         if (p.F == 2) l_powb = d.power[tb_a + N + lane];
     }
-    // (sums mode: this lane's turbine — a few doubles at addresses that depend on the context only)
-    ObsIn oi{};
-    if (SUMS) oi = wg_obs_load(p, d, ctx_id, lane < N ? lane : 0);
     float* met = d.metrics + (size_t)e * WG_N_METRICS;
     float l_met = lane < WG_N_METRICS ? met[lane] : 0.f;
     // (first 64 elements of the power deques: requested with the loads above, consumed by the deque loop below)
@@ -308,11 +297,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
     // and not kept: requesting the next context's header, deferred deque entries and rings with the first staging
     // (swap block 12.7 k -> 7.7 k cycles, but the common path slowed by as much as the tail gained); s_setprio(3) for
     // the truncating wave: no effect.)
-    if (SUMS) {
-        if (swap_obs) { if (fin) build_obs_sums<false>(p, d, ctx_id, lane, fin, nullptr, nullptr, n_pushed_live, nullptr, oi); }
-        else if (obs) build_obs_sums<MULTI>(p, d, ctx_id, lane, obs, fin, MULTI ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr,
-                                            n_pushed_live, mscr, oi);
-    } else if (!swap_obs || fin) {
+    if (!swap_obs || fin) {
         stage_rings<RL>(p, d, ctx_id, lane, my_lds, rbase, fbase, n_pushed_live);
         if (WG_GLUE_ABLATE == 3) return;
         if (swap_obs) build_obs<L>(p, d, ctx_id, lane, fin, nullptr, rbase, fbase, false, nullptr, n_pushed_live);
@@ -418,11 +403,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
             // the next episode's first observation: built by the k_flow workgroup that completed its development
             // (wg_first_obs) — copied; otherwise (per-agent buffer, duo flow kernel, restored state) built here
             const bool pre = PRE && d.next_obs_ok[nctx] != 0;
-            if (SUMS) {
-                const ObsIn on = wg_obs_load(p, d, nctx, lane < N ? lane : 0);
-                build_obs_sums<MULTI>(p, d, nctx, lane, obs, nullptr, MULTI ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr,
-                                      nnp, mscr, on);
-            } else if (pre) {
+            if (pre) {
                 const float* no = d.next_obs + (size_t)nctx * p.obs_dim;
                 for (int i = lane; i < p.obs_dim; i += WG_WAVE) obs[i] = no[i];
             } else {
@@ -459,6 +440,501 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         fin[7] = __uint_as_float(tl_w0); fin[8] = __uint_as_float((unsigned)wall_clock64());
     }
 #endif
+}
+
+
+// ===================================================================================================
+// k_glue_lean: the glue of sums-mode handles (wg_create: every observed rolling mean has history_N = 1).  One wave per env
+// like k_glue, written for the two things that bound that kernel — 4096 resident waves share 1024 SIMDs, so its ~1000
+// VALU instructions per wave WERE its 14 us, and its loads formed three dependent round trips:
+//   * the env header carries what the wave needs of the live context (time_max, rated power, push count) and the power
+//     deques' running sums: it is wave-uniform, fetched through the scalar cache and processed on the scalar unit;
+//   * the observation comes from running window sums (WgPtrs::wsum): per turbine the newest and the leaving sample of each
+//     window are read instead of the whole rings, S += newest - leaving in exact double arithmetic, mean = S / W;
+//   * the deque means of the reward come from running sums too.
+// A truncating env (a handful per launch) swaps contexts and sums the new episode's windows afresh from its rings.
+// Reference: Wind_Farm_Env.py:975-1034 (deques, reward, penalty, truncation), :804-820, :866-918; MesClass.py:70-125.
+// phase 0 = after a flow step (step()); phase 1 = end of reset().
+// ===================================================================================================
+// (rare paths out of line / in their own kernel: inlined they cost the step path ~130 spilled VGPRs and 1 KB of scratch
+// per lane — k_glue_lean ran 89 us.  They read the parameter blocks from their device-resident copies.)
+
+// the first observation of an episode that becomes live (end of reset, swap): its window sums are summed afresh from its
+// rings (n_pushed samples) into WgPtrs::wsum, slot by slot — rolled loops, nothing held in arrays: the callee's register
+// need counts against every wave of the calling kernel — and the observation is then built from the stored sums
+template <bool MULTI>
+__device__ __attribute__((noinline)) void lean_fresh_obs(const WgParams* gp, const WgPtrs* gd, const int e, const int ctx_id,
+                                                         const int lane, const int n_pushed, float* obs, float* om, float* mscr) {
+    const WgParams& p = *gp;
+    const WgPtrs& d = *gd;
+    const int N = p.N, NS = N + 1;
+    auto fresh_store = [&](const int ent) {
+        const SumsEnt q = wg_sums_ent(p, d, ctx_id, ent);
+        double* ws_ = d.wsum + (size_t)ctx_id * WG_N_SUMS * NS + ent;
+#pragma nounroll
+        for (int s = 0; s < WG_N_SUMS; ++s) {
+            if (!((q.sm >> s) & 1u)) continue;
+            const int ch = s < WG_N_CH ? s : WG_CH_WS;
+            const int off = q.farm ? p.fring_off[ch] : p.ring_off[ch];
+            const int cap = p.ring_cap[ch];
+            const int cnt = p.sum_w[s] < n_pushed ? p.sum_w[s] : n_pushed;
+            int row = (n_pushed - cnt) % cap;
+            double acc = 0.0;
+#pragma nounroll
+            for (int k = 0; k < cnt; ++k) {
+                const double v = (double)q.rb[off + row * q.stride];
+                acc += s == WG_SUM_TI2 ? v * v : v;
+                if (++row == cap) row = 0;
+            }
+            ws_[(size_t)s * NS] = acc;
+        }
+    };
+    for (int t = lane; t < N; t += WG_WAVE) fresh_store(t);
+    if (lane == 0 && p.sum_mask_f) fresh_store(N);
+    if (!obs) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have landed before it reads the sums back
+    auto ld = [&](const int ent) {
+        ObsIn o;
+        const SumsEnt q = wg_sums_ent(p, d, ctx_id, ent);
+        const double* ws_ = d.wsum + (size_t)ctx_id * WG_N_SUMS * NS + ent;
+#pragma unroll
+        for (int s = 0; s < WG_N_SUMS; ++s) o.S[s] = ((q.sm >> s) & 1u) ? __builtin_nontemporal_load(ws_ + (size_t)s * NS) : 0.0;
+#pragma unroll
+        for (int ch = 0; ch < WG_N_CH; ++ch) {
+            const int off = q.farm ? p.fring_off[ch] : p.ring_off[ch];
+            o.cur[ch] = (n_pushed > 0 && ((q.cm >> ch) & 1u)) ? q.rb[off + ((n_pushed - 1) % p.ring_cap[ch]) * q.stride] : 0.f;
+        }
+        return o;
+    };
+    build_obs_sums<MULTI, true>(p, lane, obs, nullptr, om, n_pushed, mscr, ld(lane < N ? lane : 0), ld);
+}
+
+// end of reset() for sums-mode handles (phase 1 of k_glue): the freshly developed episode goes live
+template <bool MULTI>
+__global__ void __launch_bounds__(WG_BLOCK)
+k_glue_lean_reset(const WgParams p, const WgPtrs d, const WgParams* gp, const WgPtrs* gd, const uint8_t* __restrict__ mask,
+                  float* __restrict__ obs_out, const int lds_floats_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) float glue_lds[];
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * WG_NWAVES + (threadIdx.x >> 6);
+    if (e >= p.B) return;
+    if (mask && !mask[e]) return;
+    const int N = p.N, F = p.F, PA = p.power_avg;
+    float* const mscr = MULTI ? glue_lds + (size_t)(threadIdx.x >> 6) * lds_floats_per_wave : nullptr;
+    WgEnv& env = d.env[e];
+    float* obs = obs_out ? obs_out + (size_t)e * p.obs_dim : nullptr;
+    float* om = MULTI ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr;
+    float* fq = d.farm_pow + (size_t)e * PA;
+    float* bq = d.base_pow + (size_t)e * PA;
+    // flush the episode's deferred power-deque pushes (:766, :796)
+    const int ctx_id = e * 2 + env.live;
+    WgCtx& cx = d.ctx[ctx_id];
+    const int np1 = cx.n_pushed;
+    if (lane < F) {     // wg_reset develops until every slot is ready; anything else is a bug
+        const WgSlot& sl = d.slot[ctx_id * F + lane];
+        if (sl.dev_remaining != 0 || sl.fill_remaining != 0) atomicOr(d.status, WG_STATUS_BIT_STATE);
+    }
+    if (lane == 0) {
+        const int nf = cx.pend_farm_n < PA ? cx.pend_farm_n : PA;
+        for (int q = 0; q < nf; ++q) {
+            fq[env.farm_pow_n % PA] = deque_at(d.pend_farm + (size_t)ctx_id * PA, cx.pend_farm_n, PA, q);
+            env.farm_pow_n++;
+        }
+        const int nb = cx.pend_base_n < PA ? cx.pend_base_n : PA;
+        for (int q = 0; q < nb; ++q) {
+            bq[env.base_pow_n % PA] = deque_at(d.pend_base + (size_t)ctx_id * PA, cx.pend_base_n, PA, q);
+            env.base_pow_n++;
+        }
+        cx.pend_farm_n = 0; cx.pend_base_n = 0;
+        // what the step path needs of the live context, and the power deques' running sums
+        env.time_max_live = cx.time_max; env.rated_live = cx.rated_power; env.n_pushed_live = np1;
+        {
+            const int nfq = env.farm_pow_n < PA ? env.farm_pow_n : PA, nbq = env.base_pow_n < PA ? env.base_pow_n : PA;
+            double sf = 0.0, sb = 0.0;
+            for (int q = 0; q < nfq; ++q) sf += (double)fq[q];
+            for (int q = 0; q < nbq; ++q) sb += (double)bq[q];
+            env.fsum_run = sf; env.bsum_run = sb;
+        }
+        env.timestep = 0; env.done = 0; env.steps_done = 0;
+        env.ep_return = 0.f; env.ep_power_sum = 0.f; env.ep_len = 0;
+        env.shadow_iters = p.autoreset ? plan_shadow(p, d, env.live, env.steps_done, e) : 0;
+    }
+    lean_fresh_obs<MULTI>(gp, gd, e, ctx_id, lane, np1, obs, om, mscr);
+}
+
+// Same-step autoreset of a sums-mode env, out of line (a handful of waves per launch take it; inlined, its unrolled loads
+// cost every wave of k_glue_lean its register allocation): the next episode — developed in the background — goes live.
+//   * its window sums are summed afresh from its rings (nnp samples) into WgPtrs::wsum: Lg = 2^k lanes share a turbine
+//     (N * Lg <= 64), lane `sub` of a group sums the window's samples sub, sub + Lg, ... with eight loads in flight, the
+//     partial sums meet by shuffles.  Double sums of floats are exact: whoever adds them up, the result is THE sum.  (One
+//     lane per turbine walking its 25 + 10 samples one dependent load at a time made the truncating waves last 20 us.)
+//   * !gen (no TI, nothing farm-level): the episode's first observation is written here, straight from the group sums;
+//   * the deferred power-deque pushes of its window fill (:766, :796) are merged arithmetically — lane i decides what slot
+//     i holds afterwards, stores it if it changed and contributes it to the deque's new running sum: no store -> load trip;
+//   * the finished context is retired (set up again by the next k_flow launch, WgCtx::init_pending).
+// The parameter blocks come from their device-resident copies.
+// Called at the very END of k_glue_lean, after the wave has written the step's results and the env header as if nothing
+// were swapped: nothing of the step path is live across the call (values that are get spilled where they are defined —
+// scratch stores in every wave), and this function rewrites the header fields the swap changes.
+template <bool MULTI, bool GEN>
+__device__ __attribute__((noinline)) void lean_swap(const WgParams* gp, const WgPtrs* gd, const int e, const int live, const int lane,
+                                                    const float fp, const float bp, const int fslot, const int bslot,
+                                                    const int n1f, const int n1b, const int episode_next, float* obs, float* om,
+                                                    float* mscr, const int pfn, const int pbn, const int nnp, const int time_max,
+                                                    const float rated, const bool prepared) {
+    // (pfn .. rated: the new context's header, `prepared`: the flow kernel has prepared the episode's window sums — in
+    // wsum[nctx] — and its single-agent first observation when its development completed, wg_first_obs; all fetched by the
+    // caller through the scalar cache at the top of the kernel, where it already knows that the env truncates)
+    const WgParams& p = *gp;
+    const WgPtrs& d = *gd;
+    const int N = p.N, F = p.F, PA = p.power_avg, NS = N + 1;
+    const int nctx = e * 2 + (live ^ 1);
+    WgCtx& ncx = d.ctx[nctx];
+    if (lane < F) {
+        const WgSlot& sl = d.slot[nctx * F + lane];
+        if (sl.dev_remaining != 0 || sl.fill_remaining != 0) atomicOr(d.status, WG_STATUS_BIT_STATE);
+    }
+    // ---- power deques: what slot i holds after the deferred pushes ----
+    const int mf = pfn < PA ? pfn : PA, mb = pbn < PA ? pbn : PA;
+    float* fq = d.farm_pow + (size_t)e * PA;
+    float* bq = d.base_pow + (size_t)e * PA;
+    const float* pf = d.pend_farm + (size_t)nctx * PA;
+    const float* pb = d.pend_base + (size_t)nctx * PA;
+    const int n2f = n1f + mf, n2b = n1b + mb;
+    double sf = 0.0, sb = 0.0;
+    for (int i = lane; i < PA; i += WG_WAVE) {
+        int qf = (i - n1f) % PA; if (qf < 0) qf += PA;
+        float vf = i == fslot ? fp : fq[i];
+        if (qf < mf) { vf = deque_at(pf, pfn, PA, qf); fq[i] = vf; }
+        if (i < (n2f < PA ? n2f : PA)) sf += (double)vf;
+        if (F == 2) {
+            int qb = (i - n1b) % PA; if (qb < 0) qb += PA;
+            float vb = i == bslot ? bp : bq[i];
+            if (qb < mb) { vb = deque_at(pb, pbn, PA, qb); bq[i] = vb; }
+            if (i < (n2b < PA ? n2b : PA)) sb += (double)vb;
+        }
+    }
+    bool obs_done = false;
+    if (prepared) {
+        if (lane == 0) d.next_obs_ok[nctx] = 0;      // consumed (the context holds a live episode now)
+        if (!MULTI && !GEN && obs) {
+            const float* no = d.next_obs + (size_t)nctx * p.obs_dim;
+            for (int i = lane; i < p.obs_dim; i += WG_WAVE) obs[i] = no[i];
+            obs_done = true;
+        }
+    } else {
+        // ---- window sums afresh (+ the first observation when nothing generic is in it) ----
+        int Lg = 1;
+        while (Lg < 8 && N * (Lg * 2) <= WG_WAVE) Lg *= 2;
+        const int sub = lane & (Lg - 1), per_pass = WG_WAVE / Lg;
+        const bool farm_ent = GEN && p.sum_mask_f != 0u;
+        for (int t0 = 0; t0 < N + (farm_ent ? 1 : 0); t0 += per_pass) {
+            const int ent = t0 + lane / Lg;
+            const bool have = ent < N || (ent == N && farm_ent);
+            const SumsEnt q = wg_sums_ent(p, d, nctx, have ? ent : 0);
+            double* ws_ = d.wsum + (size_t)nctx * WG_N_SUMS * NS + (have ? ent : 0);
+            float* o = (obs && !GEN && have) ? obs + (size_t)ent * p.turb_obs : nullptr;
+            float* o_m = (MULTI && om && !GEN && have) ? om + (size_t)ent * p.obs_dim_multi : nullptr;
+            int n = 0;
+#pragma nounroll
+            for (int sl = 0; sl < (GEN ? WG_N_SUMS : WG_N_CH); ++sl) {
+                const bool on = have && ((q.sm >> sl) & 1u);
+                const int ch = sl < WG_N_CH ? sl : WG_CH_WS;
+                const int off = q.farm ? p.fring_off[ch] : p.ring_off[ch];
+                const int cap = p.ring_cap[ch];
+                const int cnt = p.sum_w[sl] < nnp ? p.sum_w[sl] : nnp;
+                const int r0 = (nnp - cnt) % cap;
+                const bool cur_on = o && ((p.oc.cur_mask >> ch) & 1u) && nnp > 0;
+                const float cv = cur_on ? q.rb[off + ((nnp - 1) % cap) * q.stride] : 0.f;
+                double acc = 0.0;
+                if (on) {
+#pragma nounroll
+                    for (int k = sub; k < cnt; k += 8 * Lg) {
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            int row = r0 + min(k + u * Lg, cnt - 1); if (row >= cap) row -= cap;
+                            v[u] = q.rb[off + row * q.stride];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (k + u * Lg < cnt) acc += sl == WG_SUM_TI2 ? (double)v[u] * (double)v[u] : (double)v[u];
+                    }
+                }
+                for (int s2 = 1; s2 < Lg; s2 <<= 1) acc += __shfl_xor(acc, s2, 64);
+                if (on && sub == 0) ws_[(size_t)sl * NS] = acc;
+                // first observation, this channel's entries (wg_obs_turbine<false>: `current`, then the rolling mean)
+                if (o && sub == 0 && nnp > 0) {
+                    if (cur_on) { const float v = wg_scale_r(cv, p.oc.mn[ch], p.oc.inv_rng[ch]); o[n] = v; if (o_m) o_m[n] = v; ++n; }
+                    if ((p.oc.rol_mask >> ch) & 1u) {
+                        const float v = wg_scale_r(wg_sums_mean(p.oc, acc, ch, nnp), p.oc.mn[ch], p.oc.inv_rng[ch]);
+                        o[n] = v; if (o_m) o_m[n] = v; ++n;
+                    }
+                }
+            }
+        }
+        obs_done = !GEN;
+    }
+#pragma unroll
+    for (int s2 = 32; s2 > 0; s2 >>= 1) { sf += __shfl_xor(sf, s2, 64); sb += __shfl_xor(sb, s2, 64); }
+    if (lane == 0) {
+        ncx.pend_farm_n = 0; ncx.pend_base_n = 0;
+        // retire the finished context
+        WgCtx& rcx = d.ctx[e * 2 + live];
+        const WgEnv& env = d.env[e];
+        rcx.init_pending = 1;
+        rcx.episode_tag = episode_next;
+        rcx.snap_state = env.rng_state; rcx.snap_inc = env.rng_inc;
+        rcx.snap_has32 = env.rng_has32; rcx.snap_u32 = env.rng_u32;
+    }
+    // the env header of the new live episode (the caller has written the finished one's)
+    WgEnv& envw = d.env[e];
+    if (lane == 0) envw.live = live ^ 1;
+    if (lane == 1) envw.timestep = 0;
+    if (lane == 2) envw.steps_done = 0;
+    if (lane == 3) envw.farm_pow_n = n2f;
+    if (lane == 4) envw.base_pow_n = n2b;
+    if (lane == 5) envw.time_max_live = time_max;
+    if (lane == 6) envw.rated_live = rated;
+    if (lane == 7) envw.fsum_run = sf;
+    if (lane == 8) envw.bsum_run = sb;
+    if (lane == 9) envw.n_pushed_live = nnp;
+    if (lane == 10) envw.shadow_iters = 0;       // (the initialising workgroups of the next k_flow launch plan their own first share)
+    if (!obs_done && obs) {
+        // first observation from the stored sums (generic layouts; per-agent buffer with prepared sums)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have landed before it reads the sums back
+        auto ld = [&](const int ent) {
+            ObsIn o;
+            const SumsEnt q = wg_sums_ent(p, d, nctx, ent);
+            const double* ws_ = d.wsum + (size_t)nctx * WG_N_SUMS * NS + ent;
+#pragma unroll
+            for (int sl = 0; sl < WG_N_SUMS; ++sl) o.S[sl] = ((q.sm >> sl) & 1u) ? __builtin_nontemporal_load(ws_ + (size_t)sl * NS) : 0.0;
+#pragma unroll
+            for (int ch = 0; ch < WG_N_CH; ++ch) {
+                const int off = q.farm ? p.fring_off[ch] : p.ring_off[ch];
+                o.cur[ch] = (nnp > 0 && ((q.cm >> ch) & 1u)) ? q.rb[off + ((nnp - 1) % p.ring_cap[ch]) * q.stride] : 0.f;
+            }
+            return o;
+        };
+        build_obs_sums<MULTI, GEN>(p, lane, obs, nullptr, om, nnp, mscr, ld(lane < N ? lane : 0), ld);
+    }
+}
+
+#ifndef WG_LEAN_ABLATE
+#define WG_LEAN_ABLATE 0      // profiling builds: return from k_glue_lean after phase n (tools/glue_ablate.sh)
+#endif
+// GEN = false: no TI and nothing farm-level in the observation — the instantiation of the shipped sensor sets.
+template <bool MULTI, bool GEN>
+__global__ void __launch_bounds__(WG_BLOCK, 4)
+k_glue_lean(const WgParams p, const WgPtrs d, const WgParams* gp, const WgPtrs* gd, float* __restrict__ obs_out,
+            float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out, float* __restrict__ final_obs_out,
+            const int lds_floats_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) float glue_lds[];
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * WG_NWAVES + (threadIdx.x >> 6);
+    if (e >= p.B) return;
+    const int N = p.N, F = p.F, PA = p.power_avg;
+    float* const mscr = MULTI ? glue_lds + (size_t)(threadIdx.x >> 6) * lds_floats_per_wave : nullptr;
+    WgEnv& env = d.env[e];
+    float* obs = obs_out ? obs_out + (size_t)e * p.obs_dim : nullptr;
+    float* om = MULTI ? d.multi_out + (size_t)e * N * p.obs_dim_multi : nullptr;
+    float* fq = d.farm_pow + (size_t)e * PA;
+    float* bq = d.base_pow + (size_t)e * PA;
+    const int own = lane < N ? lane : 0;          // this lane's first entity (lanes >= N: a valid dummy)
+
+    typedef const __attribute__((address_space(4))) WgEnv* CEnvPtr;
+    typedef const __attribute__((address_space(4))) WgSlot* CSlotPtr;
+    typedef const __attribute__((address_space(4))) WgCtx* CCtxPtr;
+    typedef const __attribute__((address_space(4))) float* CFloatPtr;
+    // (the scalar cache is invalidated at every kernel start; none of these words is written by this kernel before the
+    // wave reads it)
+    const CEnvPtr ec = (CEnvPtr)(d.env + e);
+    if (ec->done) {
+        if (lane == 0) atomicOr(d.status, WG_STATUS_BIT_STATE);
+        return;
+    }
+    EnvHot ev;
+    ev.live = ec->live; ev.timestep = ec->timestep; ev.episode = ec->episode; ev.done = 0; ev.shadow_iters = 0;
+    ev.farm_pow_n = ec->farm_pow_n; ev.base_pow_n = ec->base_pow_n; ev.steps_done = ec->steps_done;
+    ev.ep_return = ec->ep_return; ev.ep_power_sum = ec->ep_power_sum; ev.ep_len = ec->ep_len;
+    int time_max = ec->time_max_live, n_pushed_live = ec->n_pushed_live;
+    float rated_power = ec->rated_live;
+    double fsum_run = ec->fsum_run, bsum_run = ec->bsum_run;
+    const int live = ev.live, nxt = live ^ 1;
+    const int ctx_id = e * 2 + live;
+    if (WG_LEAN_ABLATE == 1) { if (lane == 0 && reward_out) reward_out[e] = (float)(fsum_run + bsum_run) + (float)(ev.timestep + ev.episode + time_max + n_pushed_live); return; }
+    // an env that truncates (known from the header alone) fetches the next context's header with everything else
+    int nx_pfn = 0, nx_pbn = 0, nx_np = 0, nx_tmax = 0;
+    float nx_rated = 0.f;
+    bool nx_prep = false;
+    if (ev.timestep >= time_max && p.autoreset) {
+        const CCtxPtr nc = (CCtxPtr)(d.ctx + e * 2 + nxt);
+        nx_pfn = nc->pend_farm_n; nx_pbn = nc->pend_base_n; nx_np = nc->n_pushed; nx_tmax = nc->time_max; nx_rated = nc->rated_power;
+        nx_prep = d.next_obs_ok != nullptr && ((const __attribute__((address_space(4))) int*)d.next_obs_ok)[e * 2 + nxt] != 0;
+    }
+    // ---- every load of the step, issued together ----
+    const SumsRaw raw = wg_sums_load<GEN>(p, d, e, ctx_id, own, n_pushed_live);
+    const size_t tb_a = (size_t)(ctx_id * F) * N;
+    float l_yaw = 0.f, l_old = 0.f, l_pow = 0.f, l_powb = 0.f;
+    if (lane < N) {
+        l_yaw = d.yaw[tb_a + lane]; l_old = d.old_yaw[(size_t)e * N + lane]; l_pow = d.power[tb_a + lane];
+        if (F == 2) l_powb = d.power[tb_a + N + lane];
+    }
+    const float fp = ((CFloatPtr)d.step_farm_pow)[e];
+    const float bp = F == 2 ? ((CFloatPtr)d.step_base_pow)[e] : 0.f;
+    const int fslot = ev.farm_pow_n % PA, bslot = ev.base_pow_n % PA;      // (counts run over all episodes)
+    const float f_old = ((CFloatPtr)fq)[fslot], b_old = F == 2 ? ((CFloatPtr)bq)[bslot] : 0.f;
+    float* met = d.metrics + (size_t)e * WG_N_METRICS;
+    const float l_met = lane < WG_N_METRICS ? met[lane] : 0.f;
+    // background episode: remaining work of its farms (plan of the next step's share), pending set-up flag
+    int work = 0;
+    if (p.autoreset) {
+        const CSlotPtr bs = (CSlotPtr)(d.slot + (size_t)(e * 2 + nxt) * F);
+        for (int f = 0; f < F; ++f) work = max(work, bs[f].dev_remaining + p.K * bs[f].fill_remaining);
+        if (((CCtxPtr)(d.ctx + e * 2 + nxt))->init_pending && lane == 0) d.ctx[e * 2 + nxt].init_pending = 0;
+    }
+    if (WG_LEAN_ABLATE == 2) {
+        float acc = raw.nw[0] + raw.nw[2] + raw.lv[0] + raw.lv[2] + (float)raw.S[0] + (float)raw.S[2] + l_yaw + l_old + l_pow + l_powb + fp + bp + f_old + b_old + l_met;
+        if (reward_out) reward_out[e] = acc + (float)work;
+        return;
+    }
+
+    // power deques (:975-981): the new sample replaces the oldest one once the deque is full
+    const bool f_full = ev.farm_pow_n >= PA, b_full = ev.base_pow_n >= PA;
+    fsum_run += (double)fp - (f_full ? (double)f_old : 0.0);
+    if (F == 2) bsum_run += (double)bp - (b_full ? (double)b_old : 0.0);
+    ev.farm_pow_n++;
+    if (F == 2) ev.base_pow_n++;
+    const int nf = ev.farm_pow_n < PA ? ev.farm_pow_n : PA, nb = ev.base_pow_n < PA ? ev.base_pow_n : PA;
+    if (lane == 0) {
+        fq[fslot] = fp;
+        if (F == 2) bq[bslot] = bp;
+        if (fp != fp) atomicOr(d.status, WG_STATUS_BIT_NAN_POWER);
+    }
+    const int truncated = ev.timestep >= time_max;                                                        // :1003
+    const bool swap_obs = truncated && p.autoreset;
+    float* fin = final_obs_out ? final_obs_out + (size_t)e * p.obs_dim : nullptr;
+    const int np_step = n_pushed_live;            // pushes the window sums account for before this step's update
+    n_pushed_live += 1;
+    if (WG_LEAN_ABLATE == 3) {
+        float acc = raw.nw[0] + raw.nw[2] + raw.lv[0] + raw.lv[2] + (float)raw.S[0] + (float)raw.S[2] + l_yaw + l_old + l_pow + l_powb + l_met;
+        if (reward_out) reward_out[e] = acc + (float)work + (float)(fsum_run + bsum_run) + (float)(nf + nb);
+        return;
+    }
+
+    // action penalty sums (:804-820) and current farm powers ("Power agent", :539)
+    float pen_s = 0.f, pnow = 0.f, pbase = 0.f;
+    if (lane < N) {
+        pen_s = p.penalty_type == WG_PEN_CHANGE ? fabsf(l_old - l_yaw) : fabsf(l_yaw);
+        pnow = l_pow; pbase = l_powb;
+    }
+    for (int t = lane + WG_WAVE; t < N; t += WG_WAVE) {      // farms with more than 64 turbines
+        const float y = d.yaw[tb_a + t];
+        pen_s += p.penalty_type == WG_PEN_CHANGE ? fabsf(d.old_yaw[(size_t)e * N + t] - y) : fabsf(y);
+        pnow += d.power[tb_a + t];
+        if (F == 2) pbase += d.power[tb_a + N + t];
+    }
+    if (p.action_penalty >= 0.001) pen_s = N <= 16 ? wg_row_sum(pen_s) : wg_wave_sum(pen_s);      // (lanes >= N hold 0)
+    pnow = N <= 16 ? wg_row_sum(pnow) : wg_wave_sum(pnow);
+    if (F == 2) pbase = N <= 16 ? wg_row_sum(pbase) : wg_wave_sum(pbase);
+    pen_s = __shfl(pen_s, 0, 64); pnow = __shfl(pnow, 0, 64); pbase = __shfl(pbase, 0, 64);
+
+    double pr = 0.0;
+    switch (p.reward_mode) {
+    case WG_REW_BASELINE: pr = (fsum_run * (double)nb) / (bsum_run * (double)nf) - 1.0; break;              // :882-891: mean / mean - 1
+    case WG_REW_POWER_AVG: pr = fsum_run / ((double)nf * (double)N * (double)rated_power); break;           // :896-897
+    case WG_REW_NONE: pr = 0.0; break;
+    case WG_REW_POWER_DIFF: {                                                                              // :904-918
+        // mean of the newest tenth minus mean of the oldest tenth of the deque: the one mode that reads the deque
+        const int wsz = PA / 10;
+        double fl = 0.0, fo = 0.0;
+        int nl = 0, no = 0;
+        for (int i = lane; i < PA; i += WG_WAVE) {
+            const float fv = i == fslot ? fp : fq[i];
+            if (i < nf) {
+                int q = i - (ev.farm_pow_n - nf) % PA; if (q < 0) q += PA;      // logical index (0 = oldest) of slot i
+                if (q >= PA - wsz && q < PA) { fl += (double)fv; nl++; }
+                if (q < wsz) { fo += (double)fv; no++; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            fl += __shfl_xor(fl, o, 64); fo += __shfl_xor(fo, o, 64);
+            nl += __shfl_xor(nl, o, 64); no += __shfl_xor(no, o, 64);
+        }
+        pr = (fl / (double)nl - fo / (double)no) / N;
+        break;
+    }
+    }
+    double pen = 0.0;
+    if (p.action_penalty >= 0.001)
+        pen = p.penalty_type == WG_PEN_CHANGE ? p.action_penalty * ((double)pen_s / N) : p.action_penalty * ((double)pen_s / N / p.yaw_max_d);
+    const float reward = (float)(pr * p.power_scaling + 0.0 - pen);                                       // :989-996
+    ev.timestep += 1 + (p.extra_inc ? 1 : 0);                                                             // :1027
+    ev.steps_done += 1;
+    ev.ep_return += reward; ev.ep_power_sum += pnow; ev.ep_len += 1;
+    if (lane == 0) {
+        if (reward_out) reward_out[e] = reward;
+        if (trunc_out) trunc_out[e] = (uint8_t)truncated;
+        d.last_pow_agent[e] = pnow; d.last_pow_base[e] = pbase;
+    }
+    if (lane < WG_N_METRICS) {            // lane m owns metric m (recordEpisodeVals.py:31-64)
+        const float trf = truncated ? 1.f : 0.f;
+        float add = 0.f;
+        add = lane == WG_MET_STEP_REWARD_SUM ? reward : add;
+        add = lane == WG_MET_FARM_POWER_SUM ? pnow : add;
+        add = lane == WG_MET_BASE_POWER_SUM ? pbase : add;
+        add = lane == WG_MET_N_STEPS ? 1.f : add;
+        add = lane == WG_MET_EP_RETURN_SUM ? trf * ev.ep_return : add;
+        add = lane == WG_MET_EP_LENGTH_SUM ? trf * (float)ev.ep_len : add;
+        add = lane == WG_MET_EP_MEAN_POWER_SUM ? (truncated ? ev.ep_power_sum / (float)ev.ep_len : 0.f) : add;
+        add = lane == WG_MET_N_EPISODES ? trf : add;
+        met[lane] = l_met + add;
+    }
+    if (WG_LEAN_ABLATE == 4) {
+        float acc = raw.nw[0] + raw.nw[2] + raw.lv[0] + raw.lv[2] + (float)raw.S[0] + (float)raw.S[2];
+        if (trunc_out && acc == 123.f) trunc_out[e] = 7;
+        return;
+    }
+    if (truncated) {
+        ev.ep_return = 0.f; ev.ep_power_sum = 0.f; ev.ep_len = 0;
+        ev.episode += 1;
+        if (!p.autoreset) {
+            ev.done = 1;
+        } else {
+            // same-step autoreset: the swap itself is the LAST thing the wave does (lean_swap, below)
+        }
+    }
+    // observation (:983): the window sums of the lane's turbine advance by one sample (S += newest - leaving), then the
+    // blocks; an env that truncates with same-step autoreset keeps it as final_obs only (and leaves the sums alone: the new
+    // episode's replace them)
+    {
+        float* o1 = swap_obs ? fin : obs;
+        if (o1) {
+            auto get = [&](const int ent) { return wg_sums_apply<GEN>(p, d, ctx_id, ent, wg_sums_load<GEN>(p, d, e, ctx_id, ent, np_step), !swap_obs); };
+            const ObsIn oi = wg_sums_apply<GEN>(p, d, ctx_id, own, raw, lane < N && !swap_obs);
+            build_obs_sums<MULTI, GEN>(p, lane, o1, swap_obs ? nullptr : fin, swap_obs ? nullptr : om, np_step + 1, mscr, oi, get);
+        }
+    }
+    if (WG_LEAN_ABLATE == 5) return;
+
+    if (!p.autoreset || truncated) ev.shadow_iters = 0;      // (after a swap the initialising workgroups plan their own first share)
+    else if (work == 0) ev.shadow_iters = 0;
+    else {
+        const int inc = 1 + (p.extra_inc ? 1 : 0);
+        const long total = (long)((time_max + inc - 1) / inc) + 1;
+        ev.shadow_iters = wg_shadow_share(work, total - ev.steps_done, ev.steps_done, e);
+    }
+    env_writeback(env, ev, lane);
+    if (lane == 11) env.time_max_live = time_max;
+    if (lane == 12) env.rated_live = rated_power;
+    if (lane == 13) env.fsum_run = fsum_run;
+    if (lane == 14) env.bsum_run = bsum_run;
+    if (lane == 15) env.n_pushed_live = n_pushed_live;
+    // same-step autoreset: the next episode — developed in the background — goes live
+    if (swap_obs)
+        lean_swap<MULTI, GEN>(gp, gd, e, live, lane, fp, bp, fslot, bslot, ev.farm_pow_n, ev.base_pow_n, ev.episode + 1, obs, om, mscr,
+                              nx_pfn, nx_pbn, nx_np, nx_tmax, nx_rated, nx_prep);
 }
 
 // ===================================================================================================
@@ -673,7 +1149,8 @@ extern "C" void wg_launch_box_coarsen(const void* fine, void* out, int nx, int n
 
 // host-visible launch helpers (defined here so that the <<<>>> syntax stays in one translation unit)
 extern "C" void wg_launch_glue(const WgParams* p, const WgPtrs* d, int phase, const uint8_t* mask, float* obs,
-                               float* reward, uint8_t* trunc, float* final_obs, hipStream_t st) {
+                               float* reward, uint8_t* trunc, float* final_obs, hipStream_t st, const WgParams* gp,
+                               const WgPtrs* gd) {
     const int grid = (p->B + WG_NWAVES - 1) / WG_NWAVES;
     // rings of one env staged in LDS when they fit (<= 16 KiB per wave); otherwise read from global memory
     // (the per-agent buffer's farm-block scratch shares the wave's region: the fit is decided on the sum, so that the
@@ -681,7 +1158,6 @@ extern "C" void wg_launch_glue(const WgParams* p, const WgPtrs* d, int phase, co
     int ring_floats = p->ring_stride + p->fring_stride;
     const int scratch = d->multi_out ? p->farm_obs : 0;
     if ((size_t)(ring_floats + scratch) * 4 > 16384) ring_floats = 0;
-    if (p->sums_mode) ring_floats = 0;        // nothing is staged
     const int per_wave = ring_floats + scratch;
     const size_t lds = (size_t)per_wave * 4 * WG_NWAVES;
     // lanes per turbine in the observation's window sums: the largest power of two with N * L <= 64 (16 turbines: 4,
@@ -694,10 +1170,19 @@ extern "C" void wg_launch_glue(const WgParams* p, const WgPtrs* d, int phase, co
                                 else if (L == 4) WG_GLUE_LAUNCH(M, R, 4, P); else WG_GLUE_LAUNCH(M, R, 8, P); } while (0)
     const bool pre = d->next_obs_ok != nullptr && !d->multi_out;
     if (p->sums_mode) {
-        if (d->multi_out) hipLaunchKernelGGL((k_glue<true, false, 1, false, true>), dim3(grid), dim3(WG_BLOCK), lds, st, *p, *d, phase,
-                                             mask, obs, reward, trunc, final_obs, per_wave, ring_floats);
-        else hipLaunchKernelGGL((k_glue<false, false, 1, false, true>), dim3(grid), dim3(WG_BLOCK), lds, st, *p, *d, phase,
-                                mask, obs, reward, trunc, final_obs, per_wave, ring_floats);
+        // (gp / gd: device-resident copies of the parameter blocks, read by the rare paths that live out of line)
+        const size_t lds2 = (size_t)scratch * 4 * WG_NWAVES;
+        if (phase == 1) {
+            if (d->multi_out) hipLaunchKernelGGL((k_glue_lean_reset<true>), dim3(grid), dim3(WG_BLOCK), lds2, st, *p, *d, gp, gd, mask, obs, scratch);
+            else hipLaunchKernelGGL((k_glue_lean_reset<false>), dim3(grid), dim3(WG_BLOCK), lds2, st, *p, *d, gp, gd, mask, obs, scratch);
+        } else {
+            // generic instantiation: TI entries or anything farm-level (single-agent farm block, the per-agent blocks' farm part)
+            const bool gen = p->turb_ti || p->farm_ti || p->farm_obs > 0 || (p->sum_mask_f | p->cur_mask_f) != 0;
+#define WG_LEAN(M, G) hipLaunchKernelGGL((k_glue_lean<M, G>), dim3(grid), dim3(WG_BLOCK), lds2, st, *p, *d, gp, gd, obs, reward, trunc, final_obs, scratch)
+            if (d->multi_out) { if (gen) WG_LEAN(true, true); else WG_LEAN(true, false); }
+            else { if (gen) WG_LEAN(false, true); else WG_LEAN(false, false); }
+#undef WG_LEAN
+        }
     } else if (d->multi_out) { if (ring_floats > 0) WG_GLUE_L(true, true, false); else WG_GLUE_L(true, false, false); }
     else if (pre) { if (ring_floats > 0) WG_GLUE_L(false, true, true); else WG_GLUE_L(false, false, true); }
     else { if (ring_floats > 0) WG_GLUE_L(false, true, false); else WG_GLUE_L(false, false, false); }

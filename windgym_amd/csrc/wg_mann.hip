@@ -31,42 +31,37 @@ extern "C" int wg_set_last_error_(int code, const char* msg);      // wg_api.hip
 // 2F1(1/3, 17/6; 4/3; -x) by its Euler integral (the parameters are symmetric: with a = 17/6, b = 1/3, c = 4/3 the
 // weight (1 - t)^(c - b - 1) is 1): (1/3) int_0^1 t^(-2/3) (1 + x t)^(-17/6) dt = int_0^1 (1 + x s^3)^(-17/6) ds with
 // t = s^3, = G(U) / U with U = x^(1/3), G(U) = int_0^U (1 + u^3)^(-17/6) du — a smooth, rapidly decaying integrand
-// (adaptive Simpson in double precision).
+// (panelled 8-point Gauss-Legendre in double precision, accumulated along the table).
 static double mann_g(double u) { return std::pow(1.0 + u * u * u, -17.0 / 6.0); }
-static double simpson_rec(double a, double b, double fa, double fm, double fb, double whole, double tol, int depth) {
-    const double m = 0.5 * (a + b), lm = 0.5 * (a + m), rm = 0.5 * (m + b);
-    const double flm = mann_g(lm), frm = mann_g(rm);
-    const double left = (m - a) / 6.0 * (fa + 4.0 * flm + fm), right = (b - m) / 6.0 * (fm + 4.0 * frm + fb);
-    const double delta = left + right - whole;
-    if (depth <= 0 || std::fabs(delta) <= 15.0 * tol) return left + right + delta / 15.0;
-    return simpson_rec(a, m, fa, flm, fm, left, 0.5 * tol, depth - 1) + simpson_rec(m, b, fm, frm, fb, right, 0.5 * tol, depth - 1);
+// 8-point Gauss-Legendre on [a, b]
+static double gl8(double a, double b) {
+    static const double x[4] = {0.1834346424956498049, 0.5255324099163289858, 0.7966664774136267396, 0.9602898564975362317};
+    static const double w[4] = {0.3626837833783619830, 0.3137066458778872873, 0.2223810344533744706, 0.1012285362903762591};
+    const double c = 0.5 * (a + b), h = 0.5 * (b - a);
+    double s = 0.0;
+    for (int k = 0; k < 4; ++k) s += w[k] * (mann_g(c - h * x[k]) + mann_g(c + h * x[k]));
+    return s * h;
 }
-static double mann_G(double U) {
-    // panels that follow the integrand's scale (it falls like u^-8.5 beyond u ~ 1)
-    double s = 0.0, a = 0.0;
-    const double edges[] = {0.25, 0.5, 1.0, 2.0, 4.0, 8.0, 16.0, 64.0, 1e300};
-    for (double e : edges) {
-        const double b = U < e ? U : e;
-        if (b > a) {
-            const double fa = mann_g(a), fb = mann_g(b), fm = mann_g(0.5 * (a + b));
-            s += simpson_rec(a, b, fa, fm, fb, (b - a) / 6.0 * (fa + 4.0 * fm + fb), 1e-15, 40);
-            a = b;
-        }
-        if (U <= e) break;
-    }
+// int_a^b g with panels no wider than 1/8 (g varies on the scale of 1 around u ~ 1 and is flat or negligible elsewhere)
+static double mann_int(double a, double b) {
+    const int np = (int)std::ceil((b - a) * 8.0) < 1 ? 1 : (int)std::ceil((b - a) * 8.0);
+    double s = 0.0;
+    for (int k = 0; k < np; ++k) s += gl8(a + (b - a) * k / np, a + (b - a) * (k + 1) / np);
     return s;
-}
-static double mann_hyp2f1(double x) {          // 2F1(1/3, 17/6; 4/3; -x), x >= 0
-    if (x < 1e-9) return 1.0 - (17.0 / 24.0) * x;      // series: 1 - a b / c x, a b / c = (1/3)(17/6)/(4/3)
-    const double U = std::cbrt(x);
-    return mann_G(U) / U;
 }
 
 extern "C" int wg_mann_beta_table(double Gamma, int n, double log10_lo, double log10_hi, double* beta_out) {
     if (!beta_out || n < 2 || !(log10_hi > log10_lo)) return wg_set_last_error_(WG_ERR_INVALID, "wg_mann_beta_table: bad arguments");
-    for (int i = 0; i < n; ++i) {
+    // G(U) is accumulated along the table: U = (kL)^(-2/3) grows as kL falls, so the table is walked from its last entry
+    // (largest kL, smallest U) to its first; the integrand is negligible beyond u = 64 (g < 1e-15)
+    double G = 0.0, U_prev = 0.0;
+    for (int i = n - 1; i >= 0; --i) {
         const double kl = std::pow(10.0, log10_lo + (log10_hi - log10_lo) * i / (n - 1));
-        beta_out[i] = Gamma == 0.0 ? 0.0 : Gamma * std::pow(kl, -2.0 / 3.0) / std::sqrt(mann_hyp2f1(1.0 / (kl * kl)));
+        const double U = std::pow(kl, -2.0 / 3.0);
+        const double b = U < 64.0 ? U : 64.0;
+        if (b > U_prev) { G += mann_int(U_prev, b); U_prev = b; }
+        const double F = G / U;                               // 2F1(1/3, 17/6; 4/3; -(kL)^-2)
+        beta_out[i] = Gamma == 0.0 ? 0.0 : Gamma * std::pow(kl, -2.0 / 3.0) / std::sqrt(F);
     }
     return 0;
 }

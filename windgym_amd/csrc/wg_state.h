@@ -26,8 +26,8 @@ typedef unsigned __int128 wg_u128;
 
 enum { WG_MODE_STEP = 0, WG_MODE_RESET = 1 };
 
-// Running window sums of the sensor deques (WgPtrs::wsum), maintained by the flow kernels at every push so that the glue
-// kernel reads a handful of values per turbine instead of staging the rings ("sums mode", wg_create).  Slot s < WG_N_CH: sum
+// Running window sums of the live episode's sensor deques (WgPtrs::wsum), maintained by the lean glue kernel: per step it
+// reads the newest and the leaving sample of each window instead of staging the rings ("sums mode", wg_create).  Slot s < WG_N_CH: sum
 // of the newest min(window_len, history_len, pushed) samples of channel s — the one window a rolling mean with history_N
 // = 1 reads (MesClass.py:85-91); slots 4 / 5: sum of v and of v^2 over the whole ws deque (calc_TI, MesClass.py:220-237).
 // Double accumulators: adding and later subtracting the same float is exact, the sums do not drift.
@@ -37,6 +37,17 @@ enum { WG_SUM_TI1 = 4, WG_SUM_TI2 = 5 };
 // Sticky device status word (WgPtrs::status): one bit per condition, latched with atomicOr, so that a saturated emission
 // record cannot hide a NaN power or a step on a finished env; wg_check reports the most serious one set.
 enum { WG_STATUS_BIT_NAN_POWER = 1, WG_STATUS_BIT_STATE = 2, WG_STATUS_BIT_RANGE = 4 };
+
+// What one turbine's block of the observation is made of (sums mode, wg_obs_turbine).  Scaling with the
+// reciprocal of the range: v -> 2 (v - mn) inv_rng - 1, clipped to [-1, 1] (turb_mes._scale_val, MesClass.py:324-326, to
+// one float rounding).
+struct WgObsCfg {
+    unsigned cur_mask, rol_mask;       // channels observed through `current` / through the rolling mean (turbine level)
+    int turb_ti, turb_obs, obs_dim, obs_dim_multi;
+    int hlen[WG_N_CH], wlen[WG_N_CH];
+    float mn[WG_N_CH], inv_rng[WG_N_CH], ti_mn, inv_ti_rng;
+    double inv_w[WG_N_CH];             // 1 / min(window, history): the divisor once the window is full
+};
 
 struct WgParams {
     int B, N, F, K, P, S, NP;
@@ -78,9 +89,14 @@ struct WgParams {
     int compact;         // 1: per-turbine ring lengths (small-farm k_flow variant), see WgPtrs::roff
     int stage_ch[WG_N_CH];   // k_glue ring staging per channel: 0 = not observed, 1 = newest sample only, 2 = whole ring
     double cx0, cy0;     // farm centre (mean of the layout), the pivot of the flow-frame rotation
-    // sums mode (every observed rolling mean has history_N = 1): which slots of WgPtrs::wsum / channels of WgPtrs::wcur
-    // are maintained at turbine level (_t) and for the farm-level deques (_f); sum_w[s] = min(window, history) of slot s
+    // sums mode (every observed rolling mean has history_N = 1): the lean glue kernel keeps running window sums
+    // (WgPtrs::wsum): which slots are maintained at turbine level (_t) and for the farm-level deques (_f), which channels are
+    // observed through their newest sample; sum_w[s] = min(window, history) of slot s
     int sums_mode;
+    unsigned ring_magic[WG_N_CH];   // floor(2^32 / ring_cap) + 1 (wg_umod)
+    int ring_cap[WG_N_CH];   // physical length of the sensor rings: history_len, + 1 in sums mode (the sample leaving a window
+                             // as long as the deque must survive the push that displaces it)
+    WgObsCfg oc;
     unsigned sum_mask_t, sum_mask_f, cur_mask_t, cur_mask_f;
     int sum_w[WG_N_SUMS];
 };
@@ -137,7 +153,15 @@ struct WgEnv {
     int steps_done;      // step() calls in the running episode
     float ep_return, ep_power_sum;
     int ep_len;
-    int pad[3];
+    // lean glue kernel (sums mode): what it needs of the LIVE context, kept in the env header so that its loads depend on
+    // the env index only — set wherever `live` changes (end of reset, swap); n_pushed_live = sensor pushes of the live
+    // episode the window sums account for (the flow kernel has pushed one more when the glue runs)
+    int time_max_live;
+    float rated_live;
+    int n_pushed_live;
+    // running sums of the power deques (farm_pow / base_pow): S += new - overwritten, exact in double like the window
+    // sums; recomputed from the deques at the end of reset and at every swap
+    double fsum_run, bsum_run;
 };
 
 struct WgPtrs {
@@ -174,10 +198,10 @@ struct WgPtrs {
     // itself).  Null unless the handle runs the single-wave steady flow kernel (wg_create).
     float* next_obs;          // [B*2][obs_dim]
     int* next_obs_ok;         // [B*2]
-    // sums mode: wsum[ctx][WG_N_SUMS][N + 1] running window sums (entity N = the farm-level deques), wcur[ctx][WG_N_CH][N + 1]
-    // the newest sample of every channel observed through `current`; null otherwise
+    // sums mode: wsum[B*2][WG_N_SUMS][N + 1] running window sums of a context's deques (entity N = the farm-level deques):
+    // advanced by k_glue_lean while the episode is live, summed afresh when it goes live (end of reset; swap: by the flow
+    // kernel's wg_first_obs where it prepares the episode, else by lean_swap); null otherwise
     double* wsum;
-    float* wcur;
     int* status;              // sticky error word
     const double* wind_override;   // [B][3] (ws, wd, ti) or null; NaN = keep the sampled value
     const int* box_override;       // [B] box of the pool env e uses (FarmEval.update_tf: TF_files = [path]) or null; < 0 = draw

@@ -9,8 +9,9 @@ component (the reference rescales with ``scale_TI(TI, U)``, :617/:637/:658 — t
 env instead).  Layout: float32 [3, Nx, Ny, Nz], z fastest — what ``wg_set_turbulence_box`` expects.
 
 One box is generated per process and shared by every env of the GPU (a per-env 0.8 GB box is not an option at
-thousands of envs); episodes differ by a random horizontal offset (WG_TURB_BOX_SHIFT).  A hipFFT generator
-on the device is the "next" row f2 of SURVEY.md §8.
+thousands of envs); episodes differ by a random horizontal offset (WG_TURB_BOX_SHIFT).  The product path generates
+the box on the device (``generate_mann_box_hip`` -> wg_generate_mann_box: HIP spectral-tensor kernel + hipFFT, row f2 of
+SURVEY.md §8); the numpy version below is its restatement for tests and for the CPU oracle.
 """
 from __future__ import annotations
 
@@ -25,10 +26,27 @@ def _eddy_lifetime_beta(kL, Gamma):
     return Gamma * kL ** (-2.0 / 3.0) / np.sqrt(hyp2f1(1.0 / 3.0, 17.0 / 6.0, 4.0 / 3.0, -kL ** (-2.0)))
 
 
-def generate_mann_box(Nxyz=(1024, 128, 32), dxyz=(3.0, 3.0, 3.0), alphaepsilon=0.1, L=33.6, Gamma=3.9, seed=1234):
-    Nx, Ny, Nz = (int(n) for n in Nxyz)
+BETA_TABLE = dict(n=4096, log10_lo=-6.0, log10_hi=6.0)    # the table wg_generate_mann_box interpolates (wg_mann.hip)
+
+
+def _beta_from_table(kL, table):
+    """beta(kL) by linear interpolation in log10(kL) of a log-spaced table — what the HIP kernel does (float64 here)."""
+    lo, hi, n = BETA_TABLE["log10_lo"], BETA_TABLE["log10_hi"], len(table)
+    lk = np.log10(np.clip(kL, 10.0 ** lo, 10.0 ** hi))
+    pos = (lk - lo) * ((n - 1) / (hi - lo))
+    i0 = np.clip(np.floor(pos).astype(np.int64), 0, n - 2)
+    w = pos - i0
+    return table[i0] * (1.0 - w) + table[i0 + 1] * w
+
+
+def mann_field_from_noise(noise, dxyz=(3.0, 3.0, 3.0), alphaepsilon=0.1, L=33.6, Gamma=3.9, beta_table=None):
+    """The spectral part of the generator for GIVEN complex white noise ``noise`` [3, Nx, Ny, Nz] (E|n|^2 = 1): sheared
+    von Karman tensor times the noise, inverse FFT, unit standard deviation of u.  float64 numpy — the CPU restatement
+    the HIP generator (``generate_mann_box_hip(noise=...)``) is pinned against cell by cell (tests/test_mann_generator.py).
+    ``beta_table``: interpolate the eddy lifetime in this table (as the kernel does) instead of evaluating 2F1 per cell."""
+    noise = np.asarray(noise)
+    _, Nx, Ny, Nz = noise.shape
     dx, dy, dz = (float(d) for d in dxyz)
-    rng = np.random.default_rng(seed)
     k1 = 2 * np.pi * np.fft.fftfreq(Nx, dx)[:, None, None]
     k2 = 2 * np.pi * np.fft.fftfreq(Ny, dy)[None, :, None]
     k3 = 2 * np.pi * np.fft.fftfreq(Nz, dz)[None, None, :]
@@ -36,7 +54,7 @@ def generate_mann_box(Nxyz=(1024, 128, 32), dxyz=(3.0, 3.0, 3.0), alphaepsilon=0
     k2 = np.broadcast_to(k2, (Nx, Ny, Nz)).astype(np.float64)
     k3 = np.broadcast_to(k3, (Nx, Ny, Nz)).astype(np.float64)
     kk = np.sqrt(k1 ** 2 + k2 ** 2 + k3 ** 2)
-    beta = _eddy_lifetime_beta(kk * L, Gamma)
+    beta = _eddy_lifetime_beta(kk * L, Gamma) if beta_table is None else _beta_from_table(kk * L, np.asarray(beta_table, np.float64))
     k30 = k3 + beta * k1
     k0 = np.sqrt(k1 ** 2 + k2 ** 2 + k30 ** 2)
     k0 = np.where(k0 == 0, 1e-12, k0)
@@ -54,8 +72,7 @@ def generate_mann_box(Nxyz=(1024, 128, 32), dxyz=(3.0, 3.0, 3.0), alphaepsilon=0
     zeta2 = k2 / k1s * C1 + C2
     zeta1 = np.where(k1 == 0, -beta, zeta1)
     zeta2 = np.where(k1 == 0, 0.0, zeta2)
-    # random complex Gaussian white noise
-    n = (rng.standard_normal((3, Nx, Ny, Nz)) + 1j * rng.standard_normal((3, Nx, Ny, Nz))) / np.sqrt(2.0)
+    n = noise
     # isotropic incompressible field dZ_iso = amp * (k0 x n), then sheared
     a1 = amp * (k2 * n[2] - k30 * n[1])
     a2 = amp * (k30 * n[0] - k1 * n[2])
@@ -65,70 +82,69 @@ def generate_mann_box(Nxyz=(1024, 128, 32), dxyz=(3.0, 3.0, 3.0), alphaepsilon=0
     dZ2 = a2 + zeta2 * a3
     dZ3 = r * a3
     dV = (2 * np.pi) ** 3 / (Nx * dx * Ny * dy * Nz * dz)
-    out = np.empty((3, Nx, Ny, Nz), dtype=np.float32)
+    out = np.empty((3, Nx, Ny, Nz), dtype=np.float64)
     for c, dZ in enumerate((dZ1, dZ2, dZ3)):
         dZ = dZ.copy()
         dZ[0, 0, 0] = 0.0
-        out[c] = (np.fft.ifftn(dZ) * (Nx * Ny * Nz) * np.sqrt(dV)).real.astype(np.float32)
+        out[c] = (np.fft.ifftn(dZ) * (Nx * Ny * Nz) * np.sqrt(dV)).real
     out /= float(out[0].std())
-    return np.ascontiguousarray(out)
+    return out
 
 
-def generate_mann_box_torch(Nxyz=(2048, 512, 64), dxyz=(3.0, 3.0, 3.0), alphaepsilon=0.1, L=33.6, Gamma=3.9,
-                            seed=1234, device="cuda"):
-    """Same algorithm on the GPU: the three inverse FFTs run in hipFFT (torch.fft on ROCm), so the reference's
-    box sizes (2048x512x64 = 0.8 GB, Wind_Farm_Env.py:654; 4096x512x64, :629-633) take seconds instead of minutes.
-    The eddy-lifetime factor (a 2F1 hypergeometric function of |k|L only) is tabulated on the host with scipy and
-    interpolated on the device.  Returns a float32 CUDA tensor [3, Nx, Ny, Nz], unit std of u."""
-    import torch
+def generate_mann_box(Nxyz=(1024, 128, 32), dxyz=(3.0, 3.0, 3.0), alphaepsilon=0.1, L=33.6, Gamma=3.9, seed=1234):
     Nx, Ny, Nz = (int(n) for n in Nxyz)
-    dx, dy, dz = (float(d) for d in dxyz)
+    rng = np.random.default_rng(seed)
+    # random complex Gaussian white noise
+    n = (rng.standard_normal((3, Nx, Ny, Nz)) + 1j * rng.standard_normal((3, Nx, Ny, Nz))) / np.sqrt(2.0)
+    return np.ascontiguousarray(mann_field_from_noise(n, dxyz, alphaepsilon, L, Gamma).astype(np.float32))
+
+
+def mann_beta_table(Gamma, n=None, log10_lo=None, log10_hi=None):
+    """The eddy-lifetime table of the HIP generator (wg_mann_beta_table: 2F1 by adaptive quadrature of its Euler integral,
+    host code of libwindgym_hip.so — no GPU needed)."""
+    import ctypes as C
+    from .binding import _chk, load_library
+    n = n or BETA_TABLE["n"]
+    lo = BETA_TABLE["log10_lo"] if log10_lo is None else log10_lo
+    hi = BETA_TABLE["log10_hi"] if log10_hi is None else log10_hi
+    out = np.empty(n, dtype=np.float64)
+    _chk(load_library().wg_mann_beta_table(float(Gamma), int(n), float(lo), float(hi), out.ctypes.data_as(C.POINTER(C.c_double))),
+         "wg_mann_beta_table")
+    return out
+
+
+def generate_mann_box_hip(Nxyz=(2048, 512, 64), dxyz=(3.0, 3.0, 3.0), alphaepsilon=0.1, L=33.6, Gamma=3.9, seed=1234,
+                          device="cuda", noise=None):
+    """The box generated on the MI355X by libwindgym_hip.so (wg_generate_mann_box: spectral-tensor kernel + hipFFT; the
+    reference's sizes — 2048 x 512 x 64 = 0.8 GB, Wind_Farm_Env.py:654; 4096 x 512 x 64, :629-633 — take a fraction of a
+    second and never leave the device).  ``noise``: optional complex white noise [3, Nx, Ny, Nz] (numpy complex or a CUDA
+    float tensor [3, Nx, Ny, Nz, 2]) used instead of the built-in Philox stream keyed by ``seed``.
+    Returns a float32 CUDA tensor [3, Nx, Ny, Nz], unit std of u."""
+    import ctypes as C
+    import torch
+    from .binding import _chk, load_library
+    L_ = load_library()
+    if not torch.cuda.is_available():
+        raise RuntimeError("generate_mann_box_hip needs a HIP device (the numpy restatement is generate_mann_box)")
+    Nx, Ny, Nz = (int(n) for n in Nxyz)
     dev = torch.device(device)
-    f32, c64 = torch.float32, torch.complex64
-    g = torch.Generator(device=dev).manual_seed(int(seed))
-    k1 = (2 * np.pi * torch.fft.fftfreq(Nx, dx, device=dev, dtype=f32))[:, None, None]
-    k2 = (2 * np.pi * torch.fft.fftfreq(Ny, dy, device=dev, dtype=f32))[None, :, None]
-    k3 = (2 * np.pi * torch.fft.fftfreq(Nz, dz, device=dev, dtype=f32))[None, None, :]
-    kk = torch.sqrt(k1 ** 2 + k2 ** 2 + k3 ** 2)
-    # beta(|k| L) table: log-spaced, linear interpolation in log space
-    kl_tab = np.logspace(-6, 6, 4096)
-    beta_tab = torch.as_tensor(_eddy_lifetime_beta(kl_tab, Gamma), dtype=f32, device=dev)
-    lk = torch.log10(torch.clamp(kk * L, min=1e-6, max=1e6))
-    pos = (lk + 6.0) / 12.0 * (len(kl_tab) - 1)
-    i0 = torch.clamp(pos.floor().long(), 0, len(kl_tab) - 2)
-    w = pos - i0.to(f32)
-    beta = beta_tab[i0] * (1 - w) + beta_tab[i0 + 1] * w
-    del lk, pos, i0, w
-    k30 = k3 + beta * k1
-    k0 = torch.sqrt(k1 ** 2 + k2 ** 2 + k30 ** 2).clamp_min(1e-12)
-    kks = kk.clamp_min(1e-12)
-    E0 = alphaepsilon * L ** (5.0 / 3.0) * (k0 * L) ** 4 / (1.0 + (k0 * L) ** 2) ** (17.0 / 6.0)
-    amp = torch.sqrt(E0 / (4.0 * np.pi)) / k0 ** 2
-    del E0
-    k12 = (k1 ** 2 + k2 ** 2).expand(Nx, Ny, Nz)
-    k12s = k12.clamp_min(1e-12)
-    C1 = beta * k1 ** 2 * (k0 ** 2 - 2 * k30 ** 2 + beta * k1 * k30) / (kks ** 2 * k12s)
-    C2 = k2 * k0 ** 2 / k12s ** 1.5 * torch.atan2(beta * k1 * torch.sqrt(k12s), k0 ** 2 - k30 * k1 * beta)
-    k1s = torch.where(k1 == 0, torch.full_like(k1, 1e-12), k1)
-    zeta1 = torch.where(k1 == 0, -beta, C1 - k2 / k1s * C2)
-    zeta2 = torch.where(k1 == 0, torch.zeros_like(beta), k2 / k1s * C1 + C2)
-    del C1, C2, k12, k12s
-    shape = (Nx, Ny, Nz)
-    n = [torch.complex(torch.randn(shape, generator=g, device=dev, dtype=f32),
-                       torch.randn(shape, generator=g, device=dev, dtype=f32)) / np.sqrt(2.0) for _ in range(3)]
-    a3 = amp * (k1 * n[1] - k2 * n[0])
-    dZ = [amp * (k2 * n[2] - k30 * n[1]) + zeta1 * a3, amp * (k30 * n[0] - k1 * n[2]) + zeta2 * a3,
-          (k0 / kks) ** 2 * a3]
-    del n, a3, amp, zeta1, zeta2
-    dV = (2 * np.pi) ** 3 / (Nx * dx * Ny * dy * Nz * dz)
-    out = torch.empty((3, Nx, Ny, Nz), dtype=f32, device=dev)
-    for c in range(3):
-        z = dZ[c].to(c64)
-        z[0, 0, 0] = 0
-        out[c] = torch.fft.ifftn(z).real * (Nx * Ny * Nz * np.sqrt(dV))
-        dZ[c] = None
-    out /= out[0].std()
-    return out.contiguous()
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    out = torch.empty((3, Nx, Ny, Nz), dtype=torch.float32, device=torch.device("cuda", idx))
+    nz = None
+    if noise is not None:
+        if not isinstance(noise, torch.Tensor):
+            noise = np.asarray(noise)
+            noise = torch.from_numpy(np.stack([noise.real, noise.imag], axis=-1).astype(np.float32))
+        nz = noise.to(device=out.device, dtype=torch.float32).contiguous()
+        assert tuple(nz.shape) == (3, Nx, Ny, Nz, 2)
+    st = torch.cuda.current_stream(out.device).cuda_stream
+    _chk(L_.wg_generate_mann_box(idx, C.c_void_p(out.data_ptr()), Nx, Ny, Nz, float(dxyz[0]), float(dxyz[1]), float(dxyz[2]),
+                                 float(alphaepsilon), float(L), float(Gamma), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+                                 C.c_void_p(nz.data_ptr()) if nz is not None else None, C.c_void_p(st)), "wg_generate_mann_box")
+    return out
+
+
+generate_mann_box_torch = generate_mann_box_hip      # (rounds 1-3 generated the box with torch.fft; kept as a name only)
 
 
 # Wake-added turbulence (row a7): the isotropic small-scale box the reference's addedTurbulenceModel =
