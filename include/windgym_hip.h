@@ -345,6 +345,16 @@ int wg_generate_mann_box(int device, float* box_dev, int nx, int ny, int nz, dou
  * [1e-6, 1e6]); exported so that tests pin it against an independent 2F1.                                               */
 int wg_mann_beta_table(double Gamma, int n, double log10_lo, double log10_hi, double* beta_out);
 
+/* Steady-state farm power for a batch of cases — the inner loop of PyWakeAgent.yaw_optimizer_srf_vect
+ * (WindGym/Agents/PyWakeAgent.py:144-288: every Serial-Refine step evaluates the farm power of yaw_n candidate yaw vectors
+ * per wind condition): power_dev f32[n_cases][n_turb] (W) for ws / wd / ti f32[n_cases] and yaw_dev f32[n_cases][n_turb]
+ * (degrees, flow frame).  Layout, turbine table, rotor points and model constants are the handle's.
+ * model 0: the steady state of the env's own flow model (what wg_step converges to under constant yaws);
+ * model 1: the reference agent's py_wake model restated from the publications (Blondel & Cathelain 2020 super-Gaussian
+ *          at the rotor centre, linear superposition, Jimenez deflection, Ct cos^2(yaw)).  One kernel launch (k_steady).   */
+int wg_steady_power(wg_handle h, int model, int n_cases, const float* ws_dev, const float* wd_dev, const float* ti_dev,
+                    const float* yaw_dev, float* power_dev, void* stream);
+
 /* Rotor points at which one flow launch looked the wake-added turbulence box up (8 corners x (u, v, w) = 96 bytes each:
  * only the rotors of targets with a candidate source wake do), averaged over the window the LAST wg_kernel_timing call
  * closed — the a7 term of bench.py's algorithmic bytes.  0 without wg_config.added_turbulence.                              */

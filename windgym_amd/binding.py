@@ -32,7 +32,7 @@ UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 ABI_SYMBOLS = (
     "wg_last_error", "wg_abi_version", "wg_create", "wg_destroy", "wg_obs_dim", "wg_hist_max",
     "wg_set_turbulence_box", "wg_set_turbulence_boxes", "wg_set_added_turbulence_box", "wg_set_box_ids", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_set_step_graph", "wg_check", "wg_obs_multi", "wg_set_obs_multi_buffer",
-    "wg_get_info", "wg_get_measurements", "wg_get_windspeed", "wg_metrics", "wg_get_state", "wg_set_state", "wg_generate_mann_box", "wg_mann_beta_table", "wg_kernel_timing", "wg_added_lookups", "wg_algorithmic_bytes", "wg_flow_variant",
+    "wg_get_info", "wg_get_measurements", "wg_get_windspeed", "wg_metrics", "wg_get_state", "wg_set_state", "wg_generate_mann_box", "wg_mann_beta_table", "wg_steady_power", "wg_kernel_timing", "wg_added_lookups", "wg_algorithmic_bytes", "wg_flow_variant",
 )
 
 _lib = None
@@ -89,6 +89,7 @@ def load_library():
     L.wg_added_lookups.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.wg_generate_mann_box.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                        C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.wg_steady_power.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6
     L.wg_mann_beta_table.argtypes = [C.c_double, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]
     L.wg_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.wg_flow_variant.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -354,6 +355,21 @@ class HipBatch:
         _chk(self.L.wg_kernel_timing(self._h, int(enable), C.byref(f), C.byref(g), C.byref(n), C.byref(fs),
                                      C.byref(pt)), "wg_kernel_timing")
         return f.value, g.value, n.value, fs.value, pt.value
+
+    def steady_power(self, ws, wd, ti, yaw, model="m0"):
+        """Steady-state power per turbine [n_cases, N] (W) for the wind conditions ws / wd / ti [n_cases] and yaw vectors
+        [n_cases, N] (degrees): ONE launch of k_steady (wg_steady_power).  model "m0" = the env's own flow model,
+        "blondel_jimenez" = the reference PyWakeAgent's model."""
+        t = self.torch
+        f = lambda a: t.as_tensor(np.array(a, dtype=np.float32) if not isinstance(a, t.Tensor) else a, dtype=t.float32,
+                                  device=self.device).contiguous()          # noqa: E731
+        yaw = f(yaw).reshape(-1, self.cfg.n_turb)
+        n = yaw.shape[0]
+        ws, wd, ti = (f(a).reshape(-1).expand(n).contiguous() for a in (ws, wd, ti))
+        out = t.empty((n, self.cfg.n_turb), dtype=t.float32, device=self.device)
+        _chk(self.L.wg_steady_power(self._h, {"m0": 0, "blondel_jimenez": 1}[model], n, ws.data_ptr(), wd.data_ptr(),
+                                    ti.data_ptr(), yaw.data_ptr(), out.data_ptr(), self._stream()), "wg_steady_power")
+        return out
 
     def added_lookups(self):
         """Rotor points per flow launch at which the wake-added turbulence box was looked up (window of the last

@@ -13,6 +13,7 @@
 
 #include "wg_state.h"
 #include "wg_flow.h"
+#include "wg_steady.h"
 
 extern "C" {
 void wg_launch_flow(const FlowP*, const FlowPtrs*, int, const float*, const uint8_t*, int, hipStream_t);
@@ -27,6 +28,7 @@ void wg_launch_measurements(const WgParams*, const WgPtrs*, float*, hipStream_t)
 void wg_launch_box_coarsen(const void*, void*, int, int, int, hipStream_t);
 void wg_launch_windspeed(const FlowP*, const FlowPtrs*, int, int, const float*, int, const float*, int, float, int, float*, hipStream_t);
 void wg_launch_unready(const WgParams*, const WgPtrs*, const uint8_t*, int*, hipStream_t);
+void wg_launch_steady(const void*, const float*, const float*, const float*, const float*, float*, hipStream_t);
 }
 
 static thread_local std::string g_err;
@@ -1147,6 +1149,27 @@ extern "C" int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, do
         }
         h->ev_kind.assign(WG_MAX_TIMING_EVENTS / 2, 0);
     }
+    return 0;
+}
+
+extern "C" int wg_steady_power(wg_handle h, int model, int n_cases, const float* ws_dev, const float* wd_dev, const float* ti_dev,
+                               const float* yaw_dev, float* power_dev, void* stream) {
+    if (!h || !ws_dev || !wd_dev || !ti_dev || !yaw_dev || !power_dev) return fail(WG_ERR_INVALID, "null argument");
+    if (model != 0 && model != 1) return fail(WG_ERR_INVALID, "wg_steady_power: model must be 0 (steady state of M0) or 1 (Blondel-Cathelain + Jimenez)");
+    if (n_cases < 1) return fail(WG_ERR_INVALID, "wg_steady_power: n_cases must be >= 1");
+    if (int rc = use_device(h)) return rc;
+    SteadyP sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.n_cases = n_cases; sp.N = h->p.N; sp.S = h->p.S; sp.n_tab = h->p.n_tab; sp.model = model;
+    sp.n_quad = model == 0 ? 48 : 20;      // quadrature of the deflection integral (steady.py's defaults)
+    sp.D = h->p.D; sp.hub = h->p.hub; sp.R = 0.5f * h->p.D;
+    sp.ka = h->p.ka; sp.kb = h->p.kb; sp.eps0 = h->p.eps0; sp.hill = h->p.hill;
+    sp.tia = h->p.tia; sp.tib = h->p.tib; sp.tic = h->p.tic; sp.tid = h->p.tid;
+    sp.cx0 = h->p.cx0; sp.cy0 = h->p.cy0;
+    sp.x_pos = h->d.x_pos; sp.y_pos = h->d.y_pos; sp.rotor_dy = h->d.rotor_dy; sp.rotor_dz = h->d.rotor_dz;
+    sp.tab_ws = h->d.tab_ws; sp.tab_power = h->d.tab_power; sp.tab_ct = h->d.tab_ct;
+    wg_launch_steady(&sp, ws_dev, wd_dev, ti_dev, yaw_dev, power_dev, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

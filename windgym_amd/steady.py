@@ -174,14 +174,35 @@ def blondel_jimenez_power(x, y, ws, wd, ti, yaw, turbine=None, n_quad=20, device
 WAKE_MODELS = {"m0": None, "blondel_jimenez": blondel_jimenez_power}
 
 
+def hip_batch_for(x, y, turbine=None, n_rotor_pts=16, device=None):
+    """A minimal :class:`windgym_amd.binding.HipBatch` (one env) that carries a layout and a turbine to the device, so that
+    ``HipBatch.steady_power`` (k_steady) can evaluate steady-state farm powers for it."""
+    from .binding import HipBatch
+    from .config import EnvConfig
+    from .presets import env1_config
+    d = env1_config()
+    d["power_def"]["Power_reward"] = "Power_avg"
+    cfg = EnvConfig(turbine=turbine if turbine is not None else V80(), yaml_dict=d, turbtype="None", n_envs=1,
+                    x_pos=np.asarray(x, dtype=float), y_pos=np.asarray(y, dtype=float), n_rotor_pts=n_rotor_pts)
+    return HipBatch(cfg, device=device)
+
+
 def yaw_optimizer_srf(x, y, ws, wd, ti, turbine=None, refine_pass_n=8, yaw_n=9, yaw_max=30.0, device="cpu",
-                      model="m0"):
+                      model="m0", batch=None):
     """Serial-Refine yaw optimisation (PyWakeAgent.py:144-288) for a batch of wind conditions at once.
     ws, wd, ti: arrays of the same length C.  Returns yaw [C, N] in degrees.  model: "m0" (steady state of the build's
-    dynamic model) or "blondel_jimenez" (the reference agent's py_wake model)."""
+    dynamic model) or "blondel_jimenez" (the reference agent's py_wake model).
+    ``batch``: a HipBatch of the same layout / turbine — every refine step is then ONE launch of the HIP kernel k_steady
+    over [conditions x candidates] cases (wg_steady_power) instead of the torch restatement."""
     import torch
     fn = WAKE_MODELS[model]
     steady_state_power = fn if fn is not None else globals()["steady_state_power"]
+    if batch is not None:
+        def steady_state_power(x_, y_, ws_, wd_, ti_, yaw_, turbine_=None, device=None):      # noqa: F811
+            yaw_ = torch.as_tensor(yaw_)
+            shp = yaw_.shape
+            b = lambda a: np.broadcast_to(np.asarray(a, dtype=np.float32), shp[:-1]).reshape(-1)   # noqa: E731
+            return batch.steady_power(b(ws_), b(wd_), b(ti_), yaw_.reshape(-1, shp[-1]), model=model).double().reshape(shp)
     ws, wd, ti = (np.atleast_1d(np.asarray(a, dtype=np.float64)) for a in (ws, wd, ti))
     C, N = len(ws), len(x)
     wd = wd + 1e-3                                   # break the two-maxima tie of perfectly aligned rows (:188-189)
@@ -229,6 +250,10 @@ class SteadyStateYawAgent(BaseAgent):
         self.refine_pass_n, self.yaw_n = refine_pass_n, yaw_n
         self.turbine = turbine if turbine is not None else V80()
         self.device = device
+        # device "cuda" / "hip": the candidates of every refine step are evaluated by the HIP kernel k_steady
+        self._batch = None
+        if str(device).startswith(("cuda", "hip")):
+            self._batch = hip_batch_for(self.x_pos, self.y_pos, self.turbine)
 
     def update_wind(self, wind_speed, wind_direction, TI):
         self.wsp, self.wdir, self.TI = np.asarray([wind_speed], float), np.asarray([wind_direction], float), TI
@@ -239,11 +264,15 @@ class SteadyStateYawAgent(BaseAgent):
 
     def optimize(self):
         self.optimized_yaws = yaw_optimizer_srf(self.x_pos, self.y_pos, self.wsp, self.wdir, [self.TI], self.turbine,
-                                                self.refine_pass_n, self.yaw_n, device=self.device, model=self.model)[0]
+                                                self.refine_pass_n, self.yaw_n, device="cpu" if self._batch is not None else self.device,
+                                                model=self.model, batch=self._batch)[0]
         self.action = self.scale_yaw(self.optimized_yaws).astype(np.float32)
         self.optimized = True
 
     def power(self, yaws):
+        if self._batch is not None:
+            return float(self._batch.steady_power(self.wsp[0], self.wdir[0], self.TI, np.asarray(yaws, dtype=np.float32)[None],
+                                                  model=self.model).sum())
         fn = WAKE_MODELS[self.model] or steady_state_power
         return float(fn(self.x_pos, self.y_pos, self.wsp[0], self.wdir[0], self.TI, np.asarray(yaws, dtype=float),
                         self.turbine, device=self.device).sum())
