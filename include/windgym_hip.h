@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WG_ABI_VERSION 3
+#define WG_ABI_VERSION 4
 
 typedef enum wg_status {
     WG_OK = 0,

@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(lib_path):
     for name in declared:
         assert hasattr(L, name), f"{name} not exported"
     L.wg_abi_version.restype = C.c_int
-    assert L.wg_abi_version() == 3
+    assert L.wg_abi_version() == 4
 
 
 def test_config_struct_layout_matches_c(tmp_path):

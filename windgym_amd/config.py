@@ -18,7 +18,7 @@ import yaml
 
 from .turbine import as_tabular
 
-WG_ABI_VERSION = 3
+WG_ABI_VERSION = 4
 WG_N_CH = 4
 WG_N_METRICS = 8
 CH_NAMES = ("ws", "wd", "yaw", "power")

@@ -705,7 +705,9 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 const int tl = it >> p.S_shift, s = it & (p.S_pad - 1);
                 if (s >= p.S || !gflag[tl]) continue;
                 const int t = t0 + tl;
+#ifndef WG_NO_ADD_COUNT
                 ++add_acc;                    // (roofline accounting: one 8-corner lookup of the isotropic box)
+#endif
                 float g3[3];
                 abox_lookup(p, d, T[t].xr - tc.ws * sr.time + tc.ox, T[t].yr + (double)(rdy[s] * T[t].cg) + tc.oy,
                             p.hub_d + (double)rdz[s], g3);
@@ -1572,8 +1574,14 @@ __device__ __attribute__((noinline)) void wg_first_obs(const WgParams* gp, const
     const WgParams& p = *gp;
     const WgPtrs& d = *gd;
     if (d.next_obs == nullptr) return;
-    build_obs<1>(p, d, ctx_id, lane, d.next_obs + (size_t)ctx_id * p.obs_dim, nullptr,
-                 d.ring + (size_t)ctx_id * p.ring_stride, d.fring + (size_t)ctx_id * p.fring_stride, false, nullptr, n_pushed);
+    float* nobs = d.next_obs + (size_t)ctx_id * p.obs_dim;
+    // sums mode without TI / farm-level entries: the observation is written below from the window sums, with the arithmetic
+    // of the swap's own fallback (lean_swap) — a state restored from a blob (no prepared observation) then reproduces the
+    // uninterrupted run bit for bit.  Otherwise: the ring-based builder.
+    const bool from_sums = p.sums_mode && !(p.turb_ti || p.farm_ti || p.farm_obs > 0 || (p.sum_mask_f | p.cur_mask_f) != 0u);
+    if (!from_sums)
+        build_obs<1>(p, d, ctx_id, lane, nobs, nullptr, d.ring + (size_t)ctx_id * p.ring_stride,
+                     d.fring + (size_t)ctx_id * p.fring_stride, false, nullptr, n_pushed);
     if (p.sums_mode) {
         // sums mode (k_glue_lean): the episode's window sums, summed afresh from its rings into WgPtrs::wsum — the swap then
         // finds them ready.  Lg = 2^k lanes share an entity (turbine t, or N = the farm-level deques); lane `sub` of a group
@@ -1589,6 +1597,8 @@ __device__ __attribute__((noinline)) void wg_first_obs(const WgParams* gp, const
             const bool have = ent < N || (ent == N && farm_ent);
             const SumsEnt q = wg_sums_ent(p, d, ctx_id, have ? ent : 0);
             double* ws_ = d.wsum + (size_t)ctx_id * WG_N_SUMS * NS + (have ? ent : 0);
+            float* o = (from_sums && have) ? nobs + (size_t)ent * p.turb_obs : nullptr;
+            int n = 0;
 #pragma nounroll
             for (int sl = 0; sl < WG_N_SUMS; ++sl) {
                 const bool on = have && ((q.sm >> sl) & 1u);
@@ -1597,6 +1607,8 @@ __device__ __attribute__((noinline)) void wg_first_obs(const WgParams* gp, const
                 const int cap = p.ring_cap[ch];
                 const int cnt = p.sum_w[sl] < n_pushed ? p.sum_w[sl] : n_pushed;
                 const int r0 = (n_pushed - cnt) % cap;
+                const bool cur_on = o && sl < WG_N_CH && ((p.oc.cur_mask >> ch) & 1u) && n_pushed > 0;
+                const float cv = cur_on ? q.rb[off + ((n_pushed - 1) % cap) * q.stride] : 0.f;
                 double acc = 0.0;
                 if (on) {
 #pragma nounroll
@@ -1614,6 +1626,11 @@ __device__ __attribute__((noinline)) void wg_first_obs(const WgParams* gp, const
                 }
                 for (int s2 = 1; s2 < Lg; s2 <<= 1) acc += __shfl_xor(acc, s2, 64);
                 if (on && sub == 0) ws_[(size_t)sl * NS] = acc;
+                // (wg_obs_turbine<false>: a channel's `current` entry, then its rolling mean — as lean_swap writes them)
+                if (o && sl < WG_N_CH && sub == 0 && n_pushed > 0) {
+                    if (cur_on) o[n++] = wg_scale_r(cv, p.oc.mn[ch], p.oc.inv_rng[ch]);
+                    if ((p.oc.rol_mask >> ch) & 1u) o[n++] = wg_scale_r(wg_sums_mean(p.oc, acc, ch, n_pushed), p.oc.mn[ch], p.oc.inv_rng[ch]);
+                }
             }
         }
     }
@@ -1680,6 +1697,11 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     const bool use_mask = mode == WG_MODE_RESET && mask != nullptr;
     const uint8_t mask_byte = *(use_mask ? mask + e : reinterpret_cast<const uint8_t*>(d.env + e));
     const uint8_t masked_out = use_mask ? (uint8_t)(mask_byte == 0) : (uint8_t)0;
+    // An idle background workgroup (its context has no share of work in this launch: ~28 % of the workgroups of a cfg2
+    // launch) leaves on its header alone, before any state is requested (round 4: 0 ... +1.6 % same-box, 9 MB of reads less)
+#ifndef WG_NO_IDLE_EARLY
+    if (mode == WG_MODE_STEP && c != env_live && !init_pending && env_shadow_iters <= 0) return;
+#endif
     const int t_own = tid < N ? tid : 0;
     int dev_rem, fill_rem, cursor, n_pushed, pend_farm_n, pend_base_n;
     unsigned part0, flow0;       // accounting counters: read with the headers, so that the epilogue only stores
