@@ -23,7 +23,7 @@ void wg_launch_create(const WgParams*, const WgPtrs*, hipStream_t);
 void wg_launch_obs_multi(const WgParams*, const WgPtrs*, float*, hipStream_t);
 void wg_launch_info(const WgParams*, const WgPtrs*, int, void*, hipStream_t);
 void wg_launch_metrics(const WgParams*, const WgPtrs*, float*, int, hipStream_t);
-void wg_launch_box_repack(const float*, void*, size_t, hipStream_t);
+void wg_launch_box_repack(const float*, void*, int, int, int, hipStream_t);
 void wg_launch_measurements(const WgParams*, const WgPtrs*, float*, hipStream_t);
 void wg_launch_box_coarsen(const void*, void*, int, int, int, hipStream_t);
 void wg_launch_windspeed(const FlowP*, const FlowPtrs*, int, int, const float*, int, const float*, int, float, int, float*, hipStream_t);
@@ -692,7 +692,7 @@ extern "C" int wg_set_turbulence_boxes(wg_handle h, const float* const* boxes_de
     const size_t n_cells = (size_t)nx * ny * nz;
     HIPCHK(hipMalloc(&h->box4, n_cells * 16 * (size_t)n_boxes));
     for (int k = 0; k < n_boxes; ++k)
-        wg_launch_box_repack(boxes_dev[k], (char*)h->box4 + (size_t)k * n_cells * 16, n_cells, nullptr);
+        wg_launch_box_repack(boxes_dev[k], (char*)h->box4 + (size_t)k * n_cells * 16, nx, ny, nz, nullptr);
     HIPCHK(hipDeviceSynchronize());
     h->d.box = boxes_dev[0];
     h->p.n_boxes = n_boxes;
@@ -729,7 +729,7 @@ extern "C" int wg_set_added_turbulence_box(wg_handle h, const float* box_dev, in
     if (h->abox4) { void* q = h->abox4; h->abox4 = nullptr; HIPCHK(hipFree(q)); }
     const size_t n_cells = (size_t)nx * ny * nz;
     HIPCHK(hipMalloc(&h->abox4, n_cells * 16));
-    wg_launch_box_repack(box_dev, h->abox4, n_cells, nullptr);
+    wg_launch_box_repack(box_dev, h->abox4, nx, ny, nz, nullptr);
     HIPCHK(hipDeviceSynchronize());
     h->fd.abox4 = (const float4*)h->abox4;
     h->fp.anx = nx; h->fp.any = ny; h->fp.anz = nz;

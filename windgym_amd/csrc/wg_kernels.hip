@@ -1179,24 +1179,35 @@ extern "C" void wg_launch_measurements(const WgParams* p, const WgPtrs* d, float
     hipLaunchKernelGGL(k_measurements, dim3((p->B + WG_NWAVES - 1) / WG_NWAVES), dim3(WG_BLOCK), 0, st, *p, *d, out);
 }
 
-// planar [3][Nx][Ny][Nz] -> interleaved [Nx][Ny][Nz] x float4 (u, v, w, 0)
-__global__ void k_box_repack(const float* __restrict__ planar, float4* __restrict__ out, const size_t n_cells) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_cells) out[i] = make_float4(planar[i], planar[n_cells + i], planar[2 * n_cells + i], 0.f);
+// where cell (i, j, k) of an interleaved box lives: 4 x 4 x 4 bricks of 1 KB when every dimension is a multiple of 4, plain
+// [Nx][Ny][Nz] otherwise (the rule box_lookup_dims in wg_flow.hip applies when it reads)
+__device__ __forceinline__ size_t wg_box_cell(const int i, const int j, const int k, const int nx, const int ny, const int nz) {
+    if (((nx | ny | nz) & 3) != 0) return ((size_t)i * ny + j) * nz + k;
+    const size_t nbz = (size_t)(nz >> 2), nbyz = (size_t)(ny >> 2) * nbz;
+    return ((size_t)(i >> 2) * nbyz + (size_t)(j >> 2) * nbz + (size_t)(k >> 2)) * 64 + (size_t)((i & 3) * 16 + (j & 3) * 4 + (k & 3));
 }
-extern "C" void wg_launch_box_repack(const float* planar, void* out, size_t n_cells, hipStream_t st) {
-    hipLaunchKernelGGL(k_box_repack, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, st, planar, (float4*)out, n_cells);
+// planar [3][Nx][Ny][Nz] -> interleaved cells of float4 (u, v, w, 0), brick-ordered (wg_box_cell)
+__global__ void k_box_repack(const float* __restrict__ planar, float4* __restrict__ out, const int nx, const int ny, const int nz) {
+    const size_t n_cells = (size_t)nx * ny * nz;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cells) return;
+    const int k = (int)(i % nz), j = (int)((i / nz) % ny), ii = (int)(i / ((size_t)nz * ny));
+    out[wg_box_cell(ii, j, k, nx, ny, nz)] = make_float4(planar[i], planar[n_cells + i], planar[2 * n_cells + i], 0.f);
+}
+extern "C" void wg_launch_box_repack(const float* planar, void* out, int nx, int ny, int nz, hipStream_t st) {
+    const size_t n_cells = (size_t)nx * ny * nz;
+    hipLaunchKernelGGL(k_box_repack, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, st, planar, (float4*)out, nx, ny, nz);
 }
 
 // 4x4x4 block average of the interleaved box (summation order x, y, z innermost, float — as the oracle does);
 // output cell (i, j, k) = (v_k, w_k, v_k+1, w_k+1), k+1 periodic: see cbox_lookup_vw
-__device__ __forceinline__ void coarse_cell(const float4* __restrict__ fine, int ny, int nz, int ii, int j, int k,
+__device__ __forceinline__ void coarse_cell(const float4* __restrict__ fine, int nx, int ny, int nz, int ii, int j, int k,
                                             float& v, float& w) {
     float ay = 0.f, az = 0.f;
     for (int a = 0; a < 4; ++a)
         for (int b = 0; b < 4; ++b)
             for (int c = 0; c < 4; ++c) {
-                const float4 q = fine[((size_t)(ii * 4 + a) * ny + (j * 4 + b)) * nz + (k * 4 + c)];
+                const float4 q = fine[wg_box_cell(ii * 4 + a, j * 4 + b, k * 4 + c, nx, ny, nz)];
                 ay += q.y; az += q.z;
             }
     v = ay * (1.0f / 64.0f); w = az * (1.0f / 64.0f);
@@ -1208,8 +1219,8 @@ __global__ void k_box_coarsen(const float4* __restrict__ fine, float4* __restric
     // output layout [cny][cnz][cnx]: x fastest (see cbox_lookup_vw)
     const int ii = (int)(i % cnx), k = (int)((i / cnx) % cnz), j = (int)(i / ((size_t)cnx * cnz));
     float4 o;
-    coarse_cell(fine, ny, nz, ii, j, k, o.x, o.y);
-    coarse_cell(fine, ny, nz, ii, j, k + 1 == cnz ? 0 : k + 1, o.z, o.w);
+    coarse_cell(fine, nx, ny, nz, ii, j, k, o.x, o.y);
+    coarse_cell(fine, nx, ny, nz, ii, j, k + 1 == cnz ? 0 : k + 1, o.z, o.w);
     out[i] = o;
 }
 extern "C" void wg_launch_box_coarsen(const void* fine, void* out, int nx, int ny, int nz, hipStream_t st) {
