@@ -939,3 +939,58 @@ def test_checkpoint_resume_is_bit_identical_across_rollovers(hip):
     assert n_tr >= B
     a_env.check(); b_env.check()
     a_env.close(); b_env.close()
+
+
+@pytest.mark.parametrize("case", ["env1_4x4", "generic_ti_farm_current", "per_agent_buffer"])
+def test_lean_glue_equals_the_ring_staging_glue(hip, monkeypatch, case):
+    """k_glue_lean (running window sums, sums mode) against k_glue (rings staged and summed every step, WG_SUMS=0) on the
+    same handle configuration, step for step across rollovers: observations, final observations, rewards, truncations —
+    two independently written kernels, one answer (to float rounding: exact double sums vs float sums)."""
+    import copy
+    import torch
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.presets import env1_config
+    from windgym_amd.turbine import V80
+    d = copy.deepcopy(env1_config())
+    d["ActionMethod"] = "yaw"
+    B, multi = 6, False
+    if case == "env1_4x4":
+        d["farm"].update(nx=4, ny=4)
+    elif case == "generic_ti_farm_current":
+        d["farm"].update(nx=3, ny=2)
+        d["mes_level"].update(turb_ws=True, turb_wd=True, turb_TI=True, turb_power=True, farm_ws=True, farm_wd=True,
+                              farm_TI=True, farm_power=True)
+        d["ws_mes"].update(ws_current=True, ws_rolling_mean=True, ws_history_N=1, ws_history_length=12, ws_window_length=5)
+        d["wd_mes"].update(wd_current=True, wd_rolling_mean=True, wd_history_N=1, wd_history_length=8, wd_window_length=8)
+        d["power_mes"].update(power_current=True, power_rolling_mean=True, power_history_N=1, power_history_length=20,
+                              power_window_length=30)
+        d["yaw_mes"].update(yaw_current=True, yaw_rolling_mean=False)
+    else:
+        d["farm"].update(nx=3, ny=3)
+        d["mes_level"].update(farm_ws=True, farm_TI=True)
+        multi = True
+    kw = dict(extra_timestep_inc=True) if multi else {}
+    cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_envs=B, autoreset=True, n_passthrough=0.3, n_rotor_pts=16, **kw)
+    lean = hip.HipBatch(cfg)
+    monkeypatch.setenv("WG_SUMS", "0")
+    ring = hip.HipBatch(cfg)
+    monkeypatch.delenv("WG_SUMS")
+    ml = lean.fuse_obs_multi() if multi else None
+    mr = ring.fuse_obs_multi() if multi else None
+    seeds = 70 + np.arange(B)
+    assert (lean.reset(seeds=seeds) - ring.reset(seeds=seeds)).abs().max().item() <= 2e-6
+    rng = np.random.default_rng(2)
+    n_tr = 0
+    for step in range(200):
+        a = torch.as_tensor(rng.uniform(-1, 1, size=(B, cfg.n_turb)).astype(np.float32), device="cuda")
+        ol, rl, tl, fl = lean.step(a)
+        orr, rr, tr, fr = ring.step(a)
+        assert torch.equal(tl, tr), step
+        assert (ol - orr).abs().max().item() <= 2e-6 and (fl - fr).abs().max().item() <= 2e-6, step
+        assert (rl - rr).abs().max().item() <= 2e-6 + 1e-6 * rr.abs().max().item(), step
+        if multi:
+            assert (ml - mr).abs().max().item() <= 2e-6, step
+        n_tr += int(tl.sum().item())
+    assert n_tr >= B
+    lean.check(); ring.check()
+    lean.close(); ring.close()
