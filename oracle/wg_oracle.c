@@ -1017,6 +1017,8 @@ static void reset_env(oracle_t* o, int b, uint64_t seed, int reseed) {
     if (c->turb_mode == WG_TURB_RANDOM || c->turb_mode == WG_TURB_BOX_SHIFT)
         x->turb_seed = wgo_pcg64_integers(&e->rng, 100000);
     if (c->turb_mode == WG_TURB_BOX_SHIFT && o->box) {
+        /* the episode's seed picks one of the pool's generated realisations and an offset into it (:623-637) */
+        if (o->n_boxes > 1) x->box_id = (int)(x->turb_seed % (uint32_t)o->n_boxes);
         double fx, fy;
         wgo_turb_offset(x->turb_seed, &fx, &fy);
         x->box_ox = fx * o->bnx * o->bdx;

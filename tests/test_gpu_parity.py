@@ -822,6 +822,31 @@ def test_box_pool_draws_like_np_random_choice_and_matches_oracle(hip, oracle_lib
     assert env1.info("wind_f64").cpu().numpy()[0, 0] == ws
 
 
+def test_manngenerate_pool_seed_picks_box_and_offset(hip, oracle_lib):
+    """turbtype "MannGenerate" with a pool of K = 3 generated realisations (EnvConfig.mann_pool): the episode's seed — the
+    reference's integers(0, 100000) draw (Wind_Farm_Env.py:623) — picks the box (seed mod K) AND the offset into it; the flow
+    then reads that box, step for step against the oracle across rollovers."""
+    from windgym_amd.mann import generate_mann_box
+    spacing = (3.0, 3.0, 3.0)
+    boxes = [generate_mann_box((128, 64, 32), spacing, seed=s) for s in (11, 12, 13)]
+    B = 6
+    cfg = _turb_cfg("MannGenerate", B)
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    env.set_turbulence_boxes(boxes, spacing), orc.set_turbulence_boxes(boxes, spacing)
+    seeds = 3100 + np.arange(B)
+    np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=TURB_OBS_ATOL)
+    want = []
+    for s in seeds:
+        g = np.random.default_rng(int(s))
+        g.uniform(), g.uniform(), g.uniform()
+        want.append(int(g.integers(0, 100000)) % 3)
+    np.testing.assert_array_equal(env.info("box_id").cpu().numpy(), want)
+    np.testing.assert_array_equal(orc.info("box_id").astype(int), want)
+    n_tr = _compare_turb(env, orc, 200, np.random.default_rng(16), cfg.n_turb, B)
+    env.check()
+    assert n_tr >= B and len(set(want)) >= 2
+
+
 @pytest.mark.parametrize("case", ["rings_in_global", "current_only_and_farm", "ti_and_windows_l2"])
 def test_glue_instantiations_match_oracle(hip, oracle_lib, case):
     """k_glue is instantiated per <per-agent buffer, rings staged in LDS, lanes per turbine>; the observation's window

@@ -152,6 +152,8 @@ class EnvConfig:
     never_truncate: bool = False
     extra_timestep_inc: bool = False
     advect_full_chains: bool = False             # True: no chain pruning (exact flow-field view behind the last row)
+    mann_pool: int = 1                           # turbtype "MannGenerate": realisations generated on the device; an episode's
+                                                 # seed (Wind_Farm_Env.py:623) picks one of them and an offset into it
     yaw_defined: Optional[Sequence[float]] = None
     # constants of flow model M0, keys of wg_config without the m0_ prefix: ka, kb, eps, hill, ti_a ...
     # ti_d, fc_scale; missing keys keep the documented defaults (a calibrated M0 is configuration, not code)

@@ -297,6 +297,10 @@ __device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, c
             else cx.box_id = (int)wg_pcg_integers(rng, (uint32_t)(p.n_boxes > 0 ? p.n_boxes : 1));
         }
         if (p.turb_mode == WG_TURB_BOX_SHIFT && p.bnx > 0) {
+            // "MannGenerate" draws a fresh box per episode from its seed (:623-637).  Here the seed picks one of the
+            // n_boxes generated realisations (wg_set_turbulence_boxes: a pool generated on the device) and a horizontal
+            // offset into it: n_boxes x (Nx x Ny offsets) distinct inflows, no random number beyond the reference's draw
+            if (p.n_boxes > 1) cx.box_id = (int)(tseed % (uint32_t)p.n_boxes);
             uint32_t a, b;
             wg_philox_turb(tseed, 0u, 0u, 0u, 0x4fu, a, b);
             cx.box_ox = (double)a * (1.0 / 4294967296.0) * p.bnx * p.bdx;

@@ -87,9 +87,17 @@ def _attach_box(batch: HipBatch, cfg: EnvConfig, source):
     if source is None:
         return None
     if source[0] == "generate":
-        from .mann import generate_mann_box_torch, reference_box_spec
+        # generated on the device (wg_generate_mann_box).  turbtype "MannGenerate" with cfg.mann_pool = K > 1: K
+        # realisations (seeds 1234 ... 1234 + K - 1); every episode's seed (:623) then picks one of them AND an offset into
+        # it, instead of an offset into a single box
+        from .mann import generate_mann_box_hip, reference_box_spec
         spec = reference_box_spec(cfg.turbtype, cfg.D)
-        source = ("one", generate_mann_box_torch(device=batch.device, **spec), spec["dxyz"])
+        K = int(getattr(cfg, "mann_pool", 1) or 1) if cfg.turbtype == "MannGenerate" else 1
+        if K > 1:
+            base = spec.pop("seed")
+            source = ("pool", [generate_mann_box_hip(device=batch.device, seed=base + k, **spec) for k in range(min(K, MAX_BOX_POOL))], spec["dxyz"])
+        else:
+            source = ("one", generate_mann_box_hip(device=batch.device, **spec), spec["dxyz"])
     if source[0] == "pool":
         batch.set_turbulence_boxes(source[1], source[2])
     else:
