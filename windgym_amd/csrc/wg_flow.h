@@ -11,6 +11,10 @@
 #ifndef WG_FLOW_WAVES_CG
 #define WG_FLOW_WAVES_CG 5    // small-farm variants (compact rings, 64 / 128 threads): 96 VGPRs; measured 4 / 5 / 6 waves: 104 / 93.5 / 96 us on cfg2
 #endif
+#ifndef WG_FLOW_WAVES_DUO
+#define WG_FLOW_WAVES_DUO 4   // k_flow_duo (steady inflow): 128 VGPRs, 6 spilled instead of 35 at 96 — cfg4 (4096 workgroups = the 4096 wave
+                              // slots of 4 waves per SIMD) 36.4 -> 35.3 us same-box (round 4)
+#endif
 #ifndef WG_FLOW_WAVES_GL
 #define WG_FLOW_WAVES_GL 4    // single-wave steady variant (GL): 128 VGPRs, no spills — room for the pipelined advection pass's second quad;
                               // 4 vs 5 waves per SIMD measured equal without the pipeline (the launch is not occupancy-bound), -4.5 % with it
