@@ -620,7 +620,8 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     // farms: one wave reads 35 floats per turbine; measured on the multi-wave variants — cfg3, cfg5 — the building
     // workgroup became the flow kernel's tail: -5 % / -1.3 %).  Other handles keep the glue's own second build.
     // (sums mode: wg_first_obs prepares the episode's window sums as well, in WgPtrs::wsum)
-    if (!(h->fp.gl && !h->fp.duo)) { d.next_obs = nullptr; d.next_obs_ok = nullptr; }
+    // (k_flow_duo prepares them for sums-mode handles only: the lean glue's swap)
+    if (!((h->fp.gl && !h->fp.duo) || (h->fp.duo && p.sums_mode && p.turb_mode == WG_TURB_NONE))) { d.next_obs = nullptr; d.next_obs_ok = nullptr; }
     wg_launch_create(&p, &d, nullptr);
     if (sync_dev_params(h)) { wg_destroy(h); return WG_ERR_HIP; }
     {

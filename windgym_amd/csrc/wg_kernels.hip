@@ -589,7 +589,7 @@ __device__ __attribute__((noinline)) void lean_swap(const WgParams* gp, const Wg
     // wsum[nctx] — and its single-agent first observation when its development completed, wg_first_obs; all fetched by the
     // caller through the scalar cache at the top of the kernel, where it already knows that the env truncates)
     const int nctx = e * 2 + (live ^ 1);
-    if (!MULTI && !GEN && prepared && obs && ka->p.power_avg <= WG_WAVE) {
+    if (!GEN && prepared && obs && ka->p.power_avg <= WG_WAVE) {
         // The common swap (prepared episode, single-agent layout, deque no longer than a wave): parameters and pointers
         // from the kernarg segment (scalar cache — the device-resident copies behind gp / gd are a memory round trip
         // away), every load issued before the first store: ONE round trip on the truncating wave's tail.
@@ -616,9 +616,15 @@ __device__ __attribute__((noinline)) void lean_swap(const WgParams* gp, const Wg
         const wg_u128 r_state = envw.rng_state, r_inc = envw.rng_inc;
         const uint32_t r_has32 = envw.rng_has32, r_u32 = envw.rng_u32;
         // ---- stores ----
+        // (per-agent buffer of the PettingZoo facade: without farm-level entries agent t's row is its turbine block)
+        const int tobs = ka->p.turb_obs, odm = ka->p.obs_dim_multi;
+        auto put = [&](const int k, const float v) {
+            obs[k] = v;
+            if (MULTI && om) { const int t = k / tobs; om[(size_t)t * odm + (k - t * tobs)] = v; }
+        };
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (lane + 64 * k < obs_dim) obs[lane + 64 * k] = ov[k];
-        for (int k = lane + 256; k < obs_dim; k += WG_WAVE) obs[k] = no[k];
+        for (int k = 0; k < 4; ++k) if (lane + 64 * k < obs_dim) put(lane + 64 * k, ov[k]);
+        for (int k = lane + 256; k < obs_dim; k += WG_WAVE) put(k, no[k]);
         double sf = 0.0, sb = 0.0;
         {
             float vf = lane == fslot ? fp : f_old;
