@@ -568,84 +568,82 @@ typedef const __attribute__((address_space(4))) LeanArgs* LeanArgsPtr;
 // The common swap — prepared episode (wg_first_obs), no TI / farm-level entries, deque no longer than a wave — INLINE at the
 // very end of k_glue_lean (nothing runs after it, so it adds no live range to the step path; as a call it cost the
 // truncating waves ~1.5 us of call / frame set-up on the kernel's tail).  Every load is issued before the first store: one
-// round trip.
+// round trip.  (Measured and not kept: the same loads requested at the top of the kernel as LDS-DMA into a per-wave zone —
+// k_glue_lean 11.4 -> 12.1 us: 9 KB of LDS per workgroup and the wait-count pass's conservatism cost more than the trip.)
 template <bool MULTI, typename P, typename D>
 __device__ __forceinline__ void lean_swap_fast(const P& p, const D& d, const int e, const int live, const int lane, const float fp,
-                                               const float bp, const int fslot, const int bslot, const int n1f, const int n1b,
-                                               const int episode_next, float* obs, float* om, const int pfn, const int pbn,
-                                               const int nnp, const int time_max, const float rated) {
+                                       const float bp, const int fslot, const int bslot, const int n1f, const int n1b,
+                                       const int episode_next, float* obs, float* om, const int pfn, const int pbn,
+                                       const int nnp, const int time_max, const float rated) {
     const int nctx = e * 2 + (live ^ 1);
-            // The common swap (prepared episode, single-agent layout, deque no longer than a wave): parameters and pointers
-            // from the kernarg segment (scalar cache — the device-resident copies behind gp / gd are a memory round trip
-            // away), every load issued before the first store: ONE round trip on the truncating wave's tail.
-            const int F = p.F, PA = p.power_avg, obs_dim = p.obs_dim;
-            float* fq = d.farm_pow + (size_t)e * PA;
-            float* bq = d.base_pow + (size_t)e * PA;
-            const float* pf = d.pend_farm + (size_t)nctx * PA;
-            const float* pb = d.pend_base + (size_t)nctx * PA;
-            const float* no = d.next_obs + (size_t)nctx * obs_dim;
-            WgEnv& envw = d.env[e];
-            const int mf = pfn < PA ? pfn : PA, mb = pbn < PA ? pbn : PA;
-            const int n2f = n1f + mf, n2b = n1b + mb;
-            const int i = lane < PA ? lane : 0;
-            int qf = (i - n1f) % PA; if (qf < 0) qf += PA;
-            int qb = (i - n1b) % PA; if (qb < 0) qb += PA;
-            // ---- loads ----
-            const float f_old = fq[i], f_new = deque_at(pf, pfn > 0 ? pfn : 1, PA, qf < mf ? qf : 0);
-            const float b_old = F == 2 ? bq[i] : 0.f, b_new = F == 2 ? deque_at(pb, pbn > 0 ? pbn : 1, PA, qb < mb ? qb : 0) : 0.f;
-            float ov[4];
-    #pragma unroll
-            for (int k = 0; k < 4; ++k) ov[k] = lane + 64 * k < obs_dim ? no[lane + 64 * k] : 0.f;
-            bool unready = false;
-            if (lane < F) { const WgSlot& sl = d.slot[nctx * F + lane]; unready = sl.dev_remaining != 0 || sl.fill_remaining != 0; }
-            const wg_u128 r_state = envw.rng_state, r_inc = envw.rng_inc;
-            const uint32_t r_has32 = envw.rng_has32, r_u32 = envw.rng_u32;
-            // ---- stores ----
-            // (per-agent buffer of the PettingZoo facade: without farm-level entries agent t's row is its turbine block)
-            const int tobs = p.turb_obs, odm = p.obs_dim_multi;
-            auto put = [&](const int k, const float v) {
-                obs[k] = v;
-                if (MULTI && om) { const int t = k / tobs; om[(size_t)t * odm + (k - t * tobs)] = v; }
-            };
-    #pragma unroll
-            for (int k = 0; k < 4; ++k) if (lane + 64 * k < obs_dim) put(lane + 64 * k, ov[k]);
-            for (int k = lane + 256; k < obs_dim; k += WG_WAVE) put(k, no[k]);
-            double sf = 0.0, sb = 0.0;
-            {
-                float vf = lane == fslot ? fp : f_old;
-                if (lane < PA && qf < mf) { vf = f_new; fq[lane] = vf; }
-                if (lane < (n2f < PA ? n2f : PA)) sf = (double)vf;
-                if (F == 2) {
-                    float vb = lane == bslot ? bp : b_old;
-                    if (lane < PA && qb < mb) { vb = b_new; bq[lane] = vb; }
-                    if (lane < (n2b < PA ? n2b : PA)) sb = (double)vb;
-                }
-            }
-    #pragma unroll
-            for (int s2 = 32; s2 > 0; s2 >>= 1) { sf += __shfl_xor(sf, s2, 64); sb += __shfl_xor(sb, s2, 64); }
-            if (unready) atomicOr(d.status, WG_STATUS_BIT_STATE);
-            if (lane == 0) {
-                WgCtx& ncx = d.ctx[nctx];
-                WgCtx& rcx = d.ctx[e * 2 + live];
-                ncx.pend_farm_n = 0; ncx.pend_base_n = 0;
-                d.next_obs_ok[nctx] = 0;          // consumed (the context holds a live episode now)
-                rcx.init_pending = 1;                 // retire the finished context
-                rcx.episode_tag = episode_next;
-                rcx.snap_state = r_state; rcx.snap_inc = r_inc;
-                rcx.snap_has32 = r_has32; rcx.snap_u32 = r_u32;
-            }
-            if (lane == 0) envw.live = live ^ 1;
-            if (lane == 1) envw.timestep = 0;
-            if (lane == 2) envw.steps_done = 0;
-            if (lane == 3) envw.farm_pow_n = n2f;
-            if (lane == 4) envw.base_pow_n = n2b;
-            if (lane == 5) envw.time_max_live = time_max;
-            if (lane == 6) envw.rated_live = rated;
-            if (lane == 7) envw.fsum_run = sf;
-            if (lane == 8) envw.bsum_run = sb;
-            if (lane == 9) envw.n_pushed_live = nnp;
-            if (lane == 10) envw.shadow_iters = 0;
-            return;
+    const int F = p.F, PA = p.power_avg, obs_dim = p.obs_dim;
+    float* fq = d.farm_pow + (size_t)e * PA;
+    float* bq = d.base_pow + (size_t)e * PA;
+    const float* pf = d.pend_farm + (size_t)nctx * PA;
+    const float* pb = d.pend_base + (size_t)nctx * PA;
+    const float* no = d.next_obs + (size_t)nctx * obs_dim;
+    WgEnv& envw = d.env[e];
+    const int mf = pfn < PA ? pfn : PA, mb = pbn < PA ? pbn : PA;
+    const int n2f = n1f + mf, n2b = n1b + mb;
+    const int i = lane < PA ? lane : 0;
+    int qf = (i - n1f) % PA; if (qf < 0) qf += PA;
+    int qb = (i - n1b) % PA; if (qb < 0) qb += PA;
+    // ---- loads ----
+    const float f_old = fq[i], f_new = deque_at(pf, pfn > 0 ? pfn : 1, PA, qf < mf ? qf : 0);
+    const float b_old = F == 2 ? bq[i] : 0.f, b_new = F == 2 ? deque_at(pb, pbn > 0 ? pbn : 1, PA, qb < mb ? qb : 0) : 0.f;
+    float ov[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ov[k] = lane + 64 * k < obs_dim ? no[lane + 64 * k] : 0.f;
+    bool unready = false;
+    if (lane < F) { const WgSlot& sl = d.slot[nctx * F + lane]; unready = sl.dev_remaining != 0 || sl.fill_remaining != 0; }
+    const wg_u128 r_state = envw.rng_state, r_inc = envw.rng_inc;
+    const uint32_t r_has32 = envw.rng_has32, r_u32 = envw.rng_u32;
+    // ---- stores ----
+    // (per-agent buffer of the PettingZoo facade: without farm-level entries agent t's row is its turbine block)
+    const int tobs = p.turb_obs, odm = p.obs_dim_multi;
+    auto put = [&](const int k, const float v) {
+        obs[k] = v;
+        if (MULTI && om) { const int t = k / tobs; om[(size_t)t * odm + (k - t * tobs)] = v; }
+    };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (lane + 64 * k < obs_dim) put(lane + 64 * k, ov[k]);
+    for (int k = lane + 256; k < obs_dim; k += WG_WAVE) put(k, no[k]);
+    double sf = 0.0, sb = 0.0;
+    {
+        float vf = lane == fslot ? fp : f_old;
+        if (lane < PA && qf < mf) { vf = f_new; fq[lane] = vf; }
+        if (lane < (n2f < PA ? n2f : PA)) sf = (double)vf;
+        if (F == 2) {
+            float vb = lane == bslot ? bp : b_old;
+            if (lane < PA && qb < mb) { vb = b_new; bq[lane] = vb; }
+            if (lane < (n2b < PA ? n2b : PA)) sb = (double)vb;
+        }
+    }
+#pragma unroll
+    for (int s2 = 32; s2 > 0; s2 >>= 1) { sf += __shfl_xor(sf, s2, 64); sb += __shfl_xor(sb, s2, 64); }
+    if (unready) atomicOr(d.status, WG_STATUS_BIT_STATE);
+    if (lane == 0) {
+        WgCtx& ncx = d.ctx[nctx];
+        WgCtx& rcx = d.ctx[e * 2 + live];
+        ncx.pend_farm_n = 0; ncx.pend_base_n = 0;
+        d.next_obs_ok[nctx] = 0;          // consumed (the context holds a live episode now)
+        rcx.init_pending = 1;                 // retire the finished context
+        rcx.episode_tag = episode_next;
+        rcx.snap_state = r_state; rcx.snap_inc = r_inc;
+        rcx.snap_has32 = r_has32; rcx.snap_u32 = r_u32;
+    }
+    if (lane == 0) envw.live = live ^ 1;
+    if (lane == 1) envw.timestep = 0;
+    if (lane == 2) envw.steps_done = 0;
+    if (lane == 3) envw.farm_pow_n = n2f;
+    if (lane == 4) envw.base_pow_n = n2b;
+    if (lane == 5) envw.time_max_live = time_max;
+    if (lane == 6) envw.rated_live = rated;
+    if (lane == 7) envw.fsum_run = sf;
+    if (lane == 8) envw.bsum_run = sb;
+    if (lane == 9) envw.n_pushed_live = nnp;
+    if (lane == 10) envw.shadow_iters = 0;
+    return;
 }
 
 // Same-step autoreset of a sums-mode env, out of line (a handful of waves per launch take it; inlined, its unrolled loads
