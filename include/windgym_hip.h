@@ -151,7 +151,8 @@ typedef struct wg_config {
                                 * (Madsen et al. 2010), same advection offset as the ambient box ("Synchronized").
                                 * Ignored with turb_mode NONE (the reference has no model there, :664).              */
     int32_t no_ti_fold;        /* 1: the Crespo-Hernandez added TI is NOT folded into the k of emitted particles     */
-    int32_t deficit_model;     /* 0: Gaussian (north_star); 1: super-Gaussian of Blondel & Cathelain (2020)          */
+    int32_t deficit_model;     /* 0: Gaussian (north_star); 1: super-Gaussian of Blondel & Cathelain (2020);
+                                * 2: tabulated eddy-viscosity deficit (Ainslie / DWM; wg_set_deficit_table)          */
     int32_t reserved0_;
     double m0_km1, m0_km2;     /* DWM added-turbulence scaling constants (0.6, 0.35); 0 selects the default          */
     double m0_sg_af, m0_sg_bf, m0_sg_cf; /* super-Gaussian order n(x) = af exp(bf x/D) + cf (3.11, -0.68, 2.41)      */
@@ -329,6 +330,14 @@ int wg_set_state(wg_handle h, const void* blob_host, size_t size);
  * wg_step (an event pair per launch costs a few percent of a ~200 us step).                            */
 int wg_kernel_timing(wg_handle h, int enable, double* flow_ms_avg, double* glue_ms_avg, int* n_launches,
                      double* flow_steps_per_launch, double* particles_per_launch);
+
+/* deficit_model 2: the wake-deficit table the flow kernels sample instead of the Gaussian — what the reference's
+ * particleDeficitGenerator=jDWMAinslieGenerator() (Wind_Farm_Env.py:706, :774) solves inside DYNAMIKS, solved on the host
+ * (windgym_amd/ainslie.py restates the published DWM eddy-viscosity model).  table_dev: f32[n_ct][n_ti][n_x][n_r], the deficit
+ * fraction 1 - U / U0 at Ct uniform in [ct0, ct1], ambient TI log-uniform in [ti0, ti1], x / D uniform in [0, x_max_D],
+ * r / R uniform in [0, r_max_R] (linear between nodes; 0 from half a node inside r_max_R on).  Borrowed: the buffer must outlive the handle.  Before wg_reset.          */
+int wg_set_deficit_table(wg_handle h, const float* table_dev, int n_ct, double ct0, double ct1, int n_ti, double ti0, double ti1,
+                         int n_x, double x_max_D, int n_r, double r_max_R);
 
 /* Mann spectral-tensor turbulence box generated on the device — MannTurbulenceField.generate(alphaepsilon, L, Gamma, Nxyz,
  * dxyz, seed) of hipersim / dynamiks behind turbtype "MannFixed" / "MannGenerate" (Wind_Farm_Env.py:624-637, :649-658;

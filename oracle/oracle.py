@@ -48,7 +48,7 @@ class Oracle:
         L = lib()
         pre = "wgo_" if precision == "f64" else "wgof_"
         self._f = {n: getattr(L, pre + n) for n in (
-            "create", "destroy", "obs_dim", "hist_max", "set_flow_script", "set_turbulence_box", "set_turbulence_boxes", "set_added_turbulence_box", "set_box_ids", "reset",
+            "create", "destroy", "obs_dim", "hist_max", "set_flow_script", "set_turbulence_box", "set_turbulence_boxes", "set_added_turbulence_box", "set_deficit_table", "set_box_ids", "reset",
             "step", "obs_multi", "get_obs", "get_info", "metrics", "get_chain", "set_threads", "max_threads",
             "get_windspeed")}
         self._f["create"].restype = C.c_void_p
@@ -63,6 +63,7 @@ class Oracle:
         self._script = None
         self._box = None
         self._abox = None
+        self._dtab = None
 
     def close(self):
         if self._h:
@@ -108,6 +109,14 @@ class Oracle:
                                             C.c_int(box.shape[2]), C.c_int(box.shape[3]), C.c_double(spacing[0]),
                                             C.c_double(spacing[1]), C.c_double(spacing[2]))
 
+    def set_deficit_table(self, table, spec):
+        tb = np.ascontiguousarray(table, dtype=np.float32)
+        self._dtab = tb
+        self._f["set_deficit_table"](self._h, tb.ctypes.data_as(C.c_void_p), C.c_int(tb.shape[0]), C.c_double(spec["ct"][0]),
+                                     C.c_double(spec["ct"][-1]), C.c_int(tb.shape[1]), C.c_double(spec["ti"][0]),
+                                     C.c_double(spec["ti"][-1]), C.c_int(spec["n_x"]), C.c_double(spec["x_max_D"]),
+                                     C.c_int(spec["n_r"]), C.c_double(spec["r_max_R"]))
+
     def set_box_ids(self, ids):
         self._box_ids = None if ids is None else np.ascontiguousarray(np.broadcast_to(np.asarray(ids, dtype=np.int32), (self.B,)))
         self._f["set_box_ids"](self._h, None if ids is None else self._box_ids.ctypes.data_as(C.c_void_p))
@@ -139,6 +148,9 @@ class Oracle:
             # the default isotropic field of the wake-added turbulence: the same array the HIP batch installs
             from windgym_amd.mann import default_added_box
             self.set_added_turbulence_box(*default_added_box())
+        if self._c.deficit_model == 2 and self._dtab is None:
+            from windgym_amd.ainslie import deficit_table
+            self.set_deficit_table(*deficit_table())
         obs = np.zeros((self.B, self.obs_dim))
         sp = None
         if seeds is not None:

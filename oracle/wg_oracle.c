@@ -137,6 +137,10 @@ typedef struct oracle_t {
     const float* abox;
     int anx, any, anz;
     double adx, ady, adz;
+    /* deficit_model 2: tabulated eddy-viscosity deficit [n_ct][n_ti][n_x][n_r] (borrowed; include/windgym_hip.h) */
+    const float* dtab;
+    int an_ct, an_ti, an_x, an_r;
+    double an_ct0, an_dct, an_lti0, an_dlti, an_dx, an_dr;      /* node spacings (Ct, ln TI, x / D, r / R) */
 } oracle_t;
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -314,6 +318,14 @@ void WGO(set_added_turbulence_box)(void* h, const float* box, int nx, int ny, in
                                    double dz) {
     oracle_t* o = (oracle_t*)h;
     o->abox = box; o->anx = nx; o->any = ny; o->anz = nz; o->adx = dx; o->ady = dy; o->adz = dz;
+}
+void WGO(set_deficit_table)(void* h, const float* tab, int n_ct, double ct0, double ct1, int n_ti, double ti0, double ti1,
+                            int n_x, double x_max_D, int n_r, double r_max_R) {
+    oracle_t* o = (oracle_t*)h;
+    o->dtab = tab; o->an_ct = n_ct; o->an_ti = n_ti; o->an_x = n_x; o->an_r = n_r;
+    o->an_ct0 = ct0; o->an_dct = (ct1 - ct0) / (n_ct - 1);
+    o->an_lti0 = log(ti0); o->an_dlti = (log(ti1) - log(ti0)) / (n_ti - 1);
+    o->an_dx = x_max_D / (n_x - 1); o->an_dr = r_max_R / (n_r - 1);
 }
 void WGO(set_turbulence_box)(void* h, const float* box, int nx, int ny, int nz, double dx, double dy,
                              double dz) {
@@ -585,11 +597,57 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
             if (rc2 > rcut * rcut) continue;
             real inv2s2 = (real)1 / ((real)2 * sig * sig);
             real amp = uev * cf;
+            /* deficit_model 2: the eddy-viscosity profile 1 - U / U0 of the table at (Ct, TI_amb, x / D), 3-linear; TI_amb is
+             * what the particle's frozen growth rate encodes (k = ka TI + kb); r / R per rotor point below */
+            const int an = c->deficit_model == 2 && o->dtab;
+            real an_w[8]; size_t an_o[8];
+            if (an) {
+                real tiw = (kv - (real)c->m0_kb) / (real)c->m0_ka;
+                if (tiw < (real)1e-6) tiw = (real)1e-6;
+                real fq[3] = {(ctv - (real)o->an_ct0) / (real)o->an_dct, ((real)log((double)tiw) - (real)o->an_lti0) / (real)o->an_dlti,
+                              xd / (real)o->an_dx};
+                const int nq[3] = {o->an_ct, o->an_ti, o->an_x};
+                const size_t sq[3] = {(size_t)o->an_ti * o->an_x * o->an_r, (size_t)o->an_x * o->an_r, (size_t)o->an_r};
+                int iq[3]; real wq[3];
+                for (int a = 0; a < 3; ++a) {
+                    if (fq[a] < (real)0) fq[a] = (real)0;
+                    if (fq[a] > (real)(nq[a] - 1)) fq[a] = (real)(nq[a] - 1);
+                    iq[a] = (int)fq[a]; if (iq[a] > nq[a] - 2) iq[a] = nq[a] - 2;
+                    wq[a] = fq[a] - (real)iq[a];
+                }
+                for (int q = 0; q < 8; ++q) {
+                    an_w[q] = (q & 1 ? wq[0] : (real)1 - wq[0]) * (q & 2 ? wq[1] : (real)1 - wq[1]) * (q & 4 ? wq[2] : (real)1 - wq[2]);
+                    an_o[q] = (iq[0] + (q & 1 ? 1 : 0)) * sq[0] + (iq[1] + (q & 2 ? 1 : 0)) * sq[1] + (iq[2] + (q & 4 ? 1 : 0)) * sq[2];
+                }
+            }
             for (int s = 0; s < S; ++s) {
                 real ys = (real)x->yr[t] + (real)o->rotor_dy[s] * cg;
                 real zs = hub + (real)o->rotor_dz[s];
                 real r2 = (ys - yc) * (ys - yc) + (zs - zc) * (zs - zc);
                 real du, grad;            /* grad = |d dU / dr| / dU */
+                if (an) {
+                    real fr = R_SQRT(r2) / R_rot / (real)o->an_dr;
+                    if (!(fr < (real)o->an_r - (real)1.5)) continue;     /* beyond the table: no deficit */
+                    /* nodes m - 1, m, m + 1 around fr; node -1 mirrors node 1 (axis of symmetry) */
+                    int m = (int)(fr + (real)0.5), ml = m > 0 ? m - 1 : 1;
+                    real fa = 0, fb = 0, fc = 0;
+                    for (int q = 0; q < 8; ++q) {
+                        fa += an_w[q] * o->dtab[an_o[q] + ml]; fb += an_w[q] * o->dtab[an_o[q] + m];
+                        fc += an_w[q] * o->dtab[an_o[q] + m + 1];
+                    }
+                    real e = fr - (real)m;
+                    real frac = e < (real)0 ? fb + e * (fb - fa) : fb + e * (fc - fb);
+                    du = uev * frac;
+                    dsum += du;
+                    if (added) {
+                        /* U k_mt = km1 dU + km2 R |d dU / dr|: the slope as the centred difference of the piecewise-linear
+                         * profile over one node spacing, [f(fr + 1/2) - f(fr - 1/2)] / dr — continuous in r */
+                        real hi = fb + (e + (real)0.5) * (fc - fb), lo = fa + (e + (real)0.5) * (fb - fa);
+                        real wk = uev * (km1 * frac + km2 * R_FABS(hi - lo) / (real)o->an_dr);
+                        for (int cc = 0; cc < 3; ++cc) addsum[cc] += wk * gadd[cc][s];
+                    }
+                    continue;
+                }
                 if (sg) {
                     /* (r/D)^n / (2 (sigma/D)^2); d/dr: n (r/D)^n / (r 2 (sigma/D)^2) */
                     real rn = r2 > (real)0 ? R_POW(r2 * inv_D * inv_D, (real)0.5 * nsg) : (real)0;

@@ -31,7 +31,7 @@ UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 # every symbol include/windgym_hip.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = (
     "wg_last_error", "wg_abi_version", "wg_create", "wg_destroy", "wg_obs_dim", "wg_hist_max",
-    "wg_set_turbulence_box", "wg_set_turbulence_boxes", "wg_set_added_turbulence_box", "wg_set_box_ids", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_set_step_graph", "wg_check", "wg_obs_multi", "wg_set_obs_multi_buffer",
+    "wg_set_turbulence_box", "wg_set_turbulence_boxes", "wg_set_added_turbulence_box", "wg_set_deficit_table", "wg_set_box_ids", "wg_set_wind", "wg_set_wind_device", "wg_set_flow_script", "wg_reset", "wg_step", "wg_set_step_graph", "wg_check", "wg_obs_multi", "wg_set_obs_multi_buffer",
     "wg_get_info", "wg_get_measurements", "wg_get_windspeed", "wg_metrics", "wg_get_state", "wg_set_state", "wg_generate_mann_box", "wg_mann_beta_table", "wg_steady_power", "wg_kernel_timing", "wg_added_lookups", "wg_algorithmic_bytes", "wg_flow_variant",
 )
 
@@ -64,6 +64,8 @@ def load_library():
     L.wg_set_turbulence_box.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
                                         C.c_double, C.c_double]
     L.wg_set_box_ids.argtypes = [C.c_void_p, C.c_void_p]
+    L.wg_set_deficit_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double,
+                                       C.c_int, C.c_double, C.c_int, C.c_double]
     L.wg_set_added_turbulence_box.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
                                               C.c_double, C.c_double]
     L.wg_set_turbulence_boxes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int,
@@ -171,6 +173,9 @@ class HipBatch:
         if self._c.added_turbulence and not getattr(self, "_abox_set", False):
             from .mann import default_added_box
             self.set_added_turbulence_box(*default_added_box())
+        if self._c.deficit_model == 2 and getattr(self, "_dtab", None) is None:
+            from .ainslie import deficit_table
+            self.set_deficit_table(*deficit_table())
         _chk(self.L.wg_reset(self._h, mp, sp, C.c_void_p(self.obs.data_ptr()), self._stream()), "wg_reset")
         return self.obs
 
@@ -322,6 +327,18 @@ class HipBatch:
                                                 int(b.shape[3]), float(spacing[0]), float(spacing[1]),
                                                 float(spacing[2])), "wg_set_added_turbulence_box")
         self._abox_set = True
+
+    def set_deficit_table(self, table, spec):
+        """Deficit table of ``deficit_model`` 2 (``ainslie.deficit_table()`` is installed at the first reset by default):
+        table [n_ct, n_ti, n_x, n_r] of 1 - U / U0, ``spec`` its axes (ainslie.TABLE_SPEC)."""
+        t = self.torch
+        tb = t.as_tensor(np.ascontiguousarray(table, dtype=np.float32)).to(self.device).contiguous()
+        assert tb.ndim == 4 and tb.shape[2] == spec["n_x"] and tb.shape[3] == spec["n_r"]
+        _chk(self.L.wg_set_deficit_table(self._h, C.c_void_p(tb.data_ptr()), int(tb.shape[0]), float(spec["ct"][0]),
+                                         float(spec["ct"][-1]), int(tb.shape[1]), float(spec["ti"][0]), float(spec["ti"][-1]),
+                                         int(spec["n_x"]), float(spec["x_max_D"]), int(spec["n_r"]), float(spec["r_max_R"])),
+             "wg_set_deficit_table")
+        self._dtab = tb              # borrowed by the handle
 
     def set_turbulence_boxes(self, boxes, spacing):
         """Pool of K boxes of equal shape (turbtype "MannLoad": one TF_* file drawn per reset, :611-618)."""

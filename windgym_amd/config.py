@@ -163,7 +163,8 @@ class EnvConfig:
     # turbtype "None"), "iso" / "none" force it
     added_turbulence: str = "auto"
     wake_ti_fold: bool = True                    # Crespo-Hernandez added TI folded into the emitted particles' k (M0 §2.4)
-    deficit: str = "gaussian"                    # "gaussian" (north_star) | "super_gaussian" (Blondel & Cathelain 2020)
+    deficit: str = "gaussian"                    # "gaussian" (north_star) | "super_gaussian" (Blondel & Cathelain 2020) |
+    #                                              "ainslie" (tabulated DWM eddy-viscosity deficit, windgym_amd/ainslie.py)
     _keep: list = field(default_factory=list, repr=False)
 
     def __post_init__(self):
@@ -369,10 +370,10 @@ class EnvConfig:
             raise ValueError("added_turbulence must be 'auto', 'iso' or 'none'")
         c.added_turbulence = int(self.turbtype != "None" and self.added_turbulence in ("auto", "iso"))
         c.no_ti_fold = int(not self.wake_ti_fold)
-        if self.deficit not in ("gaussian", "super_gaussian"):
-            raise ValueError("deficit must be 'gaussian' or 'super_gaussian'")
-        c.deficit_model = int(self.deficit == "super_gaussian")
-        if c.deficit_model:
+        if self.deficit not in ("gaussian", "super_gaussian", "ainslie"):
+            raise ValueError("deficit must be 'gaussian', 'super_gaussian' or 'ainslie'")
+        c.deficit_model = ("gaussian", "super_gaussian", "ainslie").index(self.deficit)
+        if c.deficit_model == 1:
             # Blondel & Cathelain (2020), Table 2 (py_wake BlondelSuperGaussianDeficit2020 — the model of the reference's
             # PyWakeAgent): characteristic width sigma/D = (0.17 TI + 0.005) x/D + 0.2 sqrt(beta); model_constants override
             c.m0_ka, c.m0_kb, c.m0_eps = 0.17, 0.005, 0.2

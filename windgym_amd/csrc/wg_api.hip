@@ -197,7 +197,8 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             return fail(WG_ERR_INVALID, "wind ranges exceed the 16-bit emission record: need ka*sqrt(TI_max^2 + 0.34^2) + kb <= 0.25 "
                                             "(TI_max <= 0.55 with the default constants) and |hill| * ws_max <= 16 m/s");
     }
-    if (c->deficit_model != 0 && c->deficit_model != 1) return fail(WG_ERR_INVALID, "deficit_model must be 0 (Gaussian) or 1 (super-Gaussian)");
+    if (c->deficit_model < 0 || c->deficit_model > 2)
+        return fail(WG_ERR_INVALID, "deficit_model must be 0 (Gaussian), 1 (super-Gaussian) or 2 (tabulated eddy-viscosity deficit)");
     HIPCHK(hipSetDevice(device));
     wg_env_s* h = new wg_env_s();
     h->device = device;
@@ -566,9 +567,10 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         f.added = h->added; f.no_ti_fold = h->no_ti_fold; f.deficit_model = h->deficit_model;
         f.km1 = (float)h->km1; f.km2r = (float)(2.0 * h->km2 * 0.5 * p.D_d);
         f.sg_af = (float)h->sg_af; f.sg_bf = (float)h->sg_bf; f.sg_cf = (float)h->sg_cf;
-        if (h->deficit_model == 1 && !f.res) {
+        f.an_inv_ka = (float)(1.0 / defd(c->m0_ka, 0.38));
+        if (h->deficit_model != 0 && !f.res) {
             wg_destroy(h);
-            return fail(WG_ERR_UNSUPPORTED, "deficit_model 1 (super-Gaussian) is built into the compact k_flow variants only "
+            return fail(WG_ERR_UNSUPPORTED, "deficit_model 1 / 2 (super-Gaussian, eddy-viscosity table) are built into the compact k_flow variants only "
                                             "(farms of up to 32 turbines, larger ones with steady inflow)");
         }
         FlowPtrs& g = h->fd;
@@ -739,6 +741,24 @@ extern "C" int wg_set_added_turbulence_box(wg_handle h, const float* box_dev, in
     return 0;
 }
 
+extern "C" int wg_set_deficit_table(wg_handle h, const float* table_dev, int n_ct, double ct0, double ct1, int n_ti, double ti0,
+                                    double ti1, int n_x, double x_max_D, int n_r, double r_max_R) {
+    if (!h || !table_dev || n_ct < 2 || n_ti < 2 || n_x < 2 || n_r < 2 || !(ct1 > ct0) || !(ti0 > 0) || !(ti1 > ti0) || !(x_max_D > 0) ||
+        !(r_max_R > 0))
+        return fail(WG_ERR_INVALID, "wg_set_deficit_table: null pointer or bad grid");
+    if ((long long)n_ct * n_ti * n_x * n_r >= (1ll << 30)) return fail(WG_ERR_INVALID, "wg_set_deficit_table: table too large");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    drop_step_graphs(h);
+    FlowP& f = h->fp;
+    h->fd.dtab = table_dev;            // borrowed: the caller keeps the buffer alive
+    f.an_ct = n_ct; f.an_ti = n_ti; f.an_x = n_x; f.an_r = n_r;
+    f.an_ct0 = (float)ct0; f.an_inv_dct = (float)((n_ct - 1) / (ct1 - ct0));
+    f.an_lti0 = (float)std::log(ti0); f.an_inv_dlti = (float)((n_ti - 1) / (std::log(ti1) - std::log(ti0)));
+    f.an_inv_dx = (float)((n_x - 1) / x_max_D); f.an_inv_dr = (float)((n_r - 1) / r_max_R);
+    return 0;
+}
+
 extern "C" int wg_set_turbulence_box(wg_handle h, const float* box_dev, int nx, int ny, int nz, double dx,
                                      double dy, double dz) {
     const float* one[1] = {box_dev};
@@ -831,6 +851,8 @@ extern "C" int wg_reset(wg_handle h, const uint8_t* env_mask_host, const uint64_
         return fail(WG_ERR_INVALID, "turbtype Mann*: call wg_set_turbulence_box before wg_reset");
     if (h->added && !h->fd.abox4)
         return fail(WG_ERR_INVALID, "added_turbulence: call wg_set_added_turbulence_box before wg_reset");
+    if (h->deficit_model == 2 && !h->fd.dtab)
+        return fail(WG_ERR_INVALID, "deficit_model 2: call wg_set_deficit_table before wg_reset");
     const uint8_t* mask = nullptr;
     const uint64_t* seeds = nullptr;
     bool all = true;

@@ -72,6 +72,10 @@ struct FlowP {
     float km1, km2r;
     float sg_af, sg_bf, sg_cf;    // super-Gaussian order n(x) = af exp(bf x/D) + cf (deficit_model = 1)
     double inv_adx, inv_ady, inv_adz;
+    // deficit_model 2: tabulated eddy-viscosity (Ainslie / DWM) deficit, FlowPtrs::dtab [an_ct][an_ti][an_x][an_r] (wg_set_deficit_table):
+    // Ct uniform from an_ct0, TI log-uniform from exp(an_lti0), x / D and r / R uniform from 0
+    int an_ct, an_ti, an_x, an_r;
+    float an_ct0, an_inv_dct, an_lti0, an_inv_dlti, an_inv_dx, an_inv_dr, an_inv_ka;
 };
 
 struct FlowPtrs {
@@ -81,6 +85,7 @@ struct FlowPtrs {
     const float4* box4;          // interleaved copy of the turbulence box: [Nx][Ny][Nz] x (u, v, w, 0)
     const float4* box4c;         // the same block-averaged over 4x4x4 cells
     const float4* abox4;         // isotropic box of the wake-added turbulence, interleaved like box4
+    const float* dtab;           // deficit_model 2: the deficit table (see FlowP::an_*)
     float *yaw, *u, *v, *w, *ti_loc, *power, *ct;
     float* bnd;                   // [n_slots][N][4] conservative chain bounds (excursion, k, eps) + last moving emission (uint bits)
     WgSlot* slot;

@@ -325,8 +325,9 @@ __device__ __forceinline__ void wg_wait_vmem() {
 
 // One DWMFlowSimulation.step() of model M0 up to the new rotor inflow (T[t].u/v/w/ti); power and the
 // measurement are done by the caller's per-turbine tail.
-template <int NT, int TURB, bool RES, bool SGM>
-// (SGM: super-Gaussian deficit compiled in — a run-time switch in the pair loop cost the Gaussian default 5 us on cfg2)
+template <int NT, int TURB, bool RES, int SGM>
+// (SGM = deficit model compiled in: 0 Gaussian, 1 super-Gaussian, 2 tabulated eddy-viscosity (Ainslie) deficit — a
+// run-time switch in the pair loop cost the Gaussian default 5 us on cfg2)
 // (the LDS arrays that lanes exchange data through — T, pair, tiap, tmask, jnl — are deliberately NOT __restrict__: for a
 // noalias pointer the compiler may carry a value this lane loaded earlier across lds_barrier()'s memory clobber and miss
 // what another lane stored in between; the read-only tables may be)
@@ -551,7 +552,58 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sig * sig);
             // super-Gaussian option (Blondel & Cathelain 2020): order n(x), centre-line deficit from
             // mass + momentum conservation; n = 2 is the Gaussian wake
-            constexpr bool SG = SGM;
+            constexpr bool SG = SGM == 1;
+            if constexpr (SGM == 2) {
+                // Eddy-viscosity deficit (windgym_amd/ainslie.py): the fraction 1 - U / U0 tabulated over
+                // (Ct, TI_amb, x / D, r / R), sampled 4-linearly — (Ct, TI, x) once per wake, r per rotor point.  TI is what the
+                // particle's frozen wake-growth rate encodes: k = ka TI + kb.
+                const float* __restrict__ tab = d.dtab;
+                const float tiw = fmaxf((kv - p.kb) * p.an_inv_ka, 1e-6f);
+                float fc = fminf(fmaxf((ctv - p.an_ct0) * p.an_inv_dct, 0.f), (float)(p.an_ct - 1));
+                float ft = fminf(fmaxf((__logf(tiw) - p.an_lti0) * p.an_inv_dlti, 0.f), (float)(p.an_ti - 1));
+                float fx = fminf(fmaxf(xd * p.an_inv_dx, 0.f), (float)(p.an_x - 1));
+                const int ic = min((int)fc, p.an_ct - 2), it = min((int)ft, p.an_ti - 2), ix = min((int)fx, p.an_x - 2);
+                const float wc = fc - (float)ic, wt = ft - (float)it, wx = fx - (float)ix;
+                const int sx = p.an_r, st = p.an_x * sx, sc = p.an_ti * st;
+                const int base = ic * sc + it * st + ix * sx;
+                const float cgt_ = T[t].cg;
+                const float ind_ = 0.5f * (1.0f - __builtin_amdgcn_sqrtf(1.0f - ctv));
+                tiav[i] = p.no_ti_fold ? 0.f
+                                       : p.tia * fast_pow(ind_, p.tib) * ti_pow * fast_pow(fmaxf(xd, 1.0f), p.tid) * __expf(-rc2 * inv2s2);
+                float acc_ = 0.f, a0_ = 0.f, a1_ = 0.f, a2_ = 0.f;
+                const float* gt_ = ADDED ? gadd + (t << p.S_shift) * 3 : nullptr;
+                const float inv_R = 2.0f * p.inv_D;
+                for (int sI = 0; sI < p.S; ++sI) {
+                    const float dy = yt + rdy[sI] * cgt_ - yc, dz = p.hub + rdz[sI] - zc;
+                    const float fr = __builtin_amdgcn_sqrtf(dy * dy + dz * dz) * inv_R * p.an_inv_dr;
+                    if (!(fr < (float)p.an_r - 1.5f)) continue;        // beyond the table: no deficit
+                    // the profile at the r nodes m - 1, m, m + 1 around fr (3-linear in Ct, TI, x; node -1 mirrors node 1)
+                    const int m = (int)(fr + 0.5f), ml = m > 0 ? m - 1 : 1;
+                    float fa = 0.f, fb = 0.f, fc_ = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int o = base + (q & 1 ? sc : 0) + (q & 2 ? st : 0) + (q & 4 ? sx : 0);
+                        const float wq = (q & 1 ? wc : 1.0f - wc) * (q & 2 ? wt : 1.0f - wt) * (q & 4 ? wx : 1.0f - wx);
+                        fa += wq * tab[o + ml]; fb += wq * tab[o + m];
+                        if (ADDED) fc_ += wq * tab[o + m + 1]; else if (!(fr < (float)m)) fc_ += wq * tab[o + m + 1];
+                    }
+                    const float e = fr - (float)m;                       // in [-0.5, 0.5)
+                    const float frac = e < 0.f ? fb + e * (fb - fa) : fb + e * (fc_ - fb);
+                    const float du = uev * frac;
+                    acc_ += du;
+                    if (ADDED) {
+                        // U k_mt = km1 dU + km2 R |d dU / dr|, the slope as the centred difference of the piecewise-linear
+                        // profile over one node spacing (continuous in r): [f(fr + 1/2) - f(fr - 1/2)] / dr
+                        const float hi = fb + (e + 0.5f) * (fc_ - fb), lo = fa + (e + 0.5f) * (fb - fa);
+                        const float wk = uev * (p.km1 * frac + 0.5f * p.km2r * fabsf(hi - lo) * p.an_inv_dr * inv_R);
+                        a0_ += wk * gt_[sI * 3]; a1_ += wk * gt_[sI * 3 + 1]; a2_ += wk * gt_[sI * 3 + 2];
+                    }
+                }
+                if (ADDED) { addv[i] = a0_ * p.inv_S; addv[TC * N + i] = a1_ * p.inv_S; addv[2 * TC * N + i] = a2_ * p.inv_S; }
+                def[i] = acc_ * p.inv_S;
+                if (!GL) atomicOr(&tmask[tl * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
+                return;
+            }
             float nsg = 2.0f, cf;
             if (SG) {
                 nsg = p.sg_af * __expf(p.sg_bf * xd) + p.sg_cf;
@@ -1648,7 +1700,7 @@ __device__ __attribute__((noinline)) void wg_first_obs(const WgParams* gp, const
     if (lane == 0) d.next_obs_ok[ctx_id] = 1;
 }
 
-template <int NT, int TURB, bool REPLAY, bool NOISE, bool RES, bool SGM = false>
+template <int NT, int TURB, bool REPLAY, bool NOISE, bool RES, int SGM = 0>
 __global__ void __launch_bounds__(NT, TURB != WG_TURB_NONE ? WG_BOX_WAVES : (RES ? (NT == WG_WAVE ? WG_FLOW_WAVES_GL : WG_FLOW_WAVES_CG) : WG_FLOW_WAVES))
 k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict__ actions,
        const uint8_t* __restrict__ mask, const int chunk) {
@@ -2090,13 +2142,15 @@ static void launch_nt(const FlowP* p, const FlowPtrs* d, int mode, const float* 
     hipLaunchKernelGGL((k_flow<NT, TURB, REPLAY, NOISE, RES>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk)
     const int turb = (p->turb_mode >= WG_TURB_BOX) ? WG_TURB_BOX : p->turb_mode;
     if constexpr (RES) {
-        if (p->deficit_model == 1 && !replay) {      // super-Gaussian instantiations (compact variants only)
-#define WG_LAUNCH_SG(TURB, NOISE) \
-    hipLaunchKernelGGL((k_flow<NT, TURB, false, NOISE, true, true>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk)
+        if (p->deficit_model != 0 && !replay) {      // super-Gaussian / eddy-viscosity instantiations (compact variants only)
+#define WG_LAUNCH_DM(TURB, NOISE, DM) \
+    hipLaunchKernelGGL((k_flow<NT, TURB, false, NOISE, true, DM>), dim3(grid), dim3(NT), lds, st, *p, *d, mode, actions, mask, chunk)
+#define WG_LAUNCH_SG(TURB, NOISE) do { if (p->deficit_model == 1) WG_LAUNCH_DM(TURB, NOISE, 1); else WG_LAUNCH_DM(TURB, NOISE, 2); } while (0)
             if (turb == WG_TURB_NONE) { if (noise) WG_LAUNCH_SG(WG_TURB_NONE, true); else WG_LAUNCH_SG(WG_TURB_NONE, false); }
             else if (turb == WG_TURB_RANDOM) { if (noise) WG_LAUNCH_SG(WG_TURB_RANDOM, true); else WG_LAUNCH_SG(WG_TURB_RANDOM, false); }
             else { if (noise) WG_LAUNCH_SG(WG_TURB_BOX, true); else WG_LAUNCH_SG(WG_TURB_BOX, false); }
 #undef WG_LAUNCH_SG
+#undef WG_LAUNCH_DM
             return;
         }
     }
