@@ -363,6 +363,47 @@ static inline real m0_sg_cfrac(real ct, real sp, real n) {
     return a1 - R_SQRT(a);
 }
 
+/* Tabulated eddy-viscosity deficit (wg_config.deficit_model = 2; wg_set_deficit_table): the profile 1 - U / U0 at
+ * (Ct, TI_amb, x / D) is 3-linear between the table's nodes — an_setup keeps the 8 corner weights / offsets of one wake;
+ * TI_amb is what the particle's frozen growth rate encodes (k = ka TI + kb).  an_frac samples it at r / R: linear between
+ * the r nodes, 0 from half a node inside the table's edge on; *slope = |d frac / d (r / R)| as the centred difference of that
+ * piecewise-linear profile over one node spacing, [f(fr + 1/2) - f(fr - 1/2)] / dr (continuous in r; node -1 mirrors node 1). */
+typedef struct { real w[8]; size_t o[8]; } an_wake;
+static void an_setup(const oracle_t* o, real ctv, real kv, real xd, an_wake* aw) {
+    real tiw = (kv - (real)o->cfg.m0_kb) / (real)o->cfg.m0_ka;
+    if (tiw < (real)1e-6) tiw = (real)1e-6;
+    real fq[3] = {(ctv - (real)o->an_ct0) / (real)o->an_dct, ((real)log((double)tiw) - (real)o->an_lti0) / (real)o->an_dlti,
+                  xd / (real)o->an_dx};
+    const int nq[3] = {o->an_ct, o->an_ti, o->an_x};
+    const size_t sq[3] = {(size_t)o->an_ti * o->an_x * o->an_r, (size_t)o->an_x * o->an_r, (size_t)o->an_r};
+    int iq[3]; real wq[3];
+    for (int a = 0; a < 3; ++a) {
+        if (fq[a] < (real)0) fq[a] = (real)0;
+        if (fq[a] > (real)(nq[a] - 1)) fq[a] = (real)(nq[a] - 1);
+        iq[a] = (int)fq[a]; if (iq[a] > nq[a] - 2) iq[a] = nq[a] - 2;
+        wq[a] = fq[a] - (real)iq[a];
+    }
+    for (int q = 0; q < 8; ++q) {
+        aw->w[q] = (q & 1 ? wq[0] : (real)1 - wq[0]) * (q & 2 ? wq[1] : (real)1 - wq[1]) * (q & 4 ? wq[2] : (real)1 - wq[2]);
+        aw->o[q] = (iq[0] + (q & 1 ? 1 : 0)) * sq[0] + (iq[1] + (q & 2 ? 1 : 0)) * sq[1] + (iq[2] + (q & 4 ? 1 : 0)) * sq[2];
+    }
+}
+static real an_frac(const oracle_t* o, const an_wake* aw, real r_over_R, real* slope) {
+    real fr = r_over_R / (real)o->an_dr;
+    *slope = 0;
+    if (!(fr < (real)o->an_r - (real)1.5)) return 0;
+    int m = (int)(fr + (real)0.5), ml = m > 0 ? m - 1 : 1;
+    real fa = 0, fb = 0, fc = 0;
+    for (int q = 0; q < 8; ++q) {
+        fa += aw->w[q] * o->dtab[aw->o[q] + ml]; fb += aw->w[q] * o->dtab[aw->o[q] + m];
+        fc += aw->w[q] * o->dtab[aw->o[q] + m + 1];
+    }
+    real e = fr - (real)m;
+    real hi = fb + (e + (real)0.5) * (fc - fb), lo = fa + (e + (real)0.5) * (fb - fa);
+    *slope = R_FABS(hi - lo) / (real)o->an_dr;
+    return e < (real)0 ? fb + e * (fb - fa) : fb + e * (fc - fb);
+}
+
 /* trilinear, periodic lookup of one component of the frozen box at (x,y,z) metres; cell coordinates are
  * formed in double precision (x - U t reaches 1e5 m), the interpolation weights in `real` */
 static inline real cbox_lookup(const oracle_t* o, int bid, int comp, double x, double y, double z) {
@@ -597,53 +638,22 @@ static void m0_flow_step(oracle_t* o, env_t* e, int fi) {
             if (rc2 > rcut * rcut) continue;
             real inv2s2 = (real)1 / ((real)2 * sig * sig);
             real amp = uev * cf;
-            /* deficit_model 2: the eddy-viscosity profile 1 - U / U0 of the table at (Ct, TI_amb, x / D), 3-linear; TI_amb is
-             * what the particle's frozen growth rate encodes (k = ka TI + kb); r / R per rotor point below */
             const int an = c->deficit_model == 2 && o->dtab;
-            real an_w[8]; size_t an_o[8];
-            if (an) {
-                real tiw = (kv - (real)c->m0_kb) / (real)c->m0_ka;
-                if (tiw < (real)1e-6) tiw = (real)1e-6;
-                real fq[3] = {(ctv - (real)o->an_ct0) / (real)o->an_dct, ((real)log((double)tiw) - (real)o->an_lti0) / (real)o->an_dlti,
-                              xd / (real)o->an_dx};
-                const int nq[3] = {o->an_ct, o->an_ti, o->an_x};
-                const size_t sq[3] = {(size_t)o->an_ti * o->an_x * o->an_r, (size_t)o->an_x * o->an_r, (size_t)o->an_r};
-                int iq[3]; real wq[3];
-                for (int a = 0; a < 3; ++a) {
-                    if (fq[a] < (real)0) fq[a] = (real)0;
-                    if (fq[a] > (real)(nq[a] - 1)) fq[a] = (real)(nq[a] - 1);
-                    iq[a] = (int)fq[a]; if (iq[a] > nq[a] - 2) iq[a] = nq[a] - 2;
-                    wq[a] = fq[a] - (real)iq[a];
-                }
-                for (int q = 0; q < 8; ++q) {
-                    an_w[q] = (q & 1 ? wq[0] : (real)1 - wq[0]) * (q & 2 ? wq[1] : (real)1 - wq[1]) * (q & 4 ? wq[2] : (real)1 - wq[2]);
-                    an_o[q] = (iq[0] + (q & 1 ? 1 : 0)) * sq[0] + (iq[1] + (q & 2 ? 1 : 0)) * sq[1] + (iq[2] + (q & 4 ? 1 : 0)) * sq[2];
-                }
-            }
+            an_wake aw;
+            if (an) an_setup(o, ctv, kv, xd, &aw);
             for (int s = 0; s < S; ++s) {
                 real ys = (real)x->yr[t] + (real)o->rotor_dy[s] * cg;
                 real zs = hub + (real)o->rotor_dz[s];
                 real r2 = (ys - yc) * (ys - yc) + (zs - zc) * (zs - zc);
                 real du, grad;            /* grad = |d dU / dr| / dU */
                 if (an) {
-                    real fr = R_SQRT(r2) / R_rot / (real)o->an_dr;
-                    if (!(fr < (real)o->an_r - (real)1.5)) continue;     /* beyond the table: no deficit */
-                    /* nodes m - 1, m, m + 1 around fr; node -1 mirrors node 1 (axis of symmetry) */
-                    int m = (int)(fr + (real)0.5), ml = m > 0 ? m - 1 : 1;
-                    real fa = 0, fb = 0, fc = 0;
-                    for (int q = 0; q < 8; ++q) {
-                        fa += an_w[q] * o->dtab[an_o[q] + ml]; fb += an_w[q] * o->dtab[an_o[q] + m];
-                        fc += an_w[q] * o->dtab[an_o[q] + m + 1];
-                    }
-                    real e = fr - (real)m;
-                    real frac = e < (real)0 ? fb + e * (fb - fa) : fb + e * (fc - fb);
+                    real slope;
+                    real frac = an_frac(o, &aw, R_SQRT(r2) / R_rot, &slope);
                     du = uev * frac;
                     dsum += du;
                     if (added) {
-                        /* U k_mt = km1 dU + km2 R |d dU / dr|: the slope as the centred difference of the piecewise-linear
-                         * profile over one node spacing, [f(fr + 1/2) - f(fr - 1/2)] / dr — continuous in r */
-                        real hi = fb + (e + (real)0.5) * (fc - fb), lo = fa + (e + (real)0.5) * (fb - fa);
-                        real wk = uev * (km1 * frac + km2 * R_FABS(hi - lo) / (real)o->an_dr);
+                        /* U k_mt = km1 dU + km2 R |d dU / dr| (slope per R: an_frac) */
+                        real wk = uev * (km1 * frac + km2 * slope);
                         for (int cc = 0; cc < 3; ++cc) addsum[cc] += wk * gadd[cc][s];
                     }
                     continue;
@@ -1356,7 +1366,18 @@ int WGO(get_windspeed)(void* h, int b, int fi, const double* xs, int nx, const d
                 real sig = sp * D;
                 real inv2s2 = (real)1 / ((real)2 * sig * sig);
                 real r2 = ((real)py - yc) * ((real)py - yc) + ((real)z - zc) * ((real)z - zc);
-                dsum += uev * m0_cfrac(ctv, sp) * R_EXP(-r2 * inv2s2);
+                if (c->deficit_model == 2 && o->dtab) {
+                    an_wake aw; real slope;
+                    an_setup(o, ctv, kv, (real)dx * inv_D, &aw);
+                    dsum += uev * an_frac(o, &aw, R_SQRT(r2) / ((real)0.5 * D), &slope);
+                } else if (c->deficit_model == 1) {
+                    real xd = (real)dx * inv_D;
+                    real nsg = (real)c->m0_sg_af * R_EXP((real)c->m0_sg_bf * xd) + (real)c->m0_sg_cf;
+                    real rn = r2 > (real)0 ? R_POW(r2 * inv_D * inv_D, (real)0.5 * nsg) : (real)0;
+                    dsum += uev * m0_sg_cfrac(ctv, sp, nsg) * R_EXP(-rn / ((real)2 * sp * sp));
+                } else {
+                    dsum += uev * m0_cfrac(ctv, sp) * R_EXP(-r2 * inv2s2);
+                }
             }
             out[0 * plane + (size_t)ix * ny + iy] = (real)x->ws + amb[0] - dsum;
             out[1 * plane + (size_t)ix * ny + iy] = amb[1];

@@ -196,3 +196,27 @@ def test_notebook_anchor_with_the_eddy_viscosity_deficit(oracle_lib):
     dy, dz = rotor_points(16, 40.0)
     centred = 1 - np.mean(_table_lookup(tab, s, 0.8, 0.027, 8.0, np.hypot(dy, dz) / 40.0))
     assert 0.58 < centred < 0.63
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("deficit", ["ainslie", "super_gaussian"])
+def test_flow_field_view_follows_the_deficit_option(deficit, oracle_lib):
+    """wg_get_windspeed (fs.get_windspeed(XYView(...)), Wind_Farm_Env.py:1040-1083) draws the wakes with the deficit model
+    the handle was created with."""
+    import torch
+    from windgym_amd import binding
+    cfg = _cfg(deficit, n_envs=2, nx=3, ny=2, ws=10.0, ti=0.07, advect_full_chains=True)
+    cfg.wd_min, cfg.wd_max = 262.0, 278.0
+    env, orc = binding.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    env.reset(seeds=[5, 6]), orc.reset(seeds=[5, 6])
+    rng = np.random.default_rng(3)
+    for _ in range(60):
+        a = rng.uniform(-1, 1, size=(2, cfg.n_turb)).astype(np.float32)
+        env.step(torch.as_tensor(a, device="cuda")), orc.step(a)
+    tx, ty = orc.info("turb_x"), orc.info("turb_y")
+    for b in (0, 1):
+        xs = np.linspace(tx[b].min() - 100.0, tx[b].max() + 800.0, 83).astype(np.float32)
+        ys = np.linspace(ty[b].min() - 200.0, ty[b].max() + 200.0, 57).astype(np.float32)
+        got = env.windspeed(b, xs, ys).cpu().numpy()
+        np.testing.assert_allclose(got, orc.windspeed(b, xs, ys), rtol=2e-4, atol=2e-3)
+        assert (10.0 - got[0]).max() > 2.0

@@ -2196,6 +2196,30 @@ extern "C" void wg_launch_flow(const FlowP* p, const FlowPtrs* d, int mode, cons
 }
 
 // ===================================================================================================
+// one sample of the tabulated eddy-viscosity deficit (deficit_model 2; the pair evaluation of flow_step inlines the same
+// rule per wake): 1 - U / U0 at (Ct, TI_amb from the frozen growth rate, x / D, r / R)
+__device__ float an_point(const FlowP& p, const float* __restrict__ tab, const float ctv, const float kv, const float xd, const float rR) {
+    const float fr = rR * p.an_inv_dr;
+    if (!(fr < (float)p.an_r - 1.5f)) return 0.f;
+    const float tiw = fmaxf((kv - p.kb) * p.an_inv_ka, 1e-6f);
+    const float fc = fminf(fmaxf((ctv - p.an_ct0) * p.an_inv_dct, 0.f), (float)(p.an_ct - 1));
+    const float ft = fminf(fmaxf((__logf(tiw) - p.an_lti0) * p.an_inv_dlti, 0.f), (float)(p.an_ti - 1));
+    const float fx = fminf(fmaxf(xd * p.an_inv_dx, 0.f), (float)(p.an_x - 1));
+    const int ic = min((int)fc, p.an_ct - 2), it = min((int)ft, p.an_ti - 2), ix = min((int)fx, p.an_x - 2);
+    const float wc = fc - (float)ic, wt = ft - (float)it, wx = fx - (float)ix;
+    const int sx = p.an_r, st = p.an_x * sx, sc = p.an_ti * st;
+    const int base = ic * sc + it * st + ix * sx;
+    const int m = (int)(fr + 0.5f), ml = m > 0 ? m - 1 : 1;
+    float fa = 0.f, fb = 0.f, fcn = 0.f;
+    for (int q = 0; q < 8; ++q) {
+        const int o = base + (q & 1 ? sc : 0) + (q & 2 ? st : 0) + (q & 4 ? sx : 0);
+        const float wq = (q & 1 ? wc : 1.0f - wc) * (q & 2 ? wt : 1.0f - wt) * (q & 4 ? wx : 1.0f - wx);
+        fa += wq * tab[o + ml]; fb += wq * tab[o + m]; fcn += wq * tab[o + m + 1];
+    }
+    const float e = fr - (float)m;
+    return e < 0.f ? fb + e * (fb - fa) : fb + e * (fcn - fb);
+}
+
 // k_windspeed: flow-field view — (u, v, w) on an XY grid at height z of ONE farm of ONE env, in the flow frame:
 // fs.get_windspeed(XYView(z, x, y), include_wakes) behind WindFarmEnv._render_frame / init_render
 // (Wind_Farm_Env.py:1040-1083, :464-476).  One thread per grid point; the same bracketed-chain evaluation as phase A
@@ -2275,7 +2299,18 @@ k_windspeed(const FlowP p, const FlowPtrs d, const int e, const int farm, const 
         const float sig = sp * p.D;
         const float inv2s2 = 1.0f / (2.0f * sig * sig);
         const float r2 = (yp - yc) * (yp - yc) + (z - zc) * (z - zc);
-        dsum += uev * m0_cfrac(ctv, sp) * __expf(-r2 * inv2s2);
+        if (p.deficit_model == 2) {
+            dsum += uev * an_point(p, d.dtab, ctv, kv, (float)dx * p.inv_D, sqrtf(r2) * 2.0f * p.inv_D);
+        } else if (p.deficit_model == 1) {
+            const float xd = (float)dx * p.inv_D;
+            const float nsg = p.sg_af * __expf(p.sg_bf * xd) + p.sg_cf, in2 = 2.0f / nsg;
+            const float rad = exp2f(2.0f * in2 - 2.0f) - nsg * ctv / (16.0f * tgammaf(in2) * powf(sp, 2.0f * in2));
+            const float cf = exp2f(in2 - 1.0f) - sqrtf(fmaxf(rad, 0.0f));
+            const float rn = r2 > 0.f ? powf(r2 * p.inv_D * p.inv_D, 0.5f * nsg) : 0.f;
+            dsum += uev * cf * __expf(-rn / (2.0f * sp * sp));
+        } else {
+            dsum += uev * m0_cfrac(ctv, sp) * __expf(-r2 * inv2s2);
+        }
     }
     const size_t plane = (size_t)nx * ny;
     out[idx] = (float)cx.ws + amb[0] - dsum;
