@@ -6,7 +6,7 @@ WG_TIMELINE_OUT=gpurun_out/timeline.bin python bench.py --workload ${WL:-cfg2} -
 cp /tmp/lib_keep.so windgym_amd/libwindgym_hip.so
 python - <<'PY'
 import numpy as np
-raw = np.fromfile('gpurun_out/timeline.bin', dtype=np.int64).reshape(-1, 12)
+raw = np.fromfile('gpurun_out/timeline.bin', dtype=np.int64).reshape(-1, 16)
 ok = (raw[:, 8] > raw[:, 0]) & (raw[:, 0] > 0) & (raw[:, 9] > raw[:, 2]) & (raw[:, 11] > raw[:, 1])
 a = raw[ok]
 print('blocks with one full step:', len(a), 'of', len(raw))

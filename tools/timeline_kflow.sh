@@ -4,7 +4,7 @@ WG_HIPCC_FLAGS="-DWG_TIMELINE $XF" python windgym_amd/build.py > /dev/null 2>&1
 WG_TIMELINE_OUT=gpurun_out/timeline.bin python bench.py --workload ${WL:-cfg2} --steps 60 --warmup 10 --no-cpu 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['roofline']['kernel_ms'])"
 python - <<'PY'
 import numpy as np
-raw = np.fromfile('gpurun_out/timeline.bin', dtype=np.int64).reshape(-1, 12)
+raw = np.fromfile('gpurun_out/timeline.bin', dtype=np.int64).reshape(-1, 16)
 bid = np.arange(len(raw))
 ok = (raw[:, 8] > raw[:, 0]) & (raw[:, 0] > 0)
 a = raw[ok]; b = bid[ok]

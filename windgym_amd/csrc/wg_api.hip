@@ -470,6 +470,14 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
                 }
                 // (+ 12 bytes per pair for the added-turbulence contributions when that model is on)
                 off = std::max(ql, ((size_t)(h->added ? 22 : 10) * tc * p.N + 16 + 15) & ~(size_t)15);
+                f.lf_cap = 0;
+                if ((WG_LF_PAIR != 0) && (WG_PAIR_FIRST != 0) && f.block == 256 && p.turb_mode == WG_TURB_NONE) {
+                    // large-farm steady variant: results staged per candidate (layout: wg_flow.h, WG_LF_OFF_*); at least 512
+                    // candidates at once, whatever the chunked carve would have taken otherwise
+                    const size_t fixed = WG_LF_OFF_DEF(p.N);
+                    off = std::max(off, (fixed + 8 * 512 + 15) & ~(size_t)15);
+                    f.lf_cap = (int)((off - fixed) / 8);
+                }
                 // single-wave steady variant: the deficit phase's gathers are LDS-DMA requests issued before the record /
                 // quad-list phases, so the candidate list and the quad list are alive together (no aliasing) and the
                 // gathers need a landing zone
@@ -581,7 +589,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         g.dbg = nullptr;
         if (getenv("WG_TIMELINE_OUT")) {
             long long* dbgp = nullptr;
-            if (!dev_alloc(h, &dbgp, (size_t)p.B * 2 * p.F * 12, false)) g.dbg = dbgp;
+            if (!dev_alloc(h, &dbgp, (size_t)p.B * 2 * p.F * 16, false)) g.dbg = dbgp;
         }
         g.yaw = d.yaw; g.u = d.u; g.v = d.v; g.w = d.w; g.ti_loc = d.ti_loc; g.power = d.power; g.ct = d.ct;
         g.slot = d.slot; g.ctx = d.ctx; g.env = d.env; g.xr = d.xr; g.yr = d.yr; g.jneed = d.jneed;
@@ -649,7 +657,7 @@ extern "C" int wg_destroy(wg_handle h) {
     hipSetDevice(h->device);
     hipDeviceSynchronize();
     if (h->fd.dbg && getenv("WG_TIMELINE_OUT")) {      // -DWG_TIMELINE builds: dump the phase stamps of the last launch
-        const size_t n = (size_t)h->p.B * 2 * h->p.F * 12;
+        const size_t n = (size_t)h->p.B * 2 * h->p.F * 16;
         std::vector<long long> host(n);
         if (hipMemcpy(host.data(), h->fd.dbg, n * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
             if (FILE* f = fopen(getenv("WG_TIMELINE_OUT"), "wb")) { fwrite(host.data(), sizeof(long long), n, f); fclose(f); }

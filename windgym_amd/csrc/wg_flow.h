@@ -30,6 +30,29 @@
 #define WG_ADV_PIPE 1      // GL variant: software-pipelined advection pass (first quad requested before the deficit evaluation, the next
                            // quad before the current one is computed): cfg2 k_flow 61.5 -> 58.8 us same box (0 = plain loop, for A/B builds)
 #endif
+#ifndef WG_ADV_PIPE_LF
+#define WG_ADV_PIPE_LF 2   // 256-thread compact steady variant (large farms): quads requested ahead in its advection pass.  vmcnt counts
+                           // loads and stores in ONE in-order queue: a plain load-compute-store loop waits for the previous trip's
+                           // stores whenever it waits for its loads — two round trips per trip (cfg3: 20 trips of ~2 us).  Requested
+                           // before the stores, the next quads' loads no longer queue behind them.
+#endif
+#ifndef WG_FLOW_WAVES_LF
+#define WG_FLOW_WAVES_LF 4  // ... built at 4 waves per SIMD (128 VGPRs): its LDS carve allows 4 workgroups per CU anyway (cfg3: 34 KB each)
+#endif
+#ifndef WG_LF_PAIR
+#define WG_LF_PAIR 1      // 256-thread compact steady variant: pair phase over the whole farm at once — per-target source masks built
+                          // without ballots or LDS atomics, candidate list from a prefix sum (ascending (target, source) order),
+                          // results staged per CANDIDATE (0 = the chunked, densely staged phase shared with the small-farm variants)
+#endif
+// LDS layout of that phase inside the staging region (bytes; n = turbines): packed sources | masks | list offsets + wave totals |
+// candidate list (worst case n (n - 1) / 2 entries) | per-candidate deficit, added TI (lf_cap each)
+#define WG_LF_OFF_TM(n) (16 * (size_t)(n))
+#define WG_LF_OFF_BASE(n) (32 * (size_t)(n))
+#define WG_LF_OFF_CL(n) ((36 * (size_t)(n) + 4 * 8 + 15) & ~(size_t)15)
+#define WG_LF_OFF_DEF(n) ((WG_LF_OFF_CL(n) + (size_t)(n) * ((n) - 1) + 15) & ~(size_t)15)
+#ifndef WG_S_UNROLL_ALL
+#define WG_S_UNROLL_ALL 0   // 1: the rotor-point loop of the Gaussian pair evaluation unrolled by 4 in every variant (A/B builds)
+#endif
 #ifndef WG_PAIR_FIRST
 #define WG_PAIR_FIRST 1   // steady compact variant: deficit phase BEFORE the advection pass (0 = round-2 order, for A/B builds)
 #endif
@@ -41,6 +64,7 @@ struct FlowP {
     int res;                      // 1: compact per-turbine rings + pair-major deficit phases (small farms), 0: legacy streaming variant
     int pstride;                  // floats between the particle blocks of consecutive farm slots (>= NP, see wg_create)
     int target_chunk;             // targets whose pair parameters are staged in LDS at once
+    int lf_cap;                   // large-farm steady variant (WG_LF_PAIR): candidates whose results fit the staging region at once
     int lds_off_turb, lds_off_tab, lds_bytes;
     int rec_il;                   // the packed emission record is ONE interleaved array (rec_a[2 i] = ct|k, rec_a[2 i + 1] = eps|hv; rec_b = rec_a + 1):
                                   // GL handles — a pair's gathers touch one record line instead of two, an emission writes one sector
@@ -99,7 +123,7 @@ struct FlowPtrs {
     float *ring, *fring, *cur_ws, *cur_wd, *pend_farm, *pend_base, *old_yaw, *step_farm_pow, *step_base_pow;
     const float *rotor_dy, *rotor_dz, *tab_power, *tab_ct;   // tab_*: resampled on the uniform grid
     const float *script_uvw, *script_power;
-    long long* dbg;               // WG_TIMELINE debug builds: [n_blocks][12] phase stamps
+    long long* dbg;               // WG_TIMELINE debug builds: [n_blocks][16] phase stamps
     // device-resident copies of the full parameter / pointer blocks: read (scalar loads) only on the rare episode
     // initialisation path at the head of k_flow, so that the hot path keeps its slim kernel arguments
     const WgParams* gp;

@@ -125,7 +125,7 @@ __device__ __forceinline__ float tab_lookup(const float* __restrict__ ys, const 
 // debug build (-DWG_TIMELINE, env WG_TIMELINE_OUT=file): thread 0 of every workgroup records shader-clock stamps
 // at the phase boundaries of its step; wg_destroy dumps them.  This is how the per-workgroup latency budget in
 // DESIGN.md §4.1 was measured.
-__shared__ long long wg_stamps[12];
+__shared__ long long wg_stamps[16];
 #define WG_STAMP(k) do { if (threadIdx.x == 0) wg_stamps[k] = clock64(); } while (0)
 #else
 #define WG_STAMP(k) do { } while (0)
@@ -356,9 +356,11 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
 
     // staging of the compact variants' deficit phases (the `pair` region, per chunk of TC targets):
     // cl[TC*N] u16 candidate list | def[TC*N] rotor-mean deficit | tiav[TC*N] added TI
-    unsigned short* cl = reinterpret_cast<unsigned short*>(pair);
-    float* def = reinterpret_cast<float*>(cl + ((TC * N + 7) & ~7));
-    float* tiav = def + TC * N;
+    // (LF, the large-farm steady variant: staged per candidate, see lf_pair_phase)
+    constexpr bool LF = NT == 256 && RES && TURB == WG_TURB_NONE && (WG_PAIR_FIRST != 0) && (WG_LF_PAIR != 0);
+    unsigned short* cl = LF ? reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(pair) + WG_LF_OFF_CL(N)) : reinterpret_cast<unsigned short*>(pair);
+    float* def = LF ? reinterpret_cast<float*>(reinterpret_cast<char*>(pair) + WG_LF_OFF_DEF(N)) : reinterpret_cast<float*>(cl + ((TC * N + 7) & ~7));
+    float* tiav = LF ? def + p.lf_cap : def + TC * N;
     int* ncand = jnl + N + 1;
     // wake-added turbulence (wg_config.added_turbulence; turbulent inflow only): gadd[(t, sample)][3] =
     // the isotropic field at every rotor point, addv[3][TC * N] = a candidate pair's rotor-summed contribution
@@ -601,7 +603,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 }
                 if (ADDED) { addv[i] = a0_ * p.inv_S; addv[TC * N + i] = a1_ * p.inv_S; addv[2 * TC * N + i] = a2_ * p.inv_S; }
                 def[i] = acc_ * p.inv_S;
-                if (!GL) atomicOr(&tmask[tl * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
+                if (!GL && !LF) atomicOr(&tmask[tl * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
                 return;
             }
             float nsg = 2.0f, cf;
@@ -651,6 +653,14 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     const float rn = r2 > 0.f ? fast_pow(r2 * iD2, 0.5f * nsg) : 0.f;
                     acc += amp * __expf(-rn * inv2sp2);
                 }
+            } else if (LF || (WG_S_UNROLL_ALL != 0)) {
+                // (unrolled by 4: the LDS reads of the rotor-point offsets are in flight together — the rolled loop waits
+                // for two dependent LDS reads per point; same additions in the same order)
+#pragma unroll 4
+                for (int sI = 0; sI < p.S; ++sI) {
+                    const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
+                    acc += amp * __expf(-(dy * dy + dz * dz) * inv2s2);
+                }
             } else {
                 for (int sI = 0; sI < p.S; ++sI) {
                     const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
@@ -658,7 +668,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 }
             }
             def[i] = acc * p.inv_S;
-            if (!GL) atomicOr(&tmask[tl * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
+            if (!GL && !LF) atomicOr(&tmask[tl * WG_MASK_WORDS + (s2 >> 5)], 1u << (s2 & 31));
     };
     // (3)+(4) rotor-averaged inflow of the compact variants, as a closure: the steady variant runs it BEFORE the advection
     // pass (PRE), the turbulent ones after it.
@@ -803,13 +813,19 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 const int jp0 = j - n_emit, jp1 = jp0 + 1;
                 int r0 = src.head - jp0; if (r0 < 0) r0 += Rs;
                 int r1 = src.head - jp1; if (r1 < 0) r1 += Rs;
+                if (jp0 < 0) r0 = 0;      // (released in this step: nothing to fetch — any slot of the ring will do)
+                if (jp1 < 0) r1 = 0;
                 const int i0 = (WG_ABLATE & 128) ? src.roff : src.roff + r0, i1 = (WG_ABLATE & 128) ? src.roff + 1 : src.roff + r1;   // (profiling: gathers that hit one line per chain)
                 const bool g0 = jp0 >= 0, g1 = jp1 >= 0;
                 py0 = py1 = (float)src.yr; u0 = u1 = src.rue;
                 a0 = a1 = pack_a(src.rct, src.rk); b0_ = b1_ = pack_b(src.reps, src.rhv);
                 if (pl.r4) {
-                    if (g0) { const uint4 q0 = pl.r4[i0]; a0 = q0.x; b0_ = q0.y; u0 = __uint_as_float(q0.z); py0 = pl.py[i0]; }
-                    if (g1) { const uint4 q1 = pl.r4[i1]; a1 = q1.x; b1_ = q1.y; u1 = __uint_as_float(q1.z); py1 = pl.py[i1]; }
+                    // (both brackets requested together, whether needed or not — i0 / i1 are valid ring slots either way:
+                    // loads under `if (g0)` / `if (g1)` came out as two round trips, one behind the other)
+                    const uint4 q0 = pl.r4[i0], q1 = pl.r4[i1];
+                    const float y0l = pl.py[i0], y1l = pl.py[i1];
+                    if (g0) { a0 = q0.x; b0_ = q0.y; u0 = __uint_as_float(q0.z); py0 = y0l; }
+                    if (g1) { a1 = q1.x; b1_ = q1.y; u1 = __uint_as_float(q1.z); py1 = y1l; }
                 } else {
                     if (g0) { py0 = pl.py[i0]; u0 = pl.ue[i0]; a0 = pl.ra[i0]; b0_ = pl.rb[i0]; }
                     if (g1) { py1 = pl.py[i1]; u1 = pl.ue[i1]; a1 = pl.ra[i1]; b1_ = pl.rb[i1]; }
@@ -853,11 +869,167 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         }   // target chunks
         lds_barrier<NT>();
     };
+
+    // Large-farm steady variant (LF; cfg3: 80 turbines, 6400 pairs, ~520 of them interacting): the whole farm in one go.
+    //  (1) per-target masks of candidate sources: a lane holds one SOURCE (position, 5 bk, lateral reach) in registers and
+    //      walks the targets — the ballot of the conservative test is 64 bits of the target's mask; no LDS atomics, and
+    //      no LDS traffic beyond the targets' positions (per-pair reads of packed sources ran into the LDS bandwidth of a CU
+    //      shared by 16 waves);
+    //  (2) thread t: popcount -> exclusive prefix over the targets (wave scans + 4 wave totals) -> t writes its candidates
+    //      into the list at its offset: the list is in ascending (target, source) order by construction;
+    //  (3) one thread per candidate: brackets, gathers, exact evaluation -> def[c], tiav[c] (staged per candidate, lf_cap
+    //      at a time: the dense per-chunk staging of res_pair_phase needed 3 target chunks on cfg3, each with its own
+    //      gather round trip, five barriers and same-address LDS atomics);
+    //  (4) thread t sums its slice of the list in order — the same additions in the same order as the chunked phase.
+    // (Tried and dropped: half of the workgroups running the phase AFTER the advection pass, on post-step brackets, so that
+    // the streaming pass of one workgroup overlaps the ALU / LDS work of another on the same CU — 3.85 M env-steps/s in
+    // either order, 3.77 - 3.93 M mixed by workgroup parity / by blocks of 256: within run-to-run spread.)
+    auto lf_pair_phase = [&]() __attribute__((always_inline)) {
+        const float move_max = fabsf(p.hill) * ws_f * p.dt;
+        const float* xf_ = reinterpret_cast<const float*>(jnl + 2 * N + 4);
+        const float* yf_ = xf_ + N;
+        unsigned* tm = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(pair) + WG_LF_OFF_TM(N));
+        int* base = reinterpret_cast<int*>(reinterpret_cast<char*>(pair) + WG_LF_OFF_BASE(N));
+        int* wtot = jnl;                          // (jnl[0..3]: unused by the compact variants)
+        const int W = (N + 31) >> 5;
+        for (int t = tid; t < N; t += NT) { T[t].u = ws_f; T[t].v = 0.f; T[t].w = 0.f; }
+        {   // (1) lane = source (its packed bound in registers), loop over targets: the ballot of the test IS two words of
+            // the target's mask.  64 sources per wave; the waves that share a source block take every other target.
+            const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+            const int nsb = (N + 63) >> 6, per = (NT / 64) / nsb;      // source blocks (1 or 2), waves per block
+            const int sb = wv % nsb, s2 = 64 * sb + lane;
+            const bool sv = s2 < N;
+            const TurbLds& src = T[sv ? s2 : 0];
+            // PRE: src.bd is the excursion bound BEFORE this step's advection (see res_pair_phase)
+            const float bd = src.bd + (src.mvl != 0u ? move_max : 0.f);
+            const float sx = xf_[sv ? s2 : 0], sy = yf_[sv ? s2 : 0], sz = 5.0f * src.bk;
+            const float sw = p.R_rot + 5.0f * src.be * p.D + bd + 1.0e-3f * p.D;
+            // the targets' positions in registers too (lane l: targets l and 64 + l), read back with v_readlane — the loop
+            // touches no LDS; lane k keeps the ballot of the wave's k-th target and stores it afterwards
+            const int ta = __float_as_int(xf_[min(lane, N - 1)]), tb = __float_as_int(yf_[min(lane, N - 1)]);
+            const int tc_ = __float_as_int(xf_[min(64 + lane, N - 1)]), td = __float_as_int(yf_[min(64 + lane, N - 1)]);
+            const int t_first = wv / nsb;
+            unsigned long long mybal = 0ull;
+            int k = 0;
+            // |dy| <= R + 5 sigma_max + bd + margin, sigma_max = bk dx + be D  (float positions: the exact sign of dx is decided
+            // in double by the evaluation).  Branch-free: `&` on the predicates, one loop per half of the target registers.
+            auto test = [&](const int t, const int xi_, const int yi_) __attribute__((always_inline)) {
+                const float xt = __int_as_float(xi_), yt = __int_as_float(yi_);
+                const float dxf = xt - sx;
+                const bool ok = sv & (dxf >= 0.f) & (fabsf(yt - sy) - sz * dxf <= sw) & (s2 != t);
+                const unsigned long long bal = (WG_ABLATE & 2) ? 0ull : __ballot(ok);      // (profiling builds: no candidates)
+                mybal = lane == k ? bal : mybal;
+            };
+            int t = t_first;
+            const int n_lo = min(N, 64);
+            for (; t < n_lo; t += per, ++k) test(t, __builtin_amdgcn_readlane(ta, t), __builtin_amdgcn_readlane(tb, t));
+            for (; t < N; t += per, ++k) test(t, __builtin_amdgcn_readlane(tc_, t - 64), __builtin_amdgcn_readlane(td, t - 64));
+            const int tk = t_first + lane * per;
+            if (tk < N) { tm[tk * 4 + 2 * sb] = (unsigned)mybal; tm[tk * 4 + 2 * sb + 1] = (unsigned)(mybal >> 32); }
+        }
+        lds_barrier<NT>();
+        WG_STAMP(14);
+        {   // (2)
+            int cnt = 0;
+            if (tid < N) for (int w = 0; w < W; ++w) cnt += __popc(tm[tid * 4 + w]);
+            int inc = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if ((tid & 63) >= o) inc += v; }
+            if ((tid & 63) == 63) wtot[tid >> 6] = inc;
+            lds_barrier<NT>();
+            WG_STAMP(15);
+            int off = 0;
+            for (int w = 0; w < (tid >> 6); ++w) off += wtot[w];
+            if (tid < N) {
+                int o = off + inc - cnt;
+                base[tid] = o;
+                if (tid == N - 1) base[N] = off + inc;
+                for (int w = 0; w < W; ++w) {
+                    unsigned m = tm[tid * 4 + w];
+                    while (m) { cl[o++] = (unsigned short)((tid << 7) | (32 * w + __builtin_ctz(m))); m &= m - 1; }
+                }
+            }
+        }
+        lds_barrier<NT>();
+        const int nc = base[N];
+        WG_STAMP(5);
+        float dsum = 0.f, tia_max = 0.f;              // thread t's running sums over the rounds
+        for (int c0 = 0; c0 < nc; c0 += p.lf_cap) {
+            const int c1 = min(nc, c0 + p.lf_cap);
+            // (3) software-pipelined: a thread's NEXT candidate is decoded and its gathers requested before the current one
+            // is evaluated (cfg3: ~520 candidates on 256 threads — two or three trips, whose gather round trips would
+            // otherwise add up)
+            struct Cand { int t, s2, jp0; float wgt; double dx; uint4 q0, q1; float y0, y1; bool ok; };
+            auto lf_issue = [&](Cand& k, const int c) __attribute__((always_inline)) {
+                k.ok = false;
+                if (c >= c1) return;
+                const int slot = c - c0;
+                def[slot] = 0.f; tiav[slot] = 0.f;
+                const unsigned ent = cl[c];
+                k.t = (int)(ent >> 7); k.s2 = (int)(ent & 127u);
+                const TurbLds& src = T[k.s2];
+                k.dx = T[k.t].xr - src.xr;
+                if (!(k.dx > 0.0)) return;                    // (the candidate test ran on float positions)
+                const double xi = (k.dx - s_new) * p.inv_dpart;
+                const double jf = floor(xi);
+                k.wgt = (float)(xi - jf);
+                int j = (int)jf;
+                if (j < 0) { j = 0; k.wgt = 0.f; }
+                if (j + 1 > new_valid - 1) return;            // the chain has not reached the target yet
+                const int Rs = src.rlen;
+                // ages j, j + 1 after the step are ages jp, jp + 1 = j - n_emit, ... before it (negative: released in this
+                // step — the turbine's record, at the turbine)
+                k.jp0 = j - n_emit;
+                int r0 = src.head - k.jp0; if (r0 < 0) r0 += Rs;
+                int r1 = src.head - k.jp0 - 1; if (r1 < 0) r1 += Rs;
+                if (k.jp0 < 0) r0 = 0;          // (released in this step: nothing to fetch — any slot of the ring will do)
+                if (k.jp0 + 1 < 0) r1 = 0;
+                const int i0 = src.roff + r0, i1 = src.roff + r1;
+                k.q0 = pl.r4[i0]; k.q1 = pl.r4[i1];
+                k.y0 = pl.py[i0]; k.y1 = pl.py[i1];
+                k.ok = true;
+            };
+            Cand nxt;
+            lf_issue(nxt, c0 + tid);
+            for (int c = c0 + tid; c < c1; c += NT) {
+                const Cand k = nxt;
+                lf_issue(nxt, c + NT);
+                if (!k.ok) continue;
+                const TurbLds& src = T[k.s2];
+                const int jp0 = k.jp0, jp1 = jp0 + 1;
+                float py0 = k.y0, py1 = k.y1;
+                unsigned a0 = k.q0.x, b0_ = k.q0.y, a1 = k.q1.x, b1_ = k.q1.y;
+                float u0 = __uint_as_float(k.q0.z), u1 = __uint_as_float(k.q1.z);
+                if (jp0 < 0) { py0 = (float)src.yr; u0 = src.rue; a0 = pack_a(src.rct, src.rk); b0_ = pack_b(src.reps, src.rhv); }
+                if (jp1 < 0) { py1 = (float)src.yr; u1 = src.rue; a1 = pack_a(src.rct, src.rk); b1_ = pack_b(src.reps, src.rhv); }
+                if (jp0 >= 0 && jp0 < n_valid) py0 = m0_advect(py0, a0, b0_, jp0, s_off_f, p.dpart_f, p.inv_D, p.dt);
+                if (jp1 >= 0 && jp1 < n_valid) py1 = m0_advect(py1, a1, b1_, jp1, s_off_f, p.dpart_f, p.inv_D, p.dt);
+                if (c == 0) WG_STAMP(12);
+                eval_pair(c - c0, 0, k.s2, k.t, k.dx, k.wgt, py0, py1, 0.f, 0.f, a0, a1, b0_, b1_, u0, u1);
+                if (c == 0) WG_STAMP(13);
+            }
+            lds_barrier<NT>();
+            if (c0 == 0) WG_STAMP(11);
+            if (tid < N) {                                    // (4)
+                const int b0 = max(base[tid], c0), b1 = min(base[tid + 1], c1);
+                for (int c = b0; c < b1; ++c) {
+                    dsum += def[c - c0];
+                    tia_max = fmaxf(tia_max, tiav[c - c0]);
+                }
+            }
+            if (c1 < nc) lds_barrier<NT>();                   // (the next round lands in the same words)
+        }
+        if (tid < N) {
+            T[tid].u -= dsum;
+            T[tid].ti = __builtin_amdgcn_sqrtf(ti_f * ti_f + tia_max * tia_max);
+        }
+        lds_barrier<NT>();
+    };
     if (PRE && !GL) {
         // (a further flow step of the same launch — background development, reset — gathers what the previous step's
         // advection pass stored)
         if (!first_step) full_barrier<NT>();
-        res_pair_phase(std::true_type{});
+        if constexpr (LF) lf_pair_phase(); else res_pair_phase(std::true_type{});
         WG_STAMP(9);
     }
 
@@ -937,6 +1109,52 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             if (full) {
                 for (int i = kl; i < nqd; i += lpt) ql[base + i] = (unsigned short)(tag | (unsigned)i);
             }
+        } else if (LF) {
+            // large farms: list offsets from a prefix sum over the turbines (wave scans + the wave totals in jnl[0..3], which the
+            // compact variants do not use otherwise) — up to 40 lanes of a wave hitting ONE LDS counter with atomicAdd are
+            // serialised one by one
+            int cnt = 0, nqd = 0;
+            bool full = false;
+            unsigned tag = 0u;
+            if (t < ((WG_ABLATE & 1) ? 0 : N)) {
+                const TurbLds& tq = T[t];
+                const int R = tq.rlen;
+                nqd = R >> 2;
+                const bool moving = tq.mvl != 0u && (int)(sr.n_emitted - tq.mvl) < R;
+                tag = (unsigned)t << qsh;
+                full = moving || n_emit >= 4 || n_emit >= R;
+                if (full) cnt = nqd;
+                else {
+                    int prev = -1;
+                    for (int e = 0; e < n_emit; ++e) {
+                        int r = tq.head + 1 + e; if (r >= R) r -= R;
+                        if ((r >> 2) != prev) ++cnt;
+                        prev = r >> 2;
+                    }
+                }
+            }
+            const int mine = kl == 0 ? cnt : 0;
+            int inc = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if ((tid & 63) >= o) inc += v; }
+            if ((tid & 63) == 63) jnl[tid >> 6] = inc;
+            lds_barrier<NT>();
+            int woff = 0;
+            for (int w = 0; w < (tid >> 6); ++w) woff += jnl[w];
+            if (tid == NT - 1) *nq = woff + inc;
+            const int base = woff + __shfl(inc - mine, (tid & 63) & ~(lpt - 1), 64);
+            if (full) {
+                for (int i = kl; i < nqd; i += lpt) ql[base + i] = (unsigned short)(tag | (unsigned)i);
+            } else if (kl == 0 && cnt > 0) {
+                const TurbLds& tq = T[t];
+                const int R = tq.rlen;
+                int prev = -1, o = base;
+                for (int e = 0; e < n_emit; ++e) {
+                    int r = tq.head + 1 + e; if (r >= R) r -= R;
+                    if ((r >> 2) != prev) ql[o++] = (unsigned short)(tag | (unsigned)(r >> 2));
+                    prev = r >> 2;
+                }
+            }
         } else {
         if (tid == 0) *nq = 0;
         lds_barrier<NT>();
@@ -966,7 +1184,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         // pipelined advection (GLP): the loads of a lane's first listed quad are requested before the deficit evaluation
         // (its ~4 k cycles of ALU work hide their round trip), and inside the pass every lane requests its next quad
         // before it computes the current one.  Costs 12 + 12 registers: this variant is built at 4 waves per SIMD.
-        constexpr bool GLP = GL && (WG_ADV_PIPE != 0);
+        constexpr bool LFP = !GL && NT == 256 && (WG_ADV_PIPE_LF != 0);     // (large farms: see WG_ADV_PIPE_LF)
+        constexpr bool GLP = (GL && (WG_ADV_PIPE != 0)) || LFP;
         const int nlist_pre = GL ? gl_nlist : 0;
         // (two quads ahead when WG_ADV_PIPE = 2: `n_*` is the lane's next quad, `m_*` the one after it)
         struct QuadReq { float4 py; uint4 ra, rb; int t, kq, q; };
@@ -982,7 +1201,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             r.ra = reinterpret_cast<const uint4*>(pl.ra)[GL ? 2 * r.q : r.q];
             r.rb = GL ? reinterpret_cast<const uint4*>(pl.ra)[2 * r.q + 1] : reinterpret_cast<const uint4*>(pl.rb)[r.q];
         };
-        constexpr bool GLP2 = GLP && (WG_ADV_PIPE >= 2);
+        constexpr bool GLP2 = (GL && (WG_ADV_PIPE >= 2)) || (LFP && (WG_ADV_PIPE_LF >= 2));
         if (GL) {
             // deficit phase, part 2: the gathers issued before the records have landed (or do so now)
             for (int t = tid; t < N; t += NT) { T[t].u = ws_f; T[t].v = 0.f; T[t].w = 0.f; }
@@ -1044,6 +1263,10 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             WG_STAMP(9);
         }
         const int nlist = GL ? gl_nlist : *nq;
+        if (LFP) {
+            adv_request_to(nq_, tid, tid < nlist);
+            if (GLP2) adv_request_to(mq_, tid + NT, tid + NT < nlist);
+        }
         for (int c = tid; c < nlist; c += NT) {
             int t, kq, q;
             float4 py; uint4 ra, rb;
@@ -1701,7 +1924,7 @@ __device__ __attribute__((noinline)) void wg_first_obs(const WgParams* gp, const
 }
 
 template <int NT, int TURB, bool REPLAY, bool NOISE, bool RES, int SGM = 0>
-__global__ void __launch_bounds__(NT, TURB != WG_TURB_NONE ? WG_BOX_WAVES : (RES ? (NT == WG_WAVE ? WG_FLOW_WAVES_GL : WG_FLOW_WAVES_CG) : WG_FLOW_WAVES))
+__global__ void __launch_bounds__(NT, TURB != WG_TURB_NONE ? WG_BOX_WAVES : (RES ? (NT == WG_WAVE ? WG_FLOW_WAVES_GL : (NT == 256 ? WG_FLOW_WAVES_LF : WG_FLOW_WAVES_CG)) : WG_FLOW_WAVES))
 k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict__ actions,
        const uint8_t* __restrict__ mask, const int chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2116,7 +2339,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
 #ifdef WG_TIMELINE
         if (d.dbg && n_flow == 1) {
             wg_stamps[8] = clock64();
-            for (int k = 0; k < 12; ++k) d.dbg[(size_t)blockIdx.x * 12 + k] = wg_stamps[k];
+            for (int k = 0; k < 16; ++k) d.dbg[(size_t)blockIdx.x * 16 + k] = wg_stamps[k];
         }
 #endif
     }
