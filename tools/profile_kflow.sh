@@ -26,7 +26,7 @@ rows = list(cur.execute("select name, start, end from kernels order by start"))
 fl = [(e-s)/1e3 for n,s,e in rows if 'k_flow' in n]
 gl = [(e-s)/1e3 for n,s,e in rows if 'k_glue' in n]
 print("# k_flow STEP-mode launches (last 100): avg_us %.2f min %.2f max %.2f ; k_glue avg_us %.2f" % (sum(fl[-100:])/100, min(fl[-100:]), max(fl[-100:]), sum(gl[-100:])/100))
-print("# k_flow RESET-mode launches (first ones) us:", [round(x) for x in fl[:len(fl)-110]])
+print("# k_flow launches before the last 110 (reset / development, then the pre-roll steps; first 24 of %d) us:" % max(len(fl) - 110, 0), [round(x) for x in fl[:len(fl)-110][:24]])
 print("# PMC counters, k_flow STEP-mode launches, average per launch (last 100 dispatches)")
 for n in sorted(glob.glob(out + '/pmc*/p_results.db')):
     db = sqlite3.connect(n); cur = db.cursor()

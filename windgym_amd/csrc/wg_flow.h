@@ -53,6 +53,9 @@
 #ifndef WG_S_UNROLL_ALL
 #define WG_S_UNROLL_ALL 0   // 1: the rotor-point loop of the Gaussian pair evaluation unrolled by 4 in every variant (A/B builds)
 #endif
+#ifndef WG_DUO_ADV_PIPE
+#define WG_DUO_ADV_PIPE 1   // k_flow_duo: software-pipelined advection pass (0 = plain loop, for A/B builds)
+#endif
 #ifndef WG_PAIR_FIRST
 #define WG_PAIR_FIRST 1   // steady compact variant: deficit phase BEFORE the advection pass (0 = round-2 order, for A/B builds)
 #endif
