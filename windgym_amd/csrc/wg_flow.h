@@ -56,6 +56,9 @@
 #ifndef WG_DUO_ADV_PIPE
 #define WG_DUO_ADV_PIPE 1   // k_flow_duo: software-pipelined advection pass (0 = plain loop, for A/B builds)
 #endif
+#ifndef WG_GL_POSTPASS_WAIT
+#define WG_GL_POSTPASS_WAIT 1   // GL variant: the compiler-visible vmcnt(0) right after the pipelined advection pass (0: A/B builds)
+#endif
 #ifndef WG_PAIR_FIRST
 #define WG_PAIR_FIRST 1   // steady compact variant: deficit phase BEFORE the advection pass (0 = round-2 order, for A/B builds)
 #endif

@@ -1633,7 +1633,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     // (GLP: a wait the compiler's bookkeeping sees, right after the pipelined pass — the last trip's conditional request
     // otherwise stays "possibly pending" in its view around the flow-step loop and it orders the next step's register
     // writes behind it with vmcnt(0) waits that drain the LDS-DMA gathers)
-    if (RES && TURB == WG_TURB_NONE && NT == WG_WAVE && (WG_GLDS != 0) && (WG_PAIR_FIRST != 0) && (WG_ADV_PIPE != 0)) wg_wait_vmem();
+    if (RES && TURB == WG_TURB_NONE && NT == WG_WAVE && (WG_GLDS != 0) && (WG_PAIR_FIRST != 0) && (WG_ADV_PIPE != 0) && (WG_GL_POSTPASS_WAIT != 0)) wg_wait_vmem();
     sr.head = new_head; sr.n_valid = new_valid; sr.s_off = s_new; sr.time += p.dt_d; sr.istep += 1u;
     sr.n_emitted += (unsigned)n_emit;
     WG_STAMP(3);
