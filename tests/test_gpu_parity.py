@@ -350,13 +350,15 @@ def test_step_after_truncation_is_an_error(hip):
         env.check()
 
 
-@pytest.mark.parametrize("variant", ["uniform_samplemajor", "compact_pairmajor"])
+@pytest.mark.parametrize("variant", ["uniform_samplemajor", "compact_pairmajor", "compact_pairmajor_small_staging"])
 def test_horns_rev_80_turbines_matches_oracle(hip, oracle_lib, variant):
     """BASELINE.json configs[2] at test size: Horns Rev 1 layout (N = 80 > one wave, P = 416, target chunking
     in the deficit phases), B = 3, autoreset on.  "compact_pairmajor" = what bench.py --workload cfg3 runs (compact
     rings, pair-major phases in chunks of targets, 16-byte record gathers, 256 threads: the default for large farms with
     steady inflow); "uniform_samplemajor" = the round-1 large-farm variant (WG_FLOW_RES=0: uniform rings with predicate
-    pruning, (target, sample)-major phases), still the one turbulent large farms run."""
+    pruning, (target, sample)-major phases), still the one turbulent large farms run.  "..._small_staging": the same
+    kernel with room for 96 candidate results at a time (WG_LF_CAP), so that the ~500 candidates of a flow step take six
+    rounds through the staging region — same sums in the same order."""
     import os
     from windgym_amd.config import EnvConfig
     from windgym_amd.presets import horns_rev1_layout, horns_rev_config
@@ -365,12 +367,15 @@ def test_horns_rev_80_turbines_matches_oracle(hip, oracle_lib, variant):
     cfg = EnvConfig(turbine=V80(), yaml_dict=horns_rev_config(), turbtype="None", n_envs=3, autoreset=True,
                     n_passthrough=0.2, x_pos=x, y_pos=y)
     assert cfg.n_turb == 80
-    os.environ["WG_FLOW_RES"] = "1" if variant == "compact_pairmajor" else "0"
+    os.environ["WG_FLOW_RES"] = "1" if variant.startswith("compact_pairmajor") else "0"
+    if variant.endswith("small_staging"):
+        os.environ["WG_LF_CAP"] = "96"
     try:
         env = hip.HipBatch(cfg)
     finally:
         os.environ.pop("WG_FLOW_RES", None)
-    assert env.flow_variant()[:2] == (256, variant == "compact_pairmajor")
+        os.environ.pop("WG_LF_CAP", None)
+    assert env.flow_variant()[:2] == (256, variant.startswith("compact_pairmajor"))
     orc = oracle_lib.Oracle(cfg)
     seeds = 500 + np.arange(3)
     np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=OBS_ATOL)

@@ -477,6 +477,8 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
                     const size_t fixed = WG_LF_OFF_DEF(p.N);
                     off = std::max(off, (fixed + 8 * 512 + 15) & ~(size_t)15);
                     f.lf_cap = (int)((off - fixed) / 8);
+                    // (tests: a small staging capacity, so that the candidates of one flow step take several rounds)
+                    if (const char* ev = getenv("WG_LF_CAP")) f.lf_cap = std::max(64, std::min(f.lf_cap, atoi(ev)));
                 }
                 // single-wave steady variant: the deficit phase's gathers are LDS-DMA requests issued before the record /
                 // quad-list phases, so the candidate list and the quad list are alive together (no aliasing) and the
