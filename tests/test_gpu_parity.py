@@ -1024,3 +1024,26 @@ def test_lean_glue_equals_the_ring_staging_glue(hip, monkeypatch, case):
     assert n_tr >= B
     lean.check(); ring.check()
     lean.close(); ring.close()
+
+
+@pytest.mark.parametrize("nx,ny", [(16, 8), (13, 5), (11, 6)])
+def test_large_farm_variant_at_its_size_limits(hip, oracle_lib, nx, ny):
+    """The 256-thread compact steady variant (what cfg3 runs) at the edges of its mask / ballot layout: 128 turbines (the
+    build's maximum: two full 64-source blocks, four mask words), 65 and 66 (a second source block with one / two sources),
+    wind directions that wake the farm along rows and diagonals, same-step autoreset."""
+    import torch
+    from windgym_amd import presets
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.turbine import V80
+    d = presets.env1_config()
+    d["farm"].update(nx=nx, ny=ny, xDist=4, yDist=3)
+    d["wind"] = dict(ws_min=9, ws_max=11, wd_min=250, wd_max=290, TI_min=0.05, TI_max=0.1)
+    cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_envs=2, autoreset=True, n_passthrough=0.3, n_rotor_pts=8)
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    assert env.flow_variant() == (256, True, False) and cfg.n_turb == nx * ny
+    np.testing.assert_allclose(env.reset(seeds=[3, 4]).cpu().numpy(), orc.reset(seeds=[3, 4]), rtol=0, atol=OBS_ATOL)
+    rng = np.random.default_rng(0)
+    for step in range(60):
+        a = rng.uniform(-1, 1, size=(2, cfg.n_turb)).astype(np.float32)
+        _compare_step(env, orc, a, step, check_flow=(step % 20 == 0))
+    env.check()
