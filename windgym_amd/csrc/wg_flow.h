@@ -59,6 +59,9 @@
 #ifndef WG_GL_POSTPASS_WAIT
 #define WG_GL_POSTPASS_WAIT 1   // GL variant: the compiler-visible vmcnt(0) right after the pipelined advection pass (0: A/B builds)
 #endif
+#ifndef WG_BOX_XCD_PAIRS
+#define WG_BOX_XCD_PAIRS 1   // frozen-box variants: the two farms of an env on the same XCD (0 = adjacent block indices, for A/B builds)
+#endif
 #ifndef WG_PAIR_FIRST
 #define WG_PAIR_FIRST 1   // steady compact variant: deficit phase BEFORE the advection pass (0 = round-2 order, for A/B builds)
 #endif

@@ -1939,12 +1939,22 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     // (farm-major: -4 % on cfg5).
     int farm, ec;
     if (TURB == WG_TURB_BOX) {
-        ec = F == 2 ? (bid >> 1) : bid / F;
-        farm = F == 2 ? (bid & 1) : bid - ec * F;
+        if (F == 2 && (WG_BOX_XCD_PAIRS != 0) && (gridDim.x & 15u) == 0u) {
+            // (workgroup i runs on XCD i % 8, each XCD has its own L2: the two farms of an env are 8 apart in the block order,
+            // so that they land on the SAME XCD one dispatch round apart — adjacent indices share nothing but the MALL)
+            farm = (bid >> 3) & 1;
+            ec = ((bid >> 4) << 3) | (bid & 7);
+        } else {
+            ec = F == 2 ? (bid >> 1) : bid / F;
+            farm = F == 2 ? (bid & 1) : bid - ec * F;
+        }
     } else {
         const int nec = p.B * 2;
         farm = bid < nec ? 0 : bid / nec;
         ec = bid - farm * nec;
+        // (tried: an env's flow workgroups on the XCD that runs its glue wave, so that one kernel would find in its L2 what the
+        // previous one wrote last — 60.2 vs 59.8 M env-steps/s on cfg2, nothing on cfg3: the L2s are written back and invalidated
+        // at kernel boundaries; not kept)
     }
     const int e = ec >> 1;
     // Which of the env's two contexts this workgroup serves is a pseudo-random function of the env index.  The
