@@ -633,7 +633,10 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     // workgroup became the flow kernel's tail: -5 % / -1.3 %).  Other handles keep the glue's own second build.
     // (sums mode: wg_first_obs prepares the episode's window sums as well, in WgPtrs::wsum)
     // (k_flow_duo prepares them for sums-mode handles only: the lean glue's swap)
-    if (!((h->fp.gl && !h->fp.duo) || (h->fp.duo && p.sums_mode && p.turb_mode == WG_TURB_NONE))) { d.next_obs = nullptr; d.next_obs_ok = nullptr; }
+    // (round 4, sums mode: the glue's own rebuild sums every window of the new episode — 14-15 us of k_glue_lean on cfg3 /
+    // cfg5 against 10 with prepared sums — so every compact variant prepares them now; WG_FIRST_OBS_GL_ONLY=1 for A/B runs)
+    const bool prep_all = p.sums_mode && !getenv("WG_FIRST_OBS_GL_ONLY");
+    if (!((h->fp.gl && !h->fp.duo) || (h->fp.res && !h->fp.duo && prep_all) || (h->fp.duo && p.sums_mode && p.turb_mode == WG_TURB_NONE))) { d.next_obs = nullptr; d.next_obs_ok = nullptr; }
     wg_launch_create(&p, &d, nullptr);
     if (sync_dev_params(h)) { wg_destroy(h); return WG_ERR_HIP; }
     {

@@ -2354,11 +2354,12 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
 #endif
     }
     // a background episode's development ends with this launch: its first observation (wg_first_obs)
-    // (single-wave steady variant only: wg_create leaves next_obs null for every other handle)
-    if (RES && TURB == WG_TURB_NONE && NT == WG_WAVE) {
+    // (compact variants: wg_create leaves next_obs null for every other handle; the builder is single-wave code — wave 0 of a
+    // larger workgroup runs it)
+    if (RES) {
         if (mode == WG_MODE_STEP && !live_step && farm == 0 && dev_rem == 0 && fill_rem == 0) {
-            full_barrier<NT>();                  // the ring pushes have left the wave
-            wg_first_obs(ke->d.gp, ke->d.gd, ctx_id, n_pushed, tid);
+            full_barrier<NT>();                  // the ring pushes have left the workgroup
+            if (NT == WG_WAVE || tid < WG_WAVE) wg_first_obs(ke->d.gp, ke->d.gd, ctx_id, n_pushed, tid);
         }
     }
 }
