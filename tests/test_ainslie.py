@@ -220,3 +220,26 @@ def test_flow_field_view_follows_the_deficit_option(deficit, oracle_lib):
         got = env.windspeed(b, xs, ys).cpu().numpy()
         np.testing.assert_allclose(got, orc.windspeed(b, xs, ys), rtol=2e-4, atol=2e-3)
         assert (10.0 - got[0]).max() > 2.0
+
+
+@pytest.mark.gpu
+def test_gym_env_accepts_the_option(tmp_path):
+    """`WindFarmEnv(..., deficit="ainslie")`: the Gymnasium facade hands the option to the config, the binding installs the
+    table at the first reset; a waked turbine produces less than with the Gaussian profile at low TI."""
+    import yaml
+    import windgym_amd as wg
+    d = presets.env1_config()
+    d["farm"].update(nx=2, ny=1, xDist=6, yDist=4)
+    d["wind"] = dict(ws_min=8.0, ws_max=8.0, wd_min=270, wd_max=270, TI_min=0.03, TI_max=0.03)
+    d["yaw_init"] = "Zeros"
+    p = tmp_path / "farm.yaml"
+    p.write_text(yaml.safe_dump(d))
+    powers = {}
+    for dm in ("gaussian", "ainslie"):
+        env = wg.WindFarmEnv(turbine=wg.V80(), n_passthrough=2, yaml_path=str(p), turbtype="None", seed=3, deficit=dm)
+        env.reset(seed=3)
+        for _ in range(30):
+            obs, rew, term, trunc, info = env.step(np.zeros(env.action_space.shape, dtype=np.float32))
+        powers[dm] = np.asarray(info["Power pr turbine agent"] if "Power pr turbine agent" in info else info["Power agent"], dtype=np.float64)
+        env.close()
+    assert np.sum(powers["ainslie"]) < np.sum(powers["gaussian"]) * 0.99

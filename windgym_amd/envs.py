@@ -447,7 +447,13 @@ class WindFarmEnv(_EnvBase):
                  TurbBox="Default", turbtype="MannLoad", yaml_path=None, Baseline_comp=False, yaw_init=None,
                  render_mode=None, seed=None, dt_sim=1, dt_env=1, yaw_step=1, fill_window=True, sample_site=None,
                  HTC_path=None, reset_init=True, *, device=None, yaml_dict=None, n_particles=None,
-                 n_rotor_pts=16, x_pos=None, y_pos=None, turbulence_box=None):
+                 n_rotor_pts=16, x_pos=None, y_pos=None, turbulence_box=None, **model_options):
+        # model_options: switches of the flow model that have no counterpart in the reference's constructor — EnvConfig's
+        # ``deficit`` ("gaussian" | "super_gaussian" | "ainslie"), ``model_constants``, ``added_turbulence``, ``wake_ti_fold``,
+        # ``mann_pool``
+        unknown = set(model_options) - {"deficit", "model_constants", "added_turbulence", "wake_ti_fold", "mann_pool"}
+        if unknown:
+            raise TypeError(f"unexpected keyword argument(s): {sorted(unknown)}")
         if HTC_path is not None:
             raise NotImplementedError("HAWC2 turbines (HTC_path) are outside the MI355X step() path")
         self.sample_site = sample_site
@@ -463,7 +469,7 @@ class WindFarmEnv(_EnvBase):
                         fill_window=fill_window, yaml_dict=yaml_dict, n_particles=n_particles,
                         n_rotor_pts=n_rotor_pts, x_pos=x_pos, y_pos=y_pos, n_envs=1, autoreset=False,
                         advect_full_chains=True,     # single envs render: keep the far wake exact (no chain pruning)
-                        never_truncate=self._never_truncate, extra_timestep_inc=self._extra_timestep_inc)
+                        never_truncate=self._never_truncate, extra_timestep_inc=self._extra_timestep_inc, **model_options)
         self.yaw_initial = [0]
         self._overrides = {}
         self._turbulence_box = turbulence_box
