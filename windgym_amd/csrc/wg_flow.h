@@ -31,7 +31,8 @@
                            // quad before the current one is computed): cfg2 k_flow 61.5 -> 58.8 us same box (0 = plain loop, for A/B builds)
 #endif
 #ifndef WG_ADV_PIPE_LF
-#define WG_ADV_PIPE_LF 2   // 256-thread compact steady variant (large farms): quads requested ahead in its advection pass.  vmcnt counts
+#define WG_ADV_PIPE_LF 1   // 256-thread compact steady variant (large farms): quads requested ahead in its advection pass
+                           // (cfg3 same-box: 0 / 1 / 2 quads ahead = 3.80 / 4.04 / 3.93 M env-steps/s).  vmcnt counts
                            // loads and stores in ONE in-order queue: a plain load-compute-store loop waits for the previous trip's
                            // stores whenever it waits for its loads — two round trips per trip (cfg3: 20 trips of ~2 us).  Requested
                            // before the stores, the next quads' loads no longer queue behind them.
