@@ -38,7 +38,8 @@
                            // before the stores, the next quads' loads no longer queue behind them.
 #endif
 #ifndef WG_FLOW_WAVES_LF
-#define WG_FLOW_WAVES_LF 4  // ... built at 4 waves per SIMD (128 VGPRs): its LDS carve allows 4 workgroups per CU anyway (cfg3: 34 KB each)
+#define WG_FLOW_WAVES_LF 3  // ... built at 3 waves per SIMD (168 VGPRs, nothing spilled): bandwidth-bound, so three resident workgroups per
+                            // CU do (cfg3 same-box, 4 / 3 waves: 3.88 / 4.00 M env-steps/s; its LDS carve allows 4: 34 KB each)
 #endif
 #ifndef WG_LF_PAIR
 #define WG_LF_PAIR 1      // 256-thread compact steady variant: pair phase over the whole farm at once — per-target source masks built
