@@ -27,6 +27,8 @@ def hip():
 # every k_flow variant the host can select (wg_flow.hip): one workgroup of 64 / 128 / 256 threads per farm slot, and
 # "duo" = k_flow_duo, both farms of a context in one 64-lane workgroup (two-farm configs; falls back to 64 otherwise)
 BLOCKS = [64, 128, 256, "duo"]
+# "env" = k_flow_env, one wave per env with lane = farm slot x turbine (steady inflow, small farms: what cfg2 / cfg4 run)
+STEADY_BLOCKS = BLOCKS + ["env"]
 
 
 def _make_env(hip, cfg, block=None):
@@ -38,17 +40,21 @@ def _make_env(hip, cfg, block=None):
         # k_flow_duo does not carry the wake-added turbulence field (the host falls back to k_flow when it is on): the
         # duo kernel's turbulent instantiations are tested without it; the caller builds its oracle from the same cfg
         cfg.added_turbulence = "none"
-    os.environ["WG_FLOW_BLOCK"] = "64" if block == "duo" else str(block)
+    os.environ["WG_FLOW_BLOCK"] = "64" if block in ("duo", "env") else str(block)
     os.environ["WG_FLOW_DUO"] = "1" if block == "duo" else "0"
+    os.environ["WG_FLOW_ENV"] = "1" if block == "env" else "0"
     try:
         env = hip.HipBatch(cfg)
     finally:
         del os.environ["WG_FLOW_BLOCK"]
         del os.environ["WG_FLOW_DUO"]
+        del os.environ["WG_FLOW_ENV"]
     # the variant asked for is the one that runs (a silent fallback would test the wrong kernel)
     threads, compact, duo = env.flow_variant()
     two_farms = bool(cfg.baseline_comp)
-    if block == "duo":
+    if block == "env":
+        assert threads == 64 and compact and duo == 2
+    elif block == "duo":
         assert threads == 64 and compact and duo == two_farms
     else:
         assert threads == block and not duo
@@ -138,7 +144,7 @@ def _compare_step(env, orc, a, step, check_flow=True, power_rtol=2e-4):
                                    rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("block", BLOCKS)
+@pytest.mark.parametrize("block", STEADY_BLOCKS)
 def test_hip_physics_matches_oracle_step_for_step(hip, oracle_lib, block):
     """cfg2-shaped farm (4x4, yaw action, two farms), B=6, 300 steps on identical seeds and actions — in each of the
     three workgroup-size instantiations of k_flow (128 is what cfg2 / cfg4 run, 256 what cfg3 runs)."""
@@ -450,7 +456,7 @@ def test_fused_per_agent_observations_equal_the_explicit_packing(hip, oracle_lib
     env.check()
 
 
-@pytest.mark.parametrize("block", BLOCKS)
+@pytest.mark.parametrize("block", STEADY_BLOCKS)
 def test_noise_normal_matches_oracle_stream(hip, oracle_lib, block):
     """noise: "Normal" (2turb.yaml / 4turb.yaml): the Philox/Box-Muller stream is the same on both sides; the
     kernel evaluates log/cos in fast fp32 -> tolerance 2e-3 deg on the 2-deg wd noise (1e-4 of the wd scale)."""
@@ -918,7 +924,7 @@ def test_prepared_first_observation_survives_buffer_switches(hip, oracle_lib):
     B = 6
     cfg = _physics_cfg(B, autoreset=True, n_passthrough=0.25)
     env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
-    assert env.flow_variant()[0] == 64 and not env.flow_variant()[2]
+    assert env.flow_variant() == (64, True, 2)              # k_flow_env prepares the next episode's first observation too
     seeds = 900 + np.arange(B)
     np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=OBS_ATOL)
     rng = np.random.default_rng(5)
@@ -949,7 +955,7 @@ def test_checkpoint_resume_is_bit_identical_across_rollovers(hip):
     B = 8
     cfg = _physics_cfg(B, autoreset=True, n_passthrough=0.25)
     a_env, b_env = hip.HipBatch(cfg), hip.HipBatch(cfg)
-    assert a_env.flow_variant()[0] == 64 and not a_env.flow_variant()[2]
+    assert a_env.flow_variant() == (64, True, 2)
     seeds = 300 + np.arange(B)
     a_env.reset(seeds=seeds)
     rng = np.random.default_rng(9)

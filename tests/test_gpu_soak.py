@@ -50,7 +50,7 @@ def test_soak_cfg2_headline_batch_4096_envs(hip):
     B = 4096
     cfg = bench.make_cfg(B, workload="cfg2")
     env = hip.HipBatch(cfg)
-    assert env.flow_variant() == (64, True, False)          # the GL kernel the bench line times
+    assert env.flow_variant() == (64, True, 2)              # k_flow_env, the kernel the bench line times
     env.reset(seeds=1234 + np.arange(B))
     u, n_trunc = _soak(env, cfg, B, 1200, 1, check_every=200)
     assert int(n_trunc.max()) <= 3

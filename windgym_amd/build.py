@@ -8,8 +8,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwindgym_hip.so")
-SOURCES = ["wg_flow.hip", "wg_kernels.hip", "wg_api.hip", "wg_mann.hip", "wg_steady.hip"]
-HEADERS = ["wg_steady.h", "wg_state.h", "wg_device.h", "wg_obs.h", "wg_flow.h", "wg_flow_duo.inc", os.path.join("..", "..", "include", "windgym_hip.h")]
+SOURCES = ["wg_flow.hip", "wg_env.hip", "wg_kernels.hip", "wg_api.hip", "wg_mann.hip", "wg_steady.hip"]
+HEADERS = ["wg_steady.h", "wg_state.h", "wg_device.h", "wg_obs.h", "wg_flow.h", "wg_flow_dev.h", "wg_flow_duo.inc", os.path.join("..", "..", "include", "windgym_hip.h")]
 
 
 def needs_build() -> bool:

@@ -17,6 +17,7 @@
 
 extern "C" {
 void wg_launch_flow(const FlowP*, const FlowPtrs*, int, const float*, const uint8_t*, int, hipStream_t);
+void wg_launch_flow_env(const FlowP*, const FlowPtrs*, int, const float*, const uint8_t*, int, hipStream_t);
 void wg_launch_glue(const WgParams*, const WgPtrs*, int, const uint8_t*, float*, float*, uint8_t*, float*, hipStream_t, const WgParams*, const WgPtrs*);
 void wg_launch_init(const WgParams*, const WgPtrs*, const uint8_t*, const uint64_t*, hipStream_t);
 void wg_launch_create(const WgParams*, const WgPtrs*, hipStream_t);
@@ -29,6 +30,24 @@ void wg_launch_box_coarsen(const void*, void*, int, int, int, hipStream_t);
 void wg_launch_windspeed(const FlowP*, const FlowPtrs*, int, int, const float*, int, const float*, int, float, int, float*, hipStream_t);
 void wg_launch_unready(const WgParams*, const WgPtrs*, const uint8_t*, int*, hipStream_t);
 void wg_launch_steady(const void*, const float*, const float*, const float*, const float*, float*, hipStream_t);
+}
+
+// Measurement / test hooks (environment variables that select kernel variants): honoured ONLY with WG_DEBUG_HOOKS=1 — a
+// stray WG_FLOW_BLOCK in a user's shell must not silently change the kernel — and announced once on stderr when used.
+// (binding.py guards its own hooks, WG_LIB / WG_NOCHECK, the same way; tests/conftest.py sets the switch)
+static const char* wg_hook(const char* name) {
+    static const bool on = [] { const char* v = getenv("WG_DEBUG_HOOKS"); return v && v[0] == '1' && v[1] == 0; }();
+    if (!on) return nullptr;
+    const char* v = getenv(name);
+    if (v) {
+        static std::string seen;
+        const std::string tag = std::string(name) + "=" + v + ";";
+        if (seen.find(tag) == std::string::npos) {
+            seen += tag;
+            fprintf(stderr, "[windgym] WG_DEBUG_HOOKS: %s=%s\n", name, v);
+        }
+    }
+    return v;
 }
 
 static thread_local std::string g_err;
@@ -280,7 +299,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             const bool used = p.turb_on[i] || (i != WG_CH_YAW && p.farm_on[i]);
             if (used && c->ch[i].rolling_mean && c->ch[i].history_n != 1) ok = false;
         }
-        if (const char* ev = getenv("WG_SUMS")) if (atoi(ev) == 0) ok = false;
+        if (const char* ev = wg_hook("WG_SUMS")) if (atoi(ev) == 0) ok = false;
         p.sums_mode = ok ? 1 : 0;
         for (int i = 0; i < WG_N_CH; ++i) {
             p.ring_cap[i] = c->ch[i].history_len + (ok ? 1 : 0);
@@ -330,7 +349,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     size_t pstride = ((size_t)p.NP + 63) / 64;      // in 256-byte granules
     if (pstride % 2 == 0) pstride += 1;
     pstride *= 64;
-    if (const char* ev = getenv("WG_PSTRIDE_PAD")) pstride = (size_t)p.NP + (size_t)atoi(ev);
+    if (const char* ev = wg_hook("WG_PSTRIDE_PAD")) pstride = (size_t)p.NP + (size_t)atoi(ev);
     h->fp.pstride = (int)pstride;
     A(py, n_slots * pstride, true);     // (rec_a / rec_b: allocated with the kernel variant below — one interleaved array for GL handles)
 
@@ -436,12 +455,12 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         while ((1 << ql_shift) < p.P / 4) ++ql_shift;
         const bool ql_fits = ((long)p.N << ql_shift) <= 65536;
         if (!ql_fits) { f.res = 0; f.block = 256; }
-        if (const char* ev = getenv("WG_FLOW_BLOCK")) {       // tests: force an instantiation
+        if (const char* ev = wg_hook("WG_FLOW_BLOCK")) {       // tests: force an instantiation
             const int b = atoi(ev);
             if (b == 256) { f.res = 0; f.block = 256; }
             else if ((b == 64 || b == 128) && small) { f.res = 1; f.block = b; }
         }
-        if (const char* ev = getenv("WG_FLOW_RES")) {          // experiments: compact / pair-major variant for any farm size
+        if (const char* ev = wg_hook("WG_FLOW_RES")) {          // experiments: compact / pair-major variant for any farm size
             if (atoi(ev) != 0 && p.N <= 255) { f.res = 1; if (!small) f.block = 256; } else if (atoi(ev) == 0) { f.res = 0; f.block = 256; }
         }
         if (f.res && !ql_fits) { f.res = 0; f.block = 256; }       // (after the env overrides too)
@@ -478,7 +497,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
                     off = std::max(off, (fixed + 8 * 512 + 15) & ~(size_t)15);
                     f.lf_cap = (int)((off - fixed) / 8);
                     // (tests: a small staging capacity, so that the candidates of one flow step take several rounds)
-                    if (const char* ev = getenv("WG_LF_CAP")) f.lf_cap = std::max(64, std::min(f.lf_cap, atoi(ev)));
+                    if (const char* ev = wg_hook("WG_LF_CAP")) f.lf_cap = std::max(64, std::min(f.lf_cap, atoi(ev)));
                 }
                 // single-wave steady variant: the deficit phase's gathers are LDS-DMA requests issued before the record /
                 // quad-list phases, so the candidate list and the quad list are alive together (no aliasing) and the
@@ -525,7 +544,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         // (k_flow_duo does not carry the optional models: added turbulence, no TI folding)
         const bool duo_ok = f.res && small && f.block == 64 && p.F == 2 && 2 * p.N <= 64 && p.P <= 4096 && !h->added && !h->no_ti_fold && h->deficit_model == 0;
         f.duo = (duo_ok && p.NP <= 1024 && p.turb_mode == WG_TURB_NONE) ? 1 : 0;
-        if (const char* ev = getenv("WG_FLOW_DUO")) f.duo = (duo_ok && atoi(ev) != 0) ? 1 : 0;
+        if (const char* ev = wg_hook("WG_FLOW_DUO")) f.duo = (duo_ok && atoi(ev) != 0) ? 1 : 0;
         bool duo_fits = true;
         {
             const size_t n2 = 2 * (size_t)p.N;
@@ -541,6 +560,40 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             duo_fits = f.duo_lds <= lds_limit;
         }
         if (!duo_fits) f.duo = 0;
+        // k_flow_env (wg_env.hip): ONE wave per env, lane = slot * N + turbine over the env's 2 F farm slots — the default for
+        // steady inflow wherever the slots fit a wave (cfg2: 4 x 16 lanes, cfg4: 4 x 9).  It runs on the GL variant's state
+        // layout (interleaved record + 16-byte gather copy), so the two are interchangeable launch by launch.  A hook that
+        // asks for a specific older variant (WG_FLOW_BLOCK / WG_FLOW_RES / WG_FLOW_DUO) switches it off; WG_FLOW_ENV=0 / 1
+        // forces it off / on where eligible (tests run all of them).
+        {
+            const int NSl = 2 * p.F, NL = NSl * p.N;
+            bool env_ok = f.res && small && f.block == 64 && f.gl && p.turb_mode == WG_TURB_NONE && NL <= 64 && p.N <= 32 &&
+                          p.P <= 4096 && !h->added && h->deficit_model == 0;
+            // upper bound of a farm's ring quads whatever the wind direction: turbine t keeps roundup4(floor(dx_max / d) + 3)
+            // particles, dx_max <= its distance to the farthest turbine (wg_ctx_init)
+            size_t qf = 0;
+            for (int t = 0; t < p.N; ++t) {
+                double dm = 0;
+                for (int j = 0; j < p.N; ++j) dm = std::max(dm, std::hypot(c->x_pos[j] - c->x_pos[t], c->y_pos[j] - c->y_pos[t]));
+                long len = (((long)(dm / p.dpart) + 3) + 3) & ~3L;
+                if (len > p.P || p.full_chains) len = p.P;
+                qf += (size_t)len / 4;
+            }
+            const size_t clb = ((size_t)2 * NL * (p.N > 1 ? p.N - 1 : 1) + 15) & ~(size_t)15;      // candidate list: every ordered pair of a slot
+            f.env_cap = 256;
+            f.env_off_def = (int)clb;
+            const size_t stage = std::max(clb + 8 * (size_t)f.env_cap, ((size_t)2 * NSl * qf + 15) & ~(size_t)15);
+            f.env_off_turb = (int)((stage + 15) & ~(size_t)15);
+            size_t o = (size_t)f.env_off_turb + WG_ENV_TURB_LDS_BYTES + 4 * WG_ENV_SLOT_LDS_BYTES;
+            o += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S);
+            f.env_lds = (int)((o + 15) & ~(size_t)15);
+            if (f.env_lds > 32768 || f.env_lds > lds_limit) env_ok = false;
+            f.env_eps_max = std::min(1.0f, (float)(p.eps0 * std::sqrt(3.0))) + 2.0f / 65535.0f;
+            const bool asked_old = wg_hook("WG_FLOW_BLOCK") || wg_hook("WG_FLOW_RES") || wg_hook("WG_FLOW_DUO");
+            f.envw = (env_ok && !asked_old) ? 1 : 0;
+            if (const char* ev = wg_hook("WG_FLOW_ENV")) f.envw = (env_ok && atoi(ev) != 0) ? 1 : 0;
+            if (f.envw) f.duo = 0;
+        }
         // packed emission record: two arrays, or one interleaved (ct|k, eps|hv) array for the GL variant
         f.rec_il = (f.gl && !f.duo) ? 1 : 0;
         if (f.rec_il) {
@@ -589,7 +642,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         g.pz = d.pz; g.vlp = d.vlp; g.wlp = d.wlp;
         g.bnd = d.bnd;
         g.dbg = nullptr;
-        if (getenv("WG_TIMELINE_OUT")) {
+        if (wg_hook("WG_TIMELINE_OUT")) {
             long long* dbgp = nullptr;
             if (!dev_alloc(h, &dbgp, (size_t)p.B * 2 * p.F * 16, false)) g.dbg = dbgp;
         }
@@ -635,7 +688,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     // (k_flow_duo prepares them for sums-mode handles only: the lean glue's swap)
     // (round 4, sums mode: the glue's own rebuild sums every window of the new episode — 14-15 us of k_glue_lean on cfg3 /
     // cfg5 against 10 with prepared sums — so every compact variant prepares them now; WG_FIRST_OBS_GL_ONLY=1 for A/B runs)
-    const bool prep_all = p.sums_mode && !getenv("WG_FIRST_OBS_GL_ONLY");
+    const bool prep_all = p.sums_mode && !wg_hook("WG_FIRST_OBS_GL_ONLY");
     if (!((h->fp.gl && !h->fp.duo) || (h->fp.res && !h->fp.duo && prep_all) || (h->fp.duo && p.sums_mode && p.turb_mode == WG_TURB_NONE))) { d.next_obs = nullptr; d.next_obs_ok = nullptr; }
     wg_launch_create(&p, &d, nullptr);
     if (sync_dev_params(h)) { wg_destroy(h); return WG_ERR_HIP; }
@@ -647,12 +700,12 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             return fail(WG_ERR_HIP, std::string("wg_create: ") + hipGetErrorString(e));
         }
     }
-    if (const char* ev = getenv("WG_STEP_GRAPH")) h->graph_mode = atoi(ev) != 0;
-    if (getenv("WG_DEBUG"))
+    if (const char* ev = wg_hook("WG_STEP_GRAPH")) h->graph_mode = atoi(ev) != 0;
+    if (wg_hook("WG_DEBUG"))
         fprintf(stderr, "[windgym] k_flow variant: %s, %d threads, LDS %d B per workgroup, slot stride %d floats\n",
-                h->fp.duo ? "compact rings / pair-major, both farms of a context per wave"
+                h->fp.envw ? "compact rings / pair-major, one wave per env (k_flow_env)" : h->fp.duo ? "compact rings / pair-major, both farms of a context per wave"
                           : (h->fp.res ? "compact rings / pair-major" : "uniform rings / sample-major"),
-                h->fp.block, h->fp.duo ? h->fp.duo_lds : h->fp.lds_bytes, h->fp.pstride);
+                h->fp.block, h->fp.envw ? h->fp.env_lds : h->fp.duo ? h->fp.duo_lds : h->fp.lds_bytes, h->fp.pstride);
     *out = h;
     return 0;
 }
@@ -661,11 +714,11 @@ extern "C" int wg_destroy(wg_handle h) {
     if (!h) return 0;
     hipSetDevice(h->device);
     hipDeviceSynchronize();
-    if (h->fd.dbg && getenv("WG_TIMELINE_OUT")) {      // -DWG_TIMELINE builds: dump the phase stamps of the last launch
+    if (h->fd.dbg && wg_hook("WG_TIMELINE_OUT")) {      // -DWG_TIMELINE builds: dump the phase stamps of the last launch
         const size_t n = (size_t)h->p.B * 2 * h->p.F * 16;
         std::vector<long long> host(n);
         if (hipMemcpy(host.data(), h->fd.dbg, n * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
-            if (FILE* f = fopen(getenv("WG_TIMELINE_OUT"), "wb")) { fwrite(host.data(), sizeof(long long), n, f); fclose(f); }
+            if (FILE* f = fopen(wg_hook("WG_TIMELINE_OUT"), "wb")) { fwrite(host.data(), sizeof(long long), n, f); fclose(f); }
         }
     }
     drop_step_graphs(h);
@@ -975,7 +1028,7 @@ extern "C" int wg_step(wg_handle h, const float* actions_dev, float* obs_dev, fl
         if (!ok) {
             (void)hipGetLastError();
             h->graph_mode = false;
-            if (getenv("WG_DEBUG")) fprintf(stderr, "[windgym] step-graph capture failed; using direct launches\n");
+            if (wg_hook("WG_DEBUG")) fprintf(stderr, "[windgym] step-graph capture failed; using direct launches\n");
             launch_step(h, actions_dev, obs_dev, reward_dev, truncated_dev, final_obs_dev, st, false);
             const hipError_t le = hipGetLastError();
             if (le != hipSuccess) return fail(WG_ERR_HIP, std::string("wg_step: kernel launch failed: ") + hipGetErrorString(le));
@@ -1219,7 +1272,7 @@ extern "C" int wg_flow_variant(wg_handle h, int* block, int* compact, int* duo) 
     if (!h) return fail(WG_ERR_INVALID, "null handle");
     if (block) *block = h->fp.block;
     if (compact) *compact = h->fp.res;
-    if (duo) *duo = h->fp.duo;
+    if (duo) *duo = h->fp.envw ? 2 : h->fp.duo;      // 0: one farm slot per workgroup, 1: k_flow_duo, 2: k_flow_env (one wave per env)
     return 0;
 }
 
