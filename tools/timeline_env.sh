@@ -1,0 +1,25 @@
+# usage (GPU box): WL=cfg2 bash tools/timeline_env.sh [extra bench args]  -> per-phase cycles of k_flow_env's waves (one flow round)
+cd $GRAFT_REPO_ROOT
+export WG_DEBUG_HOOKS=1
+cp windgym_amd/libwindgym_hip.so /tmp/lib_keep.so
+WG_HIPCC_FLAGS="-DWG_TIMELINE $XF" python windgym_amd/build.py > /dev/null 2>&1
+WG_TIMELINE_OUT=gpurun_out/timeline_env.bin python bench.py --workload ${WL:-cfg2} --steps 60 --warmup 10 --reps 1 --no-cpu "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('value', d['value'], 'kflow ms', d['roofline']['kernel_ms'])"
+cp /tmp/lib_keep.so windgym_amd/libwindgym_hip.so
+python - <<'PY'
+import numpy as np
+raw = np.fromfile('gpurun_out/timeline_env.bin', dtype=np.int64).reshape(-1, 16)
+ok = (raw[:, 8] > raw[:, 0]) & (raw[:, 0] > 0) & (raw[:, 7] > raw[:, 6]) & (raw[:, 6] > raw[:, 3]) & (raw[:, 4] > raw[:, 1])
+a = raw[ok]
+print('waves with a consistent single round:', len(a), 'of', len(raw))
+seq = [(0, 1, 'prologue: headers + state loads + LDS set-up'), (1, 4, 'roles, clocks published'), (4, 5, 'candidate pass + list offsets'),
+       (5, 11, 'first batch of bracket gathers issued'), (11, 2, 'records'), (2, 9, 'evaluation batches + sums'),
+       (9, 10, 'quad list (+ direct emission stores)'), (10, 3, 'advection pass'), (3, 6, 'clock advance'),
+       (6, 7, 'tail (power, measurement, ring push, farm sums, schedule)'), (7, 8, 'epilogue (state stores, accounting)')]
+tot = a[:, 8] - a[:, 0]
+print('total: mean %.0f median %.0f p10 %.0f p90 %.0f' % (tot.mean(), np.median(tot), np.percentile(tot, 10), np.percentile(tot, 90)))
+for i, j, n in seq:
+    d = a[:, j] - a[:, i]
+    print(f'{n:62s} mean {d.mean():8.0f}  median {np.median(d):8.0f}  p90 {np.percentile(d, 90):8.0f}')
+st = a[:, 0] - a[:, 0].min()
+print('start spread of the waves (cycles): median %.0f p90 %.0f max %.0f ; last end %.0f' % (np.median(st), np.percentile(st, 90), st.max(), (a[:, 8] - a[:, 0].min()).max()))
+PY

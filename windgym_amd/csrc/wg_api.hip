@@ -580,12 +580,9 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
                 qf += (size_t)len / 4;
             }
             const size_t clb = ((size_t)2 * NL * (p.N > 1 ? p.N - 1 : 1) + 15) & ~(size_t)15;      // candidate list: every ordered pair of a slot
-            f.env_cap = 256;
-            f.env_off_def = (int)clb;
-            const size_t stage = std::max(clb + 8 * (size_t)f.env_cap, ((size_t)2 * NSl * qf + 15) & ~(size_t)15);
-            f.env_off_turb = (int)((stage + 15) & ~(size_t)15);
-            size_t o = (size_t)f.env_off_turb + WG_ENV_TURB_LDS_BYTES + 4 * WG_ENV_SLOT_LDS_BYTES;
-            o += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S);
+            const size_t stage = std::max((size_t)8 * WG_ENV_CAP + clb, ((size_t)2 * NSl * qf + 15) & ~(size_t)15);
+            f.env_off_tab = (int)((WG_ENV_FIXED_LDS_BYTES + stage + 15) & ~(size_t)15);
+            size_t o = (size_t)f.env_off_tab + sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S);      // power | ct | rotor points (float2)
             f.env_lds = (int)((o + 15) & ~(size_t)15);
             if (f.env_lds > 32768 || f.env_lds > lds_limit) env_ok = false;
             f.env_eps_max = std::min(1.0f, (float)(p.eps0 * std::sqrt(3.0))) + 2.0f / 65535.0f;

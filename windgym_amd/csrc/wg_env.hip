@@ -33,14 +33,44 @@
 #define WG_ENV_WAVES 4      // 128 VGPRs: 4096 envs = the chip's 4096 wave slots at 4 waves per SIMD, one dispatch round
 #endif
 
-// per-slot clock of the current flow step, published by the slot's lane t = 0 for the work items of other lanes
-struct __attribute__((aligned(8))) EnvSlotLds {
+// Per-slot record in LDS.  Everything here is uniform over the N lanes of a slot: kept in LDS (written by the slot's lane
+// t = 0, read by broadcast) instead of one VGPR per word in every lane — the kernel lives at 128 VGPRs (4 waves per SIMD:
+// 4096 envs = one dispatch round) and would need ~180 with the slot state in registers.
+struct __attribute__((aligned(16))) EnvSlotLds {
+    // schedule (one 16-byte read decides whether the slot takes the next flow step)
+    int dev_rem, fill_rem, sub, budget;
+    // clock of the current flow step
     double s_new;
     int n_emit, n_valid, new_valid;
     unsigned n_emitted;
     float s_off_f, near_f, move_max, ti_pow;
+    // the slot's persistent clock and its context's wind
+    double s_off, ws;
+    float ws_f, ti_f, wd_env, base_acc;
+    // counters this slot owns (agent farm: n_pushed, pend_farm_n; last farm: pend_base_n) and accounting
+    int n_pushed, pend_farm_n, pend_base_n, n_flow;
+    // cold words, parked here between prologue and epilogue
+    double c_time;
+    int c_head;
+    unsigned c_part, c_flow, c_istep, c_tag, n_emitted0;
 };
 static_assert(sizeof(EnvSlotLds) == WG_ENV_SLOT_LDS_BYTES, "keep WG_ENV_SLOT_LDS_BYTES in sync (wg_flow.h)");
+// fixed LDS layout (compile-time offsets from the dynamic LDS base: no address registers): cross-lane turbine fields, indexed
+// by lane g, then the slot records, then the staging region (per-candidate deficit | added TI | candidate list, aliased by the
+// quad list), then the tables (FlowP::env_off_tab)
+//   Lsrc4 (float x, float y, bk, be)   positions as floats + running bounds of the chain (candidate pass)
+//   Lrec4 (ra, rb, u_e, cos yaw)       this step's emission record, packed (pack_a / pack_b), rotor wind speed, cos(yaw)
+//   Lring (roff, rlen, head, -)        the chain's compact ring
+//   Lxr                                downwind position in double (brackets are decided in double)
+//   Lsrc2 (bd, mvl)                    excursion bound (raised by the advection pass with LDS atomics), last moving emission
+#define WG_ENV_OFF_SRC4 0
+#define WG_ENV_OFF_REC4 1024
+#define WG_ENV_OFF_RING 2048
+#define WG_ENV_OFF_XR 3072
+#define WG_ENV_OFF_SRC2 3584
+#define WG_ENV_OFF_SL 4096
+#define WG_ENV_OFF_STAGE (WG_ENV_OFF_SL + 4 * WG_ENV_SLOT_LDS_BYTES)
+static_assert(WG_ENV_OFF_STAGE == WG_ENV_FIXED_LDS_BYTES, "keep WG_ENV_FIXED_LDS_BYTES in sync (wg_flow.h)");
 
 // rare path at the head of the launch: the episode a retired context will hold (WgCtx::init_pending), both farms at once
 static __device__ __attribute__((noinline)) void env_init_episode(const WgParams* gp, const WgPtrs* gd, WgEnv* env_rw,
@@ -54,300 +84,308 @@ static __device__ __attribute__((noinline)) void env_init_episode(const WgParams
     }
 }
 
-// sum of a per-lane value over the N lanes of slot k, in the association k_flow's one-farm wave uses (its lanes 0 .. N-1:
-// row 0 of the DPP tree, the other lanes hold 0).  Result valid in every lane.
-__device__ __forceinline__ float env_slot_sum(const float v, const int k, const int N, const int tid) {
-    const float r = __shfl(v, (tid + k * N) & 63, 64);
-    const float s = tid < N ? r : 0.f;
-    return N <= 16 ? __shfl(wg_row_sum(s), 0, 64) : wg_wave_sum(s);
+// Sum of a per-lane value over the lanes of the lane's OWN slot, for all slots of the env at once, in the association
+// k_flow's one-farm wave uses (values in lanes 0 .. N-1 of row 0 / rows 0-1, zeros elsewhere: wg_row_sum / wg_wave_sum).
+// N = 16: the slots ARE the DPP rows.  Otherwise slot r is first gathered into row r (N < 16) or half r (N <= 32, F = 1).
+// Valid in every lane of a slot.
+__device__ __forceinline__ float env_slot_sums(const float v, const int N, const int NS, const int k, const int tid) {
+    if (N == 16) return wg_row_sum(v);
+    if (N < 16) {
+        const int r = tid >> 4, i = tid & 15;
+        const float x = __shfl(v, (r * N + i) & 63, 64);
+        const float s = wg_row_sum((i < N && r < NS) ? x : 0.f);
+        return __shfl(s, k << 4, 64);
+    }
+    const int h = tid >> 5, i = tid & 31;
+    const float x = __shfl(v, (h * N + i) & 63, 64);
+    float s = (i < N && h < NS) ? x : 0.f;
+    WG_ROW_REDUCE(s, wg_addf)
+    s += __shfl_xor(s, 16, 64);
+    return __shfl(s, k << 5, 64);
 }
 
+// uniform-grid table lookup (linear interpolation, 0 outside): tab_lookup with its parameters as scalars
+__device__ __forceinline__ float env_tab(const float* __restrict__ ys, const float x0, const float inv_dx, const int n_tab, const float x) {
+    const float fx = (x - x0) * inv_dx;
+    if (!(fx >= 0.0f) || fx > (float)(n_tab - 1)) return 0.0f;
+    int i = (int)fx;
+    if (i > n_tab - 2) i = n_tab - 2;
+    const float f = fx - (float)i;
+    return ys[i] + f * (ys[i + 1] - ys[i]);
+}
+
+// Register discipline (the "register cliff" of k_flow): the by-value parameter blocks are NEVER read directly.
+// Every phase fetches the parameters it needs through a fresh opaque pointer to the kernarg segment (wg_cold_args: scalar
+// loads that hit the constant cache) — nothing is held in SGPRs across phases, so nothing overflows into VGPR lanes
+// (v_readlane / v_writelane are VALU instructions: they were 15 % of what k_flow executed).
 template <bool NOISE>
 __global__ void __launch_bounds__(64, WG_ENV_WAVES)
-k_flow_env(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict__ actions,
+k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __restrict__ actions,
            const uint8_t* __restrict__ mask, const int chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, e = blockIdx.x;
-    const int N = p.N, F = p.F, P = p.P, NS = 2 * F, NL = NS * N;
+    int N, F, NS, NL;
+    float inv_N;
+    {
+        const KArgsPtr ka = wg_cold_args();
+        N = ka->p.N; F = ka->p.F; inv_N = ka->p.inv_N;
+        NS = 2 * F; NL = NS * N;
+    }
     const bool valid = tid < NL;
     const int g = valid ? tid : 0;
-    const int k = (int)(((float)g + 0.5f) * p.inv_N);      // slot of the env: ctx * F + farm
+    const int k = (int)(((float)g + 0.5f) * inv_N);         // slot of the env: ctx * F + farm
     const int t = g - k * N;
     const int c = F == 2 ? (k >> 1) : k, farm = F == 2 ? (k & 1) : 0;
-    const int ctx_id = e * 2 + c, slot_id = e * NS + k;
-    const size_t tb = (size_t)e * NL + g;                   // == slot_id * N + t
-    const size_t pb_env = (size_t)e * NS * p.pstride;       // particle block of the env's slot 0 (slot k: + k * pstride)
+
+    float4* const Lsrc4 = reinterpret_cast<float4*>(smem + WG_ENV_OFF_SRC4);
+    uint4* const Lrec4 = reinterpret_cast<uint4*>(smem + WG_ENV_OFF_REC4);
+    int4* const Lring = reinterpret_cast<int4*>(smem + WG_ENV_OFF_RING);
+    double* const Lxr = reinterpret_cast<double*>(smem + WG_ENV_OFF_XR);
+    float2* const Lsrc2 = reinterpret_cast<float2*>(smem + WG_ENV_OFF_SRC2);
+    EnvSlotLds* const SL = reinterpret_cast<EnvSlotLds*>(smem + WG_ENV_OFF_SL);
+    float* const def = reinterpret_cast<float*>(smem + WG_ENV_OFF_STAGE);
+    float* const tiav = def + WG_ENV_CAP;
+    unsigned short* const cl = reinterpret_cast<unsigned short*>(tiav + WG_ENV_CAP);
+    unsigned short* const ql = reinterpret_cast<unsigned short*>(smem + WG_ENV_OFF_STAGE);
+    EnvSlotLds& my = SL[k];
 
     WG_STAMP(0);
     // ---- prologue: every independent global load up front (one exposed round trip) ----------------------------------
-    const KArgsPtr k0 = wg_cold_args();
     typedef const __attribute__((address_space(4))) WgEnv* CEnvPtr;
-    const CEnvPtr envc = (CEnvPtr)(d.env + e);
-    const int env_live = envc->live, env_done = envc->done, env_shadow_iters = envc->shadow_iters, env_steps_done = envc->steps_done;
-    const uint64_t noise_key = envc->noise_key;
-    const bool use_mask = mode == WG_MODE_RESET && mask != nullptr;
-    const uint8_t mask_byte = *(use_mask ? mask + e : reinterpret_cast<const uint8_t*>(d.env + e));
-    const bool masked_out = use_mask && mask_byte == 0;
-
-    int dev_rem, fill_rem, cursor, n_pushed, pend_farm_n, pend_base_n, init_pending, time_max_c;
-    int s_head, n_valid;
-    unsigned part0, flow0, istep, n_emitted;
-    double s_off, s_time, ws, l_xr, l_yr;
-    float ti_f, wd_env, l_yaw, l_u, l_v, l_w, l_ti, l_pow, l_ct, l_act;
-    float4 l_bnd;
-    uint32_t episode_tag;
-    int l_roff, l_rnext;
-    auto load_state = [&]() __attribute__((always_inline)) {
-        const KArgsPtr kl = wg_cold_args();
-        const WgSlot& slot = kl->d.slot[slot_id];
-        const WgCtx& cx = kl->d.ctx[ctx_id];
-        dev_rem = slot.dev_remaining; fill_rem = slot.fill_remaining; cursor = slot.cursor;
-        s_off = slot.s_off; s_time = slot.time; s_head = slot.head; n_valid = slot.n_valid; istep = slot.istep;
-        n_emitted = slot.n_emitted; part0 = slot.part_count; flow0 = slot.flow_count;
-        ws = cx.ws; ti_f = (float)cx.ti; wd_env = (float)cx.wd;
-        n_pushed = cx.n_pushed; pend_farm_n = cx.pend_farm_n; pend_base_n = cx.pend_base_n;
-        episode_tag = (uint32_t)cx.episode_tag; init_pending = cx.init_pending; time_max_c = cx.time_max;
-        const int* ro = kl->d.roff + (size_t)ctx_id * (N + 1);
-        l_roff = ro[t]; l_rnext = ro[t + 1];
-        l_xr = kl->d.xr[(size_t)ctx_id * N + t]; l_yr = kl->d.yr[(size_t)ctx_id * N + t];
-        l_yaw = kl->d.yaw[tb]; l_u = kl->d.u[tb]; l_v = kl->d.v[tb]; l_w = kl->d.w[tb];
-        l_ti = kl->d.ti_loc[tb]; l_pow = kl->d.power[tb]; l_ct = kl->d.ct[tb];
-        l_bnd = reinterpret_cast<const float4*>(kl->d.bnd)[tb];
-    };
-    load_state();
-    const int i_tab = min(tid, p.n_tab - 1), i_s = min(tid, p.S - 1);
-    const float pf_tp = k0->d.tab_power[i_tab], pf_tc = k0->d.tab_ct[i_tab];
-    const float pf_dy = k0->d.rotor_dy[i_s], pf_dz = k0->d.rotor_dz[i_s];
-    {   // (every agent-farm lane reads its turbine's action; only the running episode's lanes use it)
-        const bool has_act = mode == WG_MODE_STEP && farm == 0;
-        const float a = *(has_act ? actions + (size_t)e * N + t : k0->d.tab_ct);
-        l_act = has_act ? a : 0.f;
-    }
-
-    // ---- roles --------------------------------------------------------------------------------------------------------
-    // role_live: this lane's slot belongs to the running episode and takes one env step (K flow sub-steps with measurement);
-    // role_dev:  its slot develops a not-yet-live episode for `budget` flow steps — the background context in STEP mode
-    //            (Wind_Farm_Env.py:722-796 hidden behind the running episode), the masked envs' live
-    //            context in RESET mode
-    const bool is_live_c = (c == env_live);
+    int env_live;
     bool role_live = false, role_dev = false;
-    int budget = 0;
-    if (mode == WG_MODE_STEP) {
-        role_live = is_live_c && !env_done;
-        role_dev = !is_live_c && p.autoreset != 0;
-        // (wave-uniform: both contexts' lanes see the background context's flag through their own loads)
-        const int bg_pending = __shfl(init_pending, (env_live ^ 1) * F * N, 64);
-        if (p.autoreset && bg_pending) {
-            // rare path (one context per truncation): set the retired context's next episode up, both farms (see k_flow)
-            const WgParams& gp = *d.gp;
-            env_init_episode(d.gp, d.gd, d.env_rw + e, e, env_live ^ 1, tid);
-            full_barrier<64>();
-            load_state();
-            const int fill_max = F == 2 ? max(gp.fill_a, gp.fill_b) : gp.fill_a;
-            const int inc = 1 + (gp.extra_inc ? 1 : 0);
-            const int tm = __shfl(time_max_c, env_live * F * N, 64);
-            const long total = (long)((tm + inc - 1) / inc) + 1;
-            const int dev0 = __shfl(dev_rem, (env_live ^ 1) * F * N, 64);
-            budget = wg_shadow_share(dev0 + p.K * fill_max, total - env_steps_done, env_steps_done, e);
-        } else {
-            budget = env_shadow_iters;
+    float yaw, tu, tti, oyaw;
+    {
+        const KArgsPtr k0 = wg_cold_args();
+        const CEnvPtr envc = (CEnvPtr)(k0->d.env + e);
+        env_live = envc->live;
+        const int env_done = envc->done, env_shadow_iters = envc->shadow_iters, env_steps_done = envc->steps_done;
+        const bool use_mask = mode == WG_MODE_RESET && mask != nullptr;
+        const uint8_t mask_byte = *(use_mask ? mask + e : reinterpret_cast<const uint8_t*>(k0->d.env + e));
+        const bool masked_out = use_mask && mask_byte == 0;
+        const unsigned ctx_id = (unsigned)(e * 2 + c), slot_id = (unsigned)(e * NS + k);
+        const unsigned tb = (unsigned)(e * NL + g);             // == slot_id * N + t
+        const unsigned tcx = ctx_id * (unsigned)N + (unsigned)t;
+
+        int dev_rem, fill_rem, n_pushed, pend_farm_n, pend_base_n, init_pending, time_max_c, n_valid, c_head;
+        unsigned n_emitted, c_part, c_flow, c_istep, c_tag;
+        double s_off, ws, l_xr, l_yr, c_time;
+        float ti_f, wd_env, l_yaw, l_u, l_ti, l_act;
+        float4 l_bnd;
+        int l_roff, l_rnext;
+        auto load_state = [&]() __attribute__((always_inline)) {
+            const KArgsPtr kl = wg_cold_args();
+            const WgSlot& slot = kl->d.slot[slot_id];
+            const WgCtx& cx = kl->d.ctx[ctx_id];
+            dev_rem = slot.dev_remaining; fill_rem = slot.fill_remaining;
+            s_off = slot.s_off; c_time = slot.time; c_head = slot.head; n_valid = slot.n_valid; c_istep = slot.istep;
+            n_emitted = slot.n_emitted; c_part = slot.part_count; c_flow = slot.flow_count;
+            ws = cx.ws; ti_f = (float)cx.ti; wd_env = (float)cx.wd;
+            n_pushed = cx.n_pushed; pend_farm_n = cx.pend_farm_n; pend_base_n = cx.pend_base_n;
+            c_tag = (unsigned)cx.episode_tag; init_pending = cx.init_pending; time_max_c = cx.time_max;
+            const int* ro = kl->d.roff + ctx_id * (unsigned)(N + 1);
+            l_roff = ro[(unsigned)t]; l_rnext = ro[(unsigned)t + 1u];
+            l_xr = kl->d.xr[tcx]; l_yr = kl->d.yr[tcx];
+            l_yaw = kl->d.yaw[tb]; l_u = kl->d.u[tb]; l_ti = kl->d.ti_loc[tb];
+            l_bnd = reinterpret_cast<const float4*>(kl->d.bnd)[tb];
+        };
+        load_state();
+        const int n_tab = k0->p.n_tab, S = k0->p.S;
+        const unsigned i_tab = (unsigned)min(tid, n_tab - 1), i_s = (unsigned)min(tid, S - 1);
+        const float pf_tp = k0->d.tab_power[i_tab], pf_tc = k0->d.tab_ct[i_tab];
+        const float pf_dy = k0->d.rotor_dy[i_s], pf_dz = k0->d.rotor_dz[i_s];
+        {   // (every agent-farm lane reads its turbine's action; only the running episode's lanes use it)
+            const bool has_act = mode == WG_MODE_STEP && farm == 0;
+            const float a = *(has_act ? actions + (unsigned)(e * N + t) : k0->d.tab_ct);
+            l_act = has_act ? a : 0.f;
         }
-    } else {
-        role_dev = is_live_c && !masked_out;
-        budget = chunk;
-    }
-    {   // nothing to do for the whole env (masked out in RESET mode, finished env without autoreset, idle background)
-        const bool any_work = valid && (role_live || (role_dev && budget > 0 && (dev_rem > 0 || fill_rem > 0)));
-        if (!__ballot(any_work)) return;
-    }
 
-    // ---- LDS carve (host mirror: wg_create, FlowP::env_*) ---------------------------------------------------------------
-    char* stage = smem;                                   // candidate list | per-candidate deficit, added TI  ∪  quad list
-    unsigned short* cl = reinterpret_cast<unsigned short*>(stage);
-    float* def = reinterpret_cast<float*>(stage + p.env_off_def);
-    float* tiav = def + p.env_cap;
-    unsigned short* ql = reinterpret_cast<unsigned short*>(stage);
-    double* Lxr = reinterpret_cast<double*>(smem + p.env_off_turb);
-    double* Lyr = Lxr + 64;
-    float* Lxf = reinterpret_cast<float*>(Lyr + 64);
-    float* Lyf = Lxf + 64;
-    float* Lbd = Lyf + 64;
-    float* Lbk = Lbd + 64;
-    float* Lbe = Lbk + 64;
-    unsigned* Lmvl = reinterpret_cast<unsigned*>(Lbe + 64);
-    unsigned* Lra = Lmvl + 64;                            // this step's emission record, packed (pack_a / pack_b)
-    unsigned* Lrb = Lra + 64;
-    float* Lrue = reinterpret_cast<float*>(Lrb + 64);
-    float* Lcg = Lrue + 64;
-    int* Lroff = reinterpret_cast<int*>(Lcg + 64);
-    int* Lrlen = Lroff + 64;
-    int* Lhead = Lrlen + 64;
-    EnvSlotLds* SL = reinterpret_cast<EnvSlotLds*>(Lhead + 64);
-    float* tabp = reinterpret_cast<float*>(SL + 4);
-    float* tabct = tabp + p.n_tab;
-    float* rdy = tabct + p.n_tab;
-    float* rdz = rdy + p.S;
+        // ---- roles ----------------------------------------------------------------------------------------------------
+        // role_live: this lane's slot belongs to the running episode and takes one env step (K flow sub-steps with
+        //            measurement);
+        // role_dev:  its slot develops a not-yet-live episode for `budget` flow steps — the background context in STEP mode
+        //            (Wind_Farm_Env.py:722-796 hidden behind the running episode), the masked envs' live
+        //            context in RESET mode
+        const bool is_live_c = (c == env_live);
+        const int autoreset = k0->p.autoreset;
+        int budget = 0;
+        if (mode == WG_MODE_STEP) {
+            role_live = is_live_c && !env_done;
+            role_dev = !is_live_c && autoreset != 0;
+            // (wave-uniform: both contexts' lanes see the background context's flag through their own loads)
+            const int bg_pending = __shfl(init_pending, (env_live ^ 1) * F * N, 64);
+            if (autoreset && bg_pending) {
+                // rare path (one context per truncation): set the retired context's next episode up, both farms (see k_flow)
+                const KArgsPtr ki = wg_cold_args();
+                const WgParams& gp = *ki->d.gp;
+                env_init_episode(ki->d.gp, ki->d.gd, ki->d.env_rw + e, e, env_live ^ 1, tid);
+                full_barrier<64>();
+                load_state();
+                const int fill_max = F == 2 ? max(gp.fill_a, gp.fill_b) : gp.fill_a;
+                const int inc = 1 + (gp.extra_inc ? 1 : 0);
+                const int tm = __shfl(time_max_c, env_live * F * N, 64);
+                const long total = (long)((tm + inc - 1) / inc) + 1;
+                const int dev0 = __shfl(dev_rem, (env_live ^ 1) * F * N, 64);
+                budget = wg_shadow_share(dev0 + gp.K * fill_max, total - env_steps_done, env_steps_done, e);
+            } else {
+                budget = env_shadow_iters;
+            }
+        } else {
+            role_dev = is_live_c && !masked_out;
+            budget = chunk;
+        }
+        {   // nothing to do for the whole env (masked out in RESET mode, finished env without autoreset, idle background)
+            const bool any_work = valid && (role_live || (role_dev && budget > 0 && (dev_rem > 0 || fill_rem > 0)));
+            if (!__ballot(any_work)) return;
+        }
 
-    const int rlen = l_rnext - l_roff;
-    int head = n_emitted == 0u ? rlen - 1 : fast_mod((int)(n_emitted - 1u), rlen, __builtin_amdgcn_rcpf((float)rlen));
-    float bd0 = l_bnd.x;        // (Lbd is the live copy: the advection pass raises it with LDS atomics)
-    float bk = l_bnd.y, be = l_bnd.z;
-    unsigned mvl = __float_as_uint(l_bnd.w);
-    if (valid) {
-        Lxr[g] = l_xr; Lyr[g] = l_yr; Lxf[g] = (float)l_xr; Lyf[g] = (float)l_yr;
-        Lbd[g] = bd0; Lbk[g] = bk; Lbe[g] = be; Lmvl[g] = mvl;
-        Lroff[g] = l_roff; Lrlen[g] = rlen; Lhead[g] = head;
-        Lcg[g] = 1.f; Lrue[g] = 0.f; Lra[g] = 0u; Lrb[g] = 0u;
+        // ---- state into LDS ---------------------------------------------------------------------------------------------
+        const KArgsPtr k1 = wg_cold_args();
+        const int rlen = l_rnext - l_roff;
+        const int head = n_emitted == 0u ? rlen - 1 : fast_mod((int)(n_emitted - 1u), rlen, __builtin_amdgcn_rcpf((float)rlen));
+        const float ws_f = (float)ws;
+        if (valid) {
+            Lxr[g] = l_xr;
+            Lsrc4[g] = make_float4((float)l_xr, (float)l_yr, l_bnd.y, l_bnd.z);
+            Lsrc2[g] = make_float2(l_bnd.x, l_bnd.w);
+            Lring[g] = make_int4(l_roff, rlen, head, k);
+            Lrec4[g] = make_uint4(0u, 0u, 0u, __float_as_uint(1.f));
+            if (t == 0) {
+                my.dev_rem = dev_rem; my.fill_rem = fill_rem; my.sub = 0; my.budget = budget;
+                my.n_valid = n_valid; my.n_emitted = n_emitted; my.n_emitted0 = n_emitted;
+                my.move_max = fabsf(k1->p.hill) * ws_f * k1->p.dt; my.ti_pow = fast_pow(ti_f, k1->p.tic);
+                my.s_off = s_off; my.ws = ws; my.ws_f = ws_f; my.ti_f = ti_f; my.wd_env = wd_env; my.base_acc = 0.f;
+                my.n_pushed = n_pushed; my.pend_farm_n = pend_farm_n; my.pend_base_n = pend_base_n; my.n_flow = 0;
+                my.c_time = c_time; my.c_head = c_head; my.c_part = c_part; my.c_flow = c_flow; my.c_istep = c_istep; my.c_tag = c_tag;
+            }
+        }
+        // tables: power | ct | rotor points as (lateral offset, squared vertical offset from the wake centre height)
+        float* const tabp = reinterpret_cast<float*>(smem + k1->p.env_off_tab);
+        float* const tabct = tabp + n_tab;
+        float2* const rpt = reinterpret_cast<float2*>(tabct + n_tab);
+        const float hub = k1->p.hub;
+        auto rp = [&](const float dy_, const float dz_) __attribute__((always_inline)) {
+            const float dz = hub + dz_ - hub;              // (k_flow: p.hub + rdz - zc, zc = hub under steady inflow)
+            return make_float2(dy_, dz * dz);
+        };
+        if (tid < n_tab) { tabp[tid] = pf_tp; tabct[tid] = pf_tc; }
+        if (tid < S) rpt[tid] = rp(pf_dy, pf_dz);
+        for (int i = tid + 64; i < n_tab; i += 64) { tabp[i] = k1->d.tab_power[i]; tabct[i] = k1->d.tab_ct[i]; }
+        for (int i = tid + 64; i < S; i += 64) rpt[i] = rp(k1->d.rotor_dy[i], k1->d.rotor_dz[i]);
+
+        // this lane's turbine (registers; the cross-lane fields live in the LDS arrays).  Steady inflow: v = w = 0 exactly
+        // (the deficits only act on u), so they are constants here and stored as such.
+        yaw = l_yaw; tu = l_u; tti = l_ti; oyaw = l_yaw;
+        // WindFarmEnv._adjust_yaws (Wind_Farm_Env.py:822-864), float32 like numpy evaluates it on a float32 action
+        if (role_live && farm == 0 && valid) {
+            const float a = l_act, ymin = k1->p.yaw_min, ymax = k1->p.yaw_max, ystep = k1->p.yaw_step;
+            if (k1->p.action_method == WG_ACT_YAW) {
+                yaw = fminf(fmaxf(yaw + a * ystep, ymin), ymax);
+            } else {
+                float tf = a + 1.0f;
+                tf = tf * 0.5f;
+                tf = tf * (ymax - ymin);
+                tf = tf + ymin;
+                const float ny = fminf(fmaxf(tf, yaw - ystep), yaw + ystep);
+                yaw = fminf(fmaxf(ny, ymin), ymax);
+            }
+        }
     }
-    if (tid < p.n_tab) { tabp[tid] = pf_tp; tabct[tid] = pf_tc; }
-    if (tid < p.S) { rdy[tid] = pf_dy; rdz[tid] = pf_dz; }
-    for (int i = tid + 64; i < p.n_tab; i += 64) { tabp[i] = k0->d.tab_power[i]; tabct[i] = k0->d.tab_ct[i]; }
-    for (int i = tid + 64; i < p.S; i += 64) { rdy[i] = k0->d.rotor_dy[i]; rdz[i] = k0->d.rotor_dz[i]; }
-
-    const float ti_pow = fast_pow(ti_f, p.tic);
-    const float ws_f = (float)ws;
-    const float yt_f = (float)l_yr;
-    // this lane's turbine (registers; the cross-lane fields live in the LDS arrays above)
-    float yaw = l_yaw, tu = l_u, tv = l_v, tw = l_w, tti = l_ti, tpow = l_pow, tct = l_ct;
-    float cg = 1.f, sg = 0.f;
+    float tpow = 0.f, tct = 0.f, cg = 1.f;
     float sws = 0.f, swd = 0.f, syaw = 0.f, sp_ = 0.f;
-    float oyaw = l_yaw;
-
-    // WindFarmEnv._adjust_yaws (Wind_Farm_Env.py:822-864), float32 like numpy evaluates it on a float32 action
-    if (role_live && farm == 0 && valid) {
-        const float a = l_act;
-        if (p.action_method == WG_ACT_YAW) {
-            yaw = fminf(fmaxf(yaw + a * p.yaw_step, p.yaw_min), p.yaw_max);
-        } else {
-            float tf = a + 1.0f;
-            tf = tf * 0.5f;
-            tf = tf * (p.yaw_max - p.yaw_min);
-            tf = tf + p.yaw_min;
-            const float ny = fminf(fmaxf(tf, yaw - p.yaw_step), yaw + p.yaw_step);
-            yaw = fminf(fmaxf(ny, p.yaw_min), p.yaw_max);
-        }
-    }
+    int part_acc = 0;
+    bool stepped = false;
     lds_barrier<64>();
     WG_STAMP(1);
 
-    int sub = 0, n_flow = 0, part_acc = 0;
-    float base_acc = 0.f;
-    bool dev_stepped = false;
-    const float inv_k = 1.0f / (float)p.K;
-    const int NN = N * N;
-    const float inv_NN = p.inv_N * p.inv_N;
-    const unsigned maskN = N >= 32 ? 0xffffffffu : (1u << N) - 1u;
-    const unsigned long long lane_lt = (1ull << tid) - 1ull;
-
     for (int round = 0;; ++round) {
-        const bool active = dev_rem > 0 || fill_rem > 0;
-        const bool stepping = valid && (role_live ? (round < p.K) : (role_dev && active && (budget > 0 || sub != 0)));
-        const unsigned long long smask = __ballot(stepping);
-        if (!smask) break;
-        // (a further flow step of the launch gathers what the previous one's advection pass stored)
-        if (round > 0) full_barrier<64>();
-        const bool is_dev = !role_live && dev_rem > 0;
-        // the stepping slots, ascending, two bits each, and this lane's rank among them
-        int na = 0, arank = 0;
-        unsigned code = 0u;
-        for (int kk = 0; kk < NS; ++kk) {
-            if ((smask >> (kk * N)) & 1ull) {
-                code |= (unsigned)kk << (2 * na);
-                if (kk < k) ++arank;
-                ++na;
-            }
-        }
+        bool stepping, is_dev;
+        int sub, K;
+        {
+            const KArgsPtr kr = wg_cold_args();
+            K = kr->p.K;
+            const int4 sch = *reinterpret_cast<const int4*>(&my.dev_rem);      // (dev_rem, fill_rem, sub, budget)
+            const bool active = sch.x > 0 || sch.y > 0;
+            stepping = valid && (role_live ? (round < K) : (role_dev && active && (sch.w > 0 || sch.z != 0)));
+            is_dev = !role_live && sch.x > 0;
+            sub = sch.z;
+            if (!__ballot(stepping)) break;
+            // (a further flow step of the launch gathers what the previous one's advection pass stored)
+            if (round > 0) full_barrier<64>();
 
-        // BasicControllers.local_yaw_controller / global_yaw_controller (BasicControllers.py:10-73): the running episode's
-        // baseline farm, every sim sub-step, not clipped
-        if (role_live && farm == 1 && stepping) {
-            if (p.base_controller == WG_CTRL_LOCAL) {
-                // (steady inflow: v == 0 exactly — the deficits only act on u — so atan(v / u) = +-0)
-                const float off = 0.f - yaw;
-                const float sgn = (float)((off > 0.f) - (off < 0.f));
-                yaw = yaw + sgn * fminf(fabsf(off), p.yaw_step);
-            } else {
-                const float sgn = (float)((yaw > 0.f) - (yaw < 0.f));
-                yaw = yaw - sgn * fminf(fabsf(yaw), p.yaw_step);
+            // BasicControllers.local_yaw_controller / global_yaw_controller (BasicControllers.py:10-73): the running episode's
+            // baseline farm, every sim sub-step, not clipped
+            if (role_live && farm == 1 && stepping) {
+                const float ystep = kr->p.yaw_step;
+                if (kr->p.base_controller == WG_CTRL_LOCAL) {
+                    // (steady inflow: v == 0 exactly — the deficits only act on u — so atan(v / u) = +-0)
+                    const float off = 0.f - yaw;
+                    const float sgn = (float)((off > 0.f) - (off < 0.f));
+                    yaw = yaw + sgn * fminf(fabsf(off), ystep);
+                } else {
+                    const float sgn = (float)((yaw > 0.f) - (yaw < 0.f));
+                    yaw = yaw - sgn * fminf(fabsf(yaw), ystep);
+                }
             }
-        }
 
-        // (0) the slot's clock: travel of its chains over this step, particles released
-        double s_new = s_off + ws * p.dt_d;
-        int n_emit = 0;
-        if (stepping) {
-            while (s_new >= p.dpart) { s_new -= p.dpart; ++n_emit; }
-            if (n_emit > P) n_emit = P;
-        }
-        int new_head = s_head + n_emit; if (new_head >= P) new_head -= P;
-        int new_valid = n_valid + n_emit; if (new_valid > P) new_valid = P;
-        const float s_off_f = (float)s_off;
-        if (stepping && t == 0) {
-            EnvSlotLds& q = SL[k];
-            q.s_new = s_new; q.n_emit = n_emit; q.n_valid = n_valid; q.new_valid = new_valid; q.n_emitted = n_emitted;
-            q.s_off_f = s_off_f;
-            // a target closer than this is bracketed by a particle released in this step
-            q.near_f = (float)(s_off + ws * p.dt_d + p.dpart) + 0.01f;
-            q.move_max = fabsf(p.hill) * ws_f * p.dt;
-            q.ti_pow = ti_pow;
+            // (0) the slot's clock: travel of its chains over this step, particles released (lane t = 0 publishes)
+            if (stepping && t == 0) {
+                const double dpart = kr->p.dpart;
+                const int P = kr->p.P;
+                const double s_off = my.s_off, adv = my.ws * kr->p.dt_d;
+                double s_new = s_off + adv;
+                int n_emit = 0;
+                while (s_new >= dpart) { s_new -= dpart; ++n_emit; }
+                if (n_emit > P) n_emit = P;
+                int new_valid = my.n_valid + n_emit; if (new_valid > P) new_valid = P;
+                my.s_new = s_new; my.n_emit = n_emit; my.new_valid = new_valid;
+                my.s_off_f = (float)s_off;
+                // a target closer than this is bracketed by a particle released in this step
+                my.near_f = (float)(s_off + adv + dpart) + 0.01f;
+            }
         }
         lds_barrier<64>();
         WG_STAMP(4);
 
-        // (2) candidate pass: every (target, source) pair of the stepping slots against the chains' running bounds (those
-        // BEFORE this step's records: they cover every particle already in the rings).  A pair close enough to be bracketed
-        // by a particle released in this step is tested against the widest record the packed format can hold.
-        int nc = 0;
-        unsigned cmask = 0u;          // lane = target: its candidate sources
-        const int npairs = na * NN;
-        const int my_first = stepping ? (arank * N + t) * N : -(1 << 20);
-        for (int i0 = 0; i0 < npairs; i0 += 4 * 64) {
-            bool cand[4];
-            int ent[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 64 + tid;
-                cand[u] = false; ent[u] = 0;
-                if (i < npairs) {
-                    const int a = (int)(((float)i + 0.5f) * inv_NN);
-                    const int r = i - a * NN;
-                    const int tl = (int)(((float)r + 0.5f) * p.inv_N);
-                    const int s2 = r - tl * N;
-                    const int kk = (int)((code >> (2 * a)) & 3u);
-                    const int gt = kk * N + tl, gs = kk * N + s2;
-                    const float dxf = Lxf[gt] - Lxf[gs];
-                    bool cd = (s2 != tl) && (dxf >= 0.f);
-                    if (cd) {
-                        const EnvSlotLds& q = SL[kk];
-                        const bool nearp = dxf < q.near_f;
-                        const float kb_ = nearp ? fmaxf(WG_K_MAX, Lbk[gs]) : Lbk[gs], eb_ = nearp ? fmaxf(p.env_eps_max, Lbe[gs]) : Lbe[gs];
-                        const float sig_max = (kb_ * (dxf * p.inv_D) + eb_) * p.D;
-                        const float bdv = Lbd[gs] + (Lmvl[gs] != 0u || nearp ? q.move_max : 0.f);
-                        const float gap = fabsf(Lyf[gt] - Lyf[gs]) - (p.R_rot + 5.0f * sig_max + bdv);
-                        cd = gap <= 1.0e-3f * p.D;
-                    }
-                    cand[u] = cd;
-                    ent[u] = (gt << 5) | s2;
-                }
+        // (2) candidate pass, lane = target: its sources are the N turbines of its own slot (every lane of a slot reads the same
+        // LDS words: a broadcast), tested against the chains' running bounds (those BEFORE this step's records: they cover every
+        // particle already in the rings).  A pair close enough to be bracketed by a particle released in this step is tested
+        // against the widest record the packed format can hold.  Bit s of cmask = source s is a candidate.
+        unsigned cmask = 0u;
+        {
+            const KArgsPtr kp = wg_cold_args();
+            const float D = kp->p.D, inv_D = kp->p.inv_D, eps_max = kp->p.env_eps_max;
+            const int gs0 = k * N;
+            const float lim0 = kp->p.R_rot + 1.0e-3f * D;
+            const float near_f = my.near_f, move_max = my.move_max;
+            const float xt_f = Lsrc4[g].x, yt_f = Lsrc4[g].y;
+#pragma unroll 4
+            for (int s2 = 0; s2 < N; ++s2) {
+                const float4 a = Lsrc4[gs0 + s2];
+                const float2 b = Lsrc2[gs0 + s2];
+                const float dxf = xt_f - a.x;
+                const bool nearp = dxf < near_f;
+                const float kb_ = nearp ? fmaxf(WG_K_MAX, a.z) : a.z, eb_ = nearp ? fmaxf(eps_max, a.w) : a.w;
+                const float sig_max = (kb_ * (dxf * inv_D) + eb_) * D;
+                const float bdv = b.x + (((__float_as_uint(b.y) != 0u) | nearp) ? move_max : 0.f);
+                const float gap = fabsf(yt_f - a.y) - (5.0f * sig_max + bdv);
+                const bool cd = (s2 != t) & (dxf >= 0.f) & (gap <= lim0);
+                cmask |= cd ? (1u << s2) : 0u;
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ib = i0 + u * 64;
-                const unsigned long long bal = __ballot(cand[u]);
-                if (cand[u]) cl[nc + __popcll(bal & lane_lt)] = (unsigned short)ent[u];
-                nc += __popcll(bal);
-                const int lo = my_first - ib;
-                if (lo < 64 && lo + N > 0) cmask |= (unsigned)(lo >= 0 ? (bal >> lo) : (bal << -lo)) & maskN;
-            }
+            if (!stepping) cmask = 0u;
         }
-        // this target's range of the list: the candidates are in ascending (target lane, source) order
-        int cbeg;
+        // this target's range of the list: ascending (target lane, source) order by construction
+        int cbeg, nc;
         {
             const int cnt = __popc(cmask);
             int inc = cnt;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (tid >= o) inc += v; }
             cbeg = inc - cnt;
+            nc = __shfl(inc, 63, 64);
+            unsigned m = cmask;
+            int o = cbeg;
+            while (m) { cl[o++] = (unsigned short)((g << 5) | __builtin_ctz(m)); m &= m - 1u; }
         }
         lds_barrier<64>();
         WG_STAMP(5);
@@ -356,195 +394,229 @@ k_flow_env(const FlowP p, const FlowPtrs d, const int mode, const float* __restr
         // m0_advect() the advection pass applies: the phase depends on nothing the pass writes).  Ages j, j + 1 after the
         // step are ages jp0 = j - n_emit, jp0 + 1 before it; negative: released in this step — the turbine's record, at the
         // turbine.  A resting chain's particles sit where they were released: their py is not fetched.
+        // (particle addresses: the env's block as a uniform base + 32-bit offsets — an env's 2 F slots span < 4 GB)
         struct Cand { uint4 q0, q1; float y0, y1; double dx; float wgt; int gt, gs, jp0, pos; bool ok, rest; };
-        auto issue = [&](Cand& cd, const int cidx, const int c0, const int c1) __attribute__((always_inline)) {
-            cd.ok = false; cd.rest = false; cd.pos = cidx - c0;
-            if (cidx >= c1) return;
-            def[cd.pos] = 0.f; tiav[cd.pos] = 0.f;          // a candidate the exact evaluation drops contributes zero
-            const unsigned en = cl[cidx];
-            cd.gt = (int)(en >> 5);
-            const int kk = (int)(((float)cd.gt + 0.5f) * p.inv_N);
-            cd.gs = kk * N + (int)(en & 31u);
-            const EnvSlotLds& q = SL[kk];
-            cd.dx = Lxr[cd.gt] - Lxr[cd.gs];
-            if (!(cd.dx > 0.0)) return;                       // (the candidate test ran on float positions)
-            const double xi = (cd.dx - q.s_new) * p.inv_dpart;
-            const double jf = floor(xi);
-            cd.wgt = (float)(xi - jf);
-            int j = (int)jf;
-            if (j < 0) { j = 0; cd.wgt = 0.f; }
-            if (j + 1 > q.new_valid - 1) return;              // the chain has not reached the target yet
-            const int Rs = Lrlen[cd.gs], hd = Lhead[cd.gs];
-            const unsigned mv = Lmvl[cd.gs];
-            cd.rest = !(mv != 0u && (int)(q.n_emitted - mv) < Rs);
-            cd.jp0 = j - q.n_emit;
-            int r0 = hd - cd.jp0; if (r0 < 0) r0 += Rs;
-            int r1 = hd - cd.jp0 - 1; if (r1 < 0) r1 += Rs;
-            if (cd.jp0 < 0) r0 = 0;           // (released in this step: nothing to fetch — any slot of the ring will do)
-            if (cd.jp0 + 1 < 0) r1 = 0;
-            const size_t sb = pb_env + (size_t)kk * p.pstride + (size_t)Lroff[cd.gs];
-            const uint4* r4 = d.rec4 + sb;
-            cd.q0 = r4[r0]; cd.q1 = r4[r1];
-            cd.y0 = 0.f; cd.y1 = 0.f;
-            if (!cd.rest) { const float* py = d.py + sb; cd.y0 = py[r0]; cd.y1 = py[r1]; }
-            cd.ok = true;
-        };
-        const int cap = p.env_cap;
-        Cand nxt;
-        issue(nxt, tid, 0, min(nc, cap));
-        WG_STAMP(11);
-
-        // (1) emission records of this step, sin / cos of the yaw
-        if (stepping) {
-            const float gy = yaw * WG_DEG2RAD_F;
-            sg = __sinf(gy); cg = __cosf(gy);
-            const float wsn = fmaxf(tu * cg + tv * sg, 0.0f);
-            const float ctx = fminf(fmaxf(tab_lookup(tabct, p, wsn) * cg * cg, 0.0f), 0.96f);
-            const float rq = __builtin_amdgcn_sqrtf(1.0f - ctx);
-            const float beta = 0.5f * (1.0f + rq) * __builtin_amdgcn_rcpf(rq);
-            const float rk = p.ka * tti + p.kb;
-            const float reps = p.eps0 * __builtin_amdgcn_sqrtf(beta);
-            const float rhv = -p.hill * sg * tu;
-            // the packed record saturates outside [0, WG_K_MAX] x [-WG_HV_MAX, WG_HV_MAX]: never silently (wg_check reports it)
-            if (rk > WG_K_MAX || fabsf(rhv) > WG_HV_MAX) atomicOr(wg_cold_args()->d.status, WG_STATUS_BIT_RANGE);
-            const unsigned na_ = pack_a(ctx, rk), nb_ = pack_b(reps, rhv);
-            bk = fmaxf(bk, rk + WG_K_MAX / 65535.0f);
-            be = fmaxf(be, reps + 1.0f / 65535.0f);
-            if (n_emit > 0 && rec_moves(nb_)) mvl = n_emitted + (unsigned)n_emit;
-            Lra[g] = na_; Lrb[g] = nb_; Lrue[g] = tu; Lcg[g] = cg;
-            Lbk[g] = bk; Lbe[g] = be; Lmvl[g] = mvl;
-        }
-        lds_barrier<64>();
-        WG_STAMP(2);
-
-        // exact evaluation, one candidate per lane and batch; results staged per candidate, `cap` at a time
         float dsum = 0.f, tia_max = 0.f;
-        for (int c0 = 0; c0 < nc; c0 += cap) {
-            const int c1 = min(nc, c0 + cap);
-            if (c0 > 0) { lds_barrier<64>(); issue(nxt, c0 + tid, c0, c1); }
-            for (int cb = c0; cb < c1; cb += 64) {
-                const Cand cd = nxt;
-                issue(nxt, cb + 64 + tid, c0, c1);
-                if (!cd.ok) continue;
-                const int gt = cd.gt, gs = cd.gs;
-                const int kk = (int)(((float)gt + 0.5f) * p.inv_N);
-                const EnvSlotLds& q = SL[kk];
-                const int jp0 = cd.jp0, jp1 = jp0 + 1;
-                const float ysrc = Lyf[gs];
-                float py0 = cd.rest ? ysrc : cd.y0, py1 = cd.rest ? ysrc : cd.y1;
-                unsigned a0 = cd.q0.x, b0_ = cd.q0.y, a1 = cd.q1.x, b1_ = cd.q1.y;
-                float u0 = __uint_as_float(cd.q0.z), u1 = __uint_as_float(cd.q1.z);
-                if (jp0 < 0) { py0 = ysrc; u0 = Lrue[gs]; a0 = Lra[gs]; b0_ = Lrb[gs]; }
-                if (jp1 < 0) { py1 = ysrc; u1 = Lrue[gs]; a1 = Lra[gs]; b1_ = Lrb[gs]; }
-                if (jp0 >= 0 && jp0 < q.n_valid) py0 = m0_advect(py0, a0, b0_, jp0, q.s_off_f, p.dpart_f, p.inv_D, p.dt);
-                if (jp1 >= 0 && jp1 < q.n_valid) py1 = m0_advect(py1, a1, b1_, jp1, q.s_off_f, p.dpart_f, p.inv_D, p.dt);
-                // interpolation, lateral cut-off, Gaussian deficit at the S rotor points (k_flow: eval_pair)
-                const float wgt = cd.wgt;
-                const float w0 = 1.0f - wgt, w1 = wgt;
-                const float yc = w0 * py0 + w1 * py1;
-                const float zc = p.hub;
-                const float kv = w0 * rec_k(a0) + w1 * rec_k(a1);
-                const float epv = w0 * rec_eps(b0_) + w1 * rec_eps(b1_);
-                const float xd = (float)cd.dx * p.inv_D;
-                const float sp = kv * xd + epv;
-                const float sig = sp * p.D;
-                const float yt = Lyf[gt];
-                const float rc2 = (yt - yc) * (yt - yc) + (p.hub - zc) * (p.hub - zc);
-                const float rcut = p.R_rot + 5.0f * sig;
-                if (rc2 > rcut * rcut) continue;
-                const float ctv = w0 * rec_ct(a0) + w1 * rec_ct(a1);
-                const float uev = w0 * u0 + w1 * u1;
-                const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sig * sig);
-                const float cf = m0_cfrac(ctv, sp);
-                // wake-added turbulence (Crespo-Hernandez), Gaussian-weighted at the hub
-                const float ind = 0.5f * (1.0f - __builtin_amdgcn_sqrtf(1.0f - ctv));
-                tiav[cd.pos] = p.no_ti_fold ? 0.f
-                                            : p.tia * fast_pow(ind, p.tib) * q.ti_pow * fast_pow(fmaxf(xd, 1.0f), p.tid) * __expf(-rc2 * inv2s2);
-                const float cgt = Lcg[gt], amp = uev * cf;
-                float acc = 0.f;
-#if WG_ENV_S_UNROLL
-#pragma unroll 4
-#endif
-                for (int sI = 0; sI < p.S; ++sI) {
-                    const float dy = yt + rdy[sI] * cgt - yc, dz = p.hub + rdz[sI] - zc;
-                    acc += amp * __expf(-(dy * dy + dz * dz) * inv2s2);
-                }
-                def[cd.pos] = acc * p.inv_S;
+        {
+            const KArgsPtr kp = wg_cold_args();
+            const unsigned pstride = (unsigned)kp->p.pstride;
+            const size_t pb_env = (size_t)e * NS * pstride;       // particle block of the env's slot 0 (slot k: + k * pstride)
+            const uint4* const r4_env = kp->d.rec4 + pb_env;
+            const float* const py_env = kp->d.py + pb_env;
+            const double inv_dpart = kp->p.inv_dpart;
+            auto issue = [&](Cand& cd, const int cidx, const int c0, const int c1) __attribute__((always_inline)) {
+                cd.ok = false; cd.rest = false; cd.pos = cidx - c0;
+                if (cidx >= c1) return;
+                def[cd.pos] = 0.f; tiav[cd.pos] = 0.f;          // a candidate the exact evaluation drops contributes zero
+                const unsigned en = cl[cidx];
+                cd.gt = (int)(en >> 5);
+                const int4 rt = Lring[cd.gt];                     // (.w = the target's slot)
+                cd.gs = rt.w * N + (int)(en & 31u);
+                const EnvSlotLds& q = SL[rt.w];
+                cd.dx = Lxr[cd.gt] - Lxr[cd.gs];
+                if (!(cd.dx > 0.0)) return;                       // (the candidate test ran on float positions)
+                const double xi = (cd.dx - q.s_new) * inv_dpart;
+                const double jf = floor(xi);
+                cd.wgt = (float)(xi - jf);
+                int j = (int)jf;
+                if (j < 0) { j = 0; cd.wgt = 0.f; }
+                if (j + 1 > q.new_valid - 1) return;              // the chain has not reached the target yet
+                const int4 rg = Lring[cd.gs];                     // (roff, rlen, head, slot)
+                const int Rs = rg.y, hd = rg.z;
+                const unsigned mv = __float_as_uint(Lsrc2[cd.gs].y);
+                cd.rest = !(mv != 0u && (int)(q.n_emitted - mv) < Rs);
+                cd.jp0 = j - q.n_emit;
+                int r0 = hd - cd.jp0; if (r0 < 0) r0 += Rs;
+                int r1 = hd - cd.jp0 - 1; if (r1 < 0) r1 += Rs;
+                if (cd.jp0 < 0) r0 = 0;           // (released in this step: nothing to fetch — any slot of the ring will do)
+                if (cd.jp0 + 1 < 0) r1 = 0;
+                const unsigned sb = (unsigned)rg.w * pstride + (unsigned)rg.x;
+                cd.q0 = r4_env[sb + (unsigned)r0]; cd.q1 = r4_env[sb + (unsigned)r1];
+                cd.y0 = 0.f; cd.y1 = 0.f;
+                if (!cd.rest) { cd.y0 = py_env[sb + (unsigned)r0]; cd.y1 = py_env[sb + (unsigned)r1]; }
+                cd.ok = true;
+            };
+            Cand nxt;
+            issue(nxt, tid, 0, min(nc, WG_ENV_CAP));
+            WG_STAMP(11);
+
+            // (1) emission records of this step, sin / cos of the yaw
+            if (stepping) {
+                const KArgsPtr kq = wg_cold_args();
+                const int n_tab = kq->p.n_tab;
+                const float* const tabct = reinterpret_cast<const float*>(smem + kq->p.env_off_tab) + n_tab;
+                const float gy = yaw * WG_DEG2RAD_F;
+                const float sg = __sinf(gy);
+                cg = __cosf(gy);
+                const float wsn = fmaxf(tu * cg, 0.0f);
+                const float ctx = fminf(fmaxf(env_tab(tabct, kq->p.tab_x0, kq->p.tab_inv_dx, n_tab, wsn) * cg * cg, 0.0f), 0.96f);
+                const float rq = __builtin_amdgcn_sqrtf(1.0f - ctx);
+                const float beta = 0.5f * (1.0f + rq) * __builtin_amdgcn_rcpf(rq);
+                const float rk = kq->p.ka * tti + kq->p.kb;
+                const float reps = kq->p.eps0 * __builtin_amdgcn_sqrtf(beta);
+                const float rhv = -kq->p.hill * sg * tu;
+                // the packed record saturates outside [0, WG_K_MAX] x [-WG_HV_MAX, WG_HV_MAX]: never silently (wg_check reports it)
+                if (rk > WG_K_MAX || fabsf(rhv) > WG_HV_MAX) atomicOr(kq->d.status, WG_STATUS_BIT_RANGE);
+                const unsigned na_ = pack_a(ctx, rk), nb_ = pack_b(reps, rhv);
+                float4 s4 = Lsrc4[g];
+                s4.z = fmaxf(s4.z, rk + WG_K_MAX / 65535.0f);
+                s4.w = fmaxf(s4.w, reps + 1.0f / 65535.0f);
+                Lsrc4[g] = s4;
+                const int n_emit = my.n_emit;
+                if (n_emit > 0 && rec_moves(nb_)) Lsrc2[g].y = __uint_as_float(my.n_emitted + (unsigned)n_emit);
+                Lrec4[g] = make_uint4(na_, nb_, __float_as_uint(tu), __float_as_uint(cg));
             }
             lds_barrier<64>();
-            // this target's slice of the round, in list order = ascending source order
-            if (stepping) {
-                const int b0 = max(cbeg, c0), b1 = min(cbeg + __popc(cmask), c1);
-                for (int cc = b0; cc < b1; ++cc) {      // (x + 0.0f == x: rejected pairs do not change the sum)
-                    dsum += def[cc - c0];
-                    tia_max = fmaxf(tia_max, tiav[cc - c0]);
+            WG_STAMP(2);
+
+            // exact evaluation, one candidate per lane and batch; results staged per candidate, WG_ENV_CAP at a time
+            const KArgsPtr ke2 = wg_cold_args();
+            const float dpart_f = ke2->p.dpart_f, inv_D = ke2->p.inv_D, D = ke2->p.D, dt = ke2->p.dt, R_rot = ke2->p.R_rot;
+            const float tia = ke2->p.no_ti_fold ? 0.f : ke2->p.tia, tib = ke2->p.tib, tid_ = ke2->p.tid, inv_S = ke2->p.inv_S;
+            const int S = ke2->p.S;
+            const float2* const rpt = reinterpret_cast<const float2*>(smem + ke2->p.env_off_tab + 8 * ke2->p.n_tab);
+            for (int c0 = 0; c0 < nc; c0 += WG_ENV_CAP) {
+                const int c1 = min(nc, c0 + WG_ENV_CAP);
+                if (c0 > 0) { lds_barrier<64>(); issue(nxt, c0 + tid, c0, c1); }
+                for (int cb = c0; cb < c1; cb += 64) {
+                    const Cand cd = nxt;
+                    issue(nxt, cb + 64 + tid, c0, c1);
+                    if (!cd.ok) continue;
+                    const int gt = cd.gt, gs = cd.gs;
+                    const float4 st = Lsrc4[gt];
+                    const float ysrc = Lsrc4[gs].y;
+                    const EnvSlotLds& q = SL[Lring[gt].w];
+                    const int jp0 = cd.jp0, jp1 = jp0 + 1;
+                    float py0 = cd.rest ? ysrc : cd.y0, py1 = cd.rest ? ysrc : cd.y1;
+                    unsigned a0 = cd.q0.x, b0_ = cd.q0.y, a1 = cd.q1.x, b1_ = cd.q1.y;
+                    float u0 = __uint_as_float(cd.q0.z), u1 = __uint_as_float(cd.q1.z);
+                    if (jp0 < 0) {      // (jp1 < 0 implies jp0 < 0)
+                        const uint4 rn = Lrec4[gs];
+                        py0 = ysrc; u0 = __uint_as_float(rn.z); a0 = rn.x; b0_ = rn.y;
+                        if (jp1 < 0) { py1 = ysrc; u1 = __uint_as_float(rn.z); a1 = rn.x; b1_ = rn.y; }
+                    }
+                    {
+                        const int nv = q.n_valid;
+                        const float sof = q.s_off_f;
+                        if (jp0 >= 0 && jp0 < nv) py0 = m0_advect(py0, a0, b0_, jp0, sof, dpart_f, inv_D, dt);
+                        if (jp1 >= 0 && jp1 < nv) py1 = m0_advect(py1, a1, b1_, jp1, sof, dpart_f, inv_D, dt);
+                    }
+                    // interpolation, lateral cut-off, Gaussian deficit at the S rotor points (k_flow: eval_pair)
+                    const float wgt = cd.wgt;
+                    const float w0 = 1.0f - wgt, w1 = wgt;
+                    const float yc = w0 * py0 + w1 * py1;
+                    const float kv = w0 * rec_k(a0) + w1 * rec_k(a1);
+                    const float epv = w0 * rec_eps(b0_) + w1 * rec_eps(b1_);
+                    const float xd = (float)cd.dx * inv_D;
+                    const float sp = kv * xd + epv;
+                    const float sig = sp * D;
+                    const float yt = st.y;
+                    const float rc2 = (yt - yc) * (yt - yc);      // (+ (hub - zc)^2 = 0: steady inflow keeps the wake centre at hub height)
+                    const float rcut = R_rot + 5.0f * sig;
+                    if (rc2 > rcut * rcut) continue;
+                    const float ctv = w0 * rec_ct(a0) + w1 * rec_ct(a1);
+                    const float uev = w0 * u0 + w1 * u1;
+                    const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sig * sig);
+                    const float cf = m0_cfrac(ctv, sp);
+                    // wake-added turbulence (Crespo-Hernandez), Gaussian-weighted at the hub
+                    const float ind = 0.5f * (1.0f - __builtin_amdgcn_sqrtf(1.0f - ctv));
+                    tiav[cd.pos] = tia * fast_pow(ind, tib) * q.ti_pow * fast_pow(fmaxf(xd, 1.0f), tid_) * __expf(-rc2 * inv2s2);
+                    const float cgt = __uint_as_float(Lrec4[gt].w), amp = uev * cf;
+                    const float ninv = -inv2s2;
+                    float acc = 0.f;
+#pragma unroll 4
+                    for (int sI = 0; sI < S; ++sI) {
+                        const float2 rp = rpt[sI];
+                        const float dy = yt + rp.x * cgt - yc;
+                        acc += amp * __expf((dy * dy + rp.y) * ninv);
+                    }
+                    def[cd.pos] = acc * inv_S;
+                }
+                lds_barrier<64>();
+                // this target's slice of the round, in list order = ascending source order
+                if (stepping) {
+                    const int b0 = max(cbeg, c0), b1 = min(cbeg + __popc(cmask), c1);
+                    for (int cc = b0; cc < b1; ++cc) {      // (x + 0.0f == x: rejected pairs do not change the sum)
+                        dsum += def[cc - c0];
+                        tia_max = fmaxf(tia_max, tiav[cc - c0]);
+                    }
                 }
             }
         }
         if (stepping) {
-            tu = ws_f; tv = 0.f; tw = 0.f;
+            const float ti_f = my.ti_f;
+            tu = my.ws_f;
             tu -= dsum;
             tti = __builtin_amdgcn_sqrtf(ti_f * ti_f + tia_max * tia_max);
         }
         lds_barrier<64>();          // (the quad list below aliases the staging arrays)
         WG_STAMP(9);
 
-        // (2) quad list of the chains that move (TurbLds::mvl, k_flow): a chain is listed whole while it may hold a particle
-        // of a yawed turbine; a resting chain only receives this step's new particles, stored straight to their ring slots
-        float* const spy = d.py + pb_env + (size_t)k * p.pstride;
-        unsigned* const sra = d.rec_a + 2 * (pb_env + (size_t)k * p.pstride);      // interleaved (ct|k, eps|hv) record
-        uint4* const sr4 = d.rec4 + pb_env + (size_t)k * p.pstride;
-        int nlist;
         {
-            int cnt = 0;
-            const int nqd = rlen >> 2;
-            bool full = false;
-            if (stepping) {
-                const bool moving = mvl != 0u && (int)(n_emitted - mvl) < rlen;
-                full = moving || n_emit >= 4 || n_emit >= rlen;
-                if (full) cnt = nqd;
-                else {
-                    const unsigned na_ = Lra[g], nb_ = Lrb[g];
+            const KArgsPtr kp = wg_cold_args();
+            const unsigned pstride = (unsigned)kp->p.pstride;
+            const size_t pb_env = (size_t)e * NS * pstride;
+            float* const py_env = kp->d.py + pb_env;
+            unsigned* const ra_env = kp->d.rec_a + 2 * pb_env;        // interleaved (ct|k, eps|hv) record
+            uint4* const r4_env = kp->d.rec4 + pb_env;
+            // (2) quad list of the chains that move (TurbLds::mvl, k_flow): a chain is listed whole while it may hold a particle
+            // of a yawed turbine; a resting chain only receives this step's new particles, stored straight to their ring slots
+            int nlist;
+            {
+                int cnt = 0, nqd = 0;
+                bool full = false;
+                if (stepping) {
+                    const int4 rg = Lring[g];                     // (roff, rlen, head, slot)
+                    const int rlen = rg.y, n_emit = my.n_emit;
+                    const unsigned mvl = __float_as_uint(Lsrc2[g].y);
+                    nqd = rlen >> 2;
+                    const bool moving = mvl != 0u && (int)(my.n_emitted - mvl) < rlen;
+                    full = moving || n_emit >= 4 || n_emit >= rlen;
+                    if (full) cnt = nqd;
+                    else if (n_emit > 0) {
+                        const unsigned sb = (unsigned)k * pstride + (unsigned)rg.x;
+                        const uint4 rn = Lrec4[g];
+                        const float y0 = Lsrc4[g].y;
 #pragma unroll
-                    for (int em = 0; em < 3; ++em) {
-                        if (em < n_emit) {
-                            int r = head + 1 + em; if (r >= rlen) r -= rlen;
-                            const int ix = l_roff + r;
-                            spy[ix] = yt_f;
-                            reinterpret_cast<uint2*>(sra)[ix] = make_uint2(na_, nb_);
-                            sr4[ix] = make_uint4(na_, nb_, __float_as_uint(Lrue[g]), 0u);
+                        for (int em = 0; em < 3; ++em) {
+                            if (em < n_emit) {
+                                int r = rg.z + 1 + em; if (r >= rlen) r -= rlen;
+                                const unsigned ix = sb + (unsigned)r;
+                                py_env[ix] = y0;
+                                reinterpret_cast<uint2*>(ra_env)[ix] = make_uint2(rn.x, rn.y);
+                                r4_env[ix] = make_uint4(rn.x, rn.y, rn.z, 0u);
+                            }
                         }
                     }
                 }
-            }
-            int inc = cnt;
+                int inc = cnt;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (tid >= o) inc += v; }
-            nlist = __shfl(inc, 63, 64);
-            if (full) {
-                const int base = inc - cnt;
-                const unsigned tag = (unsigned)g << 10;
-                for (int i = 0; i < nqd; ++i) ql[base + i] = (unsigned short)(tag | (unsigned)i);
+                for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (tid >= o) inc += v; }
+                nlist = __shfl(inc, 63, 64);
+                if (full) {
+                    const int base = inc - cnt;
+                    const unsigned tag = (unsigned)g << 10;
+                    for (int i = 0; i < nqd; ++i) ql[base + i] = (unsigned short)(tag | (unsigned)i);
+                }
             }
-        }
-        lds_barrier<64>();
-        WG_STAMP(10);
+            lds_barrier<64>();
+            WG_STAMP(10);
 
-        // advection pass, software-pipelined: a lane requests its next listed quad before it computes the current one
-        // (vmcnt counts loads and stores in ONE in-order queue: a plain load-compute-store loop waits for the previous
-        // trip's stores whenever it waits for its loads)
-        {
-            struct QuadReq { float4 py; uint4 ra, rb; int g, kq; size_t q; };
+            // advection pass, software-pipelined: a lane requests its next listed quad before it computes the current one
+            // (vmcnt counts loads and stores in ONE in-order queue: a plain load-compute-store loop waits for the previous
+            // trip's stores whenever it waits for its loads)
+            const float dpart_f = kp->p.dpart_f, inv_D = kp->p.inv_D, dt = kp->p.dt;
+            struct QuadReq { float4 py; uint4 ra, rb; int g, kq; unsigned q; };
             auto request = [&](QuadReq& r, const int cidx) __attribute__((always_inline)) {
                 const bool v = cidx < nlist;
                 const unsigned en = v ? ql[cidx] : 0u;
                 r.g = (int)(en >> 10); r.kq = (int)(en & 1023u);
-                const int kk = (int)(((float)r.g + 0.5f) * p.inv_N);
-                r.q = ((pb_env + (size_t)kk * p.pstride + (size_t)Lroff[r.g]) >> 2) + (size_t)r.kq;
+                const int4 rg = Lring[r.g];
+                r.q = (((unsigned)rg.w * pstride + (unsigned)rg.x) >> 2) + (unsigned)r.kq;      // quad index inside the env's block
                 if (v) {
-                    r.py = reinterpret_cast<const float4*>(d.py)[r.q];
-                    r.ra = reinterpret_cast<const uint4*>(d.rec_a)[2 * r.q];
-                    r.rb = reinterpret_cast<const uint4*>(d.rec_a)[2 * r.q + 1];
+                    r.py = reinterpret_cast<const float4*>(py_env)[r.q];
+                    r.ra = reinterpret_cast<const uint4*>(ra_env)[2u * r.q];
+                    r.rb = reinterpret_cast<const uint4*>(ra_env)[2u * r.q + 1u];
                 }
             };
             QuadReq nq;
@@ -554,12 +626,12 @@ k_flow_env(const FlowP p, const FlowPtrs d, const int mode, const float* __restr
                 const QuadReq cur = nq;
                 request(nq, cidx + 64);
                 const int gq = cur.g, kq = cur.kq;
-                const size_t q = cur.q;
-                const int kk = (int)(((float)gq + 0.5f) * p.inv_N);
-                const EnvSlotLds& sl = SL[kk];
+                const unsigned q = cur.q;
+                const int4 rg = Lring[gq];
+                const EnvSlotLds& sl = SL[rg.w];
                 const int n_emit_q = sl.n_emit, n_valid_q = sl.n_valid;
                 const float sof = sl.s_off_f;
-                const int R = Lrlen[gq], hd = Lhead[gq];
+                const int R = rg.y, hd = rg.z;
                 const int r0 = 4 * kq;
                 int j0 = hd - r0; if (j0 < 0) j0 += R;             // age of ring slot r0 (slot r0+i: j0-i)
                 int e0 = r0 - hd - 1; if (e0 < 0) e0 += R;         // emission index of slot r0 (r0+i: e0+i)
@@ -571,24 +643,23 @@ k_flow_env(const FlowP p, const FlowPtrs d, const int mode, const float* __restr
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     int j = j0 - i; if (j < 0) j += R;
-                    if (j < n_valid_q) pyv[i] = m0_advect(pyv[i], rav[i], rbv[i], j, sof, p.dpart_f, p.inv_D, p.dt);
+                    if (j < n_valid_q) pyv[i] = m0_advect(pyv[i], rav[i], rbv[i], j, sof, dpart_f, inv_D, dt);
                 }
-                const float y0 = Lyf[gq];
+                const float y0 = Lsrc4[gq].y;
                 if (emits) {
-                    const unsigned na_ = Lra[gq], nb_ = Lrb[gq];
-                    const unsigned ue_ = __float_as_uint(Lrue[gq]);
+                    const uint4 rn = Lrec4[gq];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         int ei = e0 + i; if (ei >= R) ei -= R;
                         if (ei < n_emit_q) {
-                            pyv[i] = y0; rav[i] = na_; rbv[i] = nb_;
-                            d.rec4[4 * q + i] = make_uint4(na_, nb_, ue_, 0u);
+                            pyv[i] = y0; rav[i] = rn.x; rbv[i] = rn.y;
+                            r4_env[4u * q + (unsigned)i] = make_uint4(rn.x, rn.y, rn.z, 0u);
                         }
                     }
-                    reinterpret_cast<uint4*>(d.rec_a)[2 * q] = make_uint4(rav[0], rbv[0], rav[1], rbv[1]);
-                    reinterpret_cast<uint4*>(d.rec_a)[2 * q + 1] = make_uint4(rav[2], rbv[2], rav[3], rbv[3]);
+                    reinterpret_cast<uint4*>(ra_env)[2u * q] = make_uint4(rav[0], rbv[0], rav[1], rbv[1]);
+                    reinterpret_cast<uint4*>(ra_env)[2u * q + 1u] = make_uint4(rav[2], rbv[2], rav[3], rbv[3]);
                 }
-                reinterpret_cast<float4*>(d.py)[q] = make_float4(pyv[0], pyv[1], pyv[2], pyv[3]);
+                reinterpret_cast<float4*>(py_env)[q] = make_float4(pyv[0], pyv[1], pyv[2], pyv[3]);
                 // (excursion bound over the VALID particles of the quad only, see k_flow)
                 float ex = 0.f;
 #pragma unroll
@@ -596,48 +667,52 @@ k_flow_env(const FlowP p, const FlowPtrs d, const int mode, const float* __restr
                     int j = j0 - i; if (j < 0) j += R;
                     if (j < n_valid_q) ex = fmaxf(ex, fabsf(pyv[i] - y0));
                 }
-                if (ex > Lbd[gq]) atomicMax(reinterpret_cast<int*>(&Lbd[gq]), __float_as_int(ex));   // ex >= 0: int order == float order
+                if (ex > Lsrc2[gq].x) atomicMax(reinterpret_cast<int*>(&Lsrc2[gq].x), __float_as_int(ex));   // ex >= 0: int order == float order
             }
         }
+        lds_barrier<64>();
         WG_STAMP(3);
 
-        // the slot's clock advances
-        if (stepping) {
-            s_head = new_head; n_valid = new_valid; s_off = s_new; s_time += p.dt_d; istep += 1u;
-            n_emitted += (unsigned)n_emit;
-            // the step's emissions are in the ring now
-            head += n_emit;
-            if (n_emit >= rlen) head %= rlen; else if (head >= rlen) head -= rlen;
-            Lhead[g] = head;
-            part_acc += min(n_valid, rlen);          // roofline accounting: particles that can still reach a rotor
-            ++n_flow;
-            --budget;
-            if (!role_live) dev_stepped = true;
-        }
-        WG_STAMP(6);
-
-        // per-turbine tail: power / thrust with the current yaw (model M0 step 5), WindFarmEnv._take_measurements
-        // (Wind_Farm_Env.py:480-495) accumulated over the K sub-steps and, at the end of the env step,
-        // farm_mes.add_measurements' ring push (MesClass.py:568-591)
+        // per-turbine tail: the step's emissions are in the ring now; power / thrust with the current yaw (model M0 step 5),
+        // WindFarmEnv._take_measurements (Wind_Farm_Env.py:480-495) accumulated over the K sub-steps and, at the end of the env
+        // step, farm_mes.add_measurements' ring push (MesClass.py:568-591)
         const bool measuring = stepping && !is_dev;
-        const bool unit_end = measuring && (sub + 1 == p.K);
+        const bool unit_end = measuring && (sub + 1 == K);
         const KArgsPtr kc = wg_cold_args();
+        const float inv_k = 1.0f / (float)K;
+        const unsigned ctx_id = (unsigned)(e * 2 + c);
         if (stepping) {
-            const float wsn = fmaxf(tu * cg + tv * sg, 0.0f);
-            tpow = tab_lookup(tabp, p, wsn);
-            tct = tab_lookup(tabct, p, wsn) * cg * cg;
+            {
+                int4 rg = Lring[g];
+                const int n_emit = my.n_emit;
+                rg.z += n_emit;
+                if (n_emit >= rg.y) rg.z %= rg.y; else if (rg.z >= rg.y) rg.z -= rg.y;
+                Lring[g].z = rg.z;
+                part_acc += min(my.new_valid, rg.y);          // roofline accounting: particles that can still reach a rotor
+            }
+            stepped = true;
+            const int n_tab = kc->p.n_tab;
+            const float tab_x0 = kc->p.tab_x0, tab_inv_dx = kc->p.tab_inv_dx;
+            const float* const tabp = reinterpret_cast<const float*>(smem + kc->p.env_off_tab);
+            const float wsn = fmaxf(tu * cg, 0.0f);
+            tpow = env_tab(tabp, tab_x0, tab_inv_dx, n_tab, wsn);
+            tct = env_tab(tabp + n_tab, tab_x0, tab_inv_dx, n_tab, wsn) * cg * cg;
             if (measuring && farm == 0) {
-                const float wsm = __builtin_amdgcn_sqrtf(tu * tu + tv * tv + tw * tw);
-                const float wdm = 0.f + wd_env;      // (steady inflow: atan(v / u) = +-0, see k_flow)
+                const float wsm = __builtin_amdgcn_sqrtf(tu * tu);
+                const float wdm = 0.f + my.wd_env;      // (steady inflow: atan(v / u) = +-0, see k_flow)
                 float val[WG_N_CH] = {sws + wsm, swd + wdm, syaw + yaw, sp_ + tpow};
                 if (unit_end) {
-                    kc->d.cur_ws[(size_t)ctx_id * N + t] = wsm;
-                    kc->d.cur_wd[(size_t)ctx_id * N + t] = wdm;
-                    if (p.K != 1) {
+                    const int n_pushed = my.n_pushed;
+                    const unsigned tcx = ctx_id * (unsigned)N + (unsigned)t;
+                    kc->d.cur_ws[tcx] = wsm;
+                    kc->d.cur_wd[tcx] = wdm;
+                    if (K != 1) {
 #pragma unroll
                         for (int ch = 0; ch < WG_N_CH; ++ch) val[ch] *= inv_k;
                     }
                     if (NOISE) {
+                        const uint64_t noise_key = ((CEnvPtr)(kc->d.env + e))->noise_key;
+                        const uint32_t episode_tag = my.c_tag;
 #pragma unroll
                         for (int ch = 0; ch < WG_N_CH; ++ch)
                             if (kc->p.noise_sigma[ch] != 0.f)
@@ -648,7 +723,7 @@ k_flow_env(const FlowP p, const FlowPtrs d, const int mode, const float* __restr
 #pragma unroll
                     for (int ch = 0; ch < WG_N_CH; ++ch) {
                         const int H = kc->p.hlen[ch];
-                        rbase[kc->p.ring_off[ch] + fast_mod(n_pushed, H, kc->p.inv_hlen[ch]) * N + t] = val[ch];      // (time-major: WgRing)
+                        rbase[(unsigned)(kc->p.ring_off[ch] + fast_mod(n_pushed, H, kc->p.inv_hlen[ch]) * N + t)] = val[ch];      // (time-major: WgRing)
                     }
                     // stage the pushed values for the farm-level mean / mean / sum
                     sws = val[0]; swd = val[1]; sp_ = val[3];
@@ -657,98 +732,100 @@ k_flow_env(const FlowP p, const FlowPtrs d, const int mode, const float* __restr
                 }
             }
         }
-        // farm-level values, slot by slot (wave-uniform loop over the stepping slots that measure)
-        const unsigned long long mmask = __ballot(measuring);
-        for (int kk = 0; kk < NS; ++kk) {
-            if (!((mmask >> (kk * N)) & 1ull)) continue;
-            const bool fk = F == 2 ? (kk & 1) : 0;
-            const bool mine = valid && k == kk;
-            const bool k_unit_end = __shfl((int)unit_end, kk * N, 64) != 0;
-            const bool k_live = (F == 2 ? (kk >> 1) : kk) == env_live && mode == WG_MODE_STEP;
-            if (fk) {
-                // fs_baseline...power().sum() (:954)
-                const float s = env_slot_sum(mine ? tpow : 0.f, kk, N, tid);
-                if (mine) base_acc += s;
-                if (k_unit_end && mine && t == 0) {
-                    const float bp = p.K == 1 ? base_acc : base_acc * inv_k;
-                    if (k_live) kc->d.step_base_pow[e] = bp;
-                    else kc->d.pend_base[(size_t)ctx_id * kc->p.power_avg + umod_small(pend_base_n, kc->p.power_avg, kc->p.pavg_magic)] = bp;
-                }
-            } else if (k_unit_end) {
-                const float a_ws = env_slot_sum(mine ? sws : 0.f, kk, N, tid), a_wd = env_slot_sum(mine ? swd : 0.f, kk, N, tid);
-                const float tot = env_slot_sum(mine ? sp_ : 0.f, kk, N, tid);
-                if (mine && t == 0) {
-                    const FlowP __attribute__((address_space(4)))& pc = kc->p;
+        // farm-level values of every measuring slot at once: agent farms push mean ws / mean wd / total power into the farm
+        // rings at the end of an env step, baseline farms add up their power every sub-step (fs_baseline...power().sum(), :954)
+        float a_ws = 0.f, a_wd = 0.f, a_pw = 0.f;
+        if (__ballot(measuring)) {
+            a_ws = env_slot_sums((measuring && farm == 0) ? sws : 0.f, N, NS, k, tid);
+            a_wd = env_slot_sums((measuring && farm == 0) ? swd : 0.f, N, NS, k, tid);
+            a_pw = env_slot_sums(measuring ? (farm == 0 ? sp_ : tpow) : 0.f, N, NS, k, tid);
+        }
+        // the slot's lane t = 0: farm-level pushes, clock advance, schedule
+        if (stepping && t == 0) {
+            const int n_emit = my.n_emit;
+            my.n_valid = my.new_valid; my.s_off = my.s_new; my.n_emitted += (unsigned)n_emit;
+            my.n_flow += 1; my.budget -= 1;
+            float base_acc = my.base_acc;
+            if (measuring && farm == 1) base_acc += a_pw;
+            if (unit_end) {
+                const FlowP __attribute__((address_space(4)))& pc = kc->p;
+                if (farm == 0) {
+                    const int n_pushed = my.n_pushed, pend_farm_n = my.pend_farm_n;
                     float* fbase = kc->d.fring + (size_t)ctx_id * pc.fring_stride;
                     fbase[pc.fring_off[WG_CH_WS] + umod_small(n_pushed, pc.hlen[WG_CH_WS], pc.hmagic[WG_CH_WS])] = a_ws * pc.inv_N;
                     fbase[pc.fring_off[WG_CH_WD] + umod_small(n_pushed, pc.hlen[WG_CH_WD], pc.hmagic[WG_CH_WD])] = a_wd * pc.inv_N;
-                    fbase[pc.fring_off[WG_CH_POWER] + umod_small(n_pushed, pc.hlen[WG_CH_POWER], pc.hmagic[WG_CH_POWER])] = tot;
-                    if (k_live) kc->d.step_farm_pow[e] = tot;
-                    else kc->d.pend_farm[(size_t)ctx_id * pc.power_avg + umod_small(pend_farm_n, pc.power_avg, pc.pavg_magic)] = tot;
+                    fbase[pc.fring_off[WG_CH_POWER] + umod_small(n_pushed, pc.hlen[WG_CH_POWER], pc.hmagic[WG_CH_POWER])] = a_pw;
+                    if (role_live) kc->d.step_farm_pow[e] = a_pw;
+                    else {
+                        kc->d.pend_farm[(size_t)ctx_id * pc.power_avg + umod_small(pend_farm_n, pc.power_avg, pc.pavg_magic)] = a_pw;
+                        my.pend_farm_n = pend_farm_n + 1;
+                    }
+                    my.n_pushed = n_pushed + 1;
+                } else {
+                    const float bp = K == 1 ? base_acc : base_acc * inv_k;
+                    if (role_live) kc->d.step_base_pow[e] = bp;
+                    else {
+                        const int pend_base_n = my.pend_base_n;
+                        kc->d.pend_base[(size_t)ctx_id * pc.power_avg + umod_small(pend_base_n, pc.power_avg, pc.pavg_magic)] = bp;
+                        my.pend_base_n = pend_base_n + 1;
+                    }
+                    base_acc = 0.f;
                 }
             }
+            my.base_acc = base_acc;
+            if (is_dev) my.dev_rem -= 1;
+            else if (sub + 1 >= K) { my.sub = 0; if (!role_live) my.fill_rem -= 1; }
+            else my.sub = sub + 1;
         }
-        // the slot's schedule
-        if (stepping) {
-            if (is_dev) --dev_rem;
-            else if (++sub >= p.K) {
-                sub = 0;
-                if (farm == 0) { sws = 0.f; swd = 0.f; syaw = 0.f; sp_ = 0.f; }
-                else base_acc = 0.f;
-                if (!role_live) --fill_rem;
-            }
-        }
-        // (context-level counters, kept by every lane of the context: both farms' pushes advance them)
-        {
-            const int ca = c * F * N;                       // the context's agent-farm lane 0
-            const bool ctx_pushed = __shfl((int)unit_end, ca, 64) != 0;
-            const bool ctx_live = c == env_live && mode == WG_MODE_STEP;
-            if (ctx_pushed) { ++n_pushed; if (!ctx_live) ++pend_farm_n; }
-            if (F == 2) {
-                const bool base_pushed = __shfl((int)unit_end, ca + N, 64) != 0;
-                if (base_pushed && !ctx_live) ++pend_base_n;
-            }
-        }
+        if (unit_end && farm == 0) { sws = 0.f; swd = 0.f; syaw = 0.f; sp_ = 0.f; }
+        lds_barrier<64>();
+        WG_STAMP(6);
     }
 
     WG_STAMP(7);
-    // ---- epilogue: the env's slots back to memory -----------------------------------------------------------------------
+    // ---- epilogue: the env's slots back to memory (the slots that took a step) ---------------------------------------------
     const KArgsPtr ke = wg_cold_args();
-    if (valid) {
-        ke->d.yaw[tb] = yaw; ke->d.u[tb] = tu; ke->d.v[tb] = tv; ke->d.w[tb] = tw;
+    const float part_slot = env_slot_sums((float)part_acc, N, NS, k, tid);      // (exact: far below 2^24)
+    if (valid && stepped) {
+        const unsigned tb = (unsigned)(e * NL + g);
+        const float4 s4 = Lsrc4[g];
+        const float2 s2 = Lsrc2[g];
+        ke->d.yaw[tb] = yaw; ke->d.u[tb] = tu; ke->d.v[tb] = 0.f; ke->d.w[tb] = 0.f;
         ke->d.ti_loc[tb] = tti; ke->d.power[tb] = tpow; ke->d.ct[tb] = tct;
-        reinterpret_cast<float4*>(ke->d.bnd)[tb] = make_float4(Lbd[g], bk, be, __uint_as_float(mvl));
-        if (role_live && farm == 0) ke->d.old_yaw[(size_t)e * N + t] = oyaw;
-    }
-    for (int kk = 0; kk < NS; ++kk) {            // roofline accounting, per slot
-        const int s = wg_wave_sum_i((valid && k == kk) ? part_acc : 0);
-        if (k == kk) part_acc = s;
-    }
-    if (valid && t == 0) {
-        WgSlot& slot = ke->d.slot[slot_id];
-        slot.part_count = part0 + (unsigned)part_acc;
-        slot.head = s_head; slot.n_valid = n_valid; slot.s_off = s_off; slot.time = s_time;
-        slot.istep = istep; slot.n_emitted = n_emitted;
-        slot.dev_remaining = dev_rem; slot.fill_remaining = fill_rem;
-        slot.flow_count = flow0 + (unsigned)n_flow;
-        WgCtx& cx = ke->d.ctx[ctx_id];
-        if (farm == 0) { cx.n_pushed = n_pushed; cx.pend_farm_n = pend_farm_n; }
-        if (farm == F - 1) cx.pend_base_n = pend_base_n;
+        reinterpret_cast<float4*>(ke->d.bnd)[tb] = make_float4(s2.x, s4.z, s4.w, s2.y);
+        if (role_live && farm == 0) ke->d.old_yaw[(unsigned)(e * N + t)] = oyaw;
+        if (t == 0) {
+            const int n_flow = my.n_flow, P = ke->p.P;
+            const double dt_d = ke->p.dt_d;
+            double tm = my.c_time;
+            for (int i = 0; i < n_flow; ++i) tm += dt_d;
+            const unsigned n_emitted = my.n_emitted;
+            int hd = my.c_head + (int)((n_emitted - my.n_emitted0) % (unsigned)P); if (hd >= P) hd -= P;
+            WgSlot& slot = ke->d.slot[(unsigned)(e * NS + k)];
+            slot.part_count = my.c_part + (unsigned)part_slot;
+            slot.head = hd; slot.n_valid = my.n_valid; slot.s_off = my.s_off; slot.time = tm;
+            slot.istep = my.c_istep + (unsigned)n_flow; slot.n_emitted = n_emitted;
+            slot.dev_remaining = my.dev_rem; slot.fill_remaining = my.fill_rem;
+            slot.flow_count = my.c_flow + (unsigned)n_flow;
+            WgCtx& cx = ke->d.ctx[(unsigned)(e * 2 + c)];
+            if (farm == 0) { cx.n_pushed = my.n_pushed; cx.pend_farm_n = my.pend_farm_n; }
+            if (farm == F - 1) cx.pend_base_n = my.pend_base_n;
+        }
     }
 #ifdef WG_TIMELINE
-    if (tid == 0 && d.dbg) {
+    if (tid == 0 && ke->d.dbg) {
         wg_stamps[8] = clock64();
-        for (int kq = 0; kq < 16; ++kq) d.dbg[(size_t)blockIdx.x * 16 + kq] = wg_stamps[kq];
+        for (int kq = 0; kq < 16; ++kq) ke->d.dbg[(size_t)blockIdx.x * 16 + kq] = wg_stamps[kq];
     }
 #endif
     // a background episode whose agent farm completed its development in this launch: its window sums and first
     // observation are prepared for the swap (wg_first_obs, see k_flow)
     if (mode == WG_MODE_STEP) {
-        const int bl = (env_live ^ 1) * F * N;            // the background context's agent-farm lane 0
-        const bool done_now = dev_stepped && dev_rem == 0 && fill_rem == 0;
-        if (__shfl((int)done_now, bl, 64)) {
+        const EnvSlotLds& bs = SL[(env_live ^ 1) * F];      // the background context's agent farm
+        if (bs.n_flow > 0 && bs.dev_rem == 0 && bs.fill_rem == 0) {
+            const int np = bs.n_pushed;
             full_barrier<64>();                            // the ring pushes have left the wave
-            wg_first_obs(ke->d.gp, ke->d.gd, e * 2 + (env_live ^ 1), __shfl(n_pushed, bl, 64), tid);
+            wg_first_obs(ke->d.gp, ke->d.gd, e * 2 + (env_live ^ 1), np, tid);
         }
     }
 }

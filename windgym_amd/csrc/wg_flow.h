@@ -85,10 +85,9 @@ struct FlowP {
     int ql_shift;                 // compact steady advection: quad-list entry = turbine << ql_shift | quad index in its ring (16 bits)
     int ql_lpt_shift;             // ... and 2^ql_lpt_shift lanes share the listing of one turbine's quads (block / N, at most 8)
     int duo, duo_off_turb, duo_lds;   // k_flow_duo (both farms of a context in one wave): enabled, LDS carve (wg_flow_duo.inc)
-    // k_flow_env (wg_env.hip: ONE wave per env, lane = slot * N + turbine): enabled; LDS carve — staging region [0, env_off_turb):
-    // candidate list (u16) | per-candidate deficit, added TI (env_cap floats each, from env_off_def), aliased by the quad list;
-    // then the turbines' cross-lane fields, the slots' clocks and the tables
-    int envw, env_lds, env_off_def, env_off_turb, env_cap;
+    // k_flow_env (wg_env.hip: ONE wave per env, lane = slot * N + turbine): enabled; bytes of dynamic LDS; offset of the tables
+    // (the rest of the carve is fixed: WG_ENV_*)
+    int envw, env_lds, env_off_tab;
     float env_eps_max;                // widest initial wake width a record can hold: min(1, eps0 sqrt(beta(ct = 0.96)))
     float dt, D, inv_D, hub, dpart_f, R_rot, inv_N, inv_S, inv_P;
     double dt_d, dpart, inv_dpart;
@@ -147,9 +146,12 @@ struct FlowPtrs {
     WgEnv* env_rw;                // == env; the initialising workgroup of farm 0 commits the advanced generator
 };
 
-// k_flow_env's LDS records (wg_env.hip): per-slot clock; cross-lane turbine fields as 64-entry arrays (2 double + 13 word arrays)
-#define WG_ENV_SLOT_LDS_BYTES 40
-#define WG_ENV_TURB_LDS_BYTES (2 * 64 * 8 + 13 * 64 * 4)
+// k_flow_env's LDS carve (wg_env.hip): fixed part (cross-lane turbine fields: three 16-byte and two 8-byte arrays of 64 entries,
+// then four slot records) | staging: per-candidate deficit, added TI (WG_ENV_CAP floats each), candidate list (u16), aliased by
+// the quad list | tables (FlowP::env_off_tab)
+#define WG_ENV_SLOT_LDS_BYTES 144
+#define WG_ENV_FIXED_LDS_BYTES (3 * 64 * 16 + 2 * 64 * 8 + 4 * WG_ENV_SLOT_LDS_BYTES)
+#define WG_ENV_CAP 256
 // sizeof(TurbLds) in wg_flow.hip; kept here so the host can size the dynamic LDS
 #define WG_TURB_LDS_BYTES 120
 // landing zone of the LDS-DMA gathers, per candidate lane: the 16-byte record copy (rec_a, rec_b, u_e, 0) of the two
