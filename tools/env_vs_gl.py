@@ -17,22 +17,33 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 
 
+MODE = sys.argv[3] if len(sys.argv) > 3 else "gl"      # "gl": env kernel vs GL; "fused": fused step vs flow + glue launches
+
+
 def make(d, envw, **kw):
+    if MODE == "fused":
+        os.environ["WG_STEP_FUSED"] = "1" if envw else "0"
+        envw = True
     os.environ["WG_FLOW_ENV"] = "1" if envw else "0"
     os.environ["WG_FLOW_DUO"] = "0"
     try:
-        cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_envs=B, autoreset=True, n_rotor_pts=16, **kw)
+        cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_envs=B, autoreset=True, n_rotor_pts=16,
+                        **{k: v for k, v in kw.items() if k != "multi"})
         env = hip.HipBatch(cfg)
     finally:
         del os.environ["WG_FLOW_ENV"]
         del os.environ["WG_FLOW_DUO"]
+        os.environ.pop("WG_STEP_FUSED", None)
     assert env.flow_variant()[2] == (2 if envw else 0), env.flow_variant()
+    if kw.pop("multi", False):
+        env.fuse_obs_multi()
     return cfg, env
 
 
 FIELDS = ["yaw_agent", "yaw_base", "rotor_uvw_agent", "rotor_uvw_base", "power_turb_agent", "power_turb_base"]
 cases = [("cfg2 4x4", presets.bench_cfg2_config(), dict(n_passthrough=1, n_particles=128)),
          ("cfg4 3x3", presets.multi_3x3_config(), dict(n_passthrough=1, n_particles=96)),
+         ("cfg4 3x3 per-agent buffer", presets.multi_3x3_config(), dict(n_passthrough=0.5, n_particles=96, multi=True)),
          ("2turb noise K", presets.two_turb_config(), dict(n_passthrough=1)),
          ("env1 2x2 wind", presets.env1_config(), dict(n_passthrough=1)),
          ("cfg2 F=1", presets._upd(presets.bench_cfg2_config(), power_def=dict(Power_reward="Power_avg")), dict(n_passthrough=1, n_particles=128))]
@@ -67,6 +78,9 @@ for name, d, kw in cases:
             if not np.array_equal(x.cpu().numpy(), y.cpu().numpy(), equal_nan=True):
                 if first_bad is None:
                     first_bad = (s, "out%d" % i, float(np.nanmax(np.abs(x.cpu().numpy().astype(np.float64) - y.cpu().numpy()))))
+        if getattr(a_env, "_multi_buf", None) is not None and not np.array_equal(a_env._multi_buf.cpu().numpy(), b_env._multi_buf.cpu().numpy()):
+            if first_bad is None:
+                first_bad = (s, "multi_buf", 0.0)
         n_tr += int(ra[2].sum())
         if s % 50 == 49 or first_bad:
             for f in FIELDS:

@@ -18,6 +18,7 @@
 extern "C" {
 void wg_launch_flow(const FlowP*, const FlowPtrs*, int, const float*, const uint8_t*, int, hipStream_t);
 void wg_launch_flow_env(const FlowP*, const FlowPtrs*, int, const float*, const uint8_t*, int, hipStream_t);
+void wg_launch_step_env(const FlowP*, const FlowPtrs*, const WgParams*, const WgPtrs*, const float*, float*, float*, uint8_t*, float*, hipStream_t);
 void wg_launch_glue(const WgParams*, const WgPtrs*, int, const uint8_t*, float*, float*, uint8_t*, float*, hipStream_t, const WgParams*, const WgPtrs*);
 void wg_launch_init(const WgParams*, const WgPtrs*, const uint8_t*, const uint64_t*, hipStream_t);
 void wg_launch_create(const WgParams*, const WgPtrs*, hipStream_t);
@@ -587,7 +588,12 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             if (f.env_lds > 32768 || f.env_lds > lds_limit) env_ok = false;
             f.env_eps_max = std::min(1.0f, (float)(p.eps0 * std::sqrt(3.0))) + 2.0f / 65535.0f;
             const bool asked_old = wg_hook("WG_FLOW_BLOCK") || wg_hook("WG_FLOW_RES") || wg_hook("WG_FLOW_DUO");
-            f.envw = (env_ok && !asked_old) ? 1 : 0;
+            // One wave per env walks a longer chain of dependent phases than one wave per farm slot (40 k against 32 k cycles on
+            // cfg2) and uses a quarter of the waves: below ~2048 envs a launch is a latency chain, not throughput, and the
+            // per-slot kernels win (cfg2, ms per step, env kernel + fused glue / k_flow + k_glue_lean: 256 envs 0.0318 / 0.0260,
+            // 1024: 0.0387 / 0.0322, 2048: 0.0436 / 0.0435, 4096: 0.0631 / 0.0682)
+            const bool big = p.B >= 2048;
+            f.envw = (env_ok && !asked_old && big) ? 1 : 0;
             if (const char* ev = wg_hook("WG_FLOW_ENV")) f.envw = (env_ok && atoi(ev) != 0) ? 1 : 0;
             if (f.envw) f.duo = 0;
         }
@@ -685,6 +691,11 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     // (k_flow_duo prepares them for sums-mode handles only: the lean glue's swap)
     // (round 4, sums mode: the glue's own rebuild sums every window of the new episode — 14-15 us of k_glue_lean on cfg3 /
     // cfg5 against 10 with prepared sums — so every compact variant prepares them now; WG_FIRST_OBS_GL_ONLY=1 for A/B runs)
+    {   // one launch per step where the env kernel runs and the lean glue's specialised instantiation applies
+        const bool gen = p.turb_ti || p.farm_ti || p.farm_obs > 0 || (p.sum_mask_f | p.cur_mask_f) != 0;
+        h->fp.env_fused = (h->fp.envw && p.sums_mode && !gen && p.power_avg <= 64) ? 1 : 0;
+        if (const char* ev = wg_hook("WG_STEP_FUSED")) h->fp.env_fused = (h->fp.env_fused && atoi(ev) != 0) ? 1 : 0;
+    }
     const bool prep_all = p.sums_mode && !wg_hook("WG_FIRST_OBS_GL_ONLY");
     if (!((h->fp.gl && !h->fp.duo) || (h->fp.res && !h->fp.duo && prep_all) || (h->fp.duo && p.sums_mode && p.turb_mode == WG_TURB_NONE))) { d.next_obs = nullptr; d.next_obs_ok = nullptr; }
     wg_launch_create(&p, &d, nullptr);
@@ -965,6 +976,14 @@ extern "C" int wg_reset(wg_handle h, const uint8_t* env_mask_host, const uint64_
 // the launches of one step(); `sample`: bracket the two kernels with timing events
 static void launch_step(wg_env_s* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* truncated_dev,
                         float* final_obs_dev, hipStream_t st, bool sample) {
+    // step() as ONE launch (k_flow_env with the glue as its tail): sums-mode handles on the env kernel whose observation has
+    // no TI / farm-level entries; a flow script (replay mode) or a missing output pointer falls back to the two launches
+    if (h->fp.env_fused && h->fd.script_uvw == nullptr) {
+        if (sample) sample = time_begin(h, 0, st);
+        wg_launch_step_env(&h->fp, &h->fd, &h->p, &h->d, actions_dev, obs_dev, reward_dev, truncated_dev, final_obs_dev, st);
+        if (sample) time_end(h, st);
+        return;
+    }
     if (sample) sample = time_begin(h, 0, st);
     wg_launch_flow(&h->fp, &h->fd, WG_MODE_STEP, actions_dev, nullptr, 0, st);
     if (sample) { time_end(h, st); sample = time_begin(h, 1, st); }

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include "wg_flow_dev.h"
+#include "wg_glue_lean.h"
 
 #ifndef WG_ENV_S_UNROLL
 #define WG_ENV_S_UNROLL 0   // 1: the rotor-point loop of the pair evaluation unrolled by 4
@@ -53,6 +54,8 @@ struct __attribute__((aligned(16))) EnvSlotLds {
     double c_time;
     int c_head;
     unsigned c_part, c_flow, c_istep, c_tag, n_emitted0;
+    float out_pw;        // the env step's farm power: agent farm total / baseline farm (what k_glue reads as step_farm_pow / step_base_pow)
+    int pad_;
 };
 static_assert(sizeof(EnvSlotLds) == WG_ENV_SLOT_LDS_BYTES, "keep WG_ENV_SLOT_LDS_BYTES in sync (wg_flow.h)");
 // fixed LDS layout (compile-time offsets from the dynamic LDS base: no address registers): cross-lane turbine fields, indexed
@@ -118,11 +121,12 @@ __device__ __forceinline__ float env_tab(const float* __restrict__ ys, const flo
 // Every phase fetches the parameters it needs through a fresh opaque pointer to the kernarg segment (wg_cold_args: scalar
 // loads that hit the constant cache) — nothing is held in SGPRs across phases, so nothing overflows into VGPR lanes
 // (v_readlane / v_writelane are VALU instructions: they were 15 % of what k_flow executed).
+struct EnvFlowOut {          // what the flow part hands to the glue tail of k_step_env
+    int env_live, bg_init_pending;
+};
 template <bool NOISE>
-__global__ void __launch_bounds__(64, WG_ENV_WAVES)
-k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __restrict__ actions,
-           const uint8_t* __restrict__ mask, const int chunk) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void env_flow(char* const smem, const int mode, const float* __restrict__ actions,
+                                         const uint8_t* __restrict__ mask, const int chunk, EnvFlowOut& out) {
     const int tid = threadIdx.x, e = blockIdx.x;
     int N, F, NS, NL;
     float inv_N;
@@ -159,6 +163,7 @@ k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __res
         const KArgsPtr k0 = wg_cold_args();
         const CEnvPtr envc = (CEnvPtr)(k0->d.env + e);
         env_live = envc->live;
+        out.env_live = env_live; out.bg_init_pending = 0;
         const int env_done = envc->done, env_shadow_iters = envc->shadow_iters, env_steps_done = envc->steps_done;
         const bool use_mask = mode == WG_MODE_RESET && mask != nullptr;
         const uint8_t mask_byte = *(use_mask ? mask + e : reinterpret_cast<const uint8_t*>(k0->d.env + e));
@@ -214,6 +219,7 @@ k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __res
             role_dev = !is_live_c && autoreset != 0;
             // (wave-uniform: both contexts' lanes see the background context's flag through their own loads)
             const int bg_pending = __shfl(init_pending, (env_live ^ 1) * F * N, 64);
+            out.bg_init_pending = autoreset && bg_pending;
             if (autoreset && bg_pending) {
                 // rare path (one context per truncation): set the retired context's next episode up, both farms (see k_flow)
                 const KArgsPtr ki = wg_cold_args();
@@ -755,6 +761,7 @@ k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __res
                     fbase[pc.fring_off[WG_CH_WS] + umod_small(n_pushed, pc.hlen[WG_CH_WS], pc.hmagic[WG_CH_WS])] = a_ws * pc.inv_N;
                     fbase[pc.fring_off[WG_CH_WD] + umod_small(n_pushed, pc.hlen[WG_CH_WD], pc.hmagic[WG_CH_WD])] = a_wd * pc.inv_N;
                     fbase[pc.fring_off[WG_CH_POWER] + umod_small(n_pushed, pc.hlen[WG_CH_POWER], pc.hmagic[WG_CH_POWER])] = a_pw;
+                    my.out_pw = a_pw;
                     if (role_live) kc->d.step_farm_pow[e] = a_pw;
                     else {
                         kc->d.pend_farm[(size_t)ctx_id * pc.power_avg + umod_small(pend_farm_n, pc.power_avg, pc.pavg_magic)] = a_pw;
@@ -763,6 +770,7 @@ k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __res
                     my.n_pushed = n_pushed + 1;
                 } else {
                     const float bp = K == 1 ? base_acc : base_acc * inv_k;
+                    my.out_pw = bp;
                     if (role_live) kc->d.step_base_pow[e] = bp;
                     else {
                         const int pend_base_n = my.pend_base_n;
@@ -830,10 +838,58 @@ k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __res
     }
 }
 
+
+// k_flow_env<NOISE, 0>: the flow step alone (RESET-mode development; handles whose glue is a separate launch).
+// k_flow_env<NOISE, 1 / 2>: step() as ONE launch — the env's wave runs its glue (lean_step: sums-mode handles without TI /
+// farm-level entries; 2 = with the per-agent observation buffer of the PettingZoo facade) as the tail of its flow step.  No
+// cross-workgroup dependency: the wave owns both contexts of its env.  (Wind_Farm_Env.py:920-1034 in one kernel.)
+template <bool NOISE, int GLUE>
+__global__ void __launch_bounds__(64, WG_ENV_WAVES)
+k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __restrict__ actions,
+           const uint8_t* __restrict__ mask, const int chunk, const WgParams gp_, const WgPtrs gd_,
+           float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out,
+           float* __restrict__ final_obs_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    EnvFlowOut fo;
+    env_flow<NOISE>(smem, mode, actions, mask, chunk, fo);
+    if (GLUE != 0) {
+        // (every store of the flow part — rings, turbine state, headers, a prepared first observation — has left the wave
+        // before the glue reads any of it back; LDS still holds the slots' records)
+        full_barrier<64>();
+        const KArgsPtr kg = wg_cold_args();
+        const int F = kg->p.F, K = kg->p.K;
+        const EnvSlotLds* const SL = reinterpret_cast<const EnvSlotLds*>(smem + WG_ENV_OFF_SL);
+        const int la = fo.env_live * F, lb = (fo.env_live ^ 1) * F;
+        LeanFused fz;
+        fz.fp = SL[la].out_pw;
+        fz.bp = F == 2 ? SL[la + 1].out_pw : 0.f;
+        int work = 0;
+        for (int f = 0; f < F; ++f) work = max(work, SL[lb + f].dev_rem + K * SL[lb + f].fill_rem);
+        fz.work = work;
+        fz.bg_init_pending = fo.bg_init_pending;
+        lean_step<GLUE == 2, false, true>(gp_, gd_, kg->d.gp, kg->d.gd, (int)blockIdx.x, (int)threadIdx.x, obs_out, reward_out, trunc_out,
+                                          final_obs_out, nullptr, fz);
+    }
+}
+
 extern "C" void wg_launch_flow_env(const FlowP* p, const FlowPtrs* d, int mode, const float* actions, const uint8_t* mask,
                                    int chunk, hipStream_t st) {
     const int grid = p->B;
     const size_t lds = p->env_lds;
-    if (p->noise) hipLaunchKernelGGL((k_flow_env<true>), dim3(grid), dim3(64), lds, st, *p, *d, mode, actions, mask, chunk);
-    else hipLaunchKernelGGL((k_flow_env<false>), dim3(grid), dim3(64), lds, st, *p, *d, mode, actions, mask, chunk);
+    static const WgParams gp0{};
+    static const WgPtrs gd0{};
+    if (p->noise) hipLaunchKernelGGL((k_flow_env<true, 0>), dim3(grid), dim3(64), lds, st, *p, *d, mode, actions, mask, chunk, gp0, gd0, nullptr, nullptr, nullptr, nullptr);
+    else hipLaunchKernelGGL((k_flow_env<false, 0>), dim3(grid), dim3(64), lds, st, *p, *d, mode, actions, mask, chunk, gp0, gd0, nullptr, nullptr, nullptr, nullptr);
+}
+
+// step() as one launch (wg_api.hip: launch_step, handles with FlowP::env_fused)
+extern "C" void wg_launch_step_env(const FlowP* p, const FlowPtrs* d, const WgParams* gp, const WgPtrs* gd, const float* actions,
+                                   float* obs, float* reward, uint8_t* trunc, float* final_obs, hipStream_t st) {
+    const int grid = p->B;
+    const size_t lds = p->env_lds;
+#define WG_STEP_ENV(NZ, G) hipLaunchKernelGGL((k_flow_env<NZ, G>), dim3(grid), dim3(64), lds, st, *p, *d, (int)WG_MODE_STEP, actions, \
+                                              (const uint8_t*)nullptr, 0, *gp, *gd, obs, reward, trunc, final_obs)
+    if (gd->multi_out) { if (p->noise) WG_STEP_ENV(true, 2); else WG_STEP_ENV(false, 2); }
+    else { if (p->noise) WG_STEP_ENV(true, 1); else WG_STEP_ENV(false, 1); }
+#undef WG_STEP_ENV
 }

@@ -88,6 +88,7 @@ struct FlowP {
     // k_flow_env (wg_env.hip: ONE wave per env, lane = slot * N + turbine): enabled; bytes of dynamic LDS; offset of the tables
     // (the rest of the carve is fixed: WG_ENV_*)
     int envw, env_lds, env_off_tab;
+    int env_fused;                    // step() as ONE launch: the env's wave runs its glue (lean_step) as the tail of its flow step
     float env_eps_max;                // widest initial wake width a record can hold: min(1, eps0 sqrt(beta(ct = 0.96)))
     float dt, D, inv_D, hub, dpart_f, R_rot, inv_N, inv_S, inv_P;
     double dt_d, dpart, inv_dpart;
