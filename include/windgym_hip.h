@@ -358,7 +358,8 @@ int wg_mann_beta_table(double Gamma, int n, double log10_lo, double log10_hi, do
  * (WindGym/Agents/PyWakeAgent.py:144-288: every Serial-Refine step evaluates the farm power of yaw_n candidate yaw vectors
  * per wind condition): power_dev f32[n_cases][n_turb] (W) for ws / wd / ti f32[n_cases] and yaw_dev f32[n_cases][n_turb]
  * (degrees, flow frame).  Layout, turbine table, rotor points and model constants are the handle's.
- * model 0: the steady state of the env's own flow model (what wg_step converges to under constant yaws);
+ * model 0: the steady state of the env's own flow model (what wg_step converges to under constant yaws) — the Gaussian
+ *          deficit with wake-TI folding; WG_ERR_UNSUPPORTED on a handle created with another deficit_model / no_ti_fold;
  * model 1: the reference agent's py_wake model restated from the publications (Blondel & Cathelain 2020 super-Gaussian
  *          at the rotor centre, linear superposition, Jimenez deflection, Ct cos^2(yaw)).  One kernel launch (k_steady).   */
 int wg_steady_power(wg_handle h, int model, int n_cases, const float* ws_dev, const float* wd_dev, const float* ti_dev,

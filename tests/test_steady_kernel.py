@@ -1,7 +1,8 @@
 """Row f4: k_steady (wg_steady_power) — the steady-state farm power of a batch of (wind condition, yaw vector) cases as ONE
 HIP kernel launch, the inner loop of the reference's PyWakeAgent.yaw_optimizer_srf_vect (PyWakeAgent.py:144-288) —
-against its fp64 torch restatement (windgym_amd/steady.py), against the converged dynamic HIP env, and through the
-reference's own test inequality (tests/test_pywake_agent.py:11-45)."""
+against the CPU restatement under oracle/ (oracle/steady_oracle.py: numpy float64, scalar loops — the product's own torch
+evaluation in windgym_amd/steady.py is checked against the same oracle in tests/test_steady_optimizer.py), against the
+converged dynamic HIP env, and through the reference's own test inequality (tests/test_pywake_agent.py:11-45)."""
 import numpy as np
 import pytest
 
@@ -13,8 +14,24 @@ def _layout():
     return x.ravel(), y.ravel()
 
 
+def _oracle_powers(model, x, y, ws, wd, ti, yaw):
+    from oracle import steady_oracle as so
+    from windgym_amd.config import rotor_points
+    from windgym_amd.turbine import V80, as_tabular
+    tab = as_tabular(V80())
+    D = float(tab.diameter())
+    ry, rz = rotor_points(16, 0.5 * D)
+    out = []
+    for c in range(len(ws)):
+        if model == "m0":
+            out.append(so.m0_steady_power(x, y, ws[c], wd[c], ti[c], yaw[c], tab.ws_tab, tab.power_tab, tab.ct_tab, D, ry, rz))
+        else:
+            out.append(so.blondel_jimenez_power(x, y, ws[c], wd[c], ti[c], yaw[c], tab.ws_tab, tab.power_tab, tab.ct_tab, D))
+    return np.array(out)
+
+
 @pytest.mark.parametrize("model", ["m0", "blondel_jimenez"])
-def test_kernel_matches_the_torch_restatement(model):
+def test_kernel_matches_the_oracle(model):
     from windgym_amd import steady
     x, y = _layout()
     rng = np.random.default_rng(3)
@@ -23,8 +40,7 @@ def test_kernel_matches_the_torch_restatement(model):
     yaw = rng.uniform(-30.0, 30.0, (C, len(x)))
     b = steady.hip_batch_for(x, y)
     got = b.steady_power(ws, wd, ti, yaw, model=model).cpu().numpy()
-    fn = steady.steady_state_power if model == "m0" else steady.blondel_jimenez_power
-    ref = fn(x, y, ws, wd, ti, yaw).numpy()
+    ref = _oracle_powers(model, x, y, ws, wd, ti, yaw)
     # fp32 kernel vs fp64 restatement: 1e-4 of the power (+ 30 W: the table's kinks amplify a rounding of the wind speed)
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=30.0)
     assert (got >= 0).all() and got.shape == (C, len(x))
@@ -85,4 +101,18 @@ def test_batched_optimizer_many_conditions_one_launch_per_refine_step():
     p_opt = b.steady_power(ws, wd, ti, yaw).sum(-1).cpu().numpy()
     p_zero = b.steady_power(ws, wd, ti, np.zeros((4, 12))).sum(-1).cpu().numpy()
     assert np.all(p_opt >= p_zero * (1 - 1e-6)) and p_opt[0] > p_zero[0] * 1.01
+    b.close()
+
+
+def test_steady_power_refuses_a_handle_with_another_deficit():
+    """model 0 is "the steady state of the handle's own flow model"; k_steady carries the Gaussian M0 only, so a handle
+    created with the super-Gaussian deficit must raise instead of returning Gaussian powers (model 1, the reference agent's
+    own wake model, does not depend on the handle's deficit)."""
+    from windgym_amd import binding, steady
+    x, y = _layout()
+    b = steady.hip_batch_for(x, y, deficit="super_gaussian")
+    yaw = np.zeros((2, len(x)))
+    with pytest.raises(binding.WindGymHipError):
+        b.steady_power([8.0, 9.0], [270.0, 265.0], [0.06, 0.06], yaw, model="m0")
+    assert b.steady_power([8.0, 9.0], [270.0, 265.0], [0.06, 0.06], yaw, model="blondel_jimenez").shape == (2, len(x))
     b.close()

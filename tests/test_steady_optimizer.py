@@ -120,3 +120,29 @@ def test_pywake_agent_reference_test():
     agent.optimize()
     assert agent.power(agent.optimized_yaws) >= nominal
     assert agent.model == "blondel_jimenez" and agent.power(agent.optimized_yaws) > agent.power([0, 0])
+
+
+# ---- the agents' batched torch evaluation against the CPU restatement under oracle/ (the checker k_steady is held to as well) ----
+@pytest.mark.parametrize("model", ["m0", "blondel_jimenez"])
+def test_torch_evaluation_matches_the_oracle_restatement(model):
+    from oracle import steady_oracle as so
+    from windgym_amd import steady
+    from windgym_amd.config import rotor_points
+    from windgym_amd.turbine import as_tabular
+    x, y = np.meshgrid(np.linspace(0, 1280, 4), np.linspace(0, 853.3, 3))
+    x, y = x.ravel(), y.ravel()
+    rng = np.random.default_rng(3)
+    C = 9
+    ws = rng.uniform(6.0, 14.0, C); wd = rng.uniform(240.0, 300.0, C); ti = rng.uniform(0.03, 0.12, C)
+    yaw = rng.uniform(-30.0, 30.0, (C, len(x)))
+    tab = as_tabular(V80())
+    D = float(tab.diameter())
+    ry, rz = rotor_points(16, 0.5 * D)
+    fn = steady.steady_state_power if model == "m0" else steady.blondel_jimenez_power
+    got = fn(x, y, ws, wd, ti, yaw).numpy()
+    for c in range(C):
+        if model == "m0":
+            ref = so.m0_steady_power(x, y, ws[c], wd[c], ti[c], yaw[c], tab.ws_tab, tab.power_tab, tab.ct_tab, D, ry, rz)
+        else:
+            ref = so.blondel_jimenez_power(x, y, ws[c], wd[c], ti[c], yaw[c], tab.ws_tab, tab.power_tab, tab.ct_tab, D)
+        np.testing.assert_allclose(got[c], ref, rtol=1e-9, atol=1e-3)

@@ -1262,6 +1262,12 @@ extern "C" int wg_steady_power(wg_handle h, int model, int n_cases, const float*
     if (!h || !ws_dev || !wd_dev || !ti_dev || !yaw_dev || !power_dev) return fail(WG_ERR_INVALID, "null argument");
     if (model != 0 && model != 1) return fail(WG_ERR_INVALID, "wg_steady_power: model must be 0 (steady state of M0) or 1 (Blondel-Cathelain + Jimenez)");
     if (n_cases < 1) return fail(WG_ERR_INVALID, "wg_steady_power: n_cases must be >= 1");
+    // model 0 is documented as the steady state of THIS handle's flow model; k_steady carries the Gaussian M0 with TI folding
+    // only — a handle created with another deficit / without the folding must not get Gaussian powers silently
+    if (model == 0 && (h->deficit_model != 0 || h->no_ti_fold))
+        return fail(WG_ERR_UNSUPPORTED, "wg_steady_power: model 0 (steady state of the handle's flow model) is implemented for the Gaussian deficit "
+                                        "with wake-TI folding only; this handle uses deficit_model " + std::to_string(h->deficit_model) +
+                                        (h->no_ti_fold ? " without TI folding" : ""));
     if (int rc = use_device(h)) return rc;
     SteadyP sp;
     memset(&sp, 0, sizeof(sp));

@@ -174,16 +174,23 @@ def blondel_jimenez_power(x, y, ws, wd, ti, yaw, turbine=None, n_quad=20, device
 WAKE_MODELS = {"m0": None, "blondel_jimenez": blondel_jimenez_power}
 
 
-def hip_batch_for(x, y, turbine=None, n_rotor_pts=16, device=None):
+def hip_batch_for(x, y, turbine=None, n_rotor_pts=16, device=None, deficit=None, model_constants=None):
     """A minimal :class:`windgym_amd.binding.HipBatch` (one env) that carries a layout and a turbine to the device, so that
-    ``HipBatch.steady_power`` (k_steady) can evaluate steady-state farm powers for it."""
+    ``HipBatch.steady_power`` (k_steady) can evaluate steady-state farm powers for it.  ``deficit`` / ``model_constants``: those
+    of the env the yaws are optimised for (EnvConfig's) — model "m0" is the steady state of THAT flow model, and the library
+    refuses it (WG_ERR_UNSUPPORTED) for a deficit k_steady does not carry rather than answering with Gaussian powers."""
     from .binding import HipBatch
     from .config import EnvConfig
     from .presets import env1_config
     d = env1_config()
     d["power_def"]["Power_reward"] = "Power_avg"
+    extra = {}
+    if deficit is not None:
+        extra["deficit"] = deficit
+    if model_constants is not None:
+        extra["model_constants"] = model_constants
     cfg = EnvConfig(turbine=turbine if turbine is not None else V80(), yaml_dict=d, turbtype="None", n_envs=1,
-                    x_pos=np.asarray(x, dtype=float), y_pos=np.asarray(y, dtype=float), n_rotor_pts=n_rotor_pts)
+                    x_pos=np.asarray(x, dtype=float), y_pos=np.asarray(y, dtype=float), n_rotor_pts=n_rotor_pts, **extra)
     return HipBatch(cfg, device=device)
 
 
@@ -236,7 +243,7 @@ class SteadyStateYawAgent(BaseAgent):
     model = "m0"
 
     def __init__(self, x_pos, y_pos, wind_speed=8, wind_dir=270, TI=0.07, yaw_max=45, yaw_min=-45, refine_pass_n=8,
-                 yaw_n=9, turbine=None, device="cpu", model=None):
+                 yaw_n=9, turbine=None, device="cpu", model=None, deficit=None, model_constants=None):
         if model is not None:
             self.model = model
         super().__init__(yaw_max, yaw_min)
@@ -253,7 +260,20 @@ class SteadyStateYawAgent(BaseAgent):
         # device "cuda" / "hip": the candidates of every refine step are evaluated by the HIP kernel k_steady
         self._batch = None
         if str(device).startswith(("cuda", "hip")):
-            self._batch = hip_batch_for(self.x_pos, self.y_pos, self.turbine)
+            self._batch = hip_batch_for(self.x_pos, self.y_pos, self.turbine, deficit=deficit, model_constants=model_constants)
+
+    def close(self):
+        """release the device handle behind device="cuda" (the agent stays usable on its torch path)"""
+        if self._batch is not None:
+            self._batch.close()
+            self._batch = None
+            self.device = "cpu"
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def update_wind(self, wind_speed, wind_direction, TI):
         self.wsp, self.wdir, self.TI = np.asarray([wind_speed], float), np.asarray([wind_direction], float), TI
