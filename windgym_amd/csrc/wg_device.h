@@ -221,6 +221,22 @@ __device__ inline int wg_wave_sum_i(int v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// inclusive prefix sum over the 64 lanes, in DPP steps only (four Kogge-Stone shifts inside each row of 16, then the row totals
+// carried across with row_bcast:15 / row_bcast:31): six VALU instructions and no LDS crossbar round trips — a __shfl_up ladder
+// is six dependent ds_bpermute_b32 (~100 cycles each on a wave's critical path)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int wg_dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ int wg_wave_scan_i(int v) {
+    v += wg_dpp_i<0x111, 0xf>(v);      // row_shr:1
+    v += wg_dpp_i<0x112, 0xf>(v);      // row_shr:2
+    v += wg_dpp_i<0x114, 0xf>(v);      // row_shr:4
+    v += wg_dpp_i<0x118, 0xf>(v);      // row_shr:8
+    v += wg_dpp_i<0x142, 0xa>(v);      // row_bcast:15 -> rows 1, 3
+    v += wg_dpp_i<0x143, 0xc>(v);      // row_bcast:31 -> rows 2, 3
+    return v;
+}
 __device__ inline float wg_wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

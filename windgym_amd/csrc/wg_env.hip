@@ -30,6 +30,14 @@
 #ifndef WG_ENV_S_UNROLL
 #define WG_ENV_S_UNROLL 0   // 1: the rotor-point loop of the pair evaluation unrolled by 4
 #endif
+#ifndef WG_ENV_PP
+#define WG_ENV_PP 0         // bit 0: two alternating request buffers in the advection pass, bit 1: in the evaluation (0: one buffer + a
+                            // register copy per trip).  Measured, cfg2 x 4096 / cfg4 x 2048, same box: 0: 67.8 / 53.5, 1: 66.0, 2: 68.0, 3: 63.0 / 50.9 M
+                            // env-steps/s — the second copy of the inlined phase costs more than the moves it saves
+#endif
+#ifndef WG_ENV_DPP_SCAN
+#define WG_ENV_DPP_SCAN 1   // list offsets from DPP prefix sums (0: __shfl_up ladders, for A/B builds: 67.0 / 52.2 against 67.8 / 53.5)
+#endif
 #ifndef WG_ENV_WAVES
 #define WG_ENV_WAVES 4      // 128 VGPRs: 4096 envs = the chip's 4096 wave slots at 4 waves per SIMD, one dispatch round
 #endif
@@ -85,6 +93,17 @@ static __device__ __attribute__((noinline)) void env_init_episode(const WgParams
         env_rw->rng_state = rng.rng_state; env_rw->rng_inc = rng.rng_inc;
         env_rw->rng_has32 = rng.rng_has32; env_rw->rng_u32 = rng.rng_u32;
     }
+}
+
+__device__ __forceinline__ int env_scan(const int v, const int tid) {
+#if WG_ENV_DPP_SCAN
+    return wg_wave_scan_i(v);
+#else
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int w = __shfl_up(inc, o, 64); if (tid >= o) inc += w; }
+    return inc;
+#endif
 }
 
 // Sum of a per-lane value over the lanes of the lane's OWN slot, for all slots of the env at once, in the association
@@ -384,11 +403,9 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
         int cbeg, nc;
         {
             const int cnt = __popc(cmask);
-            int inc = cnt;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (tid >= o) inc += v; }
+            const int inc = env_scan(cnt, tid);
             cbeg = inc - cnt;
-            nc = __shfl(inc, 63, 64);
+            nc = __builtin_amdgcn_readlane(inc, 63);
             unsigned m = cmask;
             int o = cbeg;
             while (m) { cl[o++] = (unsigned short)((g << 5) | __builtin_ctz(m)); m &= m - 1u; }
@@ -401,7 +418,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
         // step are ages jp0 = j - n_emit, jp0 + 1 before it; negative: released in this step — the turbine's record, at the
         // turbine.  A resting chain's particles sit where they were released: their py is not fetched.
         // (particle addresses: the env's block as a uniform base + 32-bit offsets — an env's 2 F slots span < 4 GB)
-        struct Cand { uint4 q0, q1; float y0, y1; double dx; float wgt; int gt, gs, jp0, pos; bool ok, rest; };
+        struct Cand { uint4 q0, q1; float y0, y1, xd, wgt; int en, jp0; bool ok, rest; };      // (en: list entry = target lane << 5 | source turbine)
         float dsum = 0.f, tia_max = 0.f;
         {
             const KArgsPtr kp = wg_cold_args();
@@ -410,26 +427,29 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
             const uint4* const r4_env = kp->d.rec4 + pb_env;
             const float* const py_env = kp->d.py + pb_env;
             const double inv_dpart = kp->p.inv_dpart;
+            const float inv_D = kp->p.inv_D;
             auto issue = [&](Cand& cd, const int cidx, const int c0, const int c1) __attribute__((always_inline)) {
-                cd.ok = false; cd.rest = false; cd.pos = cidx - c0;
+                cd.ok = false; cd.rest = false;
                 if (cidx >= c1) return;
-                def[cd.pos] = 0.f; tiav[cd.pos] = 0.f;          // a candidate the exact evaluation drops contributes zero
+                def[cidx - c0] = 0.f; tiav[cidx - c0] = 0.f;      // a candidate the exact evaluation drops contributes zero
                 const unsigned en = cl[cidx];
-                cd.gt = (int)(en >> 5);
-                const int4 rt = Lring[cd.gt];                     // (.w = the target's slot)
-                cd.gs = rt.w * N + (int)(en & 31u);
+                cd.en = (int)en;
+                const int gt = (int)(en >> 5);
+                const int4 rt = Lring[gt];                        // (.w = the target's slot)
+                const int gs = rt.w * N + (int)(en & 31u);
                 const EnvSlotLds& q = SL[rt.w];
-                cd.dx = Lxr[cd.gt] - Lxr[cd.gs];
-                if (!(cd.dx > 0.0)) return;                       // (the candidate test ran on float positions)
-                const double xi = (cd.dx - q.s_new) * inv_dpart;
+                const double dx = Lxr[gt] - Lxr[gs];
+                if (!(dx > 0.0)) return;                          // (the candidate test ran on float positions)
+                cd.xd = (float)dx * inv_D;
+                const double xi = (dx - q.s_new) * inv_dpart;
                 const double jf = floor(xi);
                 cd.wgt = (float)(xi - jf);
                 int j = (int)jf;
                 if (j < 0) { j = 0; cd.wgt = 0.f; }
                 if (j + 1 > q.new_valid - 1) return;              // the chain has not reached the target yet
-                const int4 rg = Lring[cd.gs];                     // (roff, rlen, head, slot)
+                const int4 rg = Lring[gs];                        // (roff, rlen, head, slot)
                 const int Rs = rg.y, hd = rg.z;
-                const unsigned mv = __float_as_uint(Lsrc2[cd.gs].y);
+                const unsigned mv = __float_as_uint(Lsrc2[gs].y);
                 cd.rest = !(mv != 0u && (int)(q.n_emitted - mv) < Rs);
                 cd.jp0 = j - q.n_emit;
                 int r0 = hd - cd.jp0; if (r0 < 0) r0 += Rs;
@@ -442,8 +462,8 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
                 if (!cd.rest) { cd.y0 = py_env[sb + (unsigned)r0]; cd.y1 = py_env[sb + (unsigned)r1]; }
                 cd.ok = true;
             };
-            Cand nxt;
-            issue(nxt, tid, 0, min(nc, WG_ENV_CAP));
+            Cand ca, cb_;
+            issue(ca, tid, 0, min(nc, WG_ENV_CAP));
             WG_STAMP(11);
 
             // (1) emission records of this step, sin / cos of the yaw
@@ -477,21 +497,18 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
 
             // exact evaluation, one candidate per lane and batch; results staged per candidate, WG_ENV_CAP at a time
             const KArgsPtr ke2 = wg_cold_args();
-            const float dpart_f = ke2->p.dpart_f, inv_D = ke2->p.inv_D, D = ke2->p.D, dt = ke2->p.dt, R_rot = ke2->p.R_rot;
+            const float dpart_f = ke2->p.dpart_f, D = ke2->p.D, dt = ke2->p.dt, R_rot = ke2->p.R_rot;
             const float tia = ke2->p.no_ti_fold ? 0.f : ke2->p.tia, tib = ke2->p.tib, tid_ = ke2->p.tid, inv_S = ke2->p.inv_S;
             const int S = ke2->p.S;
             const float2* const rpt = reinterpret_cast<const float2*>(smem + ke2->p.env_off_tab + 8 * ke2->p.n_tab);
-            for (int c0 = 0; c0 < nc; c0 += WG_ENV_CAP) {
-                const int c1 = min(nc, c0 + WG_ENV_CAP);
-                if (c0 > 0) { lds_barrier<64>(); issue(nxt, c0 + tid, c0, c1); }
-                for (int cb = c0; cb < c1; cb += 64) {
-                    const Cand cd = nxt;
-                    issue(nxt, cb + 64 + tid, c0, c1);
-                    if (!cd.ok) continue;
-                    const int gt = cd.gt, gs = cd.gs;
+            auto eval_cand = [&](const Cand& cd, const int pos) __attribute__((always_inline)) {
+                    if (!cd.ok) return;
+                    const int gt = cd.en >> 5;
+                    const int kt = Lring[gt].w;
+                    const int gs = kt * N + (cd.en & 31);
                     const float4 st = Lsrc4[gt];
                     const float ysrc = Lsrc4[gs].y;
-                    const EnvSlotLds& q = SL[Lring[gt].w];
+                    const EnvSlotLds& q = SL[kt];
                     const int jp0 = cd.jp0, jp1 = jp0 + 1;
                     float py0 = cd.rest ? ysrc : cd.y0, py1 = cd.rest ? ysrc : cd.y1;
                     unsigned a0 = cd.q0.x, b0_ = cd.q0.y, a1 = cd.q1.x, b1_ = cd.q1.y;
@@ -513,20 +530,20 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
                     const float yc = w0 * py0 + w1 * py1;
                     const float kv = w0 * rec_k(a0) + w1 * rec_k(a1);
                     const float epv = w0 * rec_eps(b0_) + w1 * rec_eps(b1_);
-                    const float xd = (float)cd.dx * inv_D;
+                    const float xd = cd.xd;
                     const float sp = kv * xd + epv;
                     const float sig = sp * D;
                     const float yt = st.y;
                     const float rc2 = (yt - yc) * (yt - yc);      // (+ (hub - zc)^2 = 0: steady inflow keeps the wake centre at hub height)
                     const float rcut = R_rot + 5.0f * sig;
-                    if (rc2 > rcut * rcut) continue;
+                    if (rc2 > rcut * rcut) return;
                     const float ctv = w0 * rec_ct(a0) + w1 * rec_ct(a1);
                     const float uev = w0 * u0 + w1 * u1;
                     const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sig * sig);
                     const float cf = m0_cfrac(ctv, sp);
                     // wake-added turbulence (Crespo-Hernandez), Gaussian-weighted at the hub
                     const float ind = 0.5f * (1.0f - __builtin_amdgcn_sqrtf(1.0f - ctv));
-                    tiav[cd.pos] = tia * fast_pow(ind, tib) * q.ti_pow * fast_pow(fmaxf(xd, 1.0f), tid_) * __expf(-rc2 * inv2s2);
+                    tiav[pos] = tia * fast_pow(ind, tib) * q.ti_pow * fast_pow(fmaxf(xd, 1.0f), tid_) * __expf(-rc2 * inv2s2);
                     const float cgt = __uint_as_float(Lrec4[gt].w), amp = uev * cf;
                     const float ninv = -inv2s2;
                     float acc = 0.f;
@@ -536,8 +553,27 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
                         const float dy = yt + rp.x * cgt - yc;
                         acc += amp * __expf((dy * dy + rp.y) * ninv);
                     }
-                    def[cd.pos] = acc * inv_S;
+                    def[pos] = acc * inv_S;
+            };
+            for (int c0 = 0; c0 < nc; c0 += WG_ENV_CAP) {
+                const int c1 = min(nc, c0 + WG_ENV_CAP);
+                if (c0 > 0) { lds_barrier<64>(); issue(ca, c0 + tid, c0, c1); }
+                // (two candidate buffers, alternating: the next batch's gathers are in flight while this one is evaluated)
+#if WG_ENV_PP & 2
+                for (int cb = c0; cb < c1; cb += 128) {
+                    issue(cb_, cb + 64 + tid, c0, c1);
+                    eval_cand(ca, cb - c0 + tid);
+                    if (cb + 64 >= c1) break;
+                    issue(ca, cb + 128 + tid, c0, c1);
+                    eval_cand(cb_, cb + 64 - c0 + tid);
                 }
+#else
+                for (int cb = c0; cb < c1; cb += 64) {
+                    cb_ = ca;
+                    issue(ca, cb + 64 + tid, c0, c1);
+                    eval_cand(cb_, cb - c0 + tid);
+                }
+#endif
                 lds_barrier<64>();
                 // this target's slice of the round, in list order = ascending source order
                 if (stepping) {
@@ -595,10 +631,8 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
                         }
                     }
                 }
-                int inc = cnt;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (tid >= o) inc += v; }
-                nlist = __shfl(inc, 63, 64);
+                const int inc = env_scan(cnt, tid);
+                nlist = __builtin_amdgcn_readlane(inc, 63);
                 if (full) {
                     const int base = inc - cnt;
                     const unsigned tag = (unsigned)g << 10;
@@ -625,12 +659,8 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
                     r.rb = reinterpret_cast<const uint4*>(ra_env)[2u * r.q + 1u];
                 }
             };
-            QuadReq nq;
-            nq.py = make_float4(0.f, 0.f, 0.f, 0.f); nq.ra = nq.rb = make_uint4(0u, 0u, 0u, 0u);
-            request(nq, tid);
-            for (int cidx = tid; cidx < nlist; cidx += 64) {
-                const QuadReq cur = nq;
-                request(nq, cidx + 64);
+            auto advect_quad = [&](const QuadReq& cur, const int cidx) __attribute__((always_inline)) {
+                if (cidx >= nlist) return;
                 const int gq = cur.g, kq = cur.kq;
                 const unsigned q = cur.q;
                 const int4 rg = Lring[gq];
@@ -649,7 +679,8 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     int j = j0 - i; if (j < 0) j += R;
-                    if (j < n_valid_q) pyv[i] = m0_advect(pyv[i], rav[i], rbv[i], j, sof, dpart_f, inv_D, dt);
+                    const float adv = m0_advect(pyv[i], rav[i], rbv[i], j, sof, dpart_f, inv_D, dt);
+                    pyv[i] = j < n_valid_q ? adv : pyv[i];
                 }
                 const float y0 = Lsrc4[gq].y;
                 if (emits) {
@@ -674,7 +705,26 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
                     if (j < n_valid_q) ex = fmaxf(ex, fabsf(pyv[i] - y0));
                 }
                 if (ex > Lsrc2[gq].x) atomicMax(reinterpret_cast<int*>(&Lsrc2[gq].x), __float_as_int(ex));   // ex >= 0: int order == float order
+            };
+            // (two request buffers, alternating: no register copies between the trips)
+            QuadReq qa, qb;
+            qa.py = qb.py = make_float4(0.f, 0.f, 0.f, 0.f); qa.ra = qa.rb = qb.ra = qb.rb = make_uint4(0u, 0u, 0u, 0u);
+            request(qa, tid);
+#if WG_ENV_PP & 1
+            for (int base = 0; base < nlist; base += 128) {
+                request(qb, base + 64 + tid);
+                advect_quad(qa, base + tid);
+                if (base + 64 >= nlist) break;
+                request(qa, base + 128 + tid);
+                advect_quad(qb, base + 64 + tid);
             }
+#else
+            for (int base = 0; base < nlist; base += 64) {
+                qb = qa;
+                request(qa, base + 64 + tid);
+                advect_quad(qb, base + tid);
+            }
+#endif
         }
         lds_barrier<64>();
         WG_STAMP(3);
@@ -843,6 +893,11 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
 // k_flow_env<NOISE, 1 / 2>: step() as ONE launch — the env's wave runs its glue (lean_step: sums-mode handles without TI /
 // farm-level entries; 2 = with the per-agent observation buffer of the PettingZoo facade) as the tail of its flow step.  No
 // cross-workgroup dependency: the wave owns both contexts of its env.  (Wind_Farm_Env.py:920-1034 in one kernel.)
+// the kernel's arguments as they lie in the kernarg segment
+struct EnvKArgs {
+    FlowP p; FlowPtrs d; int mode; const float* actions; const uint8_t* mask; int chunk; WgParams gp; WgPtrs gd;
+    float* obs; float* reward; uint8_t* trunc; float* final_obs;
+};
 template <bool NOISE, int GLUE>
 __global__ void __launch_bounds__(64, WG_ENV_WAVES)
 k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __restrict__ actions,
@@ -856,7 +911,10 @@ k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __res
         // (every store of the flow part — rings, turbine state, headers, a prepared first observation — has left the wave
         // before the glue reads any of it back; LDS still holds the slots' records)
         full_barrier<64>();
-        const KArgsPtr kg = wg_cold_args();
+        // (the glue's parameter blocks are read where they are used, through the opaque kernarg pointer: by value they were all
+        // fetched at the kernel's entry and 130 of them parked in VGPR lanes across the flow step)
+        typedef const __attribute__((address_space(4))) EnvKArgs* EnvKArgsPtr;
+        const EnvKArgsPtr kg = (EnvKArgsPtr)wg_cold_args();
         const int F = kg->p.F, K = kg->p.K;
         const EnvSlotLds* const SL = reinterpret_cast<const EnvSlotLds*>(smem + WG_ENV_OFF_SL);
         const int la = fo.env_live * F, lb = (fo.env_live ^ 1) * F;
@@ -867,8 +925,8 @@ k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __res
         for (int f = 0; f < F; ++f) work = max(work, SL[lb + f].dev_rem + K * SL[lb + f].fill_rem);
         fz.work = work;
         fz.bg_init_pending = fo.bg_init_pending;
-        lean_step<GLUE == 2, false, true>(gp_, gd_, kg->d.gp, kg->d.gd, (int)blockIdx.x, (int)threadIdx.x, obs_out, reward_out, trunc_out,
-                                          final_obs_out, nullptr, fz);
+        lean_step<GLUE == 2, false, true>(*(const WgParams*)&kg->gp, *(const WgPtrs*)&kg->gd, kg->d.gp, kg->d.gd, (int)blockIdx.x,
+                                          (int)threadIdx.x, kg->obs, kg->reward, kg->trunc, kg->final_obs, nullptr, fz);
     }
 }
 
