@@ -359,7 +359,7 @@ def main():
         # profiles/r03_<cfgN>_kflow_traffic.json); `traffic_source` names the file.  Only quoted for the profiled
         # workloads at their profiled size (the workload's default env count, baseline farm on, one GPU).
         traffic = traffic_source = None
-        for rnd in ("r04", "r03", "r02"):
+        for rnd in ("r05", "r04", "r03", "r02"):
             tf = os.path.join(ROOT, "profiles", f"{rnd}_kflow_traffic.json" if args.workload == "cfg2" and rnd == "r02"
                               else f"{rnd}_{args.workload}_kflow_traffic.json")
             if os.path.exists(tf) and args.envs is None and F == 2 and world == 1:
@@ -370,6 +370,23 @@ def main():
                     break
                 except Exception:
                     traffic = traffic_source = None
+        variant = env.flow_variant()[2]
+        fused = variant == 2 and glue_ms == 0.0 and flow_ms > 0
+        if fused:
+            # step() is ONE launch (k_flow_env with the env's glue as its tail): the timed kernel carries the glue's bytes too
+            # (20 N + 12 O + 20 per env step)
+            alg_bytes_flow += B * (20.0 * cfg.n_turb + 12.0 * env.obs_dim + 20.0)
+            achieved = alg_bytes_flow / (flow_ms * 1e-3) / 1e9
+        # bytes of the particles the advection passes actually touched (k_flow_env counts them on the device; the `needed`
+        # particles of the algorithmic figure include the chains that rest and are not read at all)
+        touched = added if (variant == 2 and args.workload != "cfg5") else None
+        if touched is not None:
+            added = 0.0
+            alg_bytes_flow = particles * per_particle + flow_steps * per_farm_step + (B * (20.0 * cfg.n_turb + 12.0 * env.obs_dim + 20.0) if fused else 0.0)
+            achieved = alg_bytes_flow / (flow_ms * 1e-3) / 1e9 if flow_ms > 0 else 0.0
+            bytes_per_flow_step = alg_bytes_flow / flow_steps if flow_steps > 0 else 0.0
+        touched_bytes = (touched * per_particle + (alg_bytes_flow - particles * per_particle)) if touched is not None else None
+        kernel_name = {0: "k_flow", 1: "k_flow_duo", 2: "k_flow_env"}[variant] + (" (one launch per step: flow + glue tail)" if fused else "")
         out = {
             "metric": "env-steps/sec (whole node), 16-turbine farm x 4096 envs" if args.workload == "cfg2"
                       else f"env-steps/sec (whole node), {args.workload}",
@@ -392,7 +409,12 @@ def main():
             "rccl": rccl,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "k_flow_duo" if env.flow_variant()[2] else "k_flow",
+                         # the same launch on the bytes of the particles it actually touched, and on the HBM bytes the
+                         # counters saw (committed profile of this command): wasted re-reads show as frac_traffic > frac
+                         "frac_touched": (touched_bytes / (flow_ms * 1e-3) / 1e9 / 8000.0) if (touched_bytes and flow_ms > 0) else None,
+                         "frac_traffic": (traffic / (flow_ms * 1e-3) / 1e9 / 8000.0) if (traffic and flow_ms > 0) else None,
+                         "particles_touched_per_launch": touched,
+                         "kernel": kernel_name,
                          "kernel_ms": flow_ms, "glue_kernel_ms": glue_ms, "launches_timed": n_launch,
                          "algorithmic_bytes_per_launch": alg_bytes_flow, "farm_flow_steps_per_launch": flow_steps,
                          "particles_needed_per_launch": particles,

@@ -367,7 +367,10 @@ int wg_steady_power(wg_handle h, int model, int n_cases, const float* ws_dev, co
 
 /* Rotor points at which one flow launch looked the wake-added turbulence box up (8 corners x (u, v, w) = 96 bytes each:
  * only the rotors of targets with a candidate source wake do), averaged over the window the LAST wg_kernel_timing call
- * closed — the a7 term of bench.py's algorithmic bytes.  0 without wg_config.added_turbulence.                              */
+ * closed — the a7 term of bench.py's algorithmic bytes.  0 without wg_config.added_turbulence.
+ * Steady inflow on the one-wave-per-env kernel (wg_flow_variant: 2; no such lookups exist there): the same word counts the
+ * wake particles the advection passes actually touched per launch — moving chains whole, resting chains their new particles —
+ * the numerator of bench.py's roofline.frac_touched.                                                                          */
 int wg_added_lookups(wg_handle h, double* rotor_points_per_launch);
 
 /* Algorithmic HBM bytes one wg_step() moves (the figure bench.py's roofline uses).       */

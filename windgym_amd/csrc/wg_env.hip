@@ -63,7 +63,7 @@ struct __attribute__((aligned(16))) EnvSlotLds {
     int c_head;
     unsigned c_part, c_flow, c_istep, c_tag, n_emitted0;
     float out_pw;        // the env step's farm power: agent farm total / baseline farm (what k_glue reads as step_farm_pow / step_base_pow)
-    int pad_;
+    unsigned c_add;      // WgSlot::add_count, parked like the other cold words
 };
 static_assert(sizeof(EnvSlotLds) == WG_ENV_SLOT_LDS_BYTES, "keep WG_ENV_SLOT_LDS_BYTES in sync (wg_flow.h)");
 // fixed LDS layout (compile-time offsets from the dynamic LDS base: no address registers): cross-lane turbine fields, indexed
@@ -192,7 +192,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
         const unsigned tcx = ctx_id * (unsigned)N + (unsigned)t;
 
         int dev_rem, fill_rem, n_pushed, pend_farm_n, pend_base_n, init_pending, time_max_c, n_valid, c_head;
-        unsigned n_emitted, c_part, c_flow, c_istep, c_tag;
+        unsigned n_emitted, c_part, c_flow, c_istep, c_tag, c_add;
         double s_off, ws, l_xr, l_yr, c_time;
         float ti_f, wd_env, l_yaw, l_u, l_ti, l_act;
         float4 l_bnd;
@@ -203,7 +203,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
             const WgCtx& cx = kl->d.ctx[ctx_id];
             dev_rem = slot.dev_remaining; fill_rem = slot.fill_remaining;
             s_off = slot.s_off; c_time = slot.time; c_head = slot.head; n_valid = slot.n_valid; c_istep = slot.istep;
-            n_emitted = slot.n_emitted; c_part = slot.part_count; c_flow = slot.flow_count;
+            n_emitted = slot.n_emitted; c_part = slot.part_count; c_flow = slot.flow_count; c_add = slot.add_count;
             ws = cx.ws; ti_f = (float)cx.ti; wd_env = (float)cx.wd;
             n_pushed = cx.n_pushed; pend_farm_n = cx.pend_farm_n; pend_base_n = cx.pend_base_n;
             c_tag = (unsigned)cx.episode_tag; init_pending = cx.init_pending; time_max_c = cx.time_max;
@@ -281,7 +281,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
                 my.move_max = fabsf(k1->p.hill) * ws_f * k1->p.dt; my.ti_pow = fast_pow(ti_f, k1->p.tic);
                 my.s_off = s_off; my.ws = ws; my.ws_f = ws_f; my.ti_f = ti_f; my.wd_env = wd_env; my.base_acc = 0.f;
                 my.n_pushed = n_pushed; my.pend_farm_n = pend_farm_n; my.pend_base_n = pend_base_n; my.n_flow = 0;
-                my.c_time = c_time; my.c_head = c_head; my.c_part = c_part; my.c_flow = c_flow; my.c_istep = c_istep; my.c_tag = c_tag;
+                my.c_time = c_time; my.c_head = c_head; my.c_part = c_part; my.c_flow = c_flow; my.c_istep = c_istep; my.c_tag = c_tag; my.c_add = c_add;
             }
         }
         // tables: power | ct | rotor points as (lateral offset, squared vertical offset from the wake centre height)
@@ -318,7 +318,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
     }
     float tpow = 0.f, tct = 0.f, cg = 1.f;
     float sws = 0.f, swd = 0.f, syaw = 0.f, sp_ = 0.f;
-    int part_acc = 0;
+    int part_acc = 0, stream_acc = 0;
     bool stepped = false;
     lds_barrier<64>();
     WG_STAMP(1);
@@ -614,6 +614,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
                     nqd = rlen >> 2;
                     const bool moving = mvl != 0u && (int)(my.n_emitted - mvl) < rlen;
                     full = moving || n_emit >= 4 || n_emit >= rlen;
+                    stream_acc += full ? rlen : n_emit;        // roofline accounting: particles this step reads or writes
                     if (full) cnt = nqd;
                     else if (n_emit > 0) {
                         const unsigned sb = (unsigned)k * pstride + (unsigned)rg.x;
@@ -844,6 +845,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
     // ---- epilogue: the env's slots back to memory (the slots that took a step) ---------------------------------------------
     const KArgsPtr ke = wg_cold_args();
     const float part_slot = env_slot_sums((float)part_acc, N, NS, k, tid);      // (exact: far below 2^24)
+    const float stream_slot = env_slot_sums((float)stream_acc, N, NS, k, tid);
     if (valid && stepped) {
         const unsigned tb = (unsigned)(e * NL + g);
         const float4 s4 = Lsrc4[g];
@@ -861,6 +863,8 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
             int hd = my.c_head + (int)((n_emitted - my.n_emitted0) % (unsigned)P); if (hd >= P) hd -= P;
             WgSlot& slot = ke->d.slot[(unsigned)(e * NS + k)];
             slot.part_count = my.c_part + (unsigned)part_slot;
+            slot.add_count = my.c_add + (unsigned)stream_slot;      // (steady inflow: no wake-added turbulence lookups — the word counts the
+                                                          // particles the advection passes actually touched, wg_added_lookups)
             slot.head = hd; slot.n_valid = my.n_valid; slot.s_off = my.s_off; slot.time = tm;
             slot.istep = my.c_istep + (unsigned)n_flow; slot.n_emitted = n_emitted;
             slot.dev_remaining = my.dev_rem; slot.fill_remaining = my.fill_rem;
