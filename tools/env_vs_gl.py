@@ -17,12 +17,15 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 
 
-MODE = sys.argv[3] if len(sys.argv) > 3 else "gl"      # "gl": env kernel vs GL; "fused": fused step vs flow + glue launches
+MODE = sys.argv[3] if len(sys.argv) > 3 else "gl"      # "gl": env kernel vs GL; "fused": fused step vs flow + glue launches; "wpe"
 
 
 def make(d, envw, **kw):
     if MODE == "fused":
         os.environ["WG_STEP_FUSED"] = "1" if envw else "0"
+        envw = True
+    if MODE == "wpe":      # two waves per env (one per context) against one wave per env, both with the fused glue
+        os.environ["WG_ENV_WPE"] = "2" if envw else "1"
         envw = True
     os.environ["WG_FLOW_ENV"] = "1" if envw else "0"
     os.environ["WG_FLOW_DUO"] = "0"
@@ -34,6 +37,7 @@ def make(d, envw, **kw):
         del os.environ["WG_FLOW_ENV"]
         del os.environ["WG_FLOW_DUO"]
         os.environ.pop("WG_STEP_FUSED", None)
+        os.environ.pop("WG_ENV_WPE", None)
     assert env.flow_variant()[2] == (2 if envw else 0), env.flow_variant()
     if kw.pop("multi", False):
         env.fuse_obs_multi()

@@ -1,25 +1,37 @@
 # usage (GPU box): WL=cfg2 bash tools/timeline_env.sh [extra bench args]  -> per-phase cycles of k_flow_env's waves (one flow round)
 cd $GRAFT_REPO_ROOT
-export WG_DEBUG_HOOKS=1
+export WG_DEBUG_HOOKS=1 WG_FLOW_ENV=1
 cp windgym_amd/libwindgym_hip.so /tmp/lib_keep.so
 WG_HIPCC_FLAGS="-DWG_TIMELINE $XF" python windgym_amd/build.py > /dev/null 2>&1
 WG_TIMELINE_OUT=gpurun_out/timeline_env.bin python bench.py --workload ${WL:-cfg2} --steps 60 --warmup 10 --reps 1 --no-cpu "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('value', d['value'], 'kflow ms', d['roofline']['kernel_ms'])"
 cp /tmp/lib_keep.so windgym_amd/libwindgym_hip.so
 python - <<'PY'
 import numpy as np
-raw = np.fromfile('gpurun_out/timeline_env.bin', dtype=np.int64).reshape(-1, 16)
+raw = np.fromfile('gpurun_out/timeline_env.bin', dtype=np.int64).reshape(-1, 32)
 ok = (raw[:, 8] > raw[:, 0]) & (raw[:, 0] > 0) & (raw[:, 7] > raw[:, 6]) & (raw[:, 6] > raw[:, 3]) & (raw[:, 4] > raw[:, 1])
 a = raw[ok]
 print('waves with a consistent single round:', len(a), 'of', len(raw))
 seq = [(0, 1, 'prologue: headers + state loads + LDS set-up'), (1, 4, 'roles, clocks published'), (4, 5, 'candidate pass + list offsets'),
        (5, 11, 'first batch of bracket gathers issued'), (11, 2, 'records'), (2, 9, 'evaluation batches + sums'),
        (9, 10, 'quad list (+ direct emission stores)'), (10, 3, 'advection pass'), (3, 6, 'clock advance'),
-       (6, 7, 'tail (power, measurement, ring push, farm sums, schedule)'), (7, 8, 'epilogue (state stores, accounting)')]
-tot = a[:, 8] - a[:, 0]
+       (6, 7, 'tail (power, measurement, ring push, farm sums, schedule)'), (7, 8, 'epilogue (state stores, accounting)'),
+       (8, 12, 'store drain before the glue'), (12, 13, 'glue (lean_step)')]
+fin = np.where(a[:, 13] > 0, a[:, 13], a[:, 8])
+tot = fin - a[:, 0]
 print('total: mean %.0f median %.0f p10 %.0f p90 %.0f' % (tot.mean(), np.median(tot), np.percentile(tot, 10), np.percentile(tot, 90)))
 for i, j, n in seq:
+    if (a[:, j] <= 0).all() or (a[:, i] <= 0).all():
+        continue
     d = a[:, j] - a[:, i]
     print(f'{n:62s} mean {d.mean():8.0f}  median {np.median(d):8.0f}  p90 {np.percentile(d, 90):8.0f}')
-st = a[:, 0] - a[:, 0].min()
-print('start spread of the waves (cycles): median %.0f p90 %.0f max %.0f ; last end %.0f' % (np.median(st), np.percentile(st, 90), st.max(), (a[:, 8] - a[:, 0].min()).max()))
+w0, w1 = a[:, 14], a[:, 15]
+t0 = w0.min()
+print('wall clock (100 MHz ticks -> us): wave starts median %.2f p90 %.2f max %.2f ; wave ends median %.2f p90 %.2f max %.2f ; wave life median %.2f us' % (
+    np.median(w0 - t0) / 100, np.percentile(w0 - t0, 90) / 100, (w0 - t0).max() / 100, np.median(w1 - t0) / 100, np.percentile(w1 - t0, 90) / 100, (w1 - t0).max() / 100, np.median(w1 - w0) / 100))
+life = (w1 - w0) / 100
+for name, sel in (('episode set-up at the head of the launch', a[:, 16] != 0), ('two or more flow rounds', a[:, 17] >= 2), ('first observation built', a[:, 18] != 0),
+                  ('swapped (timestep 0 after the glue)', a[:, 19] == 0), ('none of these', (a[:, 16] == 0) & (a[:, 17] < 2) & (a[:, 18] == 0) & (a[:, 19] != 0))):
+    if sel.any():
+        print('  waves with %-44s n %5d  life us: median %.2f max %.2f' % (name, sel.sum(), np.median(life[sel]), life[sel].max()))
+print('core clock (cycles per us of wave life): %.0f' % np.median(tot / np.maximum((w1 - w0) / 100, 1e-9)))
 PY

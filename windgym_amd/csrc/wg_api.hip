@@ -588,14 +588,15 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             if (f.env_lds > 32768 || f.env_lds > lds_limit) env_ok = false;
             f.env_eps_max = std::min(1.0f, (float)(p.eps0 * std::sqrt(3.0))) + 2.0f / 65535.0f;
             const bool asked_old = wg_hook("WG_FLOW_BLOCK") || wg_hook("WG_FLOW_RES") || wg_hook("WG_FLOW_DUO");
-            // One wave per env walks a longer chain of dependent phases than one wave per farm slot (40 k against 32 k cycles on
-            // cfg2) and uses a quarter of the waves: below ~2048 envs a launch is a latency chain, not throughput, and the
-            // per-slot kernels win (cfg2, ms per step, env kernel + fused glue / k_flow + k_glue_lean: 256 envs 0.0318 / 0.0260,
-            // 1024: 0.0387 / 0.0322, 2048: 0.0436 / 0.0435, 4096: 0.0631 / 0.0682)
-            const bool big = p.B >= 2048;
-            f.envw = (env_ok && !asked_old && big) ? 1 : 0;
+            f.envw = (env_ok && !asked_old) ? 1 : 0;
             if (const char* ev = wg_hook("WG_FLOW_ENV")) f.envw = (env_ok && atoi(ev) != 0) ? 1 : 0;
             if (f.envw) f.duo = 0;
+            // waves per env: two (one per context, side by side, meeting only when the env truncates) while every env's pair of
+            // waves is resident at once — 2048 envs fill the chip's 4096 wave slots; beyond that one wave per env (cfg2 ms per
+            // step, two waves / one wave / per-slot kernels + k_glue_lean: 256 envs 0.0231 / 0.0294 / 0.0260, 1024: 0.0276 /
+            // 0.0360 / 0.0322, 2048: 0.0340 / 0.0411 / 0.0435, 4096: 0.0643 / 0.0624 / 0.0682)
+            f.env_wpe = (p.B <= 2048 && 2 * f.env_lds <= lds_limit) ? 2 : 1;
+            if (const char* ev = wg_hook("WG_ENV_WPE")) f.env_wpe = (atoi(ev) == 2 && 2 * f.env_lds <= lds_limit) ? 2 : 1;
         }
         // packed emission record: two arrays, or one interleaved (ct|k, eps|hv) array for the GL variant
         f.rec_il = (f.gl && !f.duo) ? 1 : 0;

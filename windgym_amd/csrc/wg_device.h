@@ -272,8 +272,14 @@ struct WgRng {
 // remains: the episode is ready exactly at truncation.  (ceil(work/left) — the first version — front-loads: a
 // background episode needing 280 steps during a 600-step episode ran on each of the first 280 launches, so after a
 // synchronised start every launch carried twice the flow work of the steady state.)
+#ifndef WG_SHADOW_MARGIN
+#define WG_SHADOW_MARGIN 2
+#endif
 __device__ inline int wg_shadow_share(const int work, long left, const int steps_done, const int e) {
     if (work <= 0) return 0;
+    // (finished WG_SHADOW_MARGIN steps EARLY: the launch of the truncating step then carries no background work, first
+    // observation included — in the one-wave-per-env kernels the truncating wave is the launch's last one anyway)
+    left -= WG_SHADOW_MARGIN;
     if (left < 1) left = 1;
     const uint32_t phi24 = ((uint32_t)steps_done * 2654435769u + (uint32_t)e * 0x9E3779B1u) >> 8;   // [0, 2^24)
     // float arithmetic (a 64-bit integer division costs ~150 instructions on this kernel's latency chain): rcp(1) is

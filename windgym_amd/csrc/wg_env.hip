@@ -38,6 +38,10 @@
 #ifndef WG_ENV_DPP_SCAN
 #define WG_ENV_DPP_SCAN 1   // list offsets from DPP prefix sums (0: __shfl_up ladders, for A/B builds: 67.0 / 52.2 against 67.8 / 53.5)
 #endif
+#ifndef WG_ENV_PRIO
+#define WG_ENV_PRIO 0       // 1: waves on a rare, long path raise their issue priority — measured slightly SLOWER (cfg2 65.2 vs 66.5, cfg4
+                            // 54.3 vs 54.9 M env-steps/s): their extra time is their own latency chain, not contention
+#endif
 #ifndef WG_ENV_WAVES
 #define WG_ENV_WAVES 4      // 128 VGPRs: 4096 envs = the chip's 4096 wave slots at 4 waves per SIMD, one dispatch round
 #endif
@@ -64,6 +68,8 @@ struct __attribute__((aligned(16))) EnvSlotLds {
     unsigned c_part, c_flow, c_istep, c_tag, n_emitted0;
     float out_pw;        // the env step's farm power: agent farm total / baseline farm (what k_glue reads as step_farm_pow / step_base_pow)
     unsigned c_add;      // WgSlot::add_count, parked like the other cold words
+    int bg_init;         // (slot 0 of a background context's wave, WPE 2) its set-up flag was pending at the head of this launch
+    int pad_[3];
 };
 static_assert(sizeof(EnvSlotLds) == WG_ENV_SLOT_LDS_BYTES, "keep WG_ENV_SLOT_LDS_BYTES in sync (wg_flow.h)");
 // fixed LDS layout (compile-time offsets from the dynamic LDS base: no address registers): cross-lane turbine fields, indexed
@@ -140,25 +146,38 @@ __device__ __forceinline__ float env_tab(const float* __restrict__ ys, const flo
 // Every phase fetches the parameters it needs through a fresh opaque pointer to the kernarg segment (wg_cold_args: scalar
 // loads that hit the constant cache) — nothing is held in SGPRs across phases, so nothing overflows into VGPR lanes
 // (v_readlane / v_writelane are VALU instructions: they were 15 % of what k_flow executed).
+__device__ __forceinline__ bool role_dev_any(const int autoreset, const int dev_rem, const int fill_rem) {
+    return autoreset != 0 && (dev_rem > 0 || fill_rem > 0);
+}
 struct EnvFlowOut {          // what the flow part hands to the glue tail of k_step_env
     int env_live, bg_init_pending;
+    int truncates;            // the env truncates in this step (known from its header): the only case in which the glue needs the
+                              // background context's wave to have finished (WPE 2)
+    int rounds, first_obs;    // (WG_TIMELINE builds: flow rounds taken, first observation of a completed background episode built)
 };
-template <bool NOISE>
-__device__ __forceinline__ void env_flow(char* const smem, const int mode, const float* __restrict__ actions,
+// WPE = waves per env.  1: one wave serves all 2 F slots of the env (lane = slot * N + turbine).  2: a workgroup of two waves
+// per env, wave c serves the F slots of context c (lane = farm * N + turbine) in its own LDS region — the running episode's
+// step and the background episode's development then run side by side instead of one after the other, and the rare long
+// paths of the background context (episode set-up, a second flow step, the first observation) are off the live wave's chain;
+// the waves meet at ONE workgroup barrier before the live context's wave runs the glue (k_flow_env).  `smem` is the wave's
+// own region, `wv` its context.
+template <bool NOISE, int WPE>
+__device__ __forceinline__ void env_flow(char* const smem, const int wv, const int mode, const float* __restrict__ actions,
                                          const uint8_t* __restrict__ mask, const int chunk, EnvFlowOut& out) {
-    const int tid = threadIdx.x, e = blockIdx.x;
+    const int tid = threadIdx.x & 63, e = blockIdx.x;
     int N, F, NS, NL;
     float inv_N;
     {
         const KArgsPtr ka = wg_cold_args();
         N = ka->p.N; F = ka->p.F; inv_N = ka->p.inv_N;
-        NS = 2 * F; NL = NS * N;
+        NS = WPE == 2 ? F : 2 * F; NL = NS * N;              // slots / lanes served by THIS wave
     }
+    const int kbase = WPE == 2 ? wv * F : 0;                // the wave's first slot of the env
     const bool valid = tid < NL;
     const int g = valid ? tid : 0;
-    const int k = (int)(((float)g + 0.5f) * inv_N);         // slot of the env: ctx * F + farm
+    const int k = (int)(((float)g + 0.5f) * inv_N);         // slot of the wave (WPE 1: of the env = ctx * F + farm)
     const int t = g - k * N;
-    const int c = F == 2 ? (k >> 1) : k, farm = F == 2 ? (k & 1) : 0;
+    const int c = WPE == 2 ? wv : (F == 2 ? (k >> 1) : k), farm = F == 2 ? (k & 1) : 0;
 
     float4* const Lsrc4 = reinterpret_cast<float4*>(smem + WG_ENV_OFF_SRC4);
     uint4* const Lrec4 = reinterpret_cast<uint4*>(smem + WG_ENV_OFF_REC4);
@@ -182,13 +201,14 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
         const KArgsPtr k0 = wg_cold_args();
         const CEnvPtr envc = (CEnvPtr)(k0->d.env + e);
         env_live = envc->live;
-        out.env_live = env_live; out.bg_init_pending = 0;
+        out.env_live = env_live; out.bg_init_pending = 0; out.rounds = 0; out.first_obs = 0;
+        out.truncates = envc->timestep >= envc->time_max_live;
         const int env_done = envc->done, env_shadow_iters = envc->shadow_iters, env_steps_done = envc->steps_done;
         const bool use_mask = mode == WG_MODE_RESET && mask != nullptr;
         const uint8_t mask_byte = *(use_mask ? mask + e : reinterpret_cast<const uint8_t*>(k0->d.env + e));
         const bool masked_out = use_mask && mask_byte == 0;
-        const unsigned ctx_id = (unsigned)(e * 2 + c), slot_id = (unsigned)(e * NS + k);
-        const unsigned tb = (unsigned)(e * NL + g);             // == slot_id * N + t
+        const unsigned ctx_id = (unsigned)(e * 2 + c), slot_id = (unsigned)(e * 2 * F + kbase + k);
+        const unsigned tb = (unsigned)((e * 2 * F + kbase) * N + g);      // == slot_id * N + t
         const unsigned tcx = ctx_id * (unsigned)N + (unsigned)t;
 
         int dev_rem, fill_rem, n_pushed, pend_farm_n, pend_base_n, init_pending, time_max_c, n_valid, c_head;
@@ -236,8 +256,9 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
         if (mode == WG_MODE_STEP) {
             role_live = is_live_c && !env_done;
             role_dev = !is_live_c && autoreset != 0;
-            // (wave-uniform: both contexts' lanes see the background context's flag through their own loads)
-            const int bg_pending = __shfl(init_pending, (env_live ^ 1) * F * N, 64);
+            // (wave-uniform: both contexts' lanes see the background context's flag through their own loads; WPE 2: the
+            // background context's wave sees its own, the live wave gets it through LDS after the barrier)
+            const int bg_pending = WPE == 2 ? (is_live_c ? 0 : __shfl(init_pending, 0, 64)) : __shfl(init_pending, (env_live ^ 1) * F * N, 64);
             out.bg_init_pending = autoreset && bg_pending;
             if (autoreset && bg_pending) {
                 // rare path (one context per truncation): set the retired context's next episode up, both farms (see k_flow)
@@ -248,9 +269,9 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
                 load_state();
                 const int fill_max = F == 2 ? max(gp.fill_a, gp.fill_b) : gp.fill_a;
                 const int inc = 1 + (gp.extra_inc ? 1 : 0);
-                const int tm = __shfl(time_max_c, env_live * F * N, 64);
+                const int tm = WPE == 2 ? ki->d.ctx[e * 2 + env_live].time_max : __shfl(time_max_c, env_live * F * N, 64);
                 const long total = (long)((tm + inc - 1) / inc) + 1;
-                const int dev0 = __shfl(dev_rem, (env_live ^ 1) * F * N, 64);
+                const int dev0 = __shfl(dev_rem, WPE == 2 ? 0 : (env_live ^ 1) * F * N, 64);
                 budget = wg_shadow_share(dev0 + gp.K * fill_max, total - env_steps_done, env_steps_done, e);
             } else {
                 budget = env_shadow_iters;
@@ -259,10 +280,30 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
             role_dev = is_live_c && !masked_out;
             budget = chunk;
         }
+        if (WPE == 2 && valid && t == 0) {      // (what the other wave's glue reads of this one, also if it has nothing to do)
+            my.dev_rem = dev_rem; my.fill_rem = fill_rem; my.bg_init = out.bg_init_pending; my.n_flow = 0; my.out_pw = 0.f;
+        }
         {   // nothing to do for the whole env (masked out in RESET mode, finished env without autoreset, idle background)
             const bool any_work = valid && (role_live || (role_dev && budget > 0 && (dev_rem > 0 || fill_rem > 0)));
             if (!__ballot(any_work)) return;
         }
+#if WG_ENV_PRIO
+        static_assert(WPE == 1, "WG_ENV_PRIO: one wave per env only");
+        // The launch lasts as long as its slowest wave, and with ONE wave per env and one dispatch round the slowest waves are
+        // the handful per launch on a rare path — episode set-up at the head of the launch, a background context that takes
+        // two or more flow steps, the first observation of a completed episode, the swap at truncation (cfg2 x 4096: their
+        // waves lived 51-58 us against 40 for the rest and WERE the kernel's last 7 us; cfg4: 28-33 against 21).  They are
+        // known here, before the work starts: such a wave raises its issue priority over the three it shares its SIMD with.
+        if (mode == WG_MODE_STEP) {
+            const int bl = (env_live ^ 1) * F * N;              // the background context's agent-farm lane 0
+            const int b_dev = __shfl(dev_rem, bl, 64), b_fill = __shfl(fill_rem, bl, 64);
+            const bool bg_active = role_dev_any(autoreset, b_dev, b_fill);
+            const bool multi_round = bg_active && budget >= 2 && b_dev + b_fill >= 2;
+            const bool completes = bg_active && b_dev + k0->p.K * b_fill <= budget;
+            const bool truncates = envc->timestep >= envc->time_max_live;
+            if (out.bg_init_pending || multi_round || completes || truncates) __builtin_amdgcn_s_setprio(3);
+        }
+#endif
 
         // ---- state into LDS ---------------------------------------------------------------------------------------------
         const KArgsPtr k1 = wg_cold_args();
@@ -281,6 +322,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
                 my.move_max = fabsf(k1->p.hill) * ws_f * k1->p.dt; my.ti_pow = fast_pow(ti_f, k1->p.tic);
                 my.s_off = s_off; my.ws = ws; my.ws_f = ws_f; my.ti_f = ti_f; my.wd_env = wd_env; my.base_acc = 0.f;
                 my.n_pushed = n_pushed; my.pend_farm_n = pend_farm_n; my.pend_base_n = pend_base_n; my.n_flow = 0;
+                my.bg_init = out.bg_init_pending;
                 my.c_time = c_time; my.c_head = c_head; my.c_part = c_part; my.c_flow = c_flow; my.c_istep = c_istep; my.c_tag = c_tag; my.c_add = c_add;
             }
         }
@@ -335,6 +377,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
             is_dev = !role_live && sch.x > 0;
             sub = sch.z;
             if (!__ballot(stepping)) break;
+        out.rounds = round + 1;
             // (a further flow step of the launch gathers what the previous one's advection pass stored)
             if (round > 0) full_barrier<64>();
 
@@ -423,7 +466,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
         {
             const KArgsPtr kp = wg_cold_args();
             const unsigned pstride = (unsigned)kp->p.pstride;
-            const size_t pb_env = (size_t)e * NS * pstride;       // particle block of the env's slot 0 (slot k: + k * pstride)
+            const size_t pb_env = (size_t)(e * 2 * F + kbase) * pstride;      // particle block of the wave's slot 0 (slot k: + k * pstride)
             const uint4* const r4_env = kp->d.rec4 + pb_env;
             const float* const py_env = kp->d.py + pb_env;
             const double inv_dpart = kp->p.inv_dpart;
@@ -597,7 +640,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
         {
             const KArgsPtr kp = wg_cold_args();
             const unsigned pstride = (unsigned)kp->p.pstride;
-            const size_t pb_env = (size_t)e * NS * pstride;
+            const size_t pb_env = (size_t)(e * 2 * F + kbase) * pstride;
             float* const py_env = kp->d.py + pb_env;
             unsigned* const ra_env = kp->d.rec_a + 2 * pb_env;        // interleaved (ct|k, eps|hv) record
             uint4* const r4_env = kp->d.rec4 + pb_env;
@@ -847,7 +890,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
     const float part_slot = env_slot_sums((float)part_acc, N, NS, k, tid);      // (exact: far below 2^24)
     const float stream_slot = env_slot_sums((float)stream_acc, N, NS, k, tid);
     if (valid && stepped) {
-        const unsigned tb = (unsigned)(e * NL + g);
+        const unsigned tb = (unsigned)((e * 2 * F + kbase) * N + g);
         const float4 s4 = Lsrc4[g];
         const float2 s2 = Lsrc2[g];
         ke->d.yaw[tb] = yaw; ke->d.u[tb] = tu; ke->d.v[tb] = 0.f; ke->d.w[tb] = 0.f;
@@ -861,7 +904,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
             for (int i = 0; i < n_flow; ++i) tm += dt_d;
             const unsigned n_emitted = my.n_emitted;
             int hd = my.c_head + (int)((n_emitted - my.n_emitted0) % (unsigned)P); if (hd >= P) hd -= P;
-            WgSlot& slot = ke->d.slot[(unsigned)(e * NS + k)];
+            WgSlot& slot = ke->d.slot[(unsigned)(e * 2 * F + kbase + k)];
             slot.part_count = my.c_part + (unsigned)part_slot;
             slot.add_count = my.c_add + (unsigned)stream_slot;      // (steady inflow: no wake-added turbulence lookups — the word counts the
                                                           // particles the advection passes actually touched, wg_added_lookups)
@@ -874,18 +917,14 @@ __device__ __forceinline__ void env_flow(char* const smem, const int mode, const
             if (farm == F - 1) cx.pend_base_n = my.pend_base_n;
         }
     }
-#ifdef WG_TIMELINE
-    if (tid == 0 && ke->d.dbg) {
-        wg_stamps[8] = clock64();
-        for (int kq = 0; kq < 16; ++kq) ke->d.dbg[(size_t)blockIdx.x * 16 + kq] = wg_stamps[kq];
-    }
-#endif
+    WG_STAMP(8);
     // a background episode whose agent farm completed its development in this launch: its window sums and first
     // observation are prepared for the swap (wg_first_obs, see k_flow)
-    if (mode == WG_MODE_STEP) {
-        const EnvSlotLds& bs = SL[(env_live ^ 1) * F];      // the background context's agent farm
+    if (mode == WG_MODE_STEP && (WPE == 1 || c != env_live)) {
+        const EnvSlotLds& bs = SL[WPE == 2 ? 0 : (env_live ^ 1) * F];      // the background context's agent farm
         if (bs.n_flow > 0 && bs.dev_rem == 0 && bs.fill_rem == 0) {
             const int np = bs.n_pushed;
+            out.first_obs = 1;
             full_barrier<64>();                            // the ring pushes have left the wave
             wg_first_obs(ke->d.gp, ke->d.gd, e * 2 + (env_live ^ 1), np, tid);
         }
@@ -902,56 +941,110 @@ struct EnvKArgs {
     FlowP p; FlowPtrs d; int mode; const float* actions; const uint8_t* mask; int chunk; WgParams gp; WgPtrs gd;
     float* obs; float* reward; uint8_t* trunc; float* final_obs;
 };
-template <bool NOISE, int GLUE>
-__global__ void __launch_bounds__(64, WG_ENV_WAVES)
+template <bool NOISE, int GLUE, int WPE>
+__global__ void __launch_bounds__(64 * WPE, WG_ENV_WAVES)
 k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __restrict__ actions,
            const uint8_t* __restrict__ mask, const int chunk, const WgParams gp_, const WgPtrs gd_,
            float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out,
            float* __restrict__ final_obs_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef WG_TIMELINE
+    if (threadIdx.x == 0) { for (int i = 0; i < 16; ++i) wg_stamps[i] = 0; wg_stamps[14] = wall_clock64(); }
+#endif
+    // (WPE 2: wave c of the workgroup serves context c of the env, in its own LDS region)
+    const int wv = WPE == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int lds_wave = WPE == 2 ? wg_cold_args()->p.env_lds : 0;
+    char* const sm = smem + wv * lds_wave;
     EnvFlowOut fo;
-    env_flow<NOISE>(smem, mode, actions, mask, chunk, fo);
+    env_flow<NOISE, WPE>(sm, wv, mode, actions, mask, chunk, fo);
     if (GLUE != 0) {
-        // (every store of the flow part — rings, turbine state, headers, a prepared first observation — has left the wave
-        // before the glue reads any of it back; LDS still holds the slots' records)
-        full_barrier<64>();
-        // (the glue's parameter blocks are read where they are used, through the opaque kernarg pointer: by value they were all
-        // fetched at the kernel's entry and 130 of them parked in VGPR lanes across the flow step)
         typedef const __attribute__((address_space(4))) EnvKArgs* EnvKArgsPtr;
-        const EnvKArgsPtr kg = (EnvKArgsPtr)wg_cold_args();
-        const int F = kg->p.F, K = kg->p.K;
-        const EnvSlotLds* const SL = reinterpret_cast<const EnvSlotLds*>(smem + WG_ENV_OFF_SL);
-        const int la = fo.env_live * F, lb = (fo.env_live ^ 1) * F;
-        LeanFused fz;
-        fz.fp = SL[la].out_pw;
-        fz.bp = F == 2 ? SL[la + 1].out_pw : 0.f;
-        int work = 0;
-        for (int f = 0; f < F; ++f) work = max(work, SL[lb + f].dev_rem + K * SL[lb + f].fill_rem);
-        fz.work = work;
-        fz.bg_init_pending = fo.bg_init_pending;
-        lean_step<GLUE == 2, false, true>(*(const WgParams*)&kg->gp, *(const WgPtrs*)&kg->gd, kg->d.gp, kg->d.gd, (int)blockIdx.x,
-                                          (int)threadIdx.x, kg->obs, kg->reward, kg->trunc, kg->final_obs, nullptr, fz);
+        // (every store of the flow part — rings, turbine state, headers, a prepared first observation — has left the wave
+        // before anything reads it back; LDS still holds the slots' records)
+        full_barrier<64>();
+        if (WPE == 2) {
+            // Two waves per env.  The glue needs nothing of the background context's wave unless the env truncates in this step
+            // (then it swaps that context in): the waves meet at a workgroup barrier ONLY then — both know from the env's header
+            // — and otherwise run to their ends side by side: the background wave plans its own next share and clears its
+            // set-up flag, which the glue does for one wave per env.
+            if (wv != fo.env_live) {
+                const EnvKArgsPtr kb = (EnvKArgsPtr)wg_cold_args();
+                const int e = (int)blockIdx.x;
+                if (kb->p.autoreset && !fo.truncates && (threadIdx.x & 63) == 0) {
+                    const int F = kb->p.F, K = kb->p.K;
+                    const EnvSlotLds* const SLb = reinterpret_cast<const EnvSlotLds*>(sm + WG_ENV_OFF_SL);
+                    int work = 0;
+                    for (int f = 0; f < F; ++f) work = max(work, SLb[f].dev_rem + K * SLb[f].fill_rem);
+                    typedef const __attribute__((address_space(4))) WgEnv* CEnvPtr;
+                    const CEnvPtr envc = (CEnvPtr)(kb->d.env + e);
+                    const int steps_done = envc->steps_done + 1, time_max = envc->time_max_live;      // (as the glue sees them)
+                    const int inc = 1 + (kb->gp.extra_inc ? 1 : 0);
+                    const long total = (long)((time_max + inc - 1) / inc) + 1;
+                    kb->d.env_rw[e].shadow_iters = work == 0 ? 0 : wg_shadow_share(work, total - steps_done, steps_done, e);
+                }
+                if (fo.bg_init_pending && (threadIdx.x & 63) == 0) kb->d.ctx[e * 2 + wv].init_pending = 0;
+                if (fo.truncates) __builtin_amdgcn_s_waitcnt(0x0070);       // (its last stores, before the barrier releases the glue)
+            }
+            if (fo.truncates) __syncthreads();
+        }
+        if (WPE == 1 || wv == fo.env_live) {
+            // (the glue's parameter blocks are read where they are used, through the opaque kernarg pointer: by value they were
+            // all fetched at the kernel's entry and 130 of them parked in VGPR lanes across the flow step)
+            const EnvKArgsPtr kg = (EnvKArgsPtr)wg_cold_args();
+            const int F = kg->p.F, K = kg->p.K;
+            const EnvSlotLds* const SLa = reinterpret_cast<const EnvSlotLds*>(sm + WG_ENV_OFF_SL);      // the live context's slots
+            const int la = WPE == 2 ? 0 : fo.env_live * F, lb = (fo.env_live ^ 1) * F;
+            LeanFused fz;
+            fz.fp = SLa[la].out_pw;
+            fz.bp = F == 2 ? SLa[la + 1].out_pw : 0.f;
+            int work = 0;
+            if (WPE == 1) for (int f = 0; f < F; ++f) work = max(work, SLa[lb + f].dev_rem + K * SLa[lb + f].fill_rem);
+            fz.work = work;
+            fz.bg_init_pending = WPE == 2 ? 0 : fo.bg_init_pending;
+            fz.plan_elsewhere = WPE == 2;
+            WG_STAMP(12);
+            lean_step<GLUE == 2, false, true>(*(const WgParams*)&kg->gp, *(const WgPtrs*)&kg->gd, kg->d.gp, kg->d.gd, (int)blockIdx.x,
+                                              (int)(threadIdx.x & 63), kg->obs, kg->reward, kg->trunc, kg->final_obs, nullptr, fz);
+            WG_STAMP(13);
+        }
     }
+#ifdef WG_TIMELINE
+    {
+        const KArgsPtr kt = wg_cold_args();
+        if (threadIdx.x == 0 && kt->d.dbg) {
+            wg_stamps[15] = wall_clock64();
+            long long* row = kt->d.dbg + (size_t)blockIdx.x * 32;      // (the buffer holds 16 words per farm slot: 64 per env)
+            for (int kq = 0; kq < 16; ++kq) row[kq] = wg_stamps[kq];
+            row[16] = fo.bg_init_pending; row[17] = fo.rounds; row[18] = fo.first_obs;
+            row[19] = GLUE != 0 ? (long long)kt->d.env[blockIdx.x].timestep : 0;      // (0 right after a swap)
+        }
+    }
+#endif
 }
 
 extern "C" void wg_launch_flow_env(const FlowP* p, const FlowPtrs* d, int mode, const float* actions, const uint8_t* mask,
                                    int chunk, hipStream_t st) {
-    const int grid = p->B;
-    const size_t lds = p->env_lds;
+    const int grid = p->B, wpe = p->env_wpe == 2 ? 2 : 1;
+    const size_t lds = (size_t)p->env_lds * wpe;
     static const WgParams gp0{};
     static const WgPtrs gd0{};
-    if (p->noise) hipLaunchKernelGGL((k_flow_env<true, 0>), dim3(grid), dim3(64), lds, st, *p, *d, mode, actions, mask, chunk, gp0, gd0, nullptr, nullptr, nullptr, nullptr);
-    else hipLaunchKernelGGL((k_flow_env<false, 0>), dim3(grid), dim3(64), lds, st, *p, *d, mode, actions, mask, chunk, gp0, gd0, nullptr, nullptr, nullptr, nullptr);
+#define WG_FLOW_ENV(NZ, W) hipLaunchKernelGGL((k_flow_env<NZ, 0, W>), dim3(grid), dim3(64 * W), lds, st, *p, *d, mode, actions, mask, chunk, gp0, gd0, \
+                                              (float*)nullptr, (float*)nullptr, (uint8_t*)nullptr, (float*)nullptr)
+    if (wpe == 2) { if (p->noise) WG_FLOW_ENV(true, 2); else WG_FLOW_ENV(false, 2); }
+    else { if (p->noise) WG_FLOW_ENV(true, 1); else WG_FLOW_ENV(false, 1); }
+#undef WG_FLOW_ENV
 }
 
 // step() as one launch (wg_api.hip: launch_step, handles with FlowP::env_fused)
 extern "C" void wg_launch_step_env(const FlowP* p, const FlowPtrs* d, const WgParams* gp, const WgPtrs* gd, const float* actions,
                                    float* obs, float* reward, uint8_t* trunc, float* final_obs, hipStream_t st) {
-    const int grid = p->B;
-    const size_t lds = p->env_lds;
-#define WG_STEP_ENV(NZ, G) hipLaunchKernelGGL((k_flow_env<NZ, G>), dim3(grid), dim3(64), lds, st, *p, *d, (int)WG_MODE_STEP, actions, \
-                                              (const uint8_t*)nullptr, 0, *gp, *gd, obs, reward, trunc, final_obs)
-    if (gd->multi_out) { if (p->noise) WG_STEP_ENV(true, 2); else WG_STEP_ENV(false, 2); }
-    else { if (p->noise) WG_STEP_ENV(true, 1); else WG_STEP_ENV(false, 1); }
+    const int grid = p->B, wpe = p->env_wpe == 2 ? 2 : 1;
+    const size_t lds = (size_t)p->env_lds * wpe;
+#define WG_STEP_ENV(NZ, G, W) hipLaunchKernelGGL((k_flow_env<NZ, G, W>), dim3(grid), dim3(64 * W), lds, st, *p, *d, (int)WG_MODE_STEP, actions, \
+                                                 (const uint8_t*)nullptr, 0, *gp, *gd, obs, reward, trunc, final_obs)
+#define WG_STEP_ENV_W(NZ, G) do { if (wpe == 2) WG_STEP_ENV(NZ, G, 2); else WG_STEP_ENV(NZ, G, 1); } while (0)
+    if (gd->multi_out) { if (p->noise) WG_STEP_ENV_W(true, 2); else WG_STEP_ENV_W(false, 2); }
+    else { if (p->noise) WG_STEP_ENV_W(true, 1); else WG_STEP_ENV_W(false, 1); }
+#undef WG_STEP_ENV_W
 #undef WG_STEP_ENV
 }

@@ -88,6 +88,7 @@ struct FlowP {
     // k_flow_env (wg_env.hip: ONE wave per env, lane = slot * N + turbine): enabled; bytes of dynamic LDS; offset of the tables
     // (the rest of the carve is fixed: WG_ENV_*)
     int envw, env_lds, env_off_tab;
+    int env_wpe;                      // waves per env: 1, or 2 (a workgroup of two waves, one per context, each with its own LDS region of env_lds bytes)
     int env_fused;                    // step() as ONE launch: the env's wave runs its glue (lean_step) as the tail of its flow step
     float env_eps_max;                // widest initial wake width a record can hold: min(1, eps0 sqrt(beta(ct = 0.96)))
     float dt, D, inv_D, hub, dpart_f, R_rot, inv_N, inv_S, inv_P;
@@ -150,7 +151,7 @@ struct FlowPtrs {
 // k_flow_env's LDS carve (wg_env.hip): fixed part (cross-lane turbine fields: three 16-byte and two 8-byte arrays of 64 entries,
 // then four slot records) | staging: per-candidate deficit, added TI (WG_ENV_CAP floats each), candidate list (u16), aliased by
 // the quad list | tables (FlowP::env_off_tab)
-#define WG_ENV_SLOT_LDS_BYTES 144
+#define WG_ENV_SLOT_LDS_BYTES 160
 #define WG_ENV_FIXED_LDS_BYTES (3 * 64 * 16 + 2 * 64 * 8 + 4 * WG_ENV_SLOT_LDS_BYTES)
 #define WG_ENV_CAP 256
 // sizeof(TurbLds) in wg_flow.hip; kept here so the host can size the dynamic LDS

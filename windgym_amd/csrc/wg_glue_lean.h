@@ -29,7 +29,7 @@ __device__ inline EnvHot env_load(const WgEnv& env) {
     h.steps_done = env.steps_done; h.ep_return = env.ep_return; h.ep_power_sum = env.ep_power_sum; h.ep_len = env.ep_len;
     return h;
 }
-__device__ inline void env_writeback(WgEnv& env, const EnvHot& ev, const int lane) {
+__device__ inline void env_writeback(WgEnv& env, const EnvHot& ev, const int lane, const bool skip_shadow = false) {
     // one field per lane: independent fire-and-forget stores.  (A select chain "lane i stores field i" is turned by the
     // compiler into an indexed load from a scratch copy of the struct — a private-memory round trip at the very end
     // of the kernel's latency chain.)
@@ -37,7 +37,7 @@ __device__ inline void env_writeback(WgEnv& env, const EnvHot& ev, const int lan
     if (lane == 1) env.timestep = ev.timestep;
     if (lane == 2) env.episode = ev.episode;
     if (lane == 3) env.done = ev.done;
-    if (lane == 4) env.shadow_iters = ev.shadow_iters;
+    if (lane == 4 && !skip_shadow) env.shadow_iters = ev.shadow_iters;
     if (lane == 5) env.farm_pow_n = ev.farm_pow_n;
     if (lane == 6) env.base_pow_n = ev.base_pow_n;
     if (lane == 7) env.steps_done = ev.steps_done;
@@ -313,6 +313,7 @@ struct LeanFused {
     float fp, bp;             // farm power of the step: agent farm, baseline farm (WgPtrs::step_farm_pow / step_base_pow)
     int work;                 // remaining development work of the background episode: max over its farms of dev + K * fill
     int bg_init_pending;      // the background context's set-up flag was pending at the head of this launch
+    int plan_elsewhere;       // the background context's own wave plans its next share (WgEnv::shadow_iters) unless the env truncates
 };
 
 // One env's glue after its flow step: power deques, window sums -> observation, reward, penalty, truncation, metrics, the
@@ -527,7 +528,7 @@ __device__ __forceinline__ void lean_step(const WgParams& p, const WgPtrs& d, co
         const long total = (long)((time_max + inc - 1) / inc) + 1;
         ev.shadow_iters = wg_shadow_share(work, total - ev.steps_done, ev.steps_done, e);
     }
-    env_writeback(env, ev, lane);
+    env_writeback(env, ev, lane, FUSED && fz.plan_elsewhere && !truncated);
     if (lane == 11) env.time_max_live = time_max;
     if (lane == 12) env.rated_live = rated_power;
     if (lane == 13) env.fsum_run = fsum_run;
