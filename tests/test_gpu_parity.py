@@ -924,7 +924,7 @@ def test_prepared_first_observation_survives_buffer_switches(hip, oracle_lib):
     B = 6
     cfg = _physics_cfg(B, autoreset=True, n_passthrough=0.25)
     env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
-    assert env.flow_variant()[0] == 64 and not env.flow_variant()[2]
+    assert env.flow_variant() == (64, True, 2)          # k_flow_env (two waves per env) prepares the first observation too
     seeds = 900 + np.arange(B)
     np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=OBS_ATOL)
     rng = np.random.default_rng(5)
@@ -955,7 +955,7 @@ def test_checkpoint_resume_is_bit_identical_across_rollovers(hip):
     B = 8
     cfg = _physics_cfg(B, autoreset=True, n_passthrough=0.25)
     a_env, b_env = hip.HipBatch(cfg), hip.HipBatch(cfg)
-    assert a_env.flow_variant()[0] == 64 and not a_env.flow_variant()[2]
+    assert a_env.flow_variant() == (64, True, 2)
     seeds = 300 + np.arange(B)
     a_env.reset(seeds=seeds)
     rng = np.random.default_rng(9)
