@@ -25,7 +25,6 @@ from __future__ import annotations
 
 import hashlib
 import os
-import tempfile
 
 import numpy as np
 
@@ -141,17 +140,25 @@ def deficit_table():
     global _TABLE
     if _TABLE is None:
         s = TABLE_SPEC
-        # the solve takes a few seconds: keep the result next to other temporaries, keyed by this file's text
+        # the solve takes a few seconds: the result is cached in a PER-USER directory (mode 0700; WINDGYM_AMD_CACHE overrides the
+        # place, WINDGYM_AMD_NO_CACHE=1 disables it), keyed by this file's text and the numpy version, and accepted only if the
+        # checksum stored with it matches (a planted or half-written file must not change the physics silently: the oracle
+        # would load the same file and parity would still pass)
         with open(__file__, "rb") as fh:
-            key = hashlib.sha1(fh.read()).hexdigest()[:16]
-        path = os.path.join(tempfile.gettempdir(), f"windgym_amd_ainslie_{key}.npy")
-        try:
-            tab = np.load(path)
-            if tab.shape == (len(s["ct"]), len(s["ti"]), s["n_x"], s["n_r"]) and tab.dtype == np.float32:
-                _TABLE = (np.ascontiguousarray(tab), s)
-                return _TABLE
-        except (OSError, ValueError):
-            pass
+            key = hashlib.sha1(fh.read() + np.__version__.encode()).hexdigest()[:16]
+        shape = (len(s["ct"]), len(s["ti"]), s["n_x"], s["n_r"])
+        use_cache = os.environ.get("WINDGYM_AMD_NO_CACHE", "0") in ("", "0")
+        cdir = os.environ.get("WINDGYM_AMD_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "windgym_amd")
+        path = os.path.join(cdir, f"ainslie_{key}.npz")
+        if use_cache:
+            try:
+                with np.load(path) as z:
+                    tab, digest = z["table"], str(z["sha1"])
+                if tab.shape == shape and tab.dtype == np.float32 and hashlib.sha1(tab.tobytes()).hexdigest() == digest:
+                    _TABLE = (np.ascontiguousarray(tab), s)
+                    return _TABLE
+            except (OSError, ValueError, KeyError):
+                pass
         xs = np.linspace(0.0, s["x_max_D"], s["n_x"]) * 2.0                 # in R
         r, dfc = solve(s["ct"][:, None], s["ti"][None, :], xs)
         rn = np.linspace(0.0, s["r_max_R"], s["n_r"])
@@ -161,12 +168,13 @@ def deficit_table():
                 for k in range(dfc.shape[2]):
                     tab[i, j, k] = np.interp(rn, r, dfc[i, j, k], left=dfc[i, j, k, 0])
         tab = np.ascontiguousarray(np.maximum(tab, 0.0))
-        try:
-            tmp = f"{path}.{os.getpid()}.tmp"
-            with open(tmp, "wb") as fh:
-                np.save(fh, tab)
-            os.replace(tmp, path)
-        except OSError:
-            pass
+        if use_cache:
+            try:
+                os.makedirs(cdir, mode=0o700, exist_ok=True)
+                tmp = f"{path}.{os.getpid()}.tmp.npz"
+                np.savez(tmp, table=tab, sha1=np.array(hashlib.sha1(tab.tobytes()).hexdigest()))
+                os.replace(tmp, path)
+            except OSError:
+                pass
         _TABLE = (tab, s)
     return _TABLE

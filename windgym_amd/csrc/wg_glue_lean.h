@@ -134,7 +134,8 @@ __device__ __forceinline__ void lean_swap_fast(const P& p, const D& d, const int
 // cost every wave of k_glue_lean its register allocation): the next episode — developed in the background — goes live.
 //   * its window sums are summed afresh from its rings (nnp samples) into WgPtrs::wsum: Lg = 2^k lanes share a turbine
 //     (N * Lg <= 64), lane `sub` of a group sums the window's samples sub, sub + Lg, ... with eight loads in flight, the
-//     partial sums meet by shuffles.  Double sums of floats are exact: whoever adds them up, the result is THE sum.  (One
+//     partial sums meet by shuffles.  Double sums of floats are exact for the linear slots (whoever adds them up, the result is THE sum; the sum of squares behind
+//     TI rounds: wg_obs.h).  (One
 //     lane per turbine walking its 25 + 10 samples one dependent load at a time made the truncating waves last 20 us.)
 //   * !gen (no TI, nothing farm-level): the episode's first observation is written here, straight from the group sums;
 //   * the deferred power-deque pushes of its window fill (:766, :796) are merged arithmetically — lane i decides what slot

@@ -256,7 +256,12 @@ __device__ inline SumsRaw wg_sums_load(const WgParams& p, const WgPtrs& d, const
     }
     return r;
 }
-// S += newest - leaving (exact in double: adding and later subtracting the same float cancels without rounding), stored
+// S += newest - leaving, stored.  Exact in double for the LINEAR slots as long as the samples' exponents stay within ~29 bits of
+// each other (a sum of <= 100 floats then fits the 53-bit mantissa: adding and later subtracting the same float cancels without
+// rounding — wind speeds, yaws, powers of one farm do).  NOT exact for WG_SUM_TI2: v * v needs 48 mantissa bits, a window of
+// them more than 53, so that slot rounds, depends on the summation order (sequential here, grouped partial sums in
+// wg_first_obs / lean_swap) and carries its rounding through an episode — far below the 2e-6 the tests hold TI entries to, but
+// configurations WITH TI entries reproduce a checkpointed run to rounding only, not bit for bit.
 template <bool GEN>
 __device__ inline ObsIn wg_sums_apply(const WgParams& p, const WgPtrs& d, const int ctx_id, const int ent, const SumsRaw& r, const bool store) {
     constexpr int NSL = GEN ? WG_N_SUMS : WG_N_CH;

@@ -30,7 +30,8 @@ enum { WG_MODE_STEP = 0, WG_MODE_RESET = 1 };
 // reads the newest and the leaving sample of each window instead of staging the rings ("sums mode", wg_create).  Slot s < WG_N_CH: sum
 // of the newest min(window_len, history_len, pushed) samples of channel s — the one window a rolling mean with history_N
 // = 1 reads (MesClass.py:85-91); slots 4 / 5: sum of v and of v^2 over the whole ws deque (calc_TI, MesClass.py:220-237).
-// Double accumulators: adding and later subtracting the same float is exact, the sums do not drift.
+// Double accumulators: adding and later subtracting the same float is exact for the linear slots (the sums do not drift); the
+// sum of squares (WG_SUM_TI2) rounds — see wg_sums_apply (wg_obs.h).
 #define WG_N_SUMS 6
 enum { WG_SUM_TI1 = 4, WG_SUM_TI2 = 5 };
 

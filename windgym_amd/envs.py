@@ -93,9 +93,12 @@ def _attach_box(batch: HipBatch, cfg: EnvConfig, source):
         from .mann import generate_mann_box_hip, reference_box_spec
         spec = reference_box_spec(cfg.turbtype, cfg.D)
         K = int(getattr(cfg, "mann_pool", 1) or 1) if cfg.turbtype == "MannGenerate" else 1
+        if K > MAX_BOX_POOL:
+            raise ValueError(f"mann_pool = {K}: the device pool holds at most {MAX_BOX_POOL} boxes "
+                             f"(each realisation of the reference's box is ~1 GB on the device)")
         if K > 1:
             base = spec.pop("seed")
-            source = ("pool", [generate_mann_box_hip(device=batch.device, seed=base + k, **spec) for k in range(min(K, MAX_BOX_POOL))], spec["dxyz"])
+            source = ("pool", [generate_mann_box_hip(device=batch.device, seed=base + k, **spec) for k in range(K)], spec["dxyz"])
         else:
             source = ("one", generate_mann_box_hip(device=batch.device, **spec), spec["dxyz"])
     if source[0] == "pool":

@@ -149,6 +149,10 @@ class AgentEval:
         if save_figs or debug:
             raise NotImplementedError("figures / debug plots of AgentEval are not part of this build")
         kw = {k: v for k, v in self._env_kwargs.items() if v is not None}
+        is_default = [isinstance(tb, str) and tb == "Default" for tb in self.turbboxes]
+        if any(is_default) and not all(is_default):
+            raise ValueError("turbboxes mixes the placeholder 'Default' (the env's own inflow) with box files: "
+                             "name every box explicitly")
         self.multiple_eval_ds = eval_sweep(self._turbine, self._yaml, self.model, winddirs=self.winddirs,
                                            windspeeds=self.windspeeds, turbintensities=self.turbintensities,
                                            t_sim=self.t_sim, turbbox=self.turbboxes[0],
