@@ -38,6 +38,12 @@
 #ifndef WG_ENV_DPP_SCAN
 #define WG_ENV_DPP_SCAN 1   // list offsets from DPP prefix sums (0: __shfl_up ladders, for A/B builds: 67.0 / 52.2 against 67.8 / 53.5)
 #endif
+#ifndef WG_ENV_DEFER_INIT
+#define WG_ENV_DEFER_INIT 1       // one wave per env: a retired context's next episode is set up after the wave's step, not before it
+#endif
+#ifndef WG_ENV_FIRST_OBS_LATER
+#define WG_ENV_FIRST_OBS_LATER 1  // a completed background episode's first observation is built in the launch after the completing one
+#endif
 #ifndef WG_ENV_PRIO
 #define WG_ENV_PRIO 0       // 1: waves on a rare, long path raise their issue priority — measured slightly SLOWER (cfg2 65.2 vs 66.5, cfg4
                             // 54.3 vs 54.9 M env-steps/s): their extra time is their own latency chain, not contention
@@ -195,7 +201,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
     // ---- prologue: every independent global load up front (one exposed round trip) ----------------------------------
     typedef const __attribute__((address_space(4))) WgEnv* CEnvPtr;
     int env_live;
-    bool role_live = false, role_dev = false;
+    bool role_live = false, role_dev = false, defer_init = false;
     float yaw, tu, tti, oyaw;
     {
         const KArgsPtr k0 = wg_cold_args();
@@ -260,7 +266,13 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
             // background context's wave sees its own, the live wave gets it through LDS after the barrier)
             const int bg_pending = WPE == 2 ? (is_live_c ? 0 : __shfl(init_pending, 0, 64)) : __shfl(init_pending, (env_live ^ 1) * F * N, 64);
             out.bg_init_pending = autoreset && bg_pending;
-            if (autoreset && bg_pending) {
+            if (autoreset && bg_pending && WPE == 1 && (WG_ENV_DEFER_INIT != 0)) {
+                // rare path (one context per truncation): the retired context's next episode is set up AFTER this wave's step
+                // (below) — its background lanes rest in this launch, the set-up needs no reload of the wave's state, and the
+                // wave is no longer the launch's straggler (at the head of the launch it lived 55 us against 40 for the rest)
+                defer_init = true;
+                budget = 0;
+            } else if (autoreset && bg_pending) {
                 // rare path (one context per truncation): set the retired context's next episode up, both farms (see k_flow)
                 const KArgsPtr ki = wg_cold_args();
                 const WgParams& gp = *ki->d.gp;
@@ -285,7 +297,19 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
         }
         {   // nothing to do for the whole env (masked out in RESET mode, finished env without autoreset, idle background)
             const bool any_work = valid && (role_live || (role_dev && budget > 0 && (dev_rem > 0 || fill_rem > 0)));
-            if (!__ballot(any_work)) return;
+            if (!__ballot(any_work)) {
+                // (two waves per env: the resting background wave of an episode completed in an EARLIER launch prepares its
+                // first observation now — see the end of this function)
+                if (WPE == 2 && (WG_ENV_FIRST_OBS_LATER != 0) && mode == WG_MODE_STEP && !is_live_c && autoreset) {
+                    const int d0 = __shfl(dev_rem, 0, 64), f0 = __shfl(fill_rem, 0, 64), np0 = __shfl(n_pushed, 0, 64);
+                    const KArgsPtr kf = wg_cold_args();
+                    if (d0 == 0 && f0 == 0 && kf->d.gd->next_obs_ok != nullptr && kf->d.gd->next_obs_ok[ctx_id] == 0) {
+                        out.first_obs = 1;
+                        wg_first_obs(kf->d.gp, kf->d.gd, (int)ctx_id, np0, tid);
+                    }
+                }
+                return;
+            }
         }
 #if WG_ENV_PRIO
         static_assert(WPE == 1, "WG_ENV_PRIO: one wave per env only");
@@ -918,16 +942,36 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
         }
     }
     WG_STAMP(8);
-    // a background episode whose agent farm completed its development in this launch: its window sums and first
-    // observation are prepared for the swap (wg_first_obs, see k_flow)
-    if (mode == WG_MODE_STEP && (WPE == 1 || c != env_live)) {
+    // A background episode whose development is complete: its window sums and first observation are prepared for the swap
+    // (wg_first_obs, see k_flow) — in the launch AFTER the one that completed it (WG_ENV_FIRST_OBS_LATER; development ends
+    // WG_SHADOW_MARGIN steps early, so there is one): its slots rest then, and the wave that builds the observation is not also
+    // the one that took the episode's last flow steps.  An episode that completes in the very launch of the truncating step is
+    // prepared at once (one wave per env) or summed by the swap itself (lean_swap's fallback).
+    if (mode == WG_MODE_STEP && (WPE == 1 || c != env_live) && !defer_init) {
         const EnvSlotLds& bs = SL[WPE == 2 ? 0 : (env_live ^ 1) * F];      // the background context's agent farm
-        if (bs.n_flow > 0 && bs.dev_rem == 0 && bs.fill_rem == 0) {
+        const int bctx = e * 2 + (env_live ^ 1);
+        bool build = false;
+        if (ke->p.autoreset && bs.dev_rem == 0 && bs.fill_rem == 0) {
+            if (WG_ENV_FIRST_OBS_LATER != 0) build = bs.n_flow == 0 ? (ke->d.gd->next_obs_ok != nullptr && ke->d.gd->next_obs_ok[bctx] == 0) : out.truncates != 0;
+            else build = bs.n_flow > 0;
+        }
+        if (build) {
             const int np = bs.n_pushed;
             out.first_obs = 1;
             full_barrier<64>();                            // the ring pushes have left the wave
-            wg_first_obs(ke->d.gp, ke->d.gd, e * 2 + (env_live ^ 1), np, tid);
+            wg_first_obs(ke->d.gp, ke->d.gd, bctx, np, tid);
         }
+    }
+    if (defer_init) {
+        // (see the prologue) the retired context's next episode, set up after the wave's own step; the slots' remaining work goes
+        // to the LDS records the glue plans the first share from
+        env_init_episode(ke->d.gp, ke->d.gd, ke->d.env_rw + e, e, env_live ^ 1, tid);
+        full_barrier<64>();
+        if (valid && t == 0 && c != env_live) {
+            const WgSlot& slot = ke->d.slot[(unsigned)(e * 2 * F + kbase + k)];
+            my.dev_rem = slot.dev_remaining; my.fill_rem = slot.fill_remaining;
+        }
+        lds_barrier<64>();
     }
 }
 
