@@ -15,7 +15,8 @@ seq = [(0, 1, 'prologue: headers + state loads + LDS set-up'), (1, 4, 'roles, cl
        (5, 11, 'first batch of bracket gathers issued'), (11, 2, 'records'), (2, 9, 'evaluation batches + sums'),
        (9, 10, 'quad list (+ direct emission stores)'), (10, 3, 'advection pass'), (3, 6, 'clock advance'),
        (6, 7, 'tail (power, measurement, ring push, farm sums, schedule)'), (7, 8, 'epilogue (state stores, accounting)'),
-       (8, 12, 'store drain before the glue'), (12, 13, 'glue (lean_step)')]
+       (8, 12, 'store drain before the glue'), (12, 13, 'glue (lean_step)'), (12, 28, '  glue: header'), (28, 29, '  glue: loads'),
+       (29, 30, '  glue: reward, metrics'), (30, 31, '  glue: observation'), (31, 13, '  glue: plan + write-back')]
 fin = np.where(a[:, 13] > 0, a[:, 13], a[:, 8])
 tot = fin - a[:, 0]
 print('total: mean %.0f median %.0f p10 %.0f p90 %.0f' % (tot.mean(), np.median(tot), np.percentile(tot, 10), np.percentile(tot, 90)))
@@ -33,5 +34,25 @@ for name, sel in (('episode set-up at the head of the launch', a[:, 16] != 0), (
                   ('swapped (timestep 0 after the glue)', a[:, 19] == 0), ('none of these', (a[:, 16] == 0) & (a[:, 17] < 2) & (a[:, 18] == 0) & (a[:, 19] != 0))):
     if sel.any():
         print('  waves with %-44s n %5d  life us: median %.2f max %.2f' % (name, sel.sum(), np.median(life[sel]), life[sel].max()))
+c = a[:, 20:24].sum(0).astype(float)
+if c[0] > 0:
+    print('candidates per wave: listed %.1f fetched %.1f inside the 5-sigma cut %.1f (inside 3 sigma %.1f)' % tuple(c / len(a)))
+if c[0] > 0:
+    nc, nq = a[:, 20].astype(float), a[:, 24].astype(float)
+    print('quads listed per wave: mean %.1f p90 %.0f max %.0f ; candidates p90 %.0f max %.0f' % (nq.mean(), np.percentile(nq, 90), nq.max(), np.percentile(nc, 90), nc.max()))
+    print('correlation of wave life with candidates %.2f, with quads %.2f, with start time %.2f' % (np.corrcoef(life, nc)[0, 1], np.corrcoef(life, nq)[0, 1], np.corrcoef(life, (w0 - t0))[0, 1]))
+    A = np.stack([nc, nq, np.ones_like(nc)], 1)
+    co, *_ = np.linalg.lstsq(A, life, rcond=None)
+    print('least squares: life us = %.4f x candidates + %.4f x quads + %.2f ; residual std %.2f us' % (co[0], co[1], co[2], (life - A @ co).std()))
+    slow = life >= np.percentile(life, 99)
+    print('slowest 1 %% of the waves: life median %.1f, candidates median %.0f (all: %.0f), quads median %.0f (all: %.0f)' % (np.median(life[slow]), np.median(nc[slow]), np.median(nc), np.median(nq[slow]), np.median(nq)))
+    for i, j, n in seq:
+        if (a[:, j] <= 0).all() or (a[:, i] <= 0).all():
+            continue
+        d = (a[:, j] - a[:, i])
+        print('   slowest 1 %%: %-52s median %8.0f (all %8.0f)' % (n, np.median(d[slow]), np.median(d)))
+ini = a[:, 16] != 0
+if ini.any():
+    print('episode set-up (cycles; the waves that ran it): wind + yaw draws (lane 0) %s | rated power, rotation, ring layout %s | slots, turbine state %s' % (a[ini, 25].tolist(), a[ini, 26].tolist(), a[ini, 27].tolist()))
 print('core clock (cycles per us of wave life): %.0f' % np.median(tot / np.maximum((w1 - w0) / 100, 1e-9)))
 PY

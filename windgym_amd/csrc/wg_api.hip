@@ -388,6 +388,19 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     if (!rc) rc = dev_upload<double>(h, &d.x_pos, c->x_pos, p.N);
     if (!rc) rc = dev_upload<double>(h, &d.y_pos, c->y_pos, p.N);
     if (!rc && c->yaw_defined) rc = dev_upload<double>(h, &d.yaw_defined, c->yaw_defined, p.N);
+    if (!rc) {
+        // PCG64 k draws ahead, k = 0 .. max(N, 3): the LCG step s -> M s + inc composed k times is s -> A_k s + G_k inc with A_k = M^k,
+        // G_k = 1 + M + ... + M^(k-1) (mod 2^128) — the N yaw draws of an episode set-up are then one draw per lane
+        const int kmax = std::max(p.N, 3);             // (k = 3: the state after the three wind draws)
+        std::vector<uint64_t> jump((size_t)(kmax + 1) * 4);
+        wg_u128 A = 1, G = 0;
+        for (int k = 0; k <= kmax; ++k) {
+            jump[4 * (size_t)k] = (uint64_t)A; jump[4 * (size_t)k + 1] = (uint64_t)(A >> 64);
+            jump[4 * (size_t)k + 2] = (uint64_t)G; jump[4 * (size_t)k + 3] = (uint64_t)(G >> 64);
+            A = A * WG_PCG_MULT; G = G * WG_PCG_MULT + 1;
+        }
+        rc = dev_upload<uint64_t>(h, &d.pcg_jump, jump.data(), jump.size());
+    }
     if (!rc) rc = dev_upload<float>(h, &d.rotor_dy, c->rotor_dy, p.S);
     if (!rc) rc = dev_upload<float>(h, &d.rotor_dz, c->rotor_dz, p.S);
     if (!rc) rc = dev_upload<float>(h, &d.tab_ws, c->tab_ws, p.n_tab);
@@ -586,6 +599,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             size_t o = (size_t)f.env_off_tab + sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S);      // power | ct | rotor points (float2)
             f.env_lds = (int)((o + 15) & ~(size_t)15);
             if (f.env_lds > 32768 || f.env_lds > lds_limit) env_ok = false;
+            f.env_inc = 1 + (p.extra_inc ? 1 : 0);
             f.env_eps_max = std::min(1.0f, (float)(p.eps0 * std::sqrt(3.0))) + 2.0f / 65535.0f;
             const bool asked_old = wg_hook("WG_FLOW_BLOCK") || wg_hook("WG_FLOW_RES") || wg_hook("WG_FLOW_DUO");
             f.envw = (env_ok && !asked_old) ? 1 : 0;

@@ -12,7 +12,6 @@
 // PCG64 + numpy Generator.uniform / .integers (gymnasium's np_random behind the reference's sampling,
 // Wind_Farm_Env.py:557-568, WindEnv.py:24-35)
 // ---------------------------------------------------------------------------------------------------
-#define WG_PCG_MULT ((((wg_u128)2549297995355413924ULL) << 64) | (wg_u128)4865540595714422341ULL)
 
 __device__ inline uint32_t wg_ss_hashmix(uint32_t value, uint32_t& hc) {
     value ^= hc;
@@ -272,16 +271,33 @@ struct WgRng {
 // remains: the episode is ready exactly at truncation.  (ceil(work/left) — the first version — front-loads: a
 // background episode needing 280 steps during a 600-step episode ran on each of the first 280 launches, so after a
 // synchronised start every launch carried twice the flow work of the steady state.)
+#ifdef WG_TIMELINE
+// debug build (-DWG_TIMELINE, env WG_TIMELINE_OUT=file): thread 0 of every workgroup records shader-clock stamps
+// at the phase boundaries of its step; wg_destroy dumps them.  This is how the per-workgroup latency budget in
+// DESIGN.md §4.1 was measured.
+__shared__ long long wg_stamps[20];
+__shared__ int wg_counts[8];
+#define WG_STAMP(k) do { if (threadIdx.x == 0) wg_stamps[k] = clock64(); } while (0)
+#define WG_STAMP2(k) WG_STAMP(k)
+// WG_ICLK(i): cycles since the previous WG_ICLK of thread 0 into wg_counts[i] (episode set-up: wg_ctx_init)
+#define WG_ICLK0() long long wg_iclk_ = clock64()
+#define WG_ICLK(i) do { if (threadIdx.x == 0) { const long long c_ = clock64(); wg_counts[i] = (int)(c_ - wg_iclk_); wg_iclk_ = c_; } } while (0)
+#else
+#define WG_STAMP(k) do { } while (0)
+#define WG_ICLK0() do { } while (0)
+#define WG_ICLK(i) do { } while (0)
+#endif
+
 #ifndef WG_SHADOW_MARGIN
 #define WG_SHADOW_MARGIN 2
 #endif
-__device__ inline int wg_shadow_share(const int work, long left, const int steps_done, const int e) {
+__device__ inline int wg_shadow_share(const int work, long left, const int steps_done, const int e, const uint32_t phase = 0u) {
     if (work <= 0) return 0;
     // (finished WG_SHADOW_MARGIN steps EARLY: the launch of the truncating step then carries no background work, first
     // observation included — in the one-wave-per-env kernels the truncating wave is the launch's last one anyway)
     left -= WG_SHADOW_MARGIN;
     if (left < 1) left = 1;
-    const uint32_t phi24 = ((uint32_t)steps_done * 2654435769u + (uint32_t)e * 0x9E3779B1u) >> 8;   // [0, 2^24)
+    const uint32_t phi24 = ((uint32_t)steps_done * 2654435769u + (uint32_t)e * 0x9E3779B1u + phase) >> 8;   // [0, 2^24)
     // float arithmetic (a 64-bit integer division costs ~150 instructions on this kernel's latency chain): rcp(1) is
     // exact, so left == 1 still returns exactly `work`; elsewhere an off-by-one in the floor is absorbed by the
     // next step's recomputed ratio
@@ -291,23 +307,89 @@ __device__ inline int wg_shadow_share(const int work, long left, const int steps
     return it > work ? work : it;
 }
 
-template <class R>
-__device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, const int e, const int c, const int lane,
+// wg_tab_interp_wave for a table of at most 64 nodes that every lane has already loaded its node of (xs_l, ys_l: node `lane`,
+// anything beyond the table's end): the bracketing nodes come from the lanes that hold them, not from memory a second time.
+// Same arithmetic on the same values.
+__device__ inline double wg_tab_interp_lanes(const double xs_l, const double ys_l, const int n, const double x, const int lane) {
+    const int cnt = __popcll(__ballot((lane < n - 1) && (xs_l <= x)));
+    const double x_first = __shfl(xs_l, 0, 64), x_last = __shfl(xs_l, n - 1, 64);
+    const int lo = cnt > 0 ? cnt - 1 : 0, hi = lo + 1;
+    const double xl = __shfl(xs_l, lo, 64), xh = __shfl(xs_l, hi, 64), yl = __shfl(ys_l, lo, 64), yh = __shfl(ys_l, hi, 64);
+    if (!(x >= x_first) || x > x_last) return 0.0;
+    const double f = (x - xl) / (xh - xl);
+    return yl + f * (yh - yl);
+}
+
+// Episode set-up of context c of env e: wind conditions and initial yaws drawn from the env's generator, the layout rotated
+// into the flow frame, chain lengths / compact ring layout, slot clocks and turbine state of farms f_lo .. f_hi - 1.
+// Once per episode and env — but in the one-wave-per-env step kernel the wave that runs it is the launch's last (its set-up
+// took ~30 000 cycles on top of a 39 us step: ~12 dependent trips to memory and a serial chain of N draws in lane 0), so:
+//   * P / D are the parameter blocks' types WITH their address space — the fused kernel passes its own by-value arguments
+//     (scalar loads from the kernarg segment) — and __restrict__: no kernel writes the blocks, and without the promise every
+//     store here (float / double / int arrays that may overlap them, as far as the compiler knows) made the next p.x / d.x a
+//     reload;
+//   * everything the set-up reads from memory is requested up front, in one trip: layout, power table nodes, jump constants;
+//   * the draws are one per lane: the generator's state k draws ahead is A_k s + G_k inc (WgPtrs::pcg_jump), so turbine t's yaw
+//     is a function of the state after lane 0's draws — not the end of a chain of t + 1 steps (~100 instructions each).
+template <class P, class D, class R>
+__device__ inline void wg_ctx_init(const P& __restrict__ p, const D& __restrict__ d, R& rng, const int e, const int c, const int lane,
                                    const int episode_tag, const int f_lo, const int f_hi) {
     const int N = p.N, F = p.F;
     const int ctx_id = e * 2 + c;
     WgCtx& cx = d.ctx[ctx_id];
-    double ws = 0, ti = 0, wd = 0;
+    WG_ICLK0();
+    // ---- loads ----
+    const int tl = lane < N ? lane : 0;
+    const double xp_l = d.x_pos[tl], yp_l = d.y_pos[tl];
+    const int n_tab = p.n_tab;
+    const int il = lane < n_tab ? lane : n_tab - 1;
+    const double tws_l = d.tab_ws_d[il], tpw_l = d.tab_power_d[il];
+    const uint64_t* const jmp = d.pcg_jump;
+    const int kmax = N > 3 ? N : 3;                       // (the table has max(N, 3) + 1 rows)
+    uint64_t jl[4], jn[4], j3[4];
+    {
+        const int kl = lane <= kmax ? lane : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { jl[i] = jmp[4 * (size_t)kl + i]; jn[i] = jmp[4 * (size_t)N + i]; j3[i] = jmp[4 * (size_t)3 + i]; }
+    }
+    const bool yaw_rnd = p.yaw_init == WG_YAWINIT_RANDOM, yaw_def = p.yaw_init == WG_YAWINIT_DEFINED && p.has_yaw_defined;
+    const double ydef_l = yaw_def ? d.yaw_defined[tl] : 0.0;
+    double ov[3] = {0.0, 0.0, 0.0};
+    const bool has_ov = d.wind_override != nullptr;
+    if (has_ov) { ov[0] = d.wind_override[(size_t)e * 3]; ov[1] = d.wind_override[(size_t)e * 3 + 1]; ov[2] = d.wind_override[(size_t)e * 3 + 2]; }
+
+    // ---- draws ----
+    const wg_u128 inc = rng.rng_inc;                      // (the stream: set at seeding)
+    auto ahead = [&](const uint64_t* j, const wg_u128 s) {
+        const wg_u128 A = ((wg_u128)j[1] << 64) | j[0], G = ((wg_u128)j[3] << 64) | j[2];
+        return A * s + G * inc;
+    };
+    auto draw = [&](const wg_u128 s, const double lo, const double hi) {      // the uniform draw the generator in state s makes next
+        struct { wg_u128 rng_state, rng_inc; } one{s, inc};
+        return wg_pcg_uniform(one, lo, hi);
+    };
+    // _set_windconditions (:564-568): ws, ti, wd are draws 1, 2, 3 of the episode — lanes 0, 1, 2
+    double ws, ti, wd;
+    {
+        // (lane 0's copy of the state is THE state — R may live in memory, written by lane 0 alone)
+        const wg_u128 s_l = rng.rng_state;
+        uint32_t iw[4] = {(uint32_t)s_l, (uint32_t)(s_l >> 32), (uint32_t)(s_l >> 64), (uint32_t)(s_l >> 96)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) iw[i] = (uint32_t)__shfl((int)iw[i], 0, 64);
+        const wg_u128 s_in = ((wg_u128)iw[3] << 96) | ((wg_u128)iw[2] << 64) | ((wg_u128)iw[1] << 32) | (wg_u128)iw[0];
+        const double lo = lane == 0 ? p.ws_min : lane == 1 ? p.ti_min : p.wd_min;
+        const double hi = lane == 0 ? p.ws_max : lane == 1 ? p.ti_max : p.wd_max;
+        const double u = draw(ahead(jl, s_in), lo, hi);
+        ws = __shfl(u, 0, 64); ti = __shfl(u, 1, 64); wd = __shfl(u, 2, 64);
+        if (lane == 0) rng.rng_state = ahead(j3, s_in);
+    }
+    if (has_ov) {                                         // FarmEval.set_wind_vals, per env; NaN = keep the sampled value
+        if (ov[0] == ov[0]) ws = ov[0];
+        if (ov[1] == ov[1]) wd = ov[1];
+        if (ov[2] == ov[2]) ti = ov[2];
+    }
+    wg_u128 s_head = 0;           // lane 0: the generator's state after its own draws
     if (lane == 0) {
-        ws = wg_pcg_uniform(rng, p.ws_min, p.ws_max);     // _set_windconditions (:564-568)
-        ti = wg_pcg_uniform(rng, p.ti_min, p.ti_max);
-        wd = wg_pcg_uniform(rng, p.wd_min, p.wd_max);
-        if (d.wind_override) {                            // FarmEval.set_wind_vals, per env
-            const double *ov = d.wind_override + (size_t)e * 3;
-            if (ov[0] == ov[0]) ws = ov[0];
-            if (ov[1] == ov[1]) wd = ov[1];
-            if (ov[2] == ov[2]) ti = ov[2];
-        }
         uint32_t tseed = 0;
         if (p.turb_mode == WG_TURB_RANDOM || p.turb_mode == WG_TURB_BOX_SHIFT)
             tseed = wg_pcg_integers(rng, 100000);                                  // _def_site (:623, :642)
@@ -328,12 +410,7 @@ __device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, c
             cx.box_ox = (double)a * (1.0 / 4294967296.0) * p.bnx * p.bdx;
             cx.box_oy = (double)b * (1.0 / 4294967296.0) * p.bny * p.bdy;
         }
-        for (int t = 0; t < N; ++t) {                     // yaw init (:715-720); the baseline farm starts from the
-            float y0 = 0.f;                               // agent's yaws (:781)
-            if (p.yaw_init == WG_YAWINIT_RANDOM) y0 = (float)wg_pcg_uniform(rng, -p.yaw_start, p.yaw_start);
-            else if (p.yaw_init == WG_YAWINIT_DEFINED && p.has_yaw_defined) y0 = (float)d.yaw_defined[t];
-            for (int f = f_lo; f < f_hi; ++f) d.yaw[(size_t)(ctx_id * F + f) * N + t] = y0;
-        }
+        s_head = rng.rng_state;
         cx.ws = ws; cx.ti = ti; cx.wd = wd; cx.turb_seed = tseed;
         // the context-level counters have ONE writer each: n_pushed / pend_farm_n belong to farm 0's workgroup (it also
         // advances them in its epilogue), pend_base_n to the last farm's — a late initialising workgroup of the other
@@ -342,49 +419,72 @@ __device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, c
         if (f_hi == F) cx.pend_base_n = 0;
         cx.episode_tag = episode_tag;
     }
-    ws = __shfl(ws, 0, 64); ti = __shfl(ti, 0, 64); wd = __shfl(wd, 0, 64);
+    {   // yaw init (:715-720), one turbine per lane; the baseline farm starts from the agent's yaws (:781).  Random: turbine
+        // t's is draw t + 1 after lane 0's
+        uint32_t sw[4] = {(uint32_t)s_head, (uint32_t)(s_head >> 32), (uint32_t)(s_head >> 64), (uint32_t)(s_head >> 96)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sw[i] = (uint32_t)__shfl((int)sw[i], 0, 64);
+        const wg_u128 s0 = ((wg_u128)sw[3] << 96) | ((wg_u128)sw[2] << 64) | ((wg_u128)sw[1] << 32) | (wg_u128)sw[0];
+        const double ys = p.yaw_start;
+        float* const yaw_c = d.yaw + (size_t)ctx_id * F * N;
+        for (int t = lane; t < N; t += WG_WAVE) {
+            float y0 = 0.f;
+            if (yaw_rnd) {
+                uint64_t jt[4];
+                if (t < WG_WAVE) { jt[0] = jl[0]; jt[1] = jl[1]; jt[2] = jl[2]; jt[3] = jl[3]; }
+                else { for (int i = 0; i < 4; ++i) jt[i] = jmp[4 * (size_t)t + i]; }
+                y0 = (float)draw(ahead(jt, s0), -ys, ys);
+            } else if (yaw_def) y0 = (float)(t < WG_WAVE ? ydef_l : d.yaw_defined[t]);
+            for (int f = f_lo; f < f_hi; ++f) yaw_c[(size_t)f * N + t] = y0;
+        }
+        if (yaw_rnd && lane == 0) rng.rng_state = ahead(jn, s0);
+    }
+    WG_ICLK(5);
     {
-        const double rp = wg_tab_interp_wave<double>(d.tab_ws_d, d.tab_power_d, p.n_tab, ws, lane);   // :700
+        const double rp = n_tab <= WG_WAVE ? wg_tab_interp_lanes(tws_l, tpw_l, n_tab, ws, lane)
+                                            : wg_tab_interp_wave<double>(d.tab_ws_d, d.tab_power_d, n_tab, ws, lane);   // :700
         if (lane == 0) cx.rated_power = (float)rp;
     }
     // flow frame: rotate the layout by theta = 270 - wd about the farm centre
     const double th = (270.0 - wd) * (WG_PI_D / 180.0);
     const double cth = cos(th), sth = sin(th);
     const double cx0 = p.cx0, cy0 = p.cy0;
+    double* const xr_c = d.xr + (size_t)ctx_id * N;
+    double* const yr_c = d.yr + (size_t)ctx_id * N;
     double xmin = 1e300, xmax = -1e300;
     for (int t = lane; t < N; t += WG_WAVE) {
-        const double dx = d.x_pos[t] - cx0, dy = d.y_pos[t] - cy0;
+        const double dx = (t < WG_WAVE ? xp_l : d.x_pos[t]) - cx0, dy = (t < WG_WAVE ? yp_l : d.y_pos[t]) - cy0;
         const double xr = cx0 + dx * cth + dy * sth;
         const double yr = cy0 - dx * sth + dy * cth;
-        d.xr[(size_t)ctx_id * N + t] = xr;
-        d.yr[(size_t)ctx_id * N + t] = yr;
+        xr_c[t] = xr;
+        yr_c[t] = yr;
         xmin = fmin(xmin, xr); xmax = fmax(xmax, xr);
     }
     xmin = wg_wave_min_d(xmin); xmax = wg_wave_max_d(xmax);
     // chain pruning: a particle of turbine t that is older than jneed[t] has passed the most downstream turbine of
     // the farm (the bracket of the farthest target uses ages floor(dx / dpart) and + 1) and can never reach a rotor
     // again -> the advection pass stops streaming it.  Every output of step() is unchanged.
-    for (int t = lane; t < N; t += WG_WAVE) {
-        const double dx = d.x_pos[t] - cx0, dy = d.y_pos[t] - cy0;
-        const double dxm = xmax - (cx0 + dx * cth + dy * sth);
-        d.jneed[(size_t)ctx_id * N + t] = p.full_chains ? p.P : (int)(dxm / p.dpart) + 2;
-    }
-    if (p.compact) {
-        // compact rings: turbine t keeps ages 0 .. jneed[t] (R_t = jneed[t] + 1 rounded up to a multiple of 4, at
-        // most P); exclusive prefix sum over the turbines (wave scan per 64 turbines, running base), then the owner
-        // of every quad of ring slots by binary search in the offsets
-        int* ro = d.roff + (size_t)ctx_id * (N + 1);
-        int base = 0;
-        for (int t0 = 0; t0 < N; t0 += WG_WAVE) {
-            const int t = t0 + lane;
-            int len = 0;
-            if (t < N) {
-                const double dx = d.x_pos[t] - cx0, dy = d.y_pos[t] - cy0;
-                const double dxm = xmax - (cx0 + dx * cth + dy * sth);
-                const int jn = p.full_chains ? p.P : (int)(dxm / p.dpart) + 2;
-                len = (jn + 1 + 3) & ~3;
-                if (len > p.P) len = p.P;
-            }
+    // compact rings: turbine t keeps ages 0 .. jneed[t] (R_t = jneed[t] + 1 rounded up to a multiple of 4, at most P);
+    // exclusive prefix sum over the turbines (wave scan per 64 turbines, running base), then the owner of every quad of
+    // ring slots
+    const int P_ = p.P, full_chains = p.full_chains, compact = p.compact;
+    const double dpart = p.dpart;
+    int* const jneed_c = d.jneed + (size_t)ctx_id * N;
+    int* const ro = d.roff + (size_t)ctx_id * (N + 1);
+    uint8_t* const own = d.qown + (size_t)ctx_id * (p.NP >> 2);
+    int base = 0;
+    for (int t0 = 0; t0 < N; t0 += WG_WAVE) {
+        const int t = t0 + lane;
+        int len = 0;
+        if (t < N) {
+            const double dx = (t < WG_WAVE ? xp_l : d.x_pos[t]) - cx0, dy = (t < WG_WAVE ? yp_l : d.y_pos[t]) - cy0;
+            const double dxm = xmax - (cx0 + dx * cth + dy * sth);
+            const int jn_ = full_chains ? P_ : (int)(dxm / dpart) + 2;
+            jneed_c[t] = jn_;
+            len = (jn_ + 1 + 3) & ~3;
+            if (len > P_) len = P_;
+        }
+        if (compact) {
             int incl = len;
 #pragma unroll
             for (int o = 1; o < WG_WAVE; o <<= 1) {
@@ -395,14 +495,15 @@ __device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, c
                 ro[t] = base + incl - len;
                 // owner of every quad of ring slots: turbine t stamps its own quads (fire-and-forget byte stores; the
                 // earlier binary search per quad was a chain of dependent loads on the launch's critical path)
-                uint8_t* own = d.qown + (size_t)ctx_id * (p.NP >> 2);
                 const int q0 = (base + incl - len) >> 2, q1 = (base + incl) >> 2;
                 for (int q = q0; q < q1; ++q) own[q] = (uint8_t)t;
             }
             base += __shfl(incl, WG_WAVE - 1, 64);
         }
-        if (lane == 0) ro[N] = base;
     }
+    if (compact && lane == 0) ro[N] = base;
+    WG_ICLK(6);
+    const bool scripted = d.script_uvw != nullptr;
     if (lane == 0) {
         cx.dist = xmax - xmin;                                                     // :723-724
         const double t_inflow = (xmax - xmin) / ws;                                // :727
@@ -411,30 +512,34 @@ __device__ inline void wg_ctx_init(const WgParams& p, const WgPtrs& d, R& rng, c
         cx.t_developed = t_developed;
         cx.time_max = p.never_truncate ? 9999999 : (int)(t_inflow * p.n_passthrough);   // :732
         int n_dev = (int)ceil((double)t_developed / p.dt_d - 1e-9);
-        if (d.script_uvw) n_dev = 0;
+        if (scripted) n_dev = 0;
         for (int f = f_lo; f < f_hi; ++f) {
             WgSlot& s = d.slot[ctx_id * F + f];
-            s.head = p.P - 1; s.n_valid = 0; s.s_off = 0.0; s.time = 0.0; s.istep = 0; s.n_emitted = 0;
+            s.head = P_ - 1; s.n_valid = 0; s.s_off = 0.0; s.time = 0.0; s.istep = 0; s.n_emitted = 0;
             s.dev_remaining = n_dev;
             s.fill_remaining = f == 0 ? p.fill_a : p.fill_b;
         }
     }
     for (int f = f_lo; f < f_hi; ++f) {
         const size_t tb = (size_t)(ctx_id * F + f) * N;
-        const int cursor = d.script_uvw ? d.slot[ctx_id * F + f].cursor : 0;
+        const int cursor = scripted ? d.slot[ctx_id * F + f].cursor : 0;
+        float* const u_ = d.u + tb; float* const v_ = d.v + tb; float* const w_ = d.w + tb;
+        float* const ti_ = d.ti_loc + tb; float* const pw_ = d.power + tb; float* const ct_ = d.ct + tb;
+        float4* const bnd_ = reinterpret_cast<float4*>(d.bnd) + tb;
         for (int t = lane; t < N; t += WG_WAVE) {
             float u = (float)ws, v = 0.f, w = 0.f, pw = 0.f;
-            if (d.script_uvw) {
+            if (scripted) {
                 int row = cursor < p.script_rows ? cursor : p.script_rows - 1;
-                size_t base = (((size_t)f * p.script_rows + row) * p.B + e) * N;
-                u = d.script_uvw[(base + t) * 3]; v = d.script_uvw[(base + t) * 3 + 1];
-                w = d.script_uvw[(base + t) * 3 + 2]; pw = d.script_power[base + t];
+                size_t sbase = (((size_t)f * p.script_rows + row) * p.B + e) * N;
+                u = d.script_uvw[(sbase + t) * 3]; v = d.script_uvw[(sbase + t) * 3 + 1];
+                w = d.script_uvw[(sbase + t) * 3 + 2]; pw = d.script_power[sbase + t];
             }
-            d.u[tb + t] = u; d.v[tb + t] = v; d.w[tb + t] = w;
-            d.ti_loc[tb + t] = (float)ti; d.power[tb + t] = pw; d.ct[tb + t] = 0.f;
-            d.bnd[(tb + t) * 4] = 0.f; d.bnd[(tb + t) * 4 + 1] = 0.f; d.bnd[(tb + t) * 4 + 2] = 0.f; d.bnd[(tb + t) * 4 + 3] = 0.f;
+            u_[t] = u; v_[t] = v; w_[t] = w;
+            ti_[t] = (float)ti; pw_[t] = pw; ct_[t] = 0.f;
+            bnd_[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    WG_ICLK(7);
 }
 
 // ---------------------------------------------------------------------------------------------------

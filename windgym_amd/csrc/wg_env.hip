@@ -41,6 +41,9 @@
 #ifndef WG_ENV_DEFER_INIT
 #define WG_ENV_DEFER_INIT 1       // one wave per env: a retired context's next episode is set up after the wave's step, not before it
 #endif
+#ifndef WG_ENV_SPLIT_PLAN
+#define WG_ENV_SPLIT_PLAN 1       // the background episode's farms are planned one by one, half a period apart (see the prologue)
+#endif
 #ifndef WG_ENV_FIRST_OBS_LATER
 #define WG_ENV_FIRST_OBS_LATER 1  // a completed background episode's first observation is built in the launch after the completing one
 #endif
@@ -95,9 +98,11 @@ static_assert(sizeof(EnvSlotLds) == WG_ENV_SLOT_LDS_BYTES, "keep WG_ENV_SLOT_LDS
 #define WG_ENV_OFF_STAGE (WG_ENV_OFF_SL + 4 * WG_ENV_SLOT_LDS_BYTES)
 static_assert(WG_ENV_OFF_STAGE == WG_ENV_FIXED_LDS_BYTES, "keep WG_ENV_FIXED_LDS_BYTES in sync (wg_flow.h)");
 
-// rare path at the head of the launch: the episode a retired context will hold (WgCtx::init_pending), both farms at once
-static __device__ __attribute__((noinline)) void env_init_episode(const WgParams* gp, const WgPtrs* gd, WgEnv* env_rw,
-                                                                  const int e, const int c, const int lane) {
+// rare path: the episode a retired context will hold (WgCtx::init_pending), both farms at once.  KARG: the launch carries the
+// glue's parameter blocks in its own arguments (k_flow_env<., GLUE != 0>) — the set-up is inlined and reads them from there
+// (scalar loads that hit the constant cache); otherwise out of line, from the handle's copies in memory.
+static __device__ __attribute__((noinline)) void env_init_episode_mem(const WgParams* gp, const WgPtrs* gd, WgEnv* env_rw,
+                                                                      const int e, const int c, const int lane) {
     const WgCtx& cx = gd->ctx[e * 2 + c];
     WgRng rng{cx.snap_state, cx.snap_inc, cx.snap_has32, cx.snap_u32};
     wg_ctx_init(*gp, *gd, rng, e, c, lane, cx.episode_tag, 0, gp->F);
@@ -106,6 +111,9 @@ static __device__ __attribute__((noinline)) void env_init_episode(const WgParams
         env_rw->rng_has32 = rng.rng_has32; env_rw->rng_u32 = rng.rng_u32;
     }
 }
+struct EnvKArgs;
+template <bool KARG>
+__device__ __forceinline__ void env_init_episode(const int e, const int c, const int lane);
 
 __device__ __forceinline__ int env_scan(const int v, const int tid) {
 #if WG_ENV_DPP_SCAN
@@ -155,6 +163,102 @@ __device__ __forceinline__ float env_tab(const float* __restrict__ ys, const flo
 __device__ __forceinline__ bool role_dev_any(const int autoreset, const int dev_rem, const int fill_rem) {
     return autoreset != 0 && (dev_rem > 0 || fill_rem > 0);
 }
+// the kernel's arguments as they lie in the kernarg segment
+struct EnvKArgs {
+    FlowP p; FlowPtrs d; int mode; const float* actions; const uint8_t* mask; int chunk; WgParams gp; WgPtrs gd;
+    float* obs; float* reward; uint8_t* trunc; float* final_obs;
+};
+typedef const __attribute__((address_space(4))) EnvKArgs* EnvKArgsPtr;
+template <bool KARG>
+__device__ __forceinline__ void env_init_episode(const int e, const int c, const int lane) {
+    const EnvKArgsPtr kg = (EnvKArgsPtr)wg_cold_args();
+    if (!KARG) { env_init_episode_mem(kg->d.gp, kg->d.gd, kg->d.env_rw + e, e, c, lane); return; }
+    const WgCtx& cx = kg->gd.ctx[e * 2 + c];
+    WgRng rng{cx.snap_state, cx.snap_inc, cx.snap_has32, cx.snap_u32};
+    wg_ctx_init(kg->gp, kg->gd, rng, e, c, lane, cx.episode_tag, 0, kg->gp.F);
+    if (lane == 0) {
+        WgEnv* const env_rw = kg->d.env_rw + e;
+        env_rw->rng_state = rng.rng_state; env_rw->rng_inc = rng.rng_inc;
+        env_rw->rng_has32 = rng.rng_has32; env_rw->rng_u32 = rng.rng_u32;
+    }
+}
+// First observation + window sums of a completed background episode (wg_first_obs, wg_flow_dev.h) for the configurations the
+// fused step kernel serves — sums mode, no TI / farm-level entries, N <= 32 — inlined, with the parameter blocks read from the
+// kernel's own arguments (scalar loads), one uniform base + 32-bit offsets, and every load of the four windows in flight
+// together: the out-of-line generic routine waits for memory ~150 times (its loads sit behind spill reloads) and made the
+// wave that called it one of its launch's last three (59 us against 40, cfg2 x 4096).  Same partial sums in the same order:
+// bit-identical results.
+template <bool KARG>
+__device__ __forceinline__ void env_first_obs(const int ctx_id, const int n_pushed, const int lane) {
+    const EnvKArgsPtr kg = (EnvKArgsPtr)wg_cold_args();
+    bool lean = false;
+    if (KARG) {
+        const auto& p = kg->gp;
+        lean = p.sums_mode && !(p.turb_ti || p.farm_ti || p.farm_obs > 0 || (p.sum_mask_f | p.cur_mask_f) != 0u) && p.N <= 32 &&
+               kg->gd.next_obs != nullptr;
+    }
+    if (!lean) { wg_first_obs(kg->d.gp, kg->d.gd, ctx_id, n_pushed, lane); return; }
+    const auto& p = kg->gp;
+    const auto& d = kg->gd;
+    const int N = p.N, NS = N + 1;
+    int Lg = 1, lgs = 0;
+    while (Lg < 8 && N * (Lg * 2) <= WG_WAVE) { Lg *= 2; ++lgs; }
+    const int sub = lane & (Lg - 1), ent = lane >> lgs;      // (N Lg <= 64: every entity in one pass)
+    const bool have = ent < N;
+    const unsigned entc = have ? (unsigned)ent : 0u;
+    const float* const rb = d.ring + (size_t)ctx_id * p.ring_stride;
+    double* const ws_ = d.wsum + (size_t)ctx_id * WG_N_SUMS * NS + entc;
+    float* const o = d.next_obs + (size_t)ctx_id * p.obs_dim + (size_t)entc * p.turb_obs;
+    const unsigned sm = p.sum_mask_t, cmask = p.oc.cur_mask, rmask = p.oc.rol_mask;
+    float v0[WG_N_CH][8], cv[WG_N_CH];
+#pragma unroll
+    for (int sl = 0; sl < WG_N_CH; ++sl) {
+        const int off = p.ring_off[sl], cap = p.ring_cap[sl];
+        const int cnt = p.sum_w[sl] < n_pushed ? p.sum_w[sl] : n_pushed;
+        const int r0 = (n_pushed - cnt) % cap;
+        const int last = n_pushed > 0 ? (n_pushed - 1) % cap : 0;
+        cv[sl] = rb[(unsigned)(off + last * N) + entc];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {      // (clamped rows: always valid addresses, masked where they are added)
+            int row = r0 + max(min(sub + u * Lg, cnt - 1), 0); if (row >= cap) row -= cap;
+            v0[sl][u] = rb[(unsigned)(off + row * N) + entc];
+        }
+    }
+    int n = 0;
+#pragma unroll
+    for (int sl = 0; sl < WG_N_CH; ++sl) {
+        const bool on = have && ((sm >> sl) & 1u);
+        const int off = p.ring_off[sl], cap = p.ring_cap[sl];
+        const int cnt = p.sum_w[sl] < n_pushed ? p.sum_w[sl] : n_pushed;
+        const int r0 = (n_pushed - cnt) % cap;
+        double acc = 0.0;
+        if (on) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (sub + u * Lg < cnt) acc += (double)v0[sl][u];
+#pragma nounroll
+            for (int k = sub + 8 * Lg; k < cnt; k += 8 * Lg) {      // (windows beyond 8 Lg samples)
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    int row = r0 + min(k + u * Lg, cnt - 1); if (row >= cap) row -= cap;
+                    v[u] = rb[(unsigned)(off + row * N) + entc];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k + u * Lg < cnt) acc += (double)v[u];
+            }
+        }
+        for (int s2 = 1; s2 < Lg; s2 <<= 1) acc += __shfl_xor(acc, s2, 64);
+        if (on && sub == 0) ws_[(size_t)sl * NS] = acc;
+        if (have && sub == 0 && n_pushed > 0) {
+            if ((cmask >> sl) & 1u) o[n++] = wg_scale_r(cv[sl], p.oc.mn[sl], p.oc.inv_rng[sl]);
+            if ((rmask >> sl) & 1u) o[n++] = wg_scale_r(wg_sums_mean(p.oc, acc, sl, n_pushed), p.oc.mn[sl], p.oc.inv_rng[sl]);
+        }
+    }
+    if (lane == 0) d.next_obs_ok[ctx_id] = 1;
+}
+
 struct EnvFlowOut {          // what the flow part hands to the glue tail of k_step_env
     int env_live, bg_init_pending;
     int truncates;            // the env truncates in this step (known from its header): the only case in which the glue needs the
@@ -167,7 +271,7 @@ struct EnvFlowOut {          // what the flow part hands to the glue tail of k_s
 // paths of the background context (episode set-up, a second flow step, the first observation) are off the live wave's chain;
 // the waves meet at ONE workgroup barrier before the live context's wave runs the glue (k_flow_env).  `smem` is the wave's
 // own region, `wv` its context.
-template <bool NOISE, int WPE>
+template <bool NOISE, int WPE, int GLUE>
 __device__ __forceinline__ void env_flow(char* const smem, const int wv, const int mode, const float* __restrict__ actions,
                                          const uint8_t* __restrict__ mask, const int chunk, EnvFlowOut& out) {
     const int tid = threadIdx.x & 63, e = blockIdx.x;
@@ -276,7 +380,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
                 // rare path (one context per truncation): set the retired context's next episode up, both farms (see k_flow)
                 const KArgsPtr ki = wg_cold_args();
                 const WgParams& gp = *ki->d.gp;
-                env_init_episode(ki->d.gp, ki->d.gd, ki->d.env_rw + e, e, env_live ^ 1, tid);
+                env_init_episode<GLUE != 0>(e, env_live ^ 1, tid);
                 full_barrier<64>();
                 load_state();
                 const int fill_max = F == 2 ? max(gp.fill_a, gp.fill_b) : gp.fill_a;
@@ -285,6 +389,17 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
                 const long total = (long)((tm + inc - 1) / inc) + 1;
                 const int dev0 = __shfl(dev_rem, WPE == 2 ? 0 : (env_live ^ 1) * F * N, 64);
                 budget = wg_shadow_share(dev0 + gp.K * fill_max, total - env_steps_done, env_steps_done, e);
+                if (WG_ENV_SPLIT_PLAN != 0)
+                    budget = wg_shadow_share(dev_rem + gp.K * fill_rem, total - env_steps_done, env_steps_done, e, farm ? 0x80000000u : 0u);
+            } else if (WG_ENV_SPLIT_PLAN != 0) {
+                // The background episode's share of this step, planned per FARM: the flow steps its farm still needs over the env
+                // steps left (wg_shadow_share: dithered, so the expected share is exact), the baseline farm's dither half a period
+                // after the agent farm's — below one flow step per two env steps the two never step in the same launch, and a wave
+                // carries 2 F + 1 farm steps where the per-context plan (WgEnv::shadow_iters, ignored here) gave it 2 F or 3 F:
+                // the launch lasts as long as its heaviest wave.
+                const int inc = k0->p.env_inc;
+                const long total = (long)((envc->time_max_live + inc - 1) / inc) + 1;
+                budget = role_dev ? wg_shadow_share(dev_rem + k0->p.K * fill_rem, total - env_steps_done, env_steps_done, e, farm ? 0x80000000u : 0u) : 0;
             } else {
                 budget = env_shadow_iters;
             }
@@ -305,7 +420,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
                     const KArgsPtr kf = wg_cold_args();
                     if (d0 == 0 && f0 == 0 && kf->d.gd->next_obs_ok != nullptr && kf->d.gd->next_obs_ok[ctx_id] == 0) {
                         out.first_obs = 1;
-                        wg_first_obs(kf->d.gp, kf->d.gd, (int)ctx_id, np0, tid);
+                        env_first_obs<GLUE != 0>((int)ctx_id, np0, tid);
                     }
                 }
                 return;
@@ -570,6 +685,9 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
             const float2* const rpt = reinterpret_cast<const float2*>(smem + ke2->p.env_off_tab + 8 * ke2->p.n_tab);
             auto eval_cand = [&](const Cand& cd, const int pos) __attribute__((always_inline)) {
                     if (!cd.ok) return;
+#ifdef WG_TIMELINE
+                    atomicAdd(&wg_counts[1], 1);
+#endif
                     const int gt = cd.en >> 5;
                     const int kt = Lring[gt].w;
                     const int gs = kt * N + (cd.en & 31);
@@ -604,6 +722,10 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
                     const float rc2 = (yt - yc) * (yt - yc);      // (+ (hub - zc)^2 = 0: steady inflow keeps the wake centre at hub height)
                     const float rcut = R_rot + 5.0f * sig;
                     if (rc2 > rcut * rcut) return;
+#ifdef WG_TIMELINE
+                    atomicAdd(&wg_counts[2], 1);
+                    if (rc2 <= (R_rot + 3.0f * sig) * (R_rot + 3.0f * sig)) atomicAdd(&wg_counts[3], 1);
+#endif
                     const float ctv = w0 * rec_ct(a0) + w1 * rec_ct(a1);
                     const float uev = w0 * u0 + w1 * u1;
                     const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sig * sig);
@@ -622,6 +744,9 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
                     }
                     def[pos] = acc * inv_S;
             };
+#ifdef WG_TIMELINE
+            if (tid == 0) atomicAdd(&wg_counts[0], nc);
+#endif
             for (int c0 = 0; c0 < nc; c0 += WG_ENV_CAP) {
                 const int c1 = min(nc, c0 + WG_ENV_CAP);
                 if (c0 > 0) { lds_barrier<64>(); issue(ca, c0 + tid, c0, c1); }
@@ -709,6 +834,9 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
             }
             lds_barrier<64>();
             WG_STAMP(10);
+#ifdef WG_TIMELINE
+            if (tid == 0) atomicAdd(&wg_counts[4], nlist);
+#endif
 
             // advection pass, software-pipelined: a lane requests its next listed quad before it computes the current one
             // (vmcnt counts loads and stores in ONE in-order queue: a plain load-compute-store loop waits for the previous
@@ -959,13 +1087,13 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
             const int np = bs.n_pushed;
             out.first_obs = 1;
             full_barrier<64>();                            // the ring pushes have left the wave
-            wg_first_obs(ke->d.gp, ke->d.gd, bctx, np, tid);
+            env_first_obs<GLUE != 0>(bctx, np, tid);
         }
     }
     if (defer_init) {
         // (see the prologue) the retired context's next episode, set up after the wave's own step; the slots' remaining work goes
         // to the LDS records the glue plans the first share from
-        env_init_episode(ke->d.gp, ke->d.gd, ke->d.env_rw + e, e, env_live ^ 1, tid);
+        env_init_episode<GLUE != 0>(e, env_live ^ 1, tid);
         full_barrier<64>();
         if (valid && t == 0 && c != env_live) {
             const WgSlot& slot = ke->d.slot[(unsigned)(e * 2 * F + kbase + k)];
@@ -980,11 +1108,6 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
 // k_flow_env<NOISE, 1 / 2>: step() as ONE launch — the env's wave runs its glue (lean_step: sums-mode handles without TI /
 // farm-level entries; 2 = with the per-agent observation buffer of the PettingZoo facade) as the tail of its flow step.  No
 // cross-workgroup dependency: the wave owns both contexts of its env.  (Wind_Farm_Env.py:920-1034 in one kernel.)
-// the kernel's arguments as they lie in the kernarg segment
-struct EnvKArgs {
-    FlowP p; FlowPtrs d; int mode; const float* actions; const uint8_t* mask; int chunk; WgParams gp; WgPtrs gd;
-    float* obs; float* reward; uint8_t* trunc; float* final_obs;
-};
 template <bool NOISE, int GLUE, int WPE>
 __global__ void __launch_bounds__(64 * WPE, WG_ENV_WAVES)
 k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __restrict__ actions,
@@ -993,16 +1116,16 @@ k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __res
            float* __restrict__ final_obs_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef WG_TIMELINE
-    if (threadIdx.x == 0) { for (int i = 0; i < 16; ++i) wg_stamps[i] = 0; wg_stamps[14] = wall_clock64(); }
+    if (threadIdx.x == 0) { for (int i = 0; i < 20; ++i) wg_stamps[i] = 0; wg_stamps[14] = wall_clock64(); for (int i = 0; i < 8; ++i) wg_counts[i] = 0; }
+    __syncthreads();
 #endif
     // (WPE 2: wave c of the workgroup serves context c of the env, in its own LDS region)
     const int wv = WPE == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const int lds_wave = WPE == 2 ? wg_cold_args()->p.env_lds : 0;
     char* const sm = smem + wv * lds_wave;
     EnvFlowOut fo;
-    env_flow<NOISE, WPE>(sm, wv, mode, actions, mask, chunk, fo);
+    env_flow<NOISE, WPE, GLUE>(sm, wv, mode, actions, mask, chunk, fo);
     if (GLUE != 0) {
-        typedef const __attribute__((address_space(4))) EnvKArgs* EnvKArgsPtr;
         // (every store of the flow part — rings, turbine state, headers, a prepared first observation — has left the wave
         // before anything reads it back; LDS still holds the slots' records)
         full_barrier<64>();
@@ -1061,6 +1184,8 @@ k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __res
             for (int kq = 0; kq < 16; ++kq) row[kq] = wg_stamps[kq];
             row[16] = fo.bg_init_pending; row[17] = fo.rounds; row[18] = fo.first_obs;
             row[19] = GLUE != 0 ? (long long)kt->d.env[blockIdx.x].timestep : 0;      // (0 right after a swap)
+            for (int kq = 0; kq < 8; ++kq) row[20 + kq] = wg_counts[kq];
+            for (int kq = 0; kq < 4; ++kq) row[28 + kq] = wg_stamps[16 + kq];      // glue: header in / loads in / reward + metrics / observation      // candidates listed / fetched / inside 5 sigma / inside 3 sigma, quads listed
         }
     }
 #endif

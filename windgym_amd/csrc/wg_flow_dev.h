@@ -84,15 +84,6 @@ __device__ __forceinline__ float tab_lookup(const float* __restrict__ ys, const 
     return ys[i] + f * (ys[i + 1] - ys[i]);
 }
 
-#ifdef WG_TIMELINE
-// debug build (-DWG_TIMELINE, env WG_TIMELINE_OUT=file): thread 0 of every workgroup records shader-clock stamps
-// at the phase boundaries of its step; wg_destroy dumps them.  This is how the per-workgroup latency budget in
-// DESIGN.md §4.1 was measured.
-__shared__ long long wg_stamps[16];
-#define WG_STAMP(k) do { if (threadIdx.x == 0) wg_stamps[k] = clock64(); } while (0)
-#else
-#define WG_STAMP(k) do { } while (0)
-#endif
 
 // Cold parameters.  k_flow's by-value parameter blocks are ~190 dwords; everything the hot loops do not touch used to
 // stay in SGPRs across them anyway (the compiler hoists every kernarg load to the top) and the overflow — ~90 values at

@@ -353,6 +353,9 @@ __device__ __forceinline__ void lean_step(const WgParams& p, const WgPtrs& d, co
     float rated_power = wg_pin<FUSED>(ec->rated_live);
     double fsum_run = wg_pin<FUSED>(ec->fsum_run), bsum_run = wg_pin<FUSED>(ec->bsum_run);
     const int live = ev.live, nxt = live ^ 1;
+#if defined(WG_TIMELINE) && defined(WG_STAMP2)
+    if (FUSED) WG_STAMP2(16);
+#endif
     const int ctx_id = e * 2 + live;
     if (WG_LEAN_ABLATE == 1) { if (lane == 0 && reward_out) reward_out[e] = (float)(fsum_run + bsum_run) + (float)(ev.timestep + ev.episode + time_max + n_pushed_live); return; }
     // an env that truncates (known from the header alone) fetches the next context's header with everything else
@@ -397,6 +400,9 @@ __device__ __forceinline__ void lean_step(const WgParams& p, const WgPtrs& d, co
             if (wg_pin<FUSED>(((CCtxPtr)(d.ctx + e * 2 + nxt))->init_pending) && lane == 0) d.ctx[e * 2 + nxt].init_pending = 0;
         }
     }
+#if defined(WG_TIMELINE) && defined(WG_STAMP2)
+    if (FUSED) { __builtin_amdgcn_s_waitcnt(0); WG_STAMP2(17); }
+#endif
     if (WG_LEAN_ABLATE == 2) {
         float acc = raw.nw[0] + raw.nw[2] + raw.lv[0] + raw.lv[2] + (float)raw.S[0] + (float)raw.S[2] + l_yaw + l_old + l_pow + l_powb + fp + bp + f_old + b_old + l_met;
         if (reward_out) reward_out[e] = acc + (float)work;
@@ -495,6 +501,9 @@ __device__ __forceinline__ void lean_step(const WgParams& p, const WgPtrs& d, co
         add = lane == WG_MET_N_EPISODES ? trf : add;
         met[lane] = l_met + add;
     }
+#if defined(WG_TIMELINE) && defined(WG_STAMP2)
+    if (FUSED) WG_STAMP2(18);
+#endif
     if (WG_LEAN_ABLATE == 4) {
         float acc = raw.nw[0] + raw.nw[2] + raw.lv[0] + raw.lv[2] + (float)raw.S[0] + (float)raw.S[2];
         if (trunc_out && acc == 123.f) trunc_out[e] = 7;
@@ -520,6 +529,9 @@ __device__ __forceinline__ void lean_step(const WgParams& p, const WgPtrs& d, co
             build_obs_sums<MULTI, GEN>(p, lane, o1, swap_obs ? nullptr : fin, swap_obs ? nullptr : om, np_step + 1, mscr, oi, get);
         }
     }
+#if defined(WG_TIMELINE) && defined(WG_STAMP2)
+    if (FUSED) WG_STAMP2(19);
+#endif
     if (WG_LEAN_ABLATE == 5) return;
 
     if (!p.autoreset || truncated) ev.shadow_iters = 0;      // (after a swap the initialising workgroups plan their own first share)

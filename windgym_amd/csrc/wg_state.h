@@ -23,6 +23,8 @@
 #define WG_NWAVES (WG_BLOCK / WG_WAVE)
 
 typedef unsigned __int128 wg_u128;
+// numpy's PCG64 multiplier (pcg64.h: PCG_DEFAULT_MULTIPLIER_128)
+#define WG_PCG_MULT ((((wg_u128)2549297995355413924ULL) << 64) | (wg_u128)4865540595714422341ULL)
 
 enum { WG_MODE_STEP = 0, WG_MODE_RESET = 1 };
 
@@ -208,6 +210,7 @@ struct WgPtrs {
     const int* box_override;       // [B] box of the pool env e uses (FarmEval.update_tf: TF_files = [path]) or null; < 0 = draw
     // config tables
     const double *x_pos, *y_pos, *yaw_defined;
+    const uint64_t* pcg_jump;      // [max(N, 3) + 1][4]: (A_k lo, hi, G_k lo, hi), k draws ahead: state_k = A_k state_0 + G_k inc (wg_ctx_init)
     const float *rotor_dy, *rotor_dz;
     const float *tab_ws, *tab_power, *tab_ct;
     const double *tab_ws_d, *tab_power_d;
