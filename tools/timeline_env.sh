@@ -54,5 +54,10 @@ if c[0] > 0:
 ini = a[:, 16] != 0
 if ini.any():
     print('episode set-up (cycles; the waves that ran it): wind + yaw draws (lane 0) %s | rated power, rotation, ring layout %s | slots, turbine state %s' % (a[ini, 25].tolist(), a[ini, 26].tolist(), a[ini, 27].tolist()))
+order = np.argsort(-life)[:12]
+print('slowest waves: life us | candidates quads rounds | set-up first-obs swapped | advection eval glue prologue (cycles)')
+for i in order:
+    print('   %.1f | %4d %4d %d | %d %d %d | %6d %6d %6d %6d' % (life[i], a[i, 20], a[i, 24], a[i, 17], a[i, 16] != 0, a[i, 18] != 0, a[i, 19] == 0,
+          a[i, 3] - a[i, 10], a[i, 9] - a[i, 2], a[i, 13] - a[i, 12], a[i, 1] - a[i, 0]))
 print('core clock (cycles per us of wave life): %.0f' % np.median(tot / np.maximum((w1 - w0) / 100, 1e-9)))
 PY
