@@ -14,6 +14,18 @@ __global__ void k_line_read(const float* __restrict__ in, float* __restrict__ ou
     for (; i < nlines; i += (size_t)gridDim.x * blockDim.x) acc += in[i * 32];     // one float per 128-byte line
     if (acc == 1.2345f) out[0] = acc;
 }
+__global__ void k_line_read16(const float4* __restrict__ in, float* __restrict__ out, size_t nlines) {   // 16 B per 128-byte line
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    float acc = 0.f;
+    for (; i < nlines; i += (size_t)gridDim.x * blockDim.x) { const float4 v = in[i * 8]; acc += v.x + v.w; }
+    if (acc == 1.2345f) out[0] = acc;
+}
+__global__ void k_half_read(const float4* __restrict__ in, float* __restrict__ out, size_t nlines) {     // the first 64 of every 128 bytes
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    float acc = 0.f;
+    for (; i < nlines * 4; i += (size_t)gridDim.x * blockDim.x) { const float4 v = in[(i >> 2) * 8 + (i & 3)]; acc += v.x + v.w; }
+    if (acc == 1.2345f) out[0] = acc;
+}
 __global__ void k_stream_write(float4* __restrict__ out, size_t n4) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     for (; i < n4; i += (size_t)gridDim.x * blockDim.x) out[i] = make_float4(1.f, 2.f, 3.f, 4.f);
@@ -29,15 +41,20 @@ __global__ void k_line_write64(float4* __restrict__ out, size_t nlines) {       
 int main() {
     const size_t bytes = 1ull << 30;
     float4 *a; float* o;
-    hipMalloc(&a, bytes); hipMalloc(&o, 64);
-    hipMemset(a, 0, bytes);
-    hipDeviceSynchronize();
+    (void)hipMalloc(&a, bytes); (void)hipMalloc(&o, 64);
+    (void)hipMemset(a, 0, bytes);
+    (void)hipDeviceSynchronize();
+    k_stream_read<<<4096, 256>>>(a, o, bytes / 16);
+    k_line_read<<<4096, 256>>>((const float*)a, o, bytes / 128);
+    k_line_read16<<<4096, 256>>>(a, o, bytes / 128);
+    k_half_read<<<4096, 256>>>(a, o, bytes / 128);
+    // (durations in the kernel trace: does a narrow read of a line cost the bandwidth of all of its 128 bytes?)
     k_stream_read<<<4096, 256>>>(a, o, bytes / 16);
     k_line_read<<<4096, 256>>>((const float*)a, o, bytes / 128);
     k_stream_write<<<4096, 256>>>(a, bytes / 16);
     k_line_write4<<<4096, 256>>>((float*)a, bytes / 128);
     k_line_write64<<<4096, 256>>>(a, bytes / 128);
-    hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();
     printf("bytes per kernel: %zu (= %zu KiB)\n", bytes, bytes >> 10);
     return 0;
 }
