@@ -302,6 +302,12 @@ def main():
     rep_s = []
     flow_ms = glue_ms = 0.0
     n_launch = 0
+    # two events around each repetition's whole run of step() calls, on the stream the kernels are launched on: with ONE launch
+    # per step, (interval / steps) is the step kernel's duration plus the gap to the next launch — an upper bound that has no
+    # per-launch event packets in it (the events around single launches add ~5 us to a 50 us kernel)
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    region_ms = 0.0
+    region_steps = 0
     flow_steps = particles = added = 0.0
     for _ in range(args.warmup):
         step(acts[it % n_act]); it += 1
@@ -311,10 +317,13 @@ def main():
         env.kernel_timing(args.timing_period)   # HIP events around every n-th step() of the timed region
         barrier()
         t0 = time.perf_counter()
+        ev_a.record()
         for _ in range(args.steps):
             step(acts[it % n_act]); it += 1
+        ev_b.record()
         barrier()
         el = time.perf_counter() - t0
+        region_ms += ev_a.elapsed_time(ev_b); region_steps += args.steps
         f, g, n, fs, pt = env.kernel_timing(0)
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         if rccl:
@@ -372,6 +381,10 @@ def main():
                     traffic = traffic_source = None
         variant = env.flow_variant()[2]
         fused = variant == 2 and glue_ms == 0.0 and flow_ms > 0
+        per_launch_event_ms = flow_ms
+        if fused and region_steps > 0:
+            # one launch per step: the kernel cannot last longer than the stream's time per step
+            flow_ms = min(flow_ms, region_ms / region_steps)
         if fused:
             # step() is ONE launch (k_flow_env with the env's glue as its tail): the timed kernel carries the glue's bytes too
             # (20 N + 12 O + 20 per env step)
@@ -416,6 +429,9 @@ def main():
                          "particles_touched_per_launch": touched,
                          "kernel": kernel_name,
                          "kernel_ms": flow_ms, "glue_kernel_ms": glue_ms, "launches_timed": n_launch,
+                         "kernel_ms_how": ("HIP events around each repetition's run of step() calls / steps (one launch per step: kernel + gap to "
+                                           "the next launch); events around single launches measured %.4f ms" % per_launch_event_ms) if fused
+                                          else "HIP events around every n-th launch of the timed region",
                          "algorithmic_bytes_per_launch": alg_bytes_flow, "farm_flow_steps_per_launch": flow_steps,
                          "particles_needed_per_launch": particles,
                          "added_turbulence_rotor_points_per_launch": added,
