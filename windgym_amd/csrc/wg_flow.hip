@@ -1754,6 +1754,10 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     const size_t pbase = (size_t)slot_id * p.pstride;
 
     WG_STAMP(0);
+#if defined(WG_TIMELINE) && defined(WG_TIMELINE_WALL)
+    const long long wg_wall0 = wall_clock64();
+    if (tid == 0 && d.dbg) d.dbg[(size_t)blockIdx.x * 16] = 0;
+#endif
     if ((WG_ABLATE & 32) && mode == WG_MODE_STEP) return;      // profiling: cost of the dispatch alone
     // ---- prologue: issue every independent global load up front (ONE exposed memory round trip) -------
     // (cold parameters: the pointers below are read from the kernarg segment where they are used and not kept — see
@@ -2139,12 +2143,24 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
     // a background episode's development ends with this launch: its first observation (wg_first_obs)
     // (compact variants: wg_create leaves next_obs null for every other handle; the builder is single-wave code — wave 0 of a
     // larger workgroup runs it)
+    bool built_first_obs = false;
     if (RES) {
         if (mode == WG_MODE_STEP && !live_step && farm == 0 && dev_rem == 0 && fill_rem == 0) {
             full_barrier<NT>();                  // the ring pushes have left the workgroup
             if (NT == WG_WAVE || tid < WG_WAVE) wg_first_obs(ke->d.gp, ke->d.gd, ctx_id, n_pushed, tid);
+            built_first_obs = true;
         }
     }
+#if defined(WG_TIMELINE) && defined(WG_TIMELINE_WALL)
+    // (-DWG_TIMELINE_WALL, tools/timeline_wall.sh: every workgroup that took a step leaves its wall-clock start / end and what it did)
+    if (tid == 0 && d.dbg) {
+        long long* row = d.dbg + (size_t)blockIdx.x * 16;
+        row[15] = wall_clock64(); row[14] = wg_wall0; row[13] = n_flow; row[12] = (init_pending ? 1 : 0) | (built_first_obs ? 2 : 0) | (live_step ? 4 : 0);
+        row[0] = 1;
+    }
+#else
+    (void)built_first_obs;
+#endif
 }
 
 #include "wg_flow_duo.inc"
