@@ -399,7 +399,7 @@ def main():
             achieved = alg_bytes_flow / (flow_ms * 1e-3) / 1e9 if flow_ms > 0 else 0.0
             bytes_per_flow_step = alg_bytes_flow / flow_steps if flow_steps > 0 else 0.0
         touched_bytes = (touched * per_particle + (alg_bytes_flow - particles * per_particle)) if touched is not None else None
-        kernel_name = {0: "k_flow", 1: "k_flow_duo", 2: "k_flow_env"}[variant] + (" (one launch per step: flow + glue tail)" if fused else "")
+        kernel_name = {0: "k_flow", 2: "k_flow_env"}[variant] + (" (one launch per step: flow + glue tail)" if fused else "")
         out = {
             "metric": "env-steps/sec (whole node), 16-turbine farm x 4096 envs" if args.workload == "cfg2"
                       else f"env-steps/sec (whole node), {args.workload}",

@@ -377,9 +377,9 @@ int wg_added_lookups(wg_handle h, double* rotor_points_per_launch);
 int wg_algorithmic_bytes(wg_handle h, double* bytes_per_step);
 
 /* Which flow kernel the handle launches (diagnostics / tests; chosen in wg_create from the farm geometry and the inflow; the
- * hooks WG_FLOW_BLOCK / WG_FLOW_RES / WG_FLOW_DUO / WG_FLOW_ENV / WG_ENV_WPE / WG_STEP_FUSED override it, honoured only
+ * hooks WG_FLOW_BLOCK / WG_FLOW_RES / WG_FLOW_ENV / WG_ENV_WPE / WG_STEP_FUSED override it, honoured only
  * with WG_DEBUG_HOOKS=1): threads per wave-group, 1 = compact per-turbine rings with pair-major deficit phases, and the farm
- * slots one wave serves: 0 = one (k_flow), 1 = both farms of a context (k_flow_duo), 2 = every slot of an env / of one of its
+ * slots one wave serves: 0 = one (k_flow), 2 = every slot of an env / of one of its
  * contexts (k_flow_env: one or two waves per env; with the lean glue, wg_step is then ONE kernel launch).                     */
 int wg_flow_variant(wg_handle h, int* block, int* compact, int* duo);
 

@@ -24,40 +24,36 @@ def hip():
     return binding
 
 
-# every k_flow variant the host can select (wg_flow.hip): one workgroup of 64 / 128 / 256 threads per farm slot, and
-# "duo" = k_flow_duo, both farms of a context in one 64-lane workgroup (two-farm configs; falls back to 64 otherwise)
-BLOCKS = [64, 128, 256, "duo"]
-# "env" = k_flow_env, one wave per env with lane = farm slot x turbine (steady inflow, small farms: what cfg2 / cfg4 run)
-STEADY_BLOCKS = BLOCKS + ["env"]
+# every k_flow variant the host can select (wg_flow.hip): one workgroup of 64 / 128 / 256 threads per farm slot
+BLOCKS = [64, 128, 256]
+# "env" = k_flow_env, one or two waves per env with lane = farm slot x turbine (small farms: what cfg2 / cfg4 run);
+# "env1" = the same kernel forced to ONE wave per env (WG_ENV_WPE=1: what a batch of more than 2048 envs runs — the headline)
+STEADY_BLOCKS = BLOCKS + ["env", "env1"]
+# frozen-box inflow: the per-slot instantiations and "envb" = k_flow_envb (wg_envb.hip), the one-launch env kernel cfg5 runs
+BOX_BLOCKS = BLOCKS + ["envb", "envb1"]
 
 
 def _make_env(hip, cfg, block=None):
-    """HipBatch whose k_flow runs the given workgroup-size instantiation (WG_FLOW_BLOCK is read at wg_create)."""
+    """HipBatch whose flow kernel is the given instantiation (the hooks are read at wg_create)."""
     import os
     if block is None:
         return hip.HipBatch(cfg)
-    if block == "duo" and cfg.turbtype != "None":
-        # k_flow_duo does not carry the wake-added turbulence field (the host falls back to k_flow when it is on): the
-        # duo kernel's turbulent instantiations are tested without it; the caller builds its oracle from the same cfg
-        cfg.added_turbulence = "none"
-    os.environ["WG_FLOW_BLOCK"] = "64" if block in ("duo", "env") else str(block)
-    os.environ["WG_FLOW_DUO"] = "1" if block == "duo" else "0"
-    os.environ["WG_FLOW_ENV"] = "1" if block == "env" else "0"
+    envk = isinstance(block, str) and block.startswith("env")
+    hooks = {"WG_FLOW_BLOCK": "64" if envk else str(block), "WG_FLOW_ENV": "1" if envk else "0"}
+    if envk:
+        hooks["WG_ENV_WPE"] = "1" if block.endswith("1") else "2"
+    os.environ.update(hooks)
     try:
         env = hip.HipBatch(cfg)
     finally:
-        del os.environ["WG_FLOW_BLOCK"]
-        del os.environ["WG_FLOW_DUO"]
-        del os.environ["WG_FLOW_ENV"]
+        for k in hooks:
+            del os.environ[k]
     # the variant asked for is the one that runs (a silent fallback would test the wrong kernel)
-    threads, compact, duo = env.flow_variant()
-    two_farms = bool(cfg.baseline_comp)
-    if block == "env":
-        assert threads == 64 and compact and duo == 2
-    elif block == "duo":
-        assert threads == 64 and compact and duo == two_farms
+    threads, compact, slots = env.flow_variant()
+    if envk:
+        assert threads == 64 and compact and slots == 2
     else:
-        assert threads == block and not duo
+        assert threads == block and not slots
     return env
 
 
@@ -226,6 +222,32 @@ def test_edge_shapes_match_oracle(hip, oracle_lib, case):
         assert n_tr == steps                         # x_max - x_min = 0 -> time_max = 0 (Wind_Farm_Env.py:723-732)
 
 
+@pytest.mark.parametrize("block", ["env", "env1"])
+def test_one_step_episodes_on_the_env_kernel(hip, oracle_lib, block):
+    """episodes of ONE step (N = 1: x_max - x_min = 0 -> time_max = 0) on k_flow_env.  Every step truncates, so the
+    context retired by step t must be set up, developed and swapped in by step t + 1's launch: with one wave per env the
+    episode set-up may NOT be deferred behind the wave's step when that very step truncates (it was: lean_swap then raised
+    WG_STATUS_BIT_STATE and the observation windows were under-filled)."""
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.turbine import V80
+    _, meta = load_golden("env1")
+    d = meta["cfg"]
+    d["farm"].update(nx=1, ny=1)
+    d["ActionMethod"] = "yaw"
+    B = 5
+    cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_envs=B, autoreset=True, n_passthrough=1, n_rotor_pts=16)
+    env, orc = _make_env(hip, cfg, block), oracle_lib.Oracle(cfg)
+    seeds = 77 + np.arange(B)
+    np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=OBS_ATOL)
+    rng = np.random.default_rng(5)
+    for step in range(60):
+        a = rng.uniform(-1, 1, size=(B, cfg.n_turb)).astype(np.float32)
+        _compare_step(env, orc, a, step)
+        assert env.truncated.all()
+        env.check()                               # no unready background episode at any swap
+    env.close()
+
+
 def test_lds_fallback_to_uniform_rings_matches_oracle(hip, oracle_lib):
     """A small farm whose compact-variant LDS carve does not fit a workgroup (N = 32, P = 4096: the 16-bit quad list alone
     is 64 KB) must fall back to the uniform-ring variant at wg_create — not fail at the first launch — and still match
@@ -233,8 +255,8 @@ def test_lds_fallback_to_uniform_rings_matches_oracle(hip, oracle_lib):
     B = 2
     cfg = _physics_cfg(B, autoreset=True, n_passthrough=0.1, nx=8, ny=4, n_particles=4096)
     env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
-    block, compact, duo = env.flow_variant()
-    assert (block, compact, duo) == (256, False, False)
+    block, compact, slots = env.flow_variant()
+    assert (block, compact, slots) == (256, False, 0)
     seeds = 5 + np.arange(B)
     np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=OBS_ATOL)
     rng = np.random.default_rng(3)
@@ -272,12 +294,15 @@ def test_nonuniform_turbine_table_matches_oracle(hip, oracle_lib):
     env.check()
 
 
-def test_hip_autoreset_pipeline_matches_oracle(hip, oracle_lib):
+@pytest.mark.parametrize("block", [None, "env1"])
+def test_hip_autoreset_pipeline_matches_oracle(hip, oracle_lib, block):
     """Episodes are short (n_passthrough=1) so every env rolls over several times: the background-developed
-    next episode must be identical to the oracle's synchronous reset, at the exact step."""
+    next episode must be identical to the oracle's synchronous reset, at the exact step.  None = the handle's default (two
+    waves per env at this batch size); "env1" = ONE wave per env, the variant batches above 2048 envs — the headline — run:
+    deferred episode set-up, first observation built a launch later, the swap in the wave's own glue tail."""
     B = 12
     cfg = _physics_cfg(B, autoreset=True, n_passthrough=1, nx=3, ny=2)
-    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    env, orc = _make_env(hip, cfg, block), oracle_lib.Oracle(cfg)
     seeds = 77 + np.arange(B)
     np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=OBS_ATOL)
     rng = np.random.default_rng(1)
@@ -600,17 +625,15 @@ def test_mann_box_inflow_matches_oracle(hip, oracle_lib, small_mann_box, turbtyp
     assert np.std(u[..., 0]) > 0.05 and np.std(u[..., 2]) > 0.005
 
 
-@pytest.mark.parametrize("dims,spacing", [((256, 64, 32), (3.0, 3.0, 3.0)),      # coarse copy 64 x 16 x 8: masks
-                                          ((240, 72, 40), (3.0, 3.0, 3.0))])     # coarse copy 60 x 18 x 10: modulo
-@pytest.mark.parametrize("turbtype", ["MannGenerate", "Random"])
+@pytest.mark.parametrize("dims,spacing,turbtype", [((256, 64, 32), (3.0, 3.0, 3.0), "MannGenerate"),      # coarse copy 64 x 16 x 8: masks
+                                                   ((240, 72, 40), (3.0, 3.0, 3.0), "MannGenerate"),      # coarse copy 60 x 18 x 10: modulo
+                                                   ((256, 64, 32), (3.0, 3.0, 3.0), "Random")])
 def test_cfg5_shape_runs_the_instantiation_the_bench_runs(hip, oracle_lib, dims, spacing, turbtype):
     """BASELINE.json configs[4] at its real farm shape: 4 x 4 turbines x P = 128 (N P = 2048) selects
-    k_flow<128, BOX> — the instantiation bench.py --workload cfg5 times — here against the oracle, with a box whose
+    the kernel bench.py --workload cfg5 times (the handle's default) — here against the oracle, with a box whose
     block-averaged meandering copy has power-of-two dims and one whose copy has not (both divisible by 4).  "Random"
-    covers k_flow<128, RANDOM> at the same shape."""
+    covers k_flow<64, RANDOM> at the same shape (one case: it reads no box)."""
     from windgym_amd.mann import generate_mann_box
-    if turbtype == "Random" and dims[0] != 256:
-        pytest.skip("no box for Random inflow")
     B = 4
     cfg = _turb_cfg(turbtype, B, nx=4, ny=4)
     assert cfg.n_turb * cfg.n_particles == 2048
@@ -1053,3 +1076,41 @@ def test_large_farm_variant_at_its_size_limits(hip, oracle_lib, nx, ny):
         a = rng.uniform(-1, 1, size=(2, cfg.n_turb)).astype(np.float32)
         _compare_step(env, orc, a, step, check_flow=(step % 20 == 0))
     env.check()
+
+
+def test_never_truncate_long_run_keeps_the_running_ti_sums_on_the_oracle(hip, oracle_lib):
+    """in sums mode the lean glue carries the ws deque's sum and sum of squares (calc_TI, MesClass.py:220-237) as
+    RUNNING sums for the whole episode; the sum of squares rounds (v * v needs 48 mantissa bits) and the rounding is carried
+    along.  An episode that never truncates, 12 000 steps, TI entries at turbine and farm level observed: the observation must
+    stay on the oracle's (which recomputes TI from the deque every step) — i.e. the drift of the running sum of squares stays
+    orders of magnitude below the observation tolerance."""
+    import copy
+    import torch
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.presets import env1_config
+    from windgym_amd.turbine import V80
+    d = copy.deepcopy(env1_config())
+    d["ActionMethod"] = "yaw"
+    d["farm"].update(nx=3, ny=2)
+    d["mes_level"].update(turb_ws=True, turb_TI=True, farm_ws=True, farm_TI=True)
+    B = 3
+    cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_envs=B, autoreset=False, n_passthrough=1, n_rotor_pts=16,
+                    never_truncate=True)
+    env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(cfg)
+    seeds = 41 + np.arange(B)
+    np.testing.assert_allclose(env.reset(seeds=seeds).cpu().numpy(), orc.reset(seeds=seeds), rtol=0, atol=OBS_ATOL)
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for step in range(12000):
+        a = rng.uniform(-1, 1, size=(B, cfg.n_turb)).astype(np.float32)
+        obs, rew, tr, _ = env.step(torch.as_tensor(a, device="cuda"))
+        o_obs, o_rew, o_tr, _ = orc.step(a)
+        assert not o_tr.any()
+        if step % 100 == 0 or step > 11900:
+            assert not tr.any()
+            g = obs.cpu().numpy()
+            np.testing.assert_allclose(g, o_obs, rtol=0, atol=OBS_ATOL, err_msg=f"obs step {step}")
+            worst = max(worst, float(np.abs(g - o_obs).max()))
+    env.check()
+    assert worst <= OBS_ATOL
+    env.close()

@@ -81,13 +81,13 @@ def test_soak_cfg3_horns_rev_512_envs(hip):
 
 def test_soak_cfg4_multi_agent_2048_envs_fused_buffer(hip):
     """cfg4: 3x3 farm, PettingZoo per-agent observations written by the step's own glue kernel into the registered
-    buffer [B, 9, o_t + o_f], 2048 envs (k_flow_duo), double timestep increment."""
+    buffer [B, 9, o_t + o_f], 2048 envs (k_flow_env, two waves per env), double timestep increment."""
     import torch
     import bench
     B = 2048
     cfg = bench.make_cfg(B, workload="cfg4")
     env = hip.HipBatch(cfg)
-    assert env.flow_variant()[2]                 # both farms of a context per wave
+    assert env.flow_variant()[2] == 2            # k_flow_env: the env's slots in one / two waves
     multi = env.fuse_obs_multi()
     env.reset(seeds=1234 + np.arange(B))
     u, n_trunc = _soak(env, cfg, B, 1500, 2)

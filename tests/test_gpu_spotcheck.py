@@ -37,7 +37,7 @@ def _cfgs(workload, B, n_passthrough):
     return full, sub
 
 
-def _run(hip, oracle_lib, workload, B, n_passthrough, variant, turbulent=False, multi=False, min_rollovers=N_SAMPLE):
+def _run(hip, oracle_lib, workload, B, n_passthrough, variant, turbulent=False, multi=False, min_rollovers=N_SAMPLE, steps=STEPS):
     import torch
     cfg, sub = _cfgs(workload, B, n_passthrough)
     env, orc = hip.HipBatch(cfg), oracle_lib.Oracle(sub)
@@ -57,17 +57,18 @@ def _run(hip, oracle_lib, workload, B, n_passthrough, variant, turbulent=False, 
     np.testing.assert_array_equal(env.info("time_max").cpu().numpy()[idx], orc.info("time_max").astype(int))
     g = torch.Generator(device="cpu").manual_seed(0)
     n_tr = np.zeros(N_SAMPLE, dtype=int)
-    for step in range(STEPS):
+    idx_t = torch.as_tensor(idx, device="cuda")          # (the sampled rows are picked on the device: 16 rows cross PCIe, not B)
+    for step in range(steps):
         a = torch.rand((B, cfg.n_turb), generator=g) * 2 - 1
         obs, rew, tr, fin = env.step(a.cuda())
         o_obs, o_rew, o_tr, o_fin = orc.step(a.numpy()[idx])
-        np.testing.assert_array_equal(tr.cpu().numpy().astype(bool)[idx], o_tr, err_msg=f"step {step}")
-        np.testing.assert_allclose(obs.cpu().numpy()[idx], o_obs, rtol=0, atol=atol, err_msg=f"obs step {step}")
-        np.testing.assert_allclose(fin.cpu().numpy()[idx], o_fin, rtol=0, atol=atol, err_msg=f"final obs step {step}")
-        np.testing.assert_allclose(rew.cpu().numpy()[idx], o_rew, rtol=1e-3 if turbulent else 1e-4, atol=1e-3 if turbulent else OBS_ATOL,
+        np.testing.assert_array_equal(tr[idx_t].cpu().numpy().astype(bool), o_tr, err_msg=f"step {step}")
+        np.testing.assert_allclose(obs[idx_t].cpu().numpy(), o_obs, rtol=0, atol=atol, err_msg=f"obs step {step}")
+        np.testing.assert_allclose(fin[idx_t].cpu().numpy(), o_fin, rtol=0, atol=atol, err_msg=f"final obs step {step}")
+        np.testing.assert_allclose(rew[idx_t].cpu().numpy(), o_rew, rtol=1e-3 if turbulent else 1e-4, atol=1e-3 if turbulent else OBS_ATOL,
                                    err_msg=f"reward step {step}")
         n_tr += o_tr.astype(int)
-        if step % 25 == 0 or step == STEPS - 1:
+        if step % 25 == 0 or step == steps - 1:
             np.testing.assert_allclose(env.info("yaw_agent").cpu().numpy()[idx], orc.info("yaw_agent"), atol=1e-4)
             np.testing.assert_allclose(env.info("rotor_uvw_agent").cpu().numpy()[idx], orc.info("rotor_uvw_agent"),
                                        rtol=2e-3 if turbulent else 1e-4, atol=2e-3 if turbulent else 1e-4, err_msg=f"rotor wind step {step}")
@@ -84,6 +85,13 @@ def _run(hip, oracle_lib, workload, B, n_passthrough, variant, turbulent=False, 
 def test_cfg2_4096_envs_one_wave_per_env_fused_glue(hip, oracle_lib):
     """the headline batch: 4x4 farm x 4096 envs x 2 farms, k_flow_env with the glue as its tail (one launch per step)"""
     _run(hip, oracle_lib, "cfg2", 4096, 1.0, (64, True, 2))
+
+
+def test_cfg2_4096_envs_on_the_bench_schedule(hip, oracle_lib):
+    """the headline batch on the schedule the bench line times — n_passthrough = 5 (episodes of 426-1121
+    steps, background development spread over them: a fifth of the share per launch the 1.0 runs above give it) — 1250 steps, so
+    that every sampled env rolls over under that schedule; the oracle replays its 16 envs at the same length."""
+    _run(hip, oracle_lib, "cfg2", 4096, 5.0, (64, True, 2), steps=1250)
 
 
 def test_cfg3_512_envs_large_farm_variant(hip, oracle_lib):

@@ -28,14 +28,12 @@ def make(d, envw, **kw):
         os.environ["WG_ENV_WPE"] = "2" if envw else "1"
         envw = True
     os.environ["WG_FLOW_ENV"] = "1" if envw else "0"
-    os.environ["WG_FLOW_DUO"] = "0"
     try:
         cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="None", n_envs=B, autoreset=True, n_rotor_pts=16,
                         **{k: v for k, v in kw.items() if k != "multi"})
         env = hip.HipBatch(cfg)
     finally:
         del os.environ["WG_FLOW_ENV"]
-        del os.environ["WG_FLOW_DUO"]
         os.environ.pop("WG_STEP_FUSED", None)
         os.environ.pop("WG_ENV_WPE", None)
     assert env.flow_variant()[2] == (2 if envw else 0), env.flow_variant()

@@ -134,22 +134,33 @@ TABLE_SPEC = dict(ct=np.linspace(0.04, 0.96, 24), ti=0.01 * (0.70 / 0.01) ** (np
 _TABLE = None
 
 
+def _cache_dir_ok(cdir):
+    """The cache directory exists, belongs to this user and nobody else can write to it."""
+    try:
+        st = os.stat(cdir)
+    except OSError:
+        return False
+    return st.st_uid == os.getuid() and (st.st_mode & 0o022) == 0
+
+
 def deficit_table():
     """(table float32 [n_ct, n_ti, n_x, n_r], spec) — deficit fraction 1 - U / U0 at x / D = i x_max / (n_x - 1), r / R =
     j r_max / (n_r - 1).  Solved once per process (a few seconds)."""
     global _TABLE
     if _TABLE is None:
         s = TABLE_SPEC
-        # the solve takes a few seconds: the result is cached in a PER-USER directory (mode 0700; WINDGYM_AMD_CACHE overrides the
-        # place, WINDGYM_AMD_NO_CACHE=1 disables it), keyed by this file's text and the numpy version, and accepted only if the
-        # checksum stored with it matches (a planted or half-written file must not change the physics silently: the oracle
-        # would load the same file and parity would still pass)
+        # the solve takes a few seconds: the result is cached in a per-user directory (WINDGYM_AMD_CACHE overrides the place,
+        # WINDGYM_AMD_NO_CACHE=1 disables it), keyed by this file's text and the numpy version.  The checksum stored with the
+        # table detects truncation / corruption only (whoever can write the file can write a matching digest); what keeps
+        # someone else from replacing the physics — the oracle would load the same file and parity would still pass — is the
+        # directory: the cache is used only if it belongs to this user and is not writable by group / others (_cache_dir_ok).
         with open(__file__, "rb") as fh:
             key = hashlib.sha1(fh.read() + np.__version__.encode()).hexdigest()[:16]
         shape = (len(s["ct"]), len(s["ti"]), s["n_x"], s["n_r"])
         use_cache = os.environ.get("WINDGYM_AMD_NO_CACHE", "0") in ("", "0")
         cdir = os.environ.get("WINDGYM_AMD_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "windgym_amd")
         path = os.path.join(cdir, f"ainslie_{key}.npz")
+        use_cache = use_cache and (_cache_dir_ok(cdir) or not os.path.exists(cdir))
         if use_cache:
             try:
                 with np.load(path) as z:
@@ -171,6 +182,8 @@ def deficit_table():
         if use_cache:
             try:
                 os.makedirs(cdir, mode=0o700, exist_ok=True)
+                if not _cache_dir_ok(cdir):          # (an existing directory keeps its mode: makedirs does not enforce 0700)
+                    raise OSError("cache directory is shared")
                 tmp = f"{path}.{os.getpid()}.tmp.npz"
                 np.savez(tmp, table=tab, sha1=np.array(hashlib.sha1(tab.tobytes()).hexdigest()))
                 os.replace(tmp, path)

@@ -401,8 +401,8 @@ class HipBatch:
         return v.value
 
     def flow_variant(self):
-        """(threads per k_flow workgroup, compact rings / pair-major phases?, farm slots per wave: 0 = one (k_flow), 1 = both
-        farms of a context (k_flow_duo), 2 = every slot of an env (k_flow_env, one wave per env))"""
+        """(threads per k_flow workgroup, compact rings / pair-major phases?, farm slots per wave: 0 = one (k_flow),
+        2 = every slot of an env or of one of its contexts (k_flow_env / k_flow_envb: one or two waves per env))"""
         b, r, d = C.c_int(), C.c_int(), C.c_int()
         _chk(self.L.wg_flow_variant(self._h, C.byref(b), C.byref(r), C.byref(d)), "wg_flow_variant")
         return b.value, bool(r.value), d.value

@@ -1,6 +1,7 @@
 """Build libwindgym_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
 from __future__ import annotations
 
+import glob
 import os
 import subprocess
 import sys
@@ -9,18 +10,24 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwindgym_hip.so")
 SOURCES = ["wg_flow.hip", "wg_env.hip", "wg_kernels.hip", "wg_api.hip", "wg_mann.hip", "wg_steady.hip"]
-HEADERS = ["wg_steady.h", "wg_state.h", "wg_device.h", "wg_obs.h", "wg_flow.h", "wg_flow_dev.h", "wg_flow_duo.inc", os.path.join("..", "..", "include", "windgym_hip.h")]
+
+
+def _headers():
+    """Every header / include file of csrc/ (a glob: a header left out of a hand-kept list made needs_build() call a stale
+    binary fresh) + the public ABI header."""
+    hs = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")))
+    return hs + [os.path.join(HERE, "..", "include", "windgym_hip.h")]
 
 
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(f) > t for f in [os.path.join(CSRC, f) for f in SOURCES] + _headers())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the three translation units in parallel (wg_flow.hip and wg_kernels.hip take about a minute each: they
+    """Compile the translation units in parallel (wg_flow.hip and wg_kernels.hip take about a minute each: they
     hold all the kernel instantiations) and link them; objects go to a temporary directory, only the .so stays in-tree."""
     if not force and not needs_build():
         return LIB

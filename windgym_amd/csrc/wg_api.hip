@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -42,6 +43,8 @@ static const char* wg_hook(const char* name) {
     const char* v = getenv(name);
     if (v) {
         static std::string seen;
+        static std::mutex seen_mu;      // (wg_create may run on several threads at once: one handle per device)
+        std::lock_guard<std::mutex> lock(seen_mu);
         const std::string tag = std::string(name) + "=" + v + ";";
         if (seen.find(tag) == std::string::npos) {
             seen += tag;
@@ -550,34 +553,10 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             return fail(WG_ERR_UNSUPPORTED, "wg_create: k_flow needs " + std::to_string(off) + " bytes of LDS per workgroup (limit " +
                                             std::to_string(lds_limit) + "): too many turbines for one workgroup");
         }
-        // k_flow_duo: both farms of a context in one single-wave workgroup (lane = farm * N + turbine).  It executes 37 %
-        // fewer VALU instructions per farm step, which pays where the per-workgroup fixed costs dominate (cfg4, 3x3 x P=96:
-        // 43.6 -> 37.7 us) and not where the particle traffic does (cfg2 4x4 x P=128: 75 -> 78 us, cfg5 frozen box:
-        // 157 -> 172 us): default for steady inflow up to 1024 ring slots per farm.  WG_FLOW_DUO=1 / 0 forces it on
-        // (where eligible) / off (tests run both).
-        // (k_flow_duo does not carry the optional models: added turbulence, no TI folding)
-        const bool duo_ok = f.res && small && f.block == 64 && p.F == 2 && 2 * p.N <= 64 && p.P <= 4096 && !h->added && !h->no_ti_fold && h->deficit_model == 0;
-        f.duo = (duo_ok && p.NP <= 1024 && p.turb_mode == WG_TURB_NONE) ? 1 : 0;
-        if (const char* ev = wg_hook("WG_FLOW_DUO")) f.duo = (duo_ok && atoi(ev) != 0) ? 1 : 0;
-        bool duo_fits = true;
-        {
-            const size_t n2 = 2 * (size_t)p.N;
-            const size_t ccap = (size_t)p.N * (p.N - 1);            // candidate pairs of both farms
-            size_t o = std::max(((2 * ccap + 3) & ~(size_t)3) + 8 * ccap, (size_t)p.NP);   // | 16-bit quad list of both farms
-            o = (o + 15) & ~(size_t)15;
-            f.duo_off_turb = (int)o;
-            o = (o + WG_TURB_LDS_BYTES * n2 + 15) & ~(size_t)15;        // tables
-            o += 4 * (2 * (size_t)nu + 2 * (size_t)p.S);                  // candidate ranges
-            o = (o + 8 * n2 + 7) & ~(size_t)7;                            // per-farm clocks
-            o += 2 * 72 + 16;                                             // (sizeof(FarmLds) = 72) + counters
-            f.duo_lds = (int)((o + 15) & ~(size_t)15);
-            duo_fits = f.duo_lds <= lds_limit;
-        }
-        if (!duo_fits) f.duo = 0;
         // k_flow_env (wg_env.hip): ONE wave per env, lane = slot * N + turbine over the env's 2 F farm slots — the default for
         // steady inflow wherever the slots fit a wave (cfg2: 4 x 16 lanes, cfg4: 4 x 9).  It runs on the GL variant's state
         // layout (interleaved record + 16-byte gather copy), so the two are interchangeable launch by launch.  A hook that
-        // asks for a specific older variant (WG_FLOW_BLOCK / WG_FLOW_RES / WG_FLOW_DUO) switches it off; WG_FLOW_ENV=0 / 1
+        // asks for a specific older variant (WG_FLOW_BLOCK / WG_FLOW_RES) switches it off; WG_FLOW_ENV=0 / 1
         // forces it off / on where eligible (tests run all of them).
         {
             const int NSl = 2 * p.F, NL = NSl * p.N;
@@ -589,7 +568,9 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             for (int t = 0; t < p.N; ++t) {
                 double dm = 0;
                 for (int j = 0; j < p.N; ++j) dm = std::max(dm, std::hypot(c->x_pos[j] - c->x_pos[t], c->y_pos[j] - c->y_pos[t]));
-                long len = (((long)(dm / p.dpart) + 3) + 3) & ~3L;
+                // (+ 4, not + 3: the device takes floor((xmax - xr_t) / d) after a cos / sin rotation, which rounding can make one
+                // particle longer than this host bound — one more quad after rounding up; the list has no other slack)
+                long len = (((long)(dm / p.dpart) + 4) + 3) & ~3L;
                 if (len > p.P || p.full_chains) len = p.P;
                 qf += (size_t)len / 4;
             }
@@ -601,10 +582,9 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             if (f.env_lds > 32768 || f.env_lds > lds_limit) env_ok = false;
             f.env_inc = 1 + (p.extra_inc ? 1 : 0);
             f.env_eps_max = std::min(1.0f, (float)(p.eps0 * std::sqrt(3.0))) + 2.0f / 65535.0f;
-            const bool asked_old = wg_hook("WG_FLOW_BLOCK") || wg_hook("WG_FLOW_RES") || wg_hook("WG_FLOW_DUO");
+            const bool asked_old = wg_hook("WG_FLOW_BLOCK") || wg_hook("WG_FLOW_RES");
             f.envw = (env_ok && !asked_old) ? 1 : 0;
             if (const char* ev = wg_hook("WG_FLOW_ENV")) f.envw = (env_ok && atoi(ev) != 0) ? 1 : 0;
-            if (f.envw) f.duo = 0;
             // waves per env: two (one per context, side by side, meeting only when the env truncates) while every env's pair of
             // waves is resident at once — 2048 envs fill the chip's 4096 wave slots; beyond that one wave per env (cfg2 ms per
             // step, two waves / one wave / per-slot kernels + k_glue_lean: 256 envs 0.0231 / 0.0294 / 0.0260, 1024: 0.0276 /
@@ -613,7 +593,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             if (const char* ev = wg_hook("WG_ENV_WPE")) f.env_wpe = (atoi(ev) == 2 && 2 * f.env_lds <= lds_limit) ? 2 : 1;
         }
         // packed emission record: two arrays, or one interleaved (ct|k, eps|hv) array for the GL variant
-        f.rec_il = (f.gl && !f.duo) ? 1 : 0;
+        f.rec_il = f.gl ? 1 : 0;
         if (f.rec_il) {
             if (!rc) rc = dev_alloc(h, &d.rec_a, 2 * n_slots * pstride_keep, true);
             d.rec_b = d.rec_a ? d.rec_a + 1 : nullptr;
@@ -703,7 +683,6 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     // farms: one wave reads 35 floats per turbine; measured on the multi-wave variants — cfg3, cfg5 — the building
     // workgroup became the flow kernel's tail: -5 % / -1.3 %).  Other handles keep the glue's own second build.
     // (sums mode: wg_first_obs prepares the episode's window sums as well, in WgPtrs::wsum)
-    // (k_flow_duo prepares them for sums-mode handles only: the lean glue's swap)
     // (round 4, sums mode: the glue's own rebuild sums every window of the new episode — 14-15 us of k_glue_lean on cfg3 /
     // cfg5 against 10 with prepared sums — so every compact variant prepares them now; WG_FIRST_OBS_GL_ONLY=1 for A/B runs)
     {   // one launch per step where the env kernel runs and the lean glue's specialised instantiation applies
@@ -712,7 +691,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         if (const char* ev = wg_hook("WG_STEP_FUSED")) h->fp.env_fused = (h->fp.env_fused && atoi(ev) != 0) ? 1 : 0;
     }
     const bool prep_all = p.sums_mode && !wg_hook("WG_FIRST_OBS_GL_ONLY");
-    if (!((h->fp.gl && !h->fp.duo) || (h->fp.res && !h->fp.duo && prep_all) || (h->fp.duo && p.sums_mode && p.turb_mode == WG_TURB_NONE))) { d.next_obs = nullptr; d.next_obs_ok = nullptr; }
+    if (!(h->fp.gl || (h->fp.res && prep_all))) { d.next_obs = nullptr; d.next_obs_ok = nullptr; }
     wg_launch_create(&p, &d, nullptr);
     if (sync_dev_params(h)) { wg_destroy(h); return WG_ERR_HIP; }
     {
@@ -726,9 +705,9 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     if (const char* ev = wg_hook("WG_STEP_GRAPH")) h->graph_mode = atoi(ev) != 0;
     if (wg_hook("WG_DEBUG"))
         fprintf(stderr, "[windgym] k_flow variant: %s, %d threads, LDS %d B per workgroup, slot stride %d floats\n",
-                h->fp.envw ? "compact rings / pair-major, one wave per env (k_flow_env)" : h->fp.duo ? "compact rings / pair-major, both farms of a context per wave"
+                h->fp.envw ? "compact rings / pair-major, one wave per env (k_flow_env)"
                           : (h->fp.res ? "compact rings / pair-major" : "uniform rings / sample-major"),
-                h->fp.block, h->fp.envw ? h->fp.env_lds : h->fp.duo ? h->fp.duo_lds : h->fp.lds_bytes, h->fp.pstride);
+                h->fp.block, h->fp.envw ? h->fp.env_lds : h->fp.lds_bytes, h->fp.pstride);
     *out = h;
     return 0;
 }
@@ -992,7 +971,8 @@ extern "C" int wg_reset(wg_handle h, const uint8_t* env_mask_host, const uint64_
 static void launch_step(wg_env_s* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* truncated_dev,
                         float* final_obs_dev, hipStream_t st, bool sample) {
     // step() as ONE launch (k_flow_env with the glue as its tail): sums-mode handles on the env kernel whose observation has
-    // no TI / farm-level entries; a flow script (replay mode) or a missing output pointer falls back to the two launches
+    // no TI / farm-level entries; a flow script (replay mode) falls back to the two launches.  (Null output pointers are
+    // legal on either path: lean_step checks each one before it stores.)
     if (h->fp.env_fused && h->fd.script_uvw == nullptr) {
         if (sample) sample = time_begin(h, 0, st);
         wg_launch_step_env(&h->fp, &h->fd, &h->p, &h->d, actions_dev, obs_dev, reward_dev, truncated_dev, final_obs_dev, st);
@@ -1162,7 +1142,7 @@ extern "C" int wg_metrics(wg_handle h, float* out_dev, int reset_after, void* st
 struct StateHeader {
     uint32_t magic;
     int32_t abi, B, N, F, P, S, K, turb_mode, block, ring_stride, fring_stride, power_avg, n_allocs;
-    int32_t res, duo, pstride, n_boxes;      // particle-ring layout (uniform / compact rings, one or two farms per workgroup)
+    int32_t res, reserved0, pstride, n_boxes;      // particle-ring layout (uniform / compact rings); reserved0: always 0 (was: k_flow_duo)
     uint64_t payload;
 };
 static const uint32_t WG_STATE_MAGIC = 0x53474757u;   // "WGGS"
@@ -1173,7 +1153,7 @@ static StateHeader state_header(const wg_env_s* h) {
     sh.B = h->p.B; sh.N = h->p.N; sh.F = h->p.F; sh.P = h->p.P; sh.S = h->p.S; sh.K = h->p.K;
     sh.turb_mode = h->p.turb_mode; sh.block = h->fp.block; sh.ring_stride = h->p.ring_stride;
     sh.fring_stride = h->p.fring_stride; sh.power_avg = h->p.power_avg; sh.n_allocs = (int32_t)h->state_idx.size();
-    sh.res = h->fp.res; sh.duo = h->fp.duo; sh.pstride = h->fp.pstride; sh.n_boxes = h->p.n_boxes;
+    sh.res = h->fp.res; sh.reserved0 = 0; sh.pstride = h->fp.pstride; sh.n_boxes = h->p.n_boxes;
     for (size_t i : h->state_idx) sh.payload += h->allocs[i].bytes;
     return sh;
 }
@@ -1309,7 +1289,7 @@ extern "C" int wg_flow_variant(wg_handle h, int* block, int* compact, int* duo) 
     if (!h) return fail(WG_ERR_INVALID, "null handle");
     if (block) *block = h->fp.block;
     if (compact) *compact = h->fp.res;
-    if (duo) *duo = h->fp.envw ? 2 : h->fp.duo;      // 0: one farm slot per workgroup, 1: k_flow_duo, 2: k_flow_env (one wave per env)
+    if (duo) *duo = h->fp.envw ? 2 : 0;      // 0: one farm slot per workgroup, 2: k_flow_env (one or two waves per env)
     return 0;
 }
 

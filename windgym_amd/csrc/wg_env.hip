@@ -263,6 +263,8 @@ struct EnvFlowOut {          // what the flow part hands to the glue tail of k_s
     int env_live, bg_init_pending;
     int truncates;            // the env truncates in this step (known from its header): the only case in which the glue needs the
                               // background context's wave to have finished (WPE 2)
+    int steps_done, time_max_live;   // the env header as the prologue read it (before any wave of this launch can have written it): what
+                              // the background context's wave plans its next share from (WPE 2)
     int rounds, first_obs;    // (WG_TIMELINE builds: flow rounds taken, first observation of a completed background episode built)
 };
 // WPE = waves per env.  1: one wave serves all 2 F slots of the env (lane = slot * N + turbine).  2: a workgroup of two waves
@@ -309,11 +311,13 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
     float yaw, tu, tti, oyaw;
     {
         const KArgsPtr k0 = wg_cold_args();
-        const CEnvPtr envc = (CEnvPtr)(k0->d.env + e);
-        env_live = envc->live;
-        out.env_live = env_live; out.bg_init_pending = 0; out.rounds = 0; out.first_obs = 0;
-        out.truncates = envc->timestep >= envc->time_max_live;
-        const int env_done = envc->done, env_shadow_iters = envc->shadow_iters, env_steps_done = envc->steps_done;
+        // The env's 128-byte header as ONE coalesced load from the GLOBAL address space (lane i: word i), its fields broadcast
+        // with v_readlane below, where the roles are decided — NOT scalar loads through the constant address space: the glue
+        // tail of this very launch rewrites the header (such loads may be re-executed after the store, and
+        // the scalar cache does not see this launch's vector stores).
+        static_assert(sizeof(WgEnv) == 128, "the env header is loaded as 32 words");
+        const int hw = reinterpret_cast<const int*>(k0->d.env + e)[tid & 31];
+        out.bg_init_pending = 0; out.rounds = 0; out.first_obs = 0;
         const bool use_mask = mode == WG_MODE_RESET && mask != nullptr;
         const uint8_t mask_byte = *(use_mask ? mask + e : reinterpret_cast<const uint8_t*>(k0->d.env + e));
         const bool masked_out = use_mask && mask_byte == 0;
@@ -354,6 +358,23 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
             l_act = has_act ? a : 0.f;
         }
 
+#define WG_HDR_I(f) __builtin_amdgcn_readlane(hw, (int)(offsetof(WgEnv, f) / 4))
+        env_live = WG_HDR_I(live);
+        int env_done = WG_HDR_I(done), env_shadow_iters = WG_HDR_I(shadow_iters), env_steps_done = WG_HDR_I(steps_done);
+        int env_timestep = WG_HDR_I(timestep), env_time_max_live = WG_HDR_I(time_max_live);
+#undef WG_HDR_I
+        if (WPE == 2) {
+            // Two waves per env read the same header, and the live context's wave rewrites it in its glue tail.  Both waves hold
+            // their copies BEFORE either passes this barrier, so neither can see a word the other has already advanced, whatever
+            // their relative timing (the decisions both waves derive from the header — live, truncates, the
+            // background plan — must agree).  Every prologue load has been requested by now: the barrier adds no round trip.
+            asm volatile("" : "+s"(env_live), "+s"(env_done), "+s"(env_shadow_iters), "+s"(env_steps_done), "+s"(env_timestep), "+s"(env_time_max_live) : : "memory");
+            asm volatile("s_barrier" ::: "memory");
+        }
+        out.env_live = env_live;
+        out.truncates = env_timestep >= env_time_max_live;
+        out.steps_done = env_steps_done; out.time_max_live = env_time_max_live;
+
         // ---- roles ----------------------------------------------------------------------------------------------------
         // role_live: this lane's slot belongs to the running episode and takes one env step (K flow sub-steps with
         //            measurement);
@@ -370,10 +391,12 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
             // background context's wave sees its own, the live wave gets it through LDS after the barrier)
             const int bg_pending = WPE == 2 ? (is_live_c ? 0 : __shfl(init_pending, 0, 64)) : __shfl(init_pending, (env_live ^ 1) * F * N, 64);
             out.bg_init_pending = autoreset && bg_pending;
-            if (autoreset && bg_pending && WPE == 1 && (WG_ENV_DEFER_INIT != 0)) {
+            if (autoreset && bg_pending && WPE == 1 && (WG_ENV_DEFER_INIT != 0) && !out.truncates) {
                 // rare path (one context per truncation): the retired context's next episode is set up AFTER this wave's step
                 // (below) — its background lanes rest in this launch, the set-up needs no reload of the wave's state, and the
-                // wave is no longer the launch's straggler (at the head of the launch it lived 55 us against 40 for the rest)
+                // wave is no longer the launch's straggler (at the head of the launch it lived 55 us against 40 for the rest).
+                // NOT when this very step truncates (one-step episodes: time_max <= 0): the glue tail then swaps the context in
+                // in this launch and needs it developed — the head-of-launch path below gives it the whole budget
                 defer_init = true;
                 budget = 0;
             } else if (autoreset && bg_pending) {
@@ -398,7 +421,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
                 // carries 2 F + 1 farm steps where the per-context plan (WgEnv::shadow_iters, ignored here) gave it 2 F or 3 F:
                 // the launch lasts as long as its heaviest wave.
                 const int inc = k0->p.env_inc;
-                const long total = (long)((envc->time_max_live + inc - 1) / inc) + 1;
+                const long total = (long)((env_time_max_live + inc - 1) / inc) + 1;
                 budget = role_dev ? wg_shadow_share(dev_rem + k0->p.K * fill_rem, total - env_steps_done, env_steps_done, e, farm ? 0x80000000u : 0u) : 0;
             } else {
                 budget = env_shadow_iters;
@@ -439,7 +462,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
             const bool bg_active = role_dev_any(autoreset, b_dev, b_fill);
             const bool multi_round = bg_active && budget >= 2 && b_dev + b_fill >= 2;
             const bool completes = bg_active && b_dev + k0->p.K * b_fill <= budget;
-            const bool truncates = envc->timestep >= envc->time_max_live;
+            const bool truncates = out.truncates != 0;
             if (out.bg_init_pending || multi_round || completes || truncates) __builtin_amdgcn_s_setprio(3);
         }
 #endif
@@ -963,7 +986,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
                         for (int ch = 0; ch < WG_N_CH; ++ch) val[ch] *= inv_k;
                     }
                     if (NOISE) {
-                        const uint64_t noise_key = ((CEnvPtr)(kc->d.env + e))->noise_key;
+                        const uint64_t noise_key = ((CEnvPtr)(kc->d.env + e))->noise_key;      // (set by k_init only: read-only in every step kernel)
                         const uint32_t episode_tag = my.c_tag;
 #pragma unroll
                         for (int ch = 0; ch < WG_N_CH; ++ch)
@@ -1142,9 +1165,8 @@ k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __res
                     const EnvSlotLds* const SLb = reinterpret_cast<const EnvSlotLds*>(sm + WG_ENV_OFF_SL);
                     int work = 0;
                     for (int f = 0; f < F; ++f) work = max(work, SLb[f].dev_rem + K * SLb[f].fill_rem);
-                    typedef const __attribute__((address_space(4))) WgEnv* CEnvPtr;
-                    const CEnvPtr envc = (CEnvPtr)(kb->d.env + e);
-                    const int steps_done = envc->steps_done + 1, time_max = envc->time_max_live;      // (as the glue sees them)
+                    const int steps_done = fo.steps_done + 1, time_max = fo.time_max_live;      // (as the glue sees them: from the prologue's
+                                                                                              // copy — the live wave may have rewritten the header by now)
                     const int inc = 1 + (kb->gp.extra_inc ? 1 : 0);
                     const long total = (long)((time_max + inc - 1) / inc) + 1;
                     kb->d.env_rw[e].shadow_iters = work == 0 ? 0 : wg_shadow_share(work, total - steps_done, steps_done, e);

@@ -11,10 +11,6 @@
 #ifndef WG_FLOW_WAVES_CG
 #define WG_FLOW_WAVES_CG 5    // small-farm variants (compact rings, 64 / 128 threads): 96 VGPRs; measured 4 / 5 / 6 waves: 104 / 93.5 / 96 us on cfg2
 #endif
-#ifndef WG_FLOW_WAVES_DUO
-#define WG_FLOW_WAVES_DUO 4   // k_flow_duo (steady inflow): 128 VGPRs, 6 spilled instead of 35 at 96 — cfg4 (4096 workgroups = the 4096 wave
-                              // slots of 4 waves per SIMD) 36.4 -> 35.3 us same-box (round 4)
-#endif
 #ifndef WG_FLOW_WAVES_GL
 #define WG_FLOW_WAVES_GL 4    // single-wave steady variant (GL): 128 VGPRs, no spills — room for the pipelined advection pass's second quad;
                               // 4 vs 5 waves per SIMD measured equal without the pipeline (the launch is not occupancy-bound), -4.5 % with it
@@ -55,9 +51,6 @@
 #ifndef WG_S_UNROLL_ALL
 #define WG_S_UNROLL_ALL 0   // 1: the rotor-point loop of the Gaussian pair evaluation unrolled by 4 in every variant (A/B builds)
 #endif
-#ifndef WG_DUO_ADV_PIPE
-#define WG_DUO_ADV_PIPE 1   // k_flow_duo: software-pipelined advection pass (0 = plain loop, for A/B builds)
-#endif
 #ifndef WG_GL_POSTPASS_WAIT
 #define WG_GL_POSTPASS_WAIT 1   // GL variant: the compiler-visible vmcnt(0) right after the pipelined advection pass (0: A/B builds)
 #endif
@@ -84,7 +77,6 @@ struct FlowP {
                                   // landing zone of the deficit phase's LDS-DMA gathers (WG_GAT_BYTES)
     int ql_shift;                 // compact steady advection: quad-list entry = turbine << ql_shift | quad index in its ring (16 bits)
     int ql_lpt_shift;             // ... and 2^ql_lpt_shift lanes share the listing of one turbine's quads (block / N, at most 8)
-    int duo, duo_off_turb, duo_lds;   // k_flow_duo (both farms of a context in one wave): enabled, LDS carve (wg_flow_duo.inc)
     // k_flow_env (wg_env.hip: ONE wave per env, lane = slot * N + turbine): enabled; bytes of dynamic LDS; offset of the tables
     // (the rest of the carve is fixed: WG_ENV_*)
     int envw, env_lds, env_off_tab;

@@ -2163,8 +2163,6 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
 #endif
 }
 
-#include "wg_flow_duo.inc"
-
 template <int NT, bool RES>
 static void launch_nt(const FlowP* p, const FlowPtrs* d, int mode, const float* actions, const uint8_t* mask,
                       int chunk, hipStream_t st) {
@@ -2202,25 +2200,10 @@ static void launch_nt(const FlowP* p, const FlowPtrs* d, int mode, const float* 
 // One workgroup per farm slot.  Small farms (N <= 32): compact per-turbine rings + pair-major deficit phases, 64 or 128
 // threads; large farms: uniform rings with predicate pruning + (target, sample)-major deficit phases, 256 threads.
 // Chosen on the host (FlowP.res / FlowP.block).
-static void launch_duo(const FlowP* p, const FlowPtrs* d, int mode, const float* actions, const uint8_t* mask,
-                       int chunk, hipStream_t st) {
-    const int grid = p->B * 2;
-    const size_t lds = p->duo_lds;
-    const bool noise = p->noise != 0;
-#define WG_LAUNCH(TURB, NOISE) \
-    hipLaunchKernelGGL((k_flow_duo<TURB, NOISE>), dim3(grid), dim3(64), lds, st, *p, *d, mode, actions, mask, chunk)
-    const int turb = (p->turb_mode >= WG_TURB_BOX) ? WG_TURB_BOX : p->turb_mode;
-    if (turb == WG_TURB_NONE) { if (noise) WG_LAUNCH(WG_TURB_NONE, true); else WG_LAUNCH(WG_TURB_NONE, false); }
-    else if (turb == WG_TURB_RANDOM) { if (noise) WG_LAUNCH(WG_TURB_RANDOM, true); else WG_LAUNCH(WG_TURB_RANDOM, false); }
-    else { if (noise) WG_LAUNCH(WG_TURB_BOX, true); else WG_LAUNCH(WG_TURB_BOX, false); }
-#undef WG_LAUNCH
-}
-
 extern "C" void wg_launch_flow_env(const FlowP*, const FlowPtrs*, int, const float*, const uint8_t*, int, hipStream_t);
 extern "C" void wg_launch_flow(const FlowP* p, const FlowPtrs* d, int mode, const float* actions,
                                const uint8_t* mask, int chunk, hipStream_t st) {
     if (p->envw && d->script_uvw == nullptr) { wg_launch_flow_env(p, d, mode, actions, mask, chunk, st); return; }
-    if (p->duo && d->script_uvw == nullptr) { launch_duo(p, d, mode, actions, mask, chunk, st); return; }
     if (p->res) {
         if (p->block == 64) launch_nt<64, true>(p, d, mode, actions, mask, chunk, st);
         else if (p->block == 128) launch_nt<128, true>(p, d, mode, actions, mask, chunk, st);

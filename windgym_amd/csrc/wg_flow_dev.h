@@ -1,4 +1,4 @@
-// wg_flow_dev.h — device helpers shared by the flow kernels (wg_flow.hip: k_flow / k_flow_duo, wg_env.hip: k_flow_env).
+// wg_flow_dev.h — device helpers shared by the flow kernels (wg_flow.hip: k_flow, wg_env.hip: k_flow_env).
 // Everything here is `static` / inline per translation unit (the library is built without relocatable device code).
 #pragma once
 #include <hip/hip_runtime.h>

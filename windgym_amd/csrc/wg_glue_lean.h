@@ -293,22 +293,15 @@ __device__ __attribute__((noinline)) void lean_swap(const WgParams* gp, const Wg
 #ifndef WG_LEAN_ABLATE
 #define WG_LEAN_ABLATE 0      // profiling builds: return from k_glue_lean after phase n (tools/glue_ablate.sh)
 #endif
-// What the fused step kernel (k_step_env, wg_env.hip) hands over instead of the words the stand-alone kernel reads through the
-// scalar cache — those were written by the SAME launch there (the env's own flow wave, or a neighbour's sharing the cache line),
-// and the scalar cache is only invalidated at kernel boundaries.
-// A value fetched through the constant address space (scalar load) from a word this kernel writes LATER: the compiler treats
-// such memory as never written, so it may sink the load past the store or re-execute it there instead of keeping the value
-// (rematerialisation under register pressure) — and then reads the post-step word (observed in the fused kernel:
-// rewards that drift at random).  Passing the value through an opaque statement with a memory clobber pins the load above
-// every later store and makes the register the only copy the compiler knows.
-// (UNI: the address is provably wave-uniform — the fused kernel's env index is blockIdx.x — and the value lives in scalar
-// registers; otherwise the "scalar" load is a vector load with a uniform address and the value a vector register)
-template <bool UNI, class T>
-__device__ __forceinline__ T wg_pin(T v) {
-    if (UNI) asm volatile("" : "+s"(v) : : "memory");
-    else asm volatile("" : "+v"(v) : : "memory");
-    return v;
-}
+// Loads of words this kernel (or, fused, this launch) also WRITES — the env header, the power deques, the contexts' flags — go
+// through the GLOBAL address space, never the constant one: memory behind address_space(4) is "never written" to the compiler
+// (it may sink such a load below the store or re-execute it there) and is served by the scalar cache, which is not coherent
+// with this launch's vector stores (round 5 papered over both with an opaque register pin).  Wave-uniform
+// values are moved to scalar registers with v_readlane / v_readfirstlane instead, so the arithmetic on them stays on the
+// scalar unit.  What the fused step kernel (k_flow_env / k_flow_envb) hands over in LeanFused are values its flow part
+// holds in LDS anyway.
+__device__ __forceinline__ int wg_uni(const int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float wg_uni(const float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 struct LeanFused {
     float fp, bp;             // farm power of the step: agent farm, baseline farm (WgPtrs::step_farm_pow / step_base_pow)
@@ -334,24 +327,27 @@ __device__ __forceinline__ void lean_step(const WgParams& p, const WgPtrs& d, co
     float* bq = d.base_pow + (size_t)e * PA;
     const int own = lane < N ? lane : 0;          // this lane's first entity (lanes >= N: a valid dummy)
 
-    typedef const __attribute__((address_space(4))) WgEnv* CEnvPtr;
-    typedef const __attribute__((address_space(4))) WgSlot* CSlotPtr;
-    typedef const __attribute__((address_space(4))) WgCtx* CCtxPtr;
-    typedef const __attribute__((address_space(4))) float* CFloatPtr;
-    // (the scalar cache is invalidated at every kernel start; none of these words is written by this kernel before the
-    // wave reads it)
-    const CEnvPtr ec = (CEnvPtr)(d.env + e);
-    if (wg_pin<FUSED>(ec->done)) {
+    // The env's 128-byte header in ONE coalesced load: lane i (< 32) fetches 32-bit word i, the fields are broadcast with
+    // v_readlane (-> scalar registers).  A plain global load: ordered against this wave's own stores to the header below.
+    static_assert(sizeof(WgEnv) == 128, "lean_step loads the env header as 32 words");
+    const int hw = reinterpret_cast<const int*>(&env)[lane & 31];
+#define WG_HDR_I(f) __builtin_amdgcn_readlane(hw, (int)(offsetof(WgEnv, f) / 4))
+#define WG_HDR_F(f) __int_as_float(WG_HDR_I(f))
+#define WG_HDR_D(f) __hiloint2double(__builtin_amdgcn_readlane(hw, (int)(offsetof(WgEnv, f) / 4) + 1), WG_HDR_I(f))
+    if (WG_HDR_I(done)) {
         if (lane == 0) atomicOr(d.status, WG_STATUS_BIT_STATE);
         return;
     }
     EnvHot ev;
-    ev.live = wg_pin<FUSED>(ec->live); ev.timestep = wg_pin<FUSED>(ec->timestep); ev.episode = wg_pin<FUSED>(ec->episode); ev.done = 0; ev.shadow_iters = 0;
-    ev.farm_pow_n = wg_pin<FUSED>(ec->farm_pow_n); ev.base_pow_n = wg_pin<FUSED>(ec->base_pow_n); ev.steps_done = wg_pin<FUSED>(ec->steps_done);
-    ev.ep_return = wg_pin<FUSED>(ec->ep_return); ev.ep_power_sum = wg_pin<FUSED>(ec->ep_power_sum); ev.ep_len = wg_pin<FUSED>(ec->ep_len);
-    int time_max = wg_pin<FUSED>(ec->time_max_live), n_pushed_live = wg_pin<FUSED>(ec->n_pushed_live);
-    float rated_power = wg_pin<FUSED>(ec->rated_live);
-    double fsum_run = wg_pin<FUSED>(ec->fsum_run), bsum_run = wg_pin<FUSED>(ec->bsum_run);
+    ev.live = WG_HDR_I(live); ev.timestep = WG_HDR_I(timestep); ev.episode = WG_HDR_I(episode); ev.done = 0; ev.shadow_iters = 0;
+    ev.farm_pow_n = WG_HDR_I(farm_pow_n); ev.base_pow_n = WG_HDR_I(base_pow_n); ev.steps_done = WG_HDR_I(steps_done);
+    ev.ep_return = WG_HDR_F(ep_return); ev.ep_power_sum = WG_HDR_F(ep_power_sum); ev.ep_len = WG_HDR_I(ep_len);
+    int time_max = WG_HDR_I(time_max_live), n_pushed_live = WG_HDR_I(n_pushed_live);
+    float rated_power = WG_HDR_F(rated_live);
+    double fsum_run = WG_HDR_D(fsum_run), bsum_run = WG_HDR_D(bsum_run);
+#undef WG_HDR_D
+#undef WG_HDR_F
+#undef WG_HDR_I
     const int live = ev.live, nxt = live ^ 1;
 #if defined(WG_TIMELINE) && defined(WG_STAMP2)
     if (FUSED) WG_STAMP2(16);
@@ -362,17 +358,11 @@ __device__ __forceinline__ void lean_step(const WgParams& p, const WgPtrs& d, co
     int nx_pfn = 0, nx_pbn = 0, nx_np = 0, nx_tmax = 0;
     float nx_rated = 0.f;
     bool nx_prep = false;
-    if (ev.timestep >= time_max && p.autoreset) {
-        if (FUSED) {      // (this launch's flow part has just written these words: plain loads)
-            const WgCtx& nc = d.ctx[e * 2 + nxt];
-            nx_pfn = nc.pend_farm_n; nx_pbn = nc.pend_base_n; nx_np = nc.n_pushed; nx_tmax = nc.time_max; nx_rated = nc.rated_power;
-            nx_prep = d.next_obs_ok != nullptr && d.next_obs_ok[e * 2 + nxt] != 0;
-        } else {
-            const CCtxPtr nc = (CCtxPtr)(d.ctx + e * 2 + nxt);
-            nx_pfn = wg_pin<FUSED>(nc->pend_farm_n); nx_pbn = wg_pin<FUSED>(nc->pend_base_n); nx_np = wg_pin<FUSED>(nc->n_pushed);
-            nx_tmax = wg_pin<FUSED>(nc->time_max); nx_rated = wg_pin<FUSED>(nc->rated_power);
-            nx_prep = d.next_obs_ok != nullptr && wg_pin<FUSED>(((const __attribute__((address_space(4))) int*)d.next_obs_ok)[e * 2 + nxt]) != 0;
-        }
+    if (ev.timestep >= time_max && p.autoreset) {      // (rare: plain loads with a uniform address)
+        const WgCtx& nc = d.ctx[e * 2 + nxt];
+        nx_pfn = wg_uni(nc.pend_farm_n); nx_pbn = wg_uni(nc.pend_base_n); nx_np = wg_uni(nc.n_pushed); nx_tmax = wg_uni(nc.time_max);
+        nx_rated = wg_uni(nc.rated_power);
+        nx_prep = d.next_obs_ok != nullptr && wg_uni(d.next_obs_ok[e * 2 + nxt]) != 0;
     }
     // ---- every load of the step, issued together ----
     const SumsRaw raw = wg_sums_load<GEN>(p, d, e, ctx_id, own, n_pushed_live);
@@ -382,10 +372,10 @@ __device__ __forceinline__ void lean_step(const WgParams& p, const WgPtrs& d, co
         l_yaw = d.yaw[tb_a + lane]; l_old = d.old_yaw[(size_t)e * N + lane]; l_pow = d.power[tb_a + lane];
         if (F == 2) l_powb = d.power[tb_a + N + lane];
     }
-    const float fp = FUSED ? fz.fp : ((CFloatPtr)d.step_farm_pow)[e];
-    const float bp = F == 2 ? (FUSED ? fz.bp : ((CFloatPtr)d.step_base_pow)[e]) : 0.f;
+    const float fp = FUSED ? fz.fp : wg_uni(d.step_farm_pow[e]);
+    const float bp = F == 2 ? (FUSED ? fz.bp : wg_uni(d.step_base_pow[e])) : 0.f;
     const int fslot = ev.farm_pow_n % PA, bslot = ev.base_pow_n % PA;      // (counts run over all episodes)
-    const float f_old = wg_pin<FUSED>(((CFloatPtr)fq)[fslot]), b_old = F == 2 ? wg_pin<FUSED>(((CFloatPtr)bq)[bslot]) : 0.f;
+    const float f_old = wg_uni(fq[fslot]), b_old = F == 2 ? wg_uni(bq[bslot]) : 0.f;
     float* met = d.metrics + (size_t)e * WG_N_METRICS;
     const float l_met = lane < WG_N_METRICS ? met[lane] : 0.f;
     // background episode: remaining work of its farms (plan of the next step's share), pending set-up flag
@@ -395,9 +385,9 @@ __device__ __forceinline__ void lean_step(const WgParams& p, const WgPtrs& d, co
             work = fz.work;
             if (fz.bg_init_pending && lane == 0) d.ctx[e * 2 + nxt].init_pending = 0;
         } else {
-            const CSlotPtr bs = (CSlotPtr)(d.slot + (size_t)(e * 2 + nxt) * F);
-            for (int f = 0; f < F; ++f) work = max(work, bs[f].dev_remaining + p.K * bs[f].fill_remaining);
-            if (wg_pin<FUSED>(((CCtxPtr)(d.ctx + e * 2 + nxt))->init_pending) && lane == 0) d.ctx[e * 2 + nxt].init_pending = 0;
+            const WgSlot* const bs = d.slot + (size_t)(e * 2 + nxt) * F;
+            for (int f = 0; f < F; ++f) work = max(work, wg_uni(bs[f].dev_remaining) + p.K * wg_uni(bs[f].fill_remaining));
+            if (wg_uni(d.ctx[e * 2 + nxt].init_pending) && lane == 0) d.ctx[e * 2 + nxt].init_pending = 0;
         }
     }
 #if defined(WG_TIMELINE) && defined(WG_STAMP2)

@@ -362,7 +362,7 @@ k_glue(const WgParams p, const WgPtrs d, const int phase, const uint8_t* __restr
         }
         if (obs) {
             // the next episode's first observation: built by the k_flow workgroup that completed its development
-            // (wg_first_obs) — copied; otherwise (per-agent buffer, duo flow kernel, restored state) built here
+            // (wg_first_obs) — copied; otherwise (per-agent buffer, restored state) built here
             const bool pre = PRE && d.next_obs_ok[nctx] != 0;
             if (pre) {
                 const float* no = d.next_obs + (size_t)nctx * p.obs_dim;
