@@ -75,20 +75,29 @@ def test_oracle_ti_fold_switch(small_box):
     assert np.all(u[False][last] < u[True][last] - 1e-3)
 
 
+# (k_flow's instantiations under both turbulent inflows; "envb" / "envb1" = k_flow_envb, the one-launch frozen-box kernel, with two
+# waves / one wave per env — it serves the box inflow only)
+HIP_CASES = [(t, b) for t in ("MannFixed", "Random") for b in (64, 128, 256)] + [("MannFixed", "envb"), ("MannFixed", "envb1")]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("turbtype", ["MannFixed", "Random"])
-@pytest.mark.parametrize("block", [64, 128, 256])
+@pytest.mark.parametrize("turbtype,block", HIP_CASES)
 def test_hip_matches_oracle_with_added_turbulence(turbtype, block, small_box):
     import os
     import torch
     from windgym_amd import binding
     cfg = _cfg(turbtype, "iso", n_envs=3)
-    os.environ["WG_FLOW_BLOCK"] = str(block)
+    envk = isinstance(block, str)
+    hooks = {"WG_FLOW_BLOCK": "64" if envk else str(block), "WG_FLOW_ENV": "1" if envk else "0"}
+    if envk:
+        hooks["WG_ENV_WPE"] = "1" if block.endswith("1") else "2"
+    os.environ.update(hooks)
     try:
         env = binding.HipBatch(cfg)
     finally:
-        del os.environ["WG_FLOW_BLOCK"]
-    assert env.flow_variant()[0] == block
+        for k in hooks:
+            del os.environ[k]
+    assert env.flow_variant()[0] == (64 if envk else block) and env.flow_variant()[2] == (2 if envk else 0)
     o = om.Oracle(cfg)
     if turbtype != "Random":
         env.set_turbulence_box(*small_box)

@@ -604,12 +604,13 @@ def test_random_inflow_matches_oracle(hip, oracle_lib, block):
     assert n_tr >= B
 
 
-@pytest.mark.parametrize("block", BLOCKS)
+@pytest.mark.parametrize("block", BOX_BLOCKS)
 @pytest.mark.parametrize("turbtype", ["MannFixed", "MannGenerate"])
 def test_mann_box_inflow_matches_oracle(hip, oracle_lib, small_mann_box, turbtype, block):
     """BASELINE.json configs[4] at test size: frozen Mann box (trilinear, periodic, Taylor advection), DWM
     meandering of the wake particles through the low-pass filtered transverse inflow; every k_flow<NT, BOX>
-    instantiation (256: chain pruning and the 16-byte record copy together with turbulence)."""
+    instantiation (256: chain pruning and the 16-byte record copy together with turbulence) and the one-launch env kernel
+    k_flow_envb with two waves / one wave per env."""
     box, spacing = small_mann_box
     B = 5
     cfg = _turb_cfg(turbtype, B)

@@ -1,8 +1,8 @@
 """Oracle spot checks AT BENCH BATCH SIZE.  The step-for-step oracle tests of test_gpu_parity.py run a handful
 of envs; the soaks at BASELINE's batch sizes check properties only.  Here the FULL batch of each GPU config runs on the HIP
 path — the kernels, block orders and occupancies the bench line times (cfg2: one wave per env with the glue fused, 4096 envs;
-cfg3: 256-thread large-farm variant, 512 envs; cfg4: per-agent buffer, 2048 envs; cfg5: frozen-box variant, 1024 envs on a
-small box) — and the CPU oracle replays 16 of its envs, spread over the batch, on the same global seeds and actions: every step
+cfg3: 256-thread large-farm variant, 512 envs; cfg4: per-agent buffer, 2048 envs; cfg5: k_flow_envb, the one-launch frozen-box
+kernel, 1024 envs on a small box) — and the CPU oracle replays 16 of its envs, spread over the batch, on the same global seeds and actions: every step
 for 300 steps, through at least one rollover of each sampled env where the episode length allows, with the bars of DESIGN.md §6.
 (test_results_do_not_depend_on_batch_composition shows an env does not depend on its neighbours: the subset is representative.)"""
 import os
@@ -106,4 +106,4 @@ def test_cfg4_2048_envs_per_agent_buffer(hip, oracle_lib):
 
 def test_cfg5_1024_envs_frozen_box(hip, oracle_lib):
     """frozen Mann box + meandering + wake-added turbulence, 16 turbines x 1024 envs, on a small box the oracle shares"""
-    _run(hip, oracle_lib, "cfg5", 1024, 1.0, (64, True, 0), turbulent=True)
+    _run(hip, oracle_lib, "cfg5", 1024, 1.0, (64, True, 2), turbulent=True)

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwindgym_hip.so")
-SOURCES = ["wg_flow.hip", "wg_env.hip", "wg_kernels.hip", "wg_api.hip", "wg_mann.hip", "wg_steady.hip"]
+SOURCES = ["wg_flow.hip", "wg_env.hip", "wg_envb.hip", "wg_kernels.hip", "wg_api.hip", "wg_mann.hip", "wg_steady.hip"]
 
 
 def _headers():

@@ -20,6 +20,7 @@ extern "C" {
 void wg_launch_flow(const FlowP*, const FlowPtrs*, int, const float*, const uint8_t*, int, hipStream_t);
 void wg_launch_flow_env(const FlowP*, const FlowPtrs*, int, const float*, const uint8_t*, int, hipStream_t);
 void wg_launch_step_env(const FlowP*, const FlowPtrs*, const WgParams*, const WgPtrs*, const float*, float*, float*, uint8_t*, float*, hipStream_t);
+void wg_launch_step_envb(const FlowP*, const FlowPtrs*, const WgParams*, const WgPtrs*, const float*, float*, float*, uint8_t*, float*, hipStream_t);
 void wg_launch_glue(const WgParams*, const WgPtrs*, int, const uint8_t*, float*, float*, uint8_t*, float*, hipStream_t, const WgParams*, const WgPtrs*);
 void wg_launch_init(const WgParams*, const WgPtrs*, const uint8_t*, const uint64_t*, hipStream_t);
 void wg_launch_create(const WgParams*, const WgPtrs*, hipStream_t);
@@ -580,6 +581,22 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             size_t o = (size_t)f.env_off_tab + sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S);      // power | ct | rotor points (float2)
             f.env_lds = (int)((o + 15) & ~(size_t)15);
             if (f.env_lds > 32768 || f.env_lds > lds_limit) env_ok = false;
+            // k_flow_envb (wg_envb.hip): the same pattern for frozen-box inflow (cfg5) on the turbulent small-farm layout (SoA
+            // record + u_e, what k_flow<64, BOX> runs on: the two are interchangeable).  Gaussian deficit; rotor points in rows
+            // of S_pad <= 16 lanes; the wake-added field and TI folding are run-time options.
+            bool envb_ok = f.res && small && f.block == 64 && !f.gl && p.turb_mode >= WG_TURB_BOX && NL <= 64 && p.N <= 32 &&
+                           p.P <= 4096 && f.S_pad <= 16 && h->deficit_model == 0;
+            if (envb_ok) {
+                f.env_cap = 256;
+                size_t ob = WG_ENVB_FIXED_LDS_BYTES + (size_t)20 * f.env_cap;
+                f.envb_off_cl = (int)ob;
+                ob = (ob + clb + 15) & ~(size_t)15;
+                f.env_off_tab = (int)ob;
+                ob += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S);
+                f.env_lds = (int)((ob + 15) & ~(size_t)15);
+                if (f.env_lds > 32768 || f.env_lds > lds_limit) envb_ok = false;
+            }
+            env_ok = env_ok || envb_ok;
             f.env_inc = 1 + (p.extra_inc ? 1 : 0);
             f.env_eps_max = std::min(1.0f, (float)(p.eps0 * std::sqrt(3.0))) + 2.0f / 65535.0f;
             const bool asked_old = wg_hook("WG_FLOW_BLOCK") || wg_hook("WG_FLOW_RES");
@@ -705,7 +722,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     if (const char* ev = wg_hook("WG_STEP_GRAPH")) h->graph_mode = atoi(ev) != 0;
     if (wg_hook("WG_DEBUG"))
         fprintf(stderr, "[windgym] k_flow variant: %s, %d threads, LDS %d B per workgroup, slot stride %d floats\n",
-                h->fp.envw ? "compact rings / pair-major, one wave per env (k_flow_env)"
+                h->fp.envw ? (h->fp.turb_mode == WG_TURB_NONE ? "compact rings / pair-major, one wave per env (k_flow_env)" : "compact rings / sample-major, one wave per env (k_flow_envb)")
                           : (h->fp.res ? "compact rings / pair-major" : "uniform rings / sample-major"),
                 h->fp.block, h->fp.envw ? h->fp.env_lds : h->fp.lds_bytes, h->fp.pstride);
     *out = h;
@@ -975,7 +992,8 @@ static void launch_step(wg_env_s* h, const float* actions_dev, float* obs_dev, f
     // legal on either path: lean_step checks each one before it stores.)
     if (h->fp.env_fused && h->fd.script_uvw == nullptr) {
         if (sample) sample = time_begin(h, 0, st);
-        wg_launch_step_env(&h->fp, &h->fd, &h->p, &h->d, actions_dev, obs_dev, reward_dev, truncated_dev, final_obs_dev, st);
+        if (h->fp.turb_mode == WG_TURB_NONE) wg_launch_step_env(&h->fp, &h->fd, &h->p, &h->d, actions_dev, obs_dev, reward_dev, truncated_dev, final_obs_dev, st);
+        else wg_launch_step_envb(&h->fp, &h->fd, &h->p, &h->d, actions_dev, obs_dev, reward_dev, truncated_dev, final_obs_dev, st);
         if (sample) time_end(h, st);
         return;
     }

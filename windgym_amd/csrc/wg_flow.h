@@ -80,6 +80,7 @@ struct FlowP {
     // k_flow_env (wg_env.hip: ONE wave per env, lane = slot * N + turbine): enabled; bytes of dynamic LDS; offset of the tables
     // (the rest of the carve is fixed: WG_ENV_*)
     int envw, env_lds, env_off_tab;
+    int env_cap, envb_off_cl;         // k_flow_envb (wg_envb.hip, frozen-box inflow): staged wakes per chunk of targets; offset of the candidate list
     int env_wpe;                      // waves per env: 1, or 2 (a workgroup of two waves, one per context, each with its own LDS region of env_lds bytes)
     int env_fused;                    // step() as ONE launch: the env's wave runs its glue (lean_step) as the tail of its flow step
     int env_inc;                      // env time steps per step(): 1 + extra_timestep_inc (the background plan's steps left)
@@ -147,6 +148,9 @@ struct FlowPtrs {
 #define WG_ENV_SLOT_LDS_BYTES 160
 #define WG_ENV_FIXED_LDS_BYTES (3 * 64 * 16 + 2 * 64 * 8 + 4 * WG_ENV_SLOT_LDS_BYTES)
 #define WG_ENV_CAP 256
+// k_flow_envb's LDS carve (wg_envb.hip): fixed part (per-lane turbine fields + row table + four slot records of 208 bytes) |
+// staged wakes float4[env_cap] | added TI float[env_cap] | candidate list (u16) | tables (FlowP::env_off_tab)
+#define WG_ENVB_FIXED_LDS_BYTES (5952 + 4 * 208)
 // sizeof(TurbLds) in wg_flow.hip; kept here so the host can size the dynamic LDS
 #define WG_TURB_LDS_BYTES 120
 // landing zone of the LDS-DMA gathers, per candidate lane: the 16-byte record copy (rec_a, rec_b, u_e, 0) of the two
