@@ -163,6 +163,69 @@ def cpu_baseline(args):
                       f"{cfg1['f64'][1]} + {cfg1['f32'][1]} steps, incl. one ctypes call per step"}
 
 
+def api_legs(args, dev, abi_env, acts):
+    """Throughput through the API the reference's users call, beside the bare C-ABI rate, on the same
+    workload and batch: `WindFarmVecEnv.step` on CUDA tensors with the lazy info dict (examples/longer_steps_example.py:194-219
+    drives a VecEnv), the same under `RecordEpisodeVals`, which reads infos["Power agent"] on the host every step
+    (wrappers/recordEpisodeVals.py:31-64), and stable-baselines3's VecEnv protocol with numpy in / out (`as_sb3()`).
+    Per leg: env-steps/s over `--api-steps` steps between two device synchronisations (what a training loop sees), and the host
+    time of one step() call — the mean duration of the first 200 calls after a synchronisation, while the launch queue is
+    far from full, i.e. the Python + ctypes + launch cost the GPU work hides behind (or not)."""
+    import numpy as np
+    import torch
+    from windgym_amd import presets
+    from windgym_amd.envs import RecordEpisodeVals, WindFarmVecEnv
+    from windgym_amd.turbine import V80
+    B, n_act = abi_env.B, len(acts)
+    steps, warm = args.api_steps, 50
+
+    def measure(step_fn, sync):
+        for i in range(warm):
+            step_fn(i)
+        sync()
+        host = 0.0
+        for i in range(200):
+            t0 = time.perf_counter()
+            step_fn(i)
+            host += time.perf_counter() - t0
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step_fn(i)
+        sync()
+        el = time.perf_counter() - t0
+        return {"value": B * steps / el, "unit": "env-steps/s", "ms_per_step": el / steps * 1e3, "host_us_per_call": host / 200 * 1e6}
+
+    sync = lambda: torch.cuda.synchronize(dev)          # noqa: E731
+    out = {"steps": steps, "envs": B}
+    out["abi"] = measure(lambda i: abi_env.step(acts[i % n_act]), sync)
+    kw = dict(turbtype="None", n_passthrough=5, n_rotor_pts=16)
+    d = presets.bench_cfg2_config()
+    if args.one_farm:
+        d["power_def"]["Power_reward"] = "Power_avg"
+    venv = WindFarmVecEnv(V80(), B, yaml_dict=d, seed=1234, device=dev.index, as_torch=True, **kw)
+    venv.reset(seed=1234)
+    for i in range(300):          # (out of the synchronised start, like the headline's pre-roll — shorter: these legs are ratios)
+        venv.step(acts[i % n_act])
+    out["vecenv_torch"] = measure(lambda i: venv.step(acts[i % n_act]), sync)
+    rec = RecordEpisodeVals(venv)
+    out["vecenv_torch_record_episode_vals"] = measure(lambda i: rec.step(acts[i % n_act]), sync)
+    sb3 = venv.as_sb3()
+    acts_np = [a.cpu().numpy() for a in acts]
+    r = measure(lambda i: sb3.step(acts_np[i % n_act]), sync)
+    o_dim = venv.batch.obs_dim
+    r["h2d_bytes_per_step"] = B * venv.n_turb * 4
+    r["d2h_bytes_per_step"] = B * (o_dim * 4 + 4 + 1 + 4)
+    r["note"] = ("numpy actions in (one H2D copy), observations / rewards / dones / farm powers out through pinned buffers with ONE "
+                 "stream synchronisation per step + a host copy (SB3 keeps the previous observations while it steps); final "
+                 "observations cross only on steps with a truncation; infos = a persistent list of lazy per-env dicts")
+    out["sb3_numpy"] = r
+    venv.close()
+    for k in ("vecenv_torch", "vecenv_torch_record_episode_vals", "sb3_numpy"):
+        out[k]["frac_of_abi"] = out[k]["value"] / out["abi"]["value"]
+    return out
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -196,6 +259,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
                     help="wall time of the fp64 leg of the CPU sample (fp32: 0.6 x, cfg1 legs: 0.25 x each)")
     ap.add_argument("--cpu-max-steps", type=int, default=0, help="optional step cap of the CPU legs (0 = none)")
+    ap.add_argument("--api", default=None, choices=("all", "none"),
+                    help="also time the facades the reference's users call (WindFarmVecEnv, RecordEpisodeVals, SB3 VecEnv) beside the "
+                         "C ABI and report them under \"api\" (extra keys; the headline is unchanged).  Default: all for the single-GPU "
+                         "cfg2 run unless --no-cpu asks for a quick line")
+    ap.add_argument("--api-steps", type=int, default=2000, help="timed steps of each --api leg")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
                     help="weak: --envs (default: the workload's) per GPU; strong: that many envs in TOTAL, split over "
                          "the N ranks (BASELINE.json's '4096 envs sharded across 8')")
@@ -368,7 +436,7 @@ def main():
         # profiles/r03_<cfgN>_kflow_traffic.json); `traffic_source` names the file.  Only quoted for the profiled
         # workloads at their profiled size (the workload's default env count, baseline farm on, one GPU).
         traffic = traffic_source = None
-        for rnd in ("r05", "r04", "r03", "r02"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02"):
             tf = os.path.join(ROOT, "profiles", f"{rnd}_kflow_traffic.json" if args.workload == "cfg2" and rnd == "r02"
                               else f"{rnd}_{args.workload}_kflow_traffic.json")
             if os.path.exists(tf) and args.envs is None and F == 2 and world == 1:
@@ -376,6 +444,9 @@ def main():
                     traffic = json.load(open(tf))["hbm_bytes_per_launch"]
                     traffic_source = (f"{os.path.relpath(tf, ROOT)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "
                                       f"this command, FETCH_SIZE x 2 (gfx950); not collected in this run")
+                    if rnd != "r06":
+                        traffic_source = (f"WARNING: no profile of the current round's kernels for {args.workload} — STALE figure from "
+                                          + traffic_source)
                     break
                 except Exception:
                     traffic = traffic_source = None
@@ -399,7 +470,8 @@ def main():
             achieved = alg_bytes_flow / (flow_ms * 1e-3) / 1e9 if flow_ms > 0 else 0.0
             bytes_per_flow_step = alg_bytes_flow / flow_steps if flow_steps > 0 else 0.0
         touched_bytes = (touched * per_particle + (alg_bytes_flow - particles * per_particle)) if touched is not None else None
-        kernel_name = {0: "k_flow", 2: "k_flow_env"}[variant] + (" (one launch per step: flow + glue tail)" if fused else "")
+        kernel_name = {0: "k_flow", 2: "k_flow_envb" if args.workload == "cfg5" else "k_flow_env"}[variant] + \
+            (" (one launch per step: flow + glue tail)" if fused else "")
         out = {
             "metric": "env-steps/sec (whole node), 16-turbine farm x 4096 envs" if args.workload == "cfg2"
                       else f"env-steps/sec (whole node), {args.workload}",
@@ -439,6 +511,9 @@ def main():
                          "bytes_per_farm_flow_step": bytes_per_flow_step},
             "episode_metrics": {k: float(v) for k, v in m.items()},
         }
+        want_api = args.api == "all" or (args.api is None and not args.no_cpu)
+        if world == 1 and want_api and args.workload == "cfg2" and args.envs is None and not args.no_autoreset:
+            out["api"] = api_legs(args, dev, env, acts)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args)
         line = json.dumps(out)

@@ -129,3 +129,56 @@ def test_fused_step_equals_two_launches_over_5000_steps(hip):
     writes) — 5000 steps x 64 envs with ~30 rollovers per env, bit for bit against flow + k_glue_lean."""
     n_tr = _ab(hip, "fused", "cfg2_4x4", 64, 5000)
     assert n_tr >= 20 * 64
+
+
+@pytest.mark.parametrize("wpe", ["2", "1"])
+def test_box_env_kernel_agrees_with_the_per_slot_kernel(hip, wpe):
+    """k_flow_envb (wg_envb.hip: one launch per step, lanes turbine-major, sample-major deficit phase) against k_flow<64, BOX>
+    (one workgroup per farm slot + k_glue_lean) on the SAME state layout, seeds and actions, frozen Mann box with the
+    wake-added field on, through rollovers: decisions (truncations, the box-pool draw) exactly, values to float rounding — the
+    two kernels sum the rotor points and the wake-added shares in different orders (held to 2e-5 of the scaled observation;
+    both are held to the oracle's bars separately, tests/test_gpu_parity.py)."""
+    import torch
+    from windgym_amd import presets
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.mann import generate_mann_box
+    from windgym_amd.turbine import V80
+    d = presets.bench_cfg2_config()
+    B = 48
+    box, spacing = generate_mann_box((256, 64, 32), (3.0, 3.0, 3.0), seed=1234), (3.0, 3.0, 3.0)
+
+    def make(hooks):
+        os.environ.update(hooks)
+        try:
+            cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="MannGenerate", n_envs=B, autoreset=True, n_rotor_pts=16,
+                            n_passthrough=1, n_particles=128)
+            env = hip.HipBatch(cfg)
+        finally:
+            for k in hooks:
+                del os.environ[k]
+        env.set_turbulence_box(box, spacing)
+        return cfg, env
+    cfg, a_env = make({"WG_FLOW_ENV": "1", "WG_ENV_WPE": wpe})
+    _, b_env = make({"WG_FLOW_ENV": "0"})
+    assert a_env.flow_variant() == (64, True, 2) and b_env.flow_variant() == (64, True, 0)
+    seeds = 700 + np.arange(B)
+    oa, ob = a_env.reset(seeds=seeds), b_env.reset(seeds=seeds)
+    assert (oa - ob).abs().max().item() <= 2e-5
+    g = torch.Generator(device="cpu").manual_seed(7)
+    acts = (torch.rand((64, B, cfg.n_turb), generator=g) * 2 - 1).cuda()
+    n_tr = 0
+    for s in range(360):
+        ra, rb = a_env.step(acts[s % 64]), b_env.step(acts[s % 64])
+        assert torch.equal(ra[2], rb[2]), f"truncation flags differ at step {s}"
+        assert (ra[0] - rb[0]).abs().max().item() <= 2e-5, s
+        assert (ra[3] - rb[3]).abs().max().item() <= 2e-5, s
+        assert ((ra[1] - rb[1]).abs() <= 1e-4 + 1e-4 * rb[1].abs()).all(), s
+        n_tr += int(ra[2].sum())
+        if s % 60 == 59:
+            for f in FIELDS:
+                x, y = a_env.info(f).float(), b_env.info(f).float()
+                tol = 50.0 if f.startswith("power") else 2e-4
+                assert ((x - y).abs() <= tol + 1e-4 * y.abs()).all(), (s, f, float((x - y).abs().max()))
+    assert n_tr >= B
+    a_env.check(); b_env.check()
+    a_env.close(); b_env.close()

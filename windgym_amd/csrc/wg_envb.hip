@@ -34,6 +34,10 @@
 #ifndef WG_ENVB_U
 #define WG_ENVB_U 2          // ring slots per lane and trip of the particle pass (their 6 streamed words and 4 box cells in flight together)
 #endif
+#ifndef WG_ENVB_ABLATE
+#define WG_ENVB_ABLATE 0     // profiling builds only (results are wrong): 1 = no box cells for the particles, 2 = no ambient lookups at the
+                             // rotor points, 4 = no wake-added lookups, 8 = no bracket gathers of the candidates, 16 = no particle pass
+#endif
 #ifndef WG_ENVB_WAVES
 #define WG_ENVB_WAVES 4      // <= 128 VGPRs
 #endif
@@ -69,8 +73,98 @@ static_assert(sizeof(EnvbSlotLds) == 208, "EnvbSlotLds layout (WG_ENVB_OFF_* bel
 #define WG_ENVB_OFF_CR 5376       // int2[64]    (first entry, entries) of the target's slice of the candidate list
 #define WG_ENVB_OFF_ROW 5888      // u8[64]      lane of the i-th stepping (slot, turbine) row
 #define WG_ENVB_OFF_SL 5952       // EnvbSlotLds[4]
-#define WG_ENVB_OFF_STAGE (WG_ENVB_OFF_SL + 4 * 208)      // staged wakes: float4[cap] | added TI float[cap] | candidate list u16[..]
+#define WG_ENVB_OFF_PARK (WG_ENVB_OFF_SL + 4 * 208)       // float4[3][64]  the lane's turbine registers, parked across the particle / rotor phases
+#define WG_ENVB_OFF_STAGE (WG_ENVB_OFF_PARK + 3 * 1024)   // staged wakes: float4[cap] | added TI float[cap] | candidate list u16[..]
 static_assert(WG_ENVB_OFF_STAGE == WG_ENVB_FIXED_LDS_BYTES, "keep WG_ENVB_FIXED_LDS_BYTES in sync (wg_flow.h)");
+
+__device__ __forceinline__ long long envb_uni64(const long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// The 8 corners of a point in a box stored like box_lookup_dims reads it (wg_box_dev.h: 4 x 4 x 4 bricks when every dimension is
+// a multiple of 4) as 32-bit CELL offsets from the box's first cell + the trilinear weights — same cells, same weights.  The
+// kernel adds them to a base pointer that is wave-uniform wherever the wave serves one episode: the loads then carry a scalar
+// base and ONE address register each (8 x 64-bit addresses per lookup were 16 VGPRs, 32 with the wake-added box in flight too).
+// A box of the pool has fewer than 2^28 cells (wg_set_turbulence_boxes falls back to k_flow otherwise).
+template <bool POW2>
+__device__ __forceinline__ void envb_box_corners(const int bnx, const int bny, const int bnz, const double inv_dx, const double inv_dy,
+                                                 const double inv_dz, const double x, const double y, const double z, unsigned (&o)[8],
+                                                 float& tx, float& ty, float& tz) {
+    const double fx = x * inv_dx, fy = y * inv_dy, fz = z * inv_dz;
+    const double ix = floor(fx), iy = floor(fy), iz = floor(fz);
+    tx = (float)(fx - ix); ty = (float)(fy - iy); tz = (float)(fz - iz);
+    int i0, j0, k0, i1, j1, k1;
+    if (POW2) {
+        i0 = (int)ix & (bnx - 1); j0 = (int)iy & (bny - 1); k0 = (int)iz & (bnz - 1);
+        i1 = (i0 + 1) & (bnx - 1); j1 = (j0 + 1) & (bny - 1); k1 = (k0 + 1) & (bnz - 1);
+    } else {
+        i0 = (int)ix % bnx; if (i0 < 0) i0 += bnx;
+        j0 = (int)iy % bny; if (j0 < 0) j0 += bny;
+        k0 = (int)iz % bnz; if (k0 < 0) k0 += bnz;
+        i1 = i0 + 1 == bnx ? 0 : i0 + 1; j1 = j0 + 1 == bny ? 0 : j0 + 1; k1 = k0 + 1 == bnz ? 0 : k0 + 1;
+    }
+    const bool brick = ((bnx | bny | bnz) & 3) == 0;
+    const unsigned nbz = (unsigned)(bnz >> 2), nbyz = (unsigned)(bny >> 2) * nbz;
+    const unsigned X0 = brick ? (unsigned)(i0 >> 2) * nbyz * 64u + (unsigned)(i0 & 3) * 16u : (unsigned)i0 * (unsigned)bny * (unsigned)bnz;
+    const unsigned X1 = brick ? (unsigned)(i1 >> 2) * nbyz * 64u + (unsigned)(i1 & 3) * 16u : (unsigned)i1 * (unsigned)bny * (unsigned)bnz;
+    const unsigned Y0 = brick ? (unsigned)(j0 >> 2) * nbz * 64u + (unsigned)(j0 & 3) * 4u : (unsigned)j0 * (unsigned)bnz;
+    const unsigned Y1 = brick ? (unsigned)(j1 >> 2) * nbz * 64u + (unsigned)(j1 & 3) * 4u : (unsigned)j1 * (unsigned)bnz;
+    const unsigned Z0 = brick ? (unsigned)(k0 >> 2) * 64u + (unsigned)(k0 & 3) : (unsigned)k0;
+    const unsigned Z1 = brick ? (unsigned)(k1 >> 2) * 64u + (unsigned)(k1 & 3) : (unsigned)k1;
+    o[0] = X0 + Y0 + Z0; o[1] = X1 + Y0 + Z0; o[2] = X0 + Y1 + Z0; o[3] = X1 + Y1 + Z0;
+    o[4] = X0 + Y0 + Z1; o[5] = X1 + Y0 + Z1; o[6] = X0 + Y1 + Z1; o[7] = X1 + Y1 + Z1;
+}
+// (v[0..7] = v000 v100 v010 v110 v001 v101 v011 v111; the association of box_lookup_dims / the oracle: x, then y, then z)
+__device__ __forceinline__ void envb_tri3(const float4 (&v)[8], const float tx, const float ty, const float tz, float* __restrict__ out) {
+#define WG_TRI(f)                                                         \
+    ([&]() {                                                              \
+        const float c00 = v[0].f + tx * (v[1].f - v[0].f);                \
+        const float c10 = v[2].f + tx * (v[3].f - v[2].f);                \
+        const float c01 = v[4].f + tx * (v[5].f - v[4].f);                \
+        const float c11 = v[6].f + tx * (v[7].f - v[6].f);                \
+        const float d0 = c00 + ty * (c10 - c00);                          \
+        const float d1 = c01 + ty * (c11 - c01);                          \
+        return d0 + tz * (d1 - d0);                                       \
+    }())
+    out[0] = WG_TRI(x); out[1] = WG_TRI(y); out[2] = WG_TRI(z);
+#undef WG_TRI
+}
+// the 4 cells (z pairs packed) of a point in the block-averaged meandering box (cbox_lookup_vw_dims, wg_box_dev.h): offsets + weights
+template <bool POW2>
+__device__ __forceinline__ void envb_cbox_corners(const int bnx, const int bny, const int bnz, const double inv_bdx, const double inv_bdy,
+                                                  const double inv_bdz, const double x, const double y, const double z, unsigned (&o)[4],
+                                                  float& tx, float& ty, float& tz) {
+    const double fx = (x * inv_bdx - 1.5) * 0.25, fy = (y * inv_bdy - 1.5) * 0.25, fz = (z * inv_bdz - 1.5) * 0.25;
+    const double ix = floor(fx), iy = floor(fy), iz = floor(fz);
+    tx = (float)(fx - ix); ty = (float)(fy - iy); tz = (float)(fz - iz);
+    int i0, j0, k0, i1, j1;
+    if (POW2) {
+        i0 = (int)ix & (bnx - 1); j0 = (int)iy & (bny - 1); k0 = (int)iz & (bnz - 1);
+        i1 = (i0 + 1) & (bnx - 1); j1 = (j0 + 1) & (bny - 1);
+    } else {
+        i0 = (int)ix % bnx; if (i0 < 0) i0 += bnx;
+        j0 = (int)iy % bny; if (j0 < 0) j0 += bny;
+        k0 = (int)iz % bnz; if (k0 < 0) k0 += bnz;
+        i1 = i0 + 1 == bnx ? 0 : i0 + 1; j1 = j0 + 1 == bny ? 0 : j0 + 1;
+    }
+    const unsigned r0 = ((unsigned)j0 * (unsigned)bnz + (unsigned)k0) * (unsigned)bnx, r1 = ((unsigned)j1 * (unsigned)bnz + (unsigned)k0) * (unsigned)bnx;
+    o[0] = r0 + (unsigned)i0; o[1] = r0 + (unsigned)i1; o[2] = r1 + (unsigned)i0; o[3] = r1 + (unsigned)i1;
+}
+__device__ __forceinline__ void envb_tri2(const float4 (&c)[4], const float tx, const float ty, const float tz, float& fv, float& fw) {
+#define WG_TRI2(lo, hi)                                                   \
+    ([&]() {                                                              \
+        const float e00 = c[0].lo + tx * (c[1].lo - c[0].lo);             \
+        const float e10 = c[2].lo + tx * (c[3].lo - c[2].lo);             \
+        const float e01 = c[0].hi + tx * (c[1].hi - c[0].hi);             \
+        const float e11 = c[2].hi + tx * (c[3].hi - c[2].hi);             \
+        const float d0 = e00 + ty * (e10 - e00);                          \
+        const float d1 = e01 + ty * (e11 - e01);                          \
+        return d0 + tz * (d1 - d0);                                       \
+    }())
+    fv = WG_TRI2(x, z); fw = WG_TRI2(y, w);
+#undef WG_TRI2
+}
 
 // sum of a per-lane value over the lanes of the lane's OWN slot (lanes g = t * NS + k with the same k), all slots at once;
 // lanes beyond the wave's turbines must pass 0.  Valid in every lane.
@@ -106,6 +200,7 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
     int2* const Lcr = reinterpret_cast<int2*>(smem + WG_ENVB_OFF_CR);
     unsigned char* const Lrow = reinterpret_cast<unsigned char*>(smem + WG_ENVB_OFF_ROW);
     EnvbSlotLds* const SL = reinterpret_cast<EnvbSlotLds*>(smem + WG_ENVB_OFF_SL);
+    float4* const Lpark = reinterpret_cast<float4*>(smem + WG_ENVB_OFF_PARK);
     EnvbSlotLds& my = SL[k];
 
     // ---- prologue: every independent global load up front (one exposed round trip) ----------------------------------
@@ -364,6 +459,12 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
             Lring[g].w = hn;
             part_acc += min(my.new_valid, rg.y);          // roofline accounting: particles that can still reach a rotor
         }
+        // Register discipline: nothing of the lane's turbine is needed until the tail — parked in LDS across the two phases
+        // that want the registers for loads in flight (particle pass: streamed words + box cells of two trips; rotor points:
+        // 16 box cells per lane).  The rotor inflow (u, v, w, ti) lives in Luvw anyway.
+        Lpark[tid] = make_float4(yaw, oyaw, mvl_bits, sg);
+        Lpark[64 + tid] = make_float4(sws, swd, syaw, sp_);
+        Lpark[128 + tid] = make_float4(tpow, tct, __int_as_float(part_acc), cg);
         lds_barrier<64>();
 
         // (2) particle pass: every valid particle of the stepping farms meanders with the low-pass filtered transverse inflow at
@@ -375,7 +476,7 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
             const unsigned pstride = (unsigned)kp->p.pstride;
             const float dpart_f = kp->p.dpart_f, inv_D = kp->p.inv_D, dt = kp->p.dt, hub = kp->p.hub;
             const int n_ctx_w = WPE == 2 ? 1 : 2;
-            for (int cc = 0; cc < n_ctx_w; ++cc) {
+            for (int cc = 0; cc < ((WG_ENVB_ABLATE & 16) ? 0 : n_ctx_w); ++cc) {
                 const int k0s = WPE == 2 ? 0 : cc * F;                         // the context's first slot of the wave
                 const int st0 = SL[k0s].stepping, st1 = F == 2 ? SL[k0s + 1].stepping : 0;
                 if (!(st0 | st1)) continue;
@@ -388,70 +489,99 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
                 const float sof = q.s_off_f, sig = q.sig, alpha = q.alpha;
                 const double xshift = q.xshift, oy = q.oy;
                 const unsigned ctxw = (unsigned)(e * 2 + (WPE == 2 ? wv : cc));
-                const size_t pb = (size_t)(e * 2 * F + kbase + kf) * pstride;
-                float* const py_ = kp->d.py + pb; float* const pz_ = kp->d.pz + pb;
-                float* const vl_ = kp->d.vlp + pb; float* const wl_ = kp->d.wlp + pb;
-                unsigned* const ra_ = kp->d.rec_a + pb; unsigned* const rb_ = kp->d.rec_b + pb;
-                float* const ue_ = kp->d.u_e + pb;
+                // (particle addresses: the env's block as a wave-uniform base + a 32-bit offset per lane — an env's 2 F slots span
+                // less than 4 GB — so every access carries a scalar base and one address register)
+                const size_t pbe = (size_t)(e * 2 * F) * pstride;
+                const unsigned po = (unsigned)(kbase + kf) * pstride;                  // this lane's farm slot inside the env's block
+                float* const py_ = kp->d.py + pbe; float* const pz_ = kp->d.pz + pbe;
+                float* const vl_ = kp->d.vlp + pbe; float* const wl_ = kp->d.wlp + pbe;
+                unsigned* const ra_ = kp->d.rec_a + pbe; unsigned* const rb_ = kp->d.rec_b + pbe;
+                float* const ue_ = kp->d.u_e + pbe;
                 const uint8_t* const own_ = kp->d.qown + (size_t)ctxw * (unsigned)(kp->p.NP >> 2);
-                const float4* const cbox = kp->d.box4c ? kp->d.box4c + q.cbox_cell0 : nullptr;
-                const float4* const fbox = kp->d.box4 + q.box_cell0;
+                // (the two farms of a context read the same box of the pool: a wave-uniform base pointer)
+                const float4* const cbox = kp->d.box4c ? kp->d.box4c + envb_uni64(SL[k0s].cbox_cell0) : nullptr;
+                const float4* const fbox = kp->d.box4 + envb_uni64(SL[k0s].box_cell0);
                 auto pass = [&](auto coarse_tag, auto pow2_tag) __attribute__((always_inline)) {
                     constexpr bool COARSE = decltype(coarse_tag)::value;
                     constexpr bool POW2 = decltype(pow2_tag)::value;
-                    constexpr int U = WG_ENVB_U;
+                    constexpr int U = COARSE ? WG_ENVB_U : 1;      // (boxes without a block-averaged copy: 8 cells per particle, one at a time)
+                    constexpr int NCELL = COARSE ? 4 : 8;
                     const KArgsPtr kb = wg_cold_args();
                     const int cnx = kb->p.cnx, cny = kb->p.cny, cnz = kb->p.cnz, bnx = kb->p.bnx, bny = kb->p.bny, bnz = kb->p.bnz;
                     const double ibx = kb->p.inv_bdx, iby = kb->p.inv_bdy, ibz = kb->p.inv_bdz;
-                    for (int b0 = 0; b0 < L; b0 += lpf * U) {
-                        float pyv[U], pzv[U], vls[U], wls[U], fv[U], fw[U];
-                        unsigned ras[U], rbs[U];
-                        int jv[U], gv[U];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {      // (every streamed word of the U slots is requested before the first lookup waits)
-                            const int ix = min(b0 + u * lpf + l, L - 1);
-                            pyv[u] = py_[ix]; pzv[u] = pz_[ix];
-                            vls[u] = vl_[ix]; wls[u] = wl_[ix]; ras[u] = ra_[ix]; rbs[u] = rb_[ix];
-                            gv[u] = own_[ix >> 2];
-                        }
+                    // software pipeline: the streamed words of the NEXT trip are requested before this trip's box cells are —
+                    // a trip exposes one memory round trip (its gathers), not two
+                    struct PReq { float py, pz, vl, wl; unsigned ra, rb; int own; };
+                    PReq nx[U];
+                    auto request = [&](PReq (&r)[U], const int b0) __attribute__((always_inline)) {
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
                             const int ix = min(b0 + u * lpf + l, L - 1);
-                            const int gq = (gv[u] << nsh) + kf;                       // lane of (turbine, slot)
+                            const unsigned ia = po + (unsigned)ix;
+                            r[u].py = py_[ia]; r[u].pz = pz_[ia]; r[u].vl = vl_[ia]; r[u].wl = wl_[ia];
+                            r[u].ra = ra_[ia]; r[u].rb = rb_[ia]; r[u].own = own_[(unsigned)ix >> 2];
+                        }
+                    };
+                    request(nx, 0);
+                    for (int b0 = 0; b0 < L; b0 += lpf * U) {
+                        PReq cu[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) cu[u] = nx[u];
+                        request(nx, b0 + lpf * U);
+                        float4 cell[U][NCELL];
+                        float wx[U], wy[U], wz[U];
+                        int jv[U], gv[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int ix = min(b0 + u * lpf + l, L - 1);
+                            const int gq = (cu[u].own << nsh) + kf;                   // lane of (turbine, slot)
                             gv[u] = gq;
                             const int4 rg = Lring[gq];
                             int j = rg.z - (ix - rg.x); if (j < 0) j += rg.y;
                             jv[u] = j;
                             const float xrel = sof + (float)j * dpart_f;
-                            const double bx = Lxr[gq] + (double)xrel + xshift, by = (double)pyv[u] + oy, bz = (double)pzv[u];
-                            if (COARSE) cbox_lookup_vw_dims<POW2>(cbox, cnx, cny, cnz, ibx, iby, ibz, bx, by, bz, fv[u], fw[u]);
-                            else { float f3[3]; box_lookup_dims<POW2>(fbox, bnx, bny, bnz, ibx, iby, ibz, bx, by, bz, f3); fv[u] = f3[1]; fw[u] = f3[2]; }
+                            const double bx = Lxr[gq] + (double)xrel + xshift, by = (double)cu[u].py + oy, bz = (double)cu[u].pz;
+                            unsigned oc[NCELL];
+                            if constexpr (COARSE) envb_cbox_corners<POW2>(cnx, cny, cnz, ibx, iby, ibz, bx, by, bz, oc, wx[u], wy[u], wz[u]);
+                            else envb_box_corners<POW2>(bnx, bny, bnz, ibx, iby, ibz, bx, by, bz, oc, wx[u], wy[u], wz[u]);
+                            const float4* const bb = COARSE ? cbox : fbox;
+#pragma unroll
+                            for (int i = 0; i < NCELL; ++i) cell[u][i] = (WG_ENVB_ABLATE & 1) ? make_float4(wx[u], wy[u], wz[u], (float)oc[i]) : bb[oc[i]];
                         }
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
                             const int ix = b0 + u * lpf + l;
                             if (ix >= L) continue;
+                            const unsigned ia = po + (unsigned)ix;
                             const int j = jv[u], gq = gv[u];
                             const int R = Lring[gq].y;
-                            float vlv = vls[u], wlv = wls[u];
-                            const unsigned rav = ras[u], rbv = rbs[u];
+                            float fv, fw;
+                            if constexpr (COARSE) {
+                                envb_tri2(cell[u], wx[u], wy[u], wz[u], fv, fw);
+                            } else {
+                                float f3[3];
+                                envb_tri3(cell[u], wx[u], wy[u], wz[u], f3);
+                                fv = f3[1]; fw = f3[2];
+                            }
+                            float pyv = cu[u].py, pzv = cu[u].pz, vlv = cu[u].vl, wlv = cu[u].wl;
+                            const unsigned rav = cu[u].ra, rbv = cu[u].rb;
                             if (j < n_valid) {
                                 const float xrel = sof + (float)j * dpart_f;
                                 const float sp = rec_k(rav) * (xrel * inv_D) + rec_eps(rbv);
-                                vlv += alpha * (sig * fv[u] - vlv);
-                                wlv += alpha * (sig * fw[u] - wlv);
-                                pyv[u] += (rec_hv(rbv) * m0_cfrac(rec_ct(rav), sp) + vlv) * dt;
-                                pzv[u] += wlv * dt;
+                                vlv += alpha * (sig * fv - vlv);
+                                wlv += alpha * (sig * fw - wlv);
+                                pyv += (rec_hv(rbv) * m0_cfrac(rec_ct(rav), sp) + vlv) * dt;
+                                pzv += wlv * dt;
                             }
                             const float y0 = Lsrc4[gq].y;
                             if (R - 1 - j < n_emit) {                                 // (= (r - head - 1) mod R: emission index of this slot)
                                 const uint4 rn = Lrec4[gq];
-                                pyv[u] = y0; pzv[u] = hub; vlv = 0.f; wlv = 0.f;
-                                ra_[ix] = rn.x; rb_[ix] = rn.y; ue_[ix] = __uint_as_float(rn.z);
+                                pyv = y0; pzv = hub; vlv = 0.f; wlv = 0.f;
+                                ra_[ia] = rn.x; rb_[ia] = rn.y; ue_[ia] = __uint_as_float(rn.z);
                             }
-                            const float ex = j < n_valid ? fabsf(pyv[u] - y0) + fabsf(pzv[u] - hub) : 0.f;   // (valid particles only)
+                            const float ex = j < n_valid ? fabsf(pyv - y0) + fabsf(pzv - hub) : 0.f;   // (valid particles only)
                             if (ex > Lbd[gq]) atomicMax(reinterpret_cast<int*>(&Lbd[gq]), __float_as_int(ex));   // ex >= 0: int order == float order
-                            py_[ix] = pyv[u]; pz_[ix] = pzv[u]; vl_[ix] = vlv; wl_[ix] = wlv;
+                            py_[ia] = pyv; pz_[ia] = pzv; vl_[ia] = vlv; wl_[ia] = wlv;
                         }
                     }
                 };
@@ -523,6 +653,9 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
                     const double inv_dpart = kp->p.inv_dpart;
                     const float inv_D = kp->p.inv_D, D = kp->p.D, hub = kp->p.hub, R_rot = kp->p.R_rot;
                     const float tia = kp->p.no_ti_fold ? 0.f : kp->p.tia, tib = kp->p.tib, tid_ = kp->p.tid;
+                    const size_t pbe = (size_t)(e * 2 * F) * pstride;
+                    const float* const py_e = kp->d.py + pbe; const float* const pz_e = kp->d.pz + pbe; const float* const ue_e = kp->d.u_e + pbe;
+                    const unsigned* const ra_e = kp->d.rec_a + pbe; const unsigned* const rb_e = kp->d.rec_b + pbe;
                     for (int cb = base; cb < top; cb += 64) {
                         const int cidx = cb + tid;
                         if (cidx < top) {
@@ -546,11 +679,18 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
                                 const int Rs = rg.y;
                                 int r0 = rg.w - j; if (r0 < 0) r0 += Rs;
                                 int r1 = r0 - 1; if (r1 < 0) r1 += Rs;
-                                const size_t sb = (size_t)(e * 2 * F + kbase + kt) * pstride + (unsigned)rg.x;
-                                const size_t i0 = sb + (unsigned)r0, i1 = sb + (unsigned)r1;
-                                const float py0 = kp->d.py[i0], py1 = kp->d.py[i1], pz0 = kp->d.pz[i0], pz1 = kp->d.pz[i1];
-                                const float u0 = kp->d.u_e[i0], u1 = kp->d.u_e[i1];
-                                const unsigned a0 = kp->d.rec_a[i0], a1 = kp->d.rec_a[i1], b0_ = kp->d.rec_b[i0], b1_ = kp->d.rec_b[i1];
+                                const unsigned sb = (unsigned)(kbase + kt) * pstride + (unsigned)rg.x;      // (inside the env's block)
+                                const unsigned i0 = sb + (unsigned)r0, i1 = sb + (unsigned)r1;
+#if WG_ENVB_ABLATE & 8
+                                const uint4 rr = Lrec4[gs];
+                                const float py0 = Lsrc4[gs].y + 1e-9f * (float)i0, py1 = py0 + 1e-9f * (float)i1, pz0 = hub, pz1 = hub;
+                                const float u0 = __uint_as_float(rr.z), u1 = u0;
+                                const unsigned a0 = rr.x, a1 = rr.x, b0_ = rr.y, b1_ = rr.y;
+#else
+                                const float py0 = py_e[i0], py1 = py_e[i1], pz0 = pz_e[i0], pz1 = pz_e[i1];
+                                const float u0 = ue_e[i0], u1 = ue_e[i1];
+                                const unsigned a0 = ra_e[i0], a1 = ra_e[i1], b0_ = rb_e[i0], b1_ = rb_e[i1];
+#endif
                                 const float w0 = 1.0f - wgt, w1 = wgt;
                                 const float yc = w0 * py0 + w1 * py1;
                                 const float zc = w0 * pz0 + w1 * pz1;
@@ -589,32 +729,43 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
                     const float rdy_s = rdy[min(s, S - 1)], rdz_s = rdz[min(s, S - 1)];
                     const float hub = kp->p.hub, inv_S = kp->p.inv_S, km1 = kp->p.km1, km2r = kp->p.km2r;
                     const double hub_d = kp->p.hub_d;
+                    // (two waves per env: the wave serves ONE episode — a wave-uniform base pointer of its box)
+                    const long long ucell0 = WPE == 2 ? envb_uni64(SL[0].box_cell0) : 0;
                     auto rows = [&](auto pow2_tag, auto apow2_tag) __attribute__((always_inline)) {
                         constexpr bool POW2 = decltype(pow2_tag)::value;
                         constexpr bool APOW2 = decltype(apow2_tag)::value;
                         const KArgsPtr kb = wg_cold_args();
+                        const float4* const abox = kb->d.abox4;
                         for (int r0 = rho_lo; r0 < rho_hi; r0 += rpp) {
                             const int rho = r0 + (tid >> sshift);
                             const bool live = rho < rho_hi && s < S;
                             const int gt = Lrow[min(rho, max(rho_hi - 1, 0))];
                             const int kt = gt & (NS - 1);
                             const EnvbSlotLds& q = SL[kt];
-                            const float cgt = __uint_as_float(Lrec4[gt].w);
-                            const double xr = Lxr[gt], yr = Lyr[gt];
-                            const int2 cr = Lcr[gt];
                             float amb[3] = {0.f, 0.f, 0.f}, g3[3] = {0.f, 0.f, 0.f};
-                            const bool addl = ADDED && live && cr.y > 0;
+                            float acc = 0.f, accw = 0.f, tia_max = 0.f;
+                            bool addl = false;
                             if (live) {
+                                const float cgt = __uint_as_float(Lrec4[gt].w);
+                                const double xr = Lxr[gt], yr = Lyr[gt];
+                                const int2 cr = Lcr[gt];
+                                addl = ADDED && cr.y > 0;
                                 const double bx = xr - q.ws * q.time + q.ox;
                                 const double by = yr + (double)(rdy_s * cgt) + q.oy, bz = hub_d + (double)rdz_s;
-                                box_lookup_dims<POW2>(kb->d.box4 + q.box_cell0, kb->p.bnx, kb->p.bny, kb->p.bnz, kb->p.inv_bdx, kb->p.inv_bdy,
-                                                      kb->p.inv_bdz, bx, by, bz, amb);
-                                if (addl)
-                                    box_lookup_dims<APOW2>(kb->d.abox4, kb->p.anx, kb->p.any, kb->p.anz, kb->p.inv_adx, kb->p.inv_ady,
-                                                           kb->p.inv_adz, bx, by, bz, g3);
-                            }
-                            float acc = 0.f, tia_max = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
-                            if (live) {
+                                // the 8 + 8 cells of the point are requested first; the wakes of the row's target are summed while they
+                                // are in flight (the sums need nothing of the lookups: the wake-added share is (sum of weights) x field)
+                                const float4* const fb = kb->d.box4 + (WPE == 2 ? ucell0 : q.box_cell0);
+                                unsigned oa[8], ob[8];
+                                float4 va[8], vb[8];
+                                float ax, ay, az, gx = 0.f, gy_ = 0.f, gz = 0.f;
+                                envb_box_corners<POW2>(kb->p.bnx, kb->p.bny, kb->p.bnz, kb->p.inv_bdx, kb->p.inv_bdy, kb->p.inv_bdz, bx, by, bz, oa, ax, ay, az);
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) va[i] = (WG_ENVB_ABLATE & 2) ? make_float4(ax, ay, az, (float)oa[i]) : fb[oa[i]];
+                                if (addl) {
+                                    envb_box_corners<APOW2>(kb->p.anx, kb->p.any, kb->p.anz, kb->p.inv_adx, kb->p.inv_ady, kb->p.inv_adz, bx, by, bz, ob, gx, gy_, gz);
+#pragma unroll
+                                    for (int i = 0; i < 8; ++i) vb[i] = (WG_ENVB_ABLATE & 4) ? make_float4(gx, gy_, gz, (float)ob[i]) : abox[ob[i]];
+                                }
                                 const float ys = (float)yr + rdy_s * cgt, zs = hub + rdz_s;
                                 for (int cq = cr.x; cq < cr.x + cr.y; ++cq) {       // ascending source order
                                     const float4 pw = pp[cq - base];
@@ -623,12 +774,12 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
                                     const float r2 = dy * dy + dz * dz;
                                     const float du = pw.w * __expf(-r2 * pw.z);
                                     acc += du;
-                                    if (ADDED) {
-                                        const float wk = du * (km1 + km2r * pw.z * __builtin_amdgcn_sqrtf(r2));
-                                        a0 += wk * g3[0]; a1 += wk * g3[1]; a2 += wk * g3[2];
-                                    }
+                                    if (ADDED) accw += du * (km1 + km2r * pw.z * __builtin_amdgcn_sqrtf(r2));
                                 }
+                                envb_tri3(va, ax, ay, az, amb);
+                                if (addl) envb_tri3(vb, gx, gy_, gz, g3);
                             }
+                            float a0 = accw * g3[0], a1 = accw * g3[1], a2 = accw * g3[2];
                             if (S_pad == 16) {
                                 acc = wg_row_sum(acc); amb[0] = wg_row_sum(amb[0]); amb[1] = wg_row_sum(amb[1]); amb[2] = wg_row_sum(amb[2]);
                                 if (ADDED) { a0 = wg_row_sum(a0); a1 = wg_row_sum(a1); a2 = wg_row_sum(a2); }
@@ -665,12 +816,15 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
         const KArgsPtr kc = wg_cold_args();
         const float inv_k = 1.0f / (float)K;
         const unsigned ctx_id = (unsigned)(e * 2 + c);
+        {   // the lane's turbine back from LDS; its rotor inflow as the rotor-point phase left it (a resting slot's: unchanged)
+            const float4 pa = Lpark[tid], pb = Lpark[64 + tid], pc = Lpark[128 + tid], r = Luvw[g];
+            yaw = pa.x; oyaw = pa.y; mvl_bits = pa.z; sg = pa.w;
+            sws = pb.x; swd = pb.y; syaw = pb.z; sp_ = pb.w;
+            tpow = pc.x; tct = pc.y; part_acc = __float_as_int(pc.z); cg = pc.w;
+            tu = r.x; tv = r.y; tw = r.z; tti = r.w;
+        }
         if (stepping) {
-            {
-                const float4 r = Luvw[g];
-                tu = r.x; tv = r.y; tw = r.z; tti = r.w;
-                Lring[g].z = Lring[g].w;          // the step's emissions are in the ring now
-            }
+            Lring[g].z = Lring[g].w;              // the step's emissions are in the ring now
             stepped = true;
             const int n_tab = kc->p.n_tab;
             const float tab_x0 = kc->p.tab_x0, tab_inv_dx = kc->p.tab_inv_dx;

@@ -221,6 +221,7 @@ class WindFarmVecEnv(_gym_vector_base()):
         self._global_offset = 0          # first global env index of this shard (set by shard())
         self._actions = self.torch.zeros((self.num_envs, self.n_turb), dtype=self.torch.float32,
                                          device=self.batch.device)
+        self._term = None
 
     # -- sharding: env i of the *global* batch is always seeded base_seed + i ------------------------
     def shard(self, rank: int, world: int, n_envs_total: Optional[int] = None):
@@ -247,7 +248,9 @@ class WindFarmVecEnv(_gym_vector_base()):
         obs = self.batch.reset(seeds=seeds, mask=mask)
         return self._out(obs), self.infos()
 
-    def step(self, actions):
+    def _step_device(self, actions):
+        """The step on device tensors: actions uploaded into the persistent buffer if they are not a CUDA tensor already, the
+        site-sampling table refreshed, ONE wg_step.  Returns HipBatch.step's views (obs, reward, truncated u8, final_obs)."""
         t = self.torch
         if not isinstance(actions, t.Tensor):
             # (np.array copies: a read-only view — np.broadcast_to in eval_sweep — must not be wrapped as a writable tensor)
@@ -258,10 +261,18 @@ class WindFarmVecEnv(_gym_vector_base()):
             actions = self._actions
         if self._site is not None:
             self._site.refresh()
-        obs, rew, trunc, fin = self.batch.step(actions)
-        term = t.zeros_like(trunc, dtype=t.bool)                         # terminated is always False (:1029)
+        return self.batch.step(actions)
+
+    def step(self, actions):
+        t = self.torch
+        obs, rew, trunc, fin = self._step_device(actions)
+        # No torch kernels on the step path (measured: bench.py --api, the facade at >= 90 % of the bare ABI rate): `terminated`
+        # is always False (:1029) — one persistent all-False tensor; `truncated` is the ABI's 0 / 1 byte tensor viewed as bool.
+        if self._term is None:
+            self._term = t.zeros((self.num_envs,), dtype=t.bool, device=self.batch.device)
+        term = self._term
         infos = self.infos(step=True)
-        trunc_b = self._out(trunc.bool())
+        trunc_b = self._out(trunc.view(t.bool))
         # gymnasium's vector info convention: a value array plus a "_key" mask of the envs it is valid for.  final_obs stays
         # a dense [B, obs_dim] array (rows of envs that did not truncate are unspecified) instead of gymnasium's per-env
         # object array: no per-env host objects on the step path
@@ -319,6 +330,10 @@ class SB3VecEnv(_sb3_base()):
         self.action_space = venv.single_action_space
         self.render_mode = None
         self._actions = None
+        # the step's host arrays (what the per-env info views read) and, on a real batch, pinned staging buffers
+        self._power = self._trunc = self._fin = self._fin_dev = None
+        self._pin = None
+        self._infos = [_SB3Info(self, i) for i in range(self.num_envs)]
         base = type(self).__mro__[1]
         if base is not object:
             base.__init__(self, venv.num_envs, self.observation_space, self.action_space)
@@ -330,18 +345,42 @@ class SB3VecEnv(_sb3_base()):
     def step_async(self, actions):
         self._actions = actions
 
+    def _step_wait_device(self):
+        """A real WindFarmVecEnv: drive the batch on device tensors and cross PCIe once per step — observations, rewards,
+        truncation flags and farm powers through pinned buffers with ONE stream synchronisation; the final observations only
+        on a step in which some env truncated (bench.py --api sb3 states the cost of this path)."""
+        v = self.venv
+        t = v.torch
+        obs, rew, trunc, fin = v._step_device(self._actions)
+        power = v.batch.info("step_power_agent")
+        if self._pin is None:
+            self._pin = tuple(t.empty(x.shape, dtype=x.dtype, pin_memory=True) for x in (obs, rew, trunc, power))
+        for h, d in zip(self._pin, (obs, rew, trunc, power)):
+            h.copy_(d, non_blocking=True)
+        t.cuda.current_stream(v.batch.device).synchronize()
+        # (fresh host arrays: SB3 keeps the previous step's observations while it calls step() again)
+        o, r, tr, pw = (h.numpy().copy() for h in self._pin)
+        self._power, self._trunc = pw, tr.astype(bool)
+        self._fin, self._fin_dev = None, (fin if self._trunc.any() else None)
+        return o, r, self._trunc, self._infos
+
+    def _fin_row(self, i):
+        if self._fin is None:
+            self._fin = _np(self._fin_dev)
+        return self._fin[i]
+
     def step_wait(self):
         v = self.venv
+        if hasattr(v, "_step_device") and hasattr(v, "batch"):
+            return self._step_wait_device()
         obs, rew, term, trunc, infos = v.step(self._actions)
         obs, rew, trunc = (np.asarray(_np(x) if v.as_torch else x) for x in (obs, rew, trunc))
         fin = infos["final_obs"]
-        fin = _np(fin) if v.as_torch else fin
+        self._fin, self._fin_dev = (_np(fin) if v.as_torch else np.asarray(fin)), None
         power = infos["Power agent"]
-        power = _np(power) if v.as_torch else np.asarray(power)
-        out = [{"Power agent": float(power[i]), "TimeLimit.truncated": bool(trunc[i])} for i in range(self.num_envs)]
-        for i in np.nonzero(trunc)[0]:
-            out[i]["terminal_observation"] = fin[i]
-        return obs, rew, trunc.astype(bool), out
+        self._power = _np(power) if v.as_torch else np.asarray(power)
+        self._trunc = trunc.astype(bool)
+        return obs, rew, self._trunc, self._infos
 
     def step(self, actions):
         self.step_async(actions)
@@ -375,6 +414,64 @@ class SB3VecEnv(_sb3_base()):
 
     def render(self, mode=None):
         return None
+
+
+class _SB3Info(dict):
+    """``infos[i]`` of SB3's list-of-dicts protocol: a dict whose three standard entries — "Power agent",
+    "TimeLimit.truncated" and, for an env that truncated in this step, "terminal_observation" — are read from the adapter's
+    arrays of the step just taken when they are asked for.  The list and its 4096 dicts are built ONCE: rebuilding them cost
+    ~1.5 ms of Python per step against a 55 us GPU step (bench.py --api sb3).  Like SB3's own buffers the views are valid until
+    the next ``step()``; ``copy()`` / ``dict(info)`` give a plain snapshot (what VecMonitor and friends do before they add keys)."""
+    __slots__ = ("_a", "_i")
+    _LAZY = ("Power agent", "TimeLimit.truncated", "terminal_observation")
+
+    def __init__(self, adapter, i):
+        super().__init__()
+        self._a, self._i = adapter, i
+
+    def __missing__(self, key):
+        a, i = self._a, self._i
+        if key == "Power agent":
+            return float(a._power[i])
+        if key == "TimeLimit.truncated":
+            return bool(a._trunc[i])
+        if key == "terminal_observation" and a._trunc is not None and a._trunc[i]:
+            return a._fin_row(i)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        if dict.__contains__(self, key):
+            return True
+        if key == "terminal_observation":
+            return self._a._trunc is not None and bool(self._a._trunc[self._i])
+        return key in self._LAZY and self._a._power is not None
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def keys(self):
+        return [k for k in self._LAZY if k in self] + [k for k in dict.keys(self) if k not in self._LAZY]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def copy(self):
+        return dict(self.items())
+
+    def __repr__(self):
+        return repr(self.copy())
 
 
 _INFO_KEYS = {
