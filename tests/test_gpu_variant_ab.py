@@ -182,3 +182,49 @@ def test_box_env_kernel_agrees_with_the_per_slot_kernel(hip, wpe):
     assert n_tr >= B
     a_env.check(); b_env.check()
     a_env.close(); b_env.close()
+
+
+def test_stencil_records_equal_the_brick_ordered_box_bit_for_bit(hip):
+    """k_flow_envb reads a rotor point's 8 box corners from ONE 128-byte stencil record (FlowPtrs::box8 / abox8: 8 x the box in
+    HBM) where the pool is small enough, else cell by cell from the brick-ordered box: the same cells with the same weights
+    in the same association — every output and the whole state must be BIT-identical (WG_NO_BOX8 keeps the records from being
+    built).  A box whose dimensions are not powers of two: the records wrap their indices in double, the bricks with %."""
+    import torch
+    from windgym_amd import presets
+    from windgym_amd.config import EnvConfig
+    from windgym_amd.mann import generate_mann_box
+    from windgym_amd.turbine import V80
+    d = presets.bench_cfg2_config()
+    B = 24
+    box, spacing = generate_mann_box((240, 72, 40), (3.0, 3.0, 3.0), seed=77), (3.0, 3.0, 3.0)
+    envs = []
+    for no8 in (False, True):
+        cfg = EnvConfig(turbine=V80(), yaml_dict=d, turbtype="MannGenerate", n_envs=B, autoreset=True, n_rotor_pts=16,
+                        n_passthrough=1, n_particles=128)
+        env = hip.HipBatch(cfg)
+        assert env.flow_variant() == (64, True, 2)
+        if no8:
+            os.environ["WG_NO_BOX8"] = "1"
+        try:
+            env.set_turbulence_box(box, spacing)
+            from windgym_amd.mann import default_added_box
+            env.set_added_turbulence_box(*default_added_box())
+        finally:
+            os.environ.pop("WG_NO_BOX8", None)
+        envs.append(env)
+    a_env, b_env = envs
+    seeds = 70 + np.arange(B)
+    assert torch.equal(a_env.reset(seeds=seeds), b_env.reset(seeds=seeds))
+    g = torch.Generator(device="cpu").manual_seed(9)
+    acts = (torch.rand((32, B, cfg.n_turb), generator=g) * 2 - 1).cuda()
+    n_tr = 0
+    for s_ in range(260):
+        ra, rb = a_env.step(acts[s_ % 32]), b_env.step(acts[s_ % 32])
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), s_
+        n_tr += int(ra[2].sum())
+    assert n_tr >= B
+    assert torch.equal(a_env.info("rotor_uvw_agent"), b_env.info("rotor_uvw_agent"))
+    assert a_env.get_state() == b_env.get_state()
+    a_env.check(); b_env.check()
+    a_env.close(); b_env.close()

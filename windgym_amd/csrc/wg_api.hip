@@ -30,6 +30,7 @@ void wg_launch_metrics(const WgParams*, const WgPtrs*, float*, int, hipStream_t)
 void wg_launch_box_repack(const float*, void*, int, int, int, hipStream_t);
 void wg_launch_measurements(const WgParams*, const WgPtrs*, float*, hipStream_t);
 void wg_launch_box_coarsen(const void*, void*, int, int, int, hipStream_t);
+void wg_launch_box_stencil(const void*, void*, int, int, int, hipStream_t);
 void wg_launch_windspeed(const FlowP*, const FlowPtrs*, int, int, const float*, int, const float*, int, float, int, float*, hipStream_t);
 void wg_launch_unready(const WgParams*, const WgPtrs*, const uint8_t*, int*, hipStream_t);
 void wg_launch_steady(const void*, const float*, const float*, const float*, const float*, float*, hipStream_t);
@@ -86,6 +87,8 @@ struct wg_env_s {
     void* box4c = nullptr;           // block-averaged copy for the particle lookups (owned)
     int* box_ids_dev = nullptr;      // wg_set_box_ids
     void* abox4 = nullptr;           // interleaved isotropic box of the wake-added turbulence (owned)
+    void* box8 = nullptr;            // stencil records of the box pool / of the wake-added box (owned; FlowPtrs::box8, k_flow_envb)
+    void* abox8 = nullptr;
     int added = 0, no_ti_fold = 0, deficit_model = 0;   // wg_config model options
     double km1 = 0.6, km2 = 0.35, sg_af = 3.11, sg_bf = -0.68, sg_cf = 2.41;
     double* wind_dev = nullptr;      // per-env wind override (wg_set_wind)
@@ -747,6 +750,8 @@ extern "C" int wg_destroy(wg_handle h) {
     if (h->box4) hipFree(h->box4);
     if (h->box4c) hipFree(h->box4c);
     if (h->abox4) hipFree(h->abox4);
+    if (h->box8) hipFree(h->box8);
+    if (h->abox8) hipFree(h->abox8);
     delete h;
     return 0;
 }
@@ -763,6 +768,24 @@ extern "C" int wg_hist_max(wg_handle h, int* hist_max) {
     return 0;
 }
 
+// Stencil records of a box pool (FlowPtrs::box8 / abox8) for handles that run k_flow_envb: 8 x the interleaved copy.  Built only
+// while the whole pool's records stay below a quarter of the device memory and a box below 2^28 cells (32-bit record offsets);
+// otherwise the kernel keeps reading the brick-ordered box (same cells, same weights: the results are identical either way).
+static int build_stencil_records(wg_env_s* h, void** owned, const float4** kernel_ptr, const void* box4, int n_boxes, int nx, int ny, int nz) {
+    *kernel_ptr = nullptr;
+    if (!(h->fp.envw && h->fp.turb_mode != WG_TURB_NONE) || wg_hook("WG_NO_BOX8")) return 0;
+    const size_t n_cells = (size_t)nx * ny * nz, bytes = n_cells * 128 * (size_t)n_boxes;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    if (n_cells >= ((size_t)1 << 28) || bytes > total_b / 4 || bytes > free_b / 2) return 0;
+    if (hipMalloc(owned, bytes) != hipSuccess) { *owned = nullptr; (void)hipGetLastError(); return 0; }
+    for (int k = 0; k < n_boxes; ++k)
+        wg_launch_box_stencil((const char*)box4 + (size_t)k * n_cells * 16, (char*)*owned + (size_t)k * n_cells * 128, nx, ny, nz, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    *kernel_ptr = (const float4*)*owned;
+    return 0;
+}
+
 extern "C" int wg_set_turbulence_boxes(wg_handle h, const float* const* boxes_dev, int n_boxes, int nx, int ny, int nz,
                                        double dx, double dy, double dz) {
     if (!h) return fail(WG_ERR_INVALID, "null handle");
@@ -774,7 +797,8 @@ extern "C" int wg_set_turbulence_boxes(wg_handle h, const float* const* boxes_de
     HIPCHK(hipDeviceSynchronize());
     drop_step_graphs(h);           // the kernel arguments captured in them are about to change
     // the kernel-side pointers are cleared first: a failure below must not leave them dangling
-    h->d.box = nullptr; h->fd.box4 = nullptr; h->fd.box4c = nullptr; h->fp.coarse = 0;
+    h->d.box = nullptr; h->fd.box4 = nullptr; h->fd.box4c = nullptr; h->fd.box8 = nullptr; h->fp.coarse = 0;
+    if (h->box8) { void* q = h->box8; h->box8 = nullptr; HIPCHK(hipFree(q)); }
     if (h->box4) { void* q = h->box4; h->box4 = nullptr; HIPCHK(hipFree(q)); }
     if (h->box4c) { void* q = h->box4c; h->box4c = nullptr; HIPCHK(hipFree(q)); }
     const size_t n_cells = (size_t)nx * ny * nz;
@@ -786,6 +810,11 @@ extern "C" int wg_set_turbulence_boxes(wg_handle h, const float* const* boxes_de
     h->p.n_boxes = n_boxes;
     h->p.bnx = nx; h->p.bny = ny; h->p.bnz = nz; h->p.bdx = dx; h->p.bdy = dy; h->p.bdz = dz;
     h->fd.box4 = (const float4*)h->box4;
+    if (h->fp.envw && h->fp.turb_mode != WG_TURB_NONE && n_cells >= ((size_t)1 << 28)) {
+        // (k_flow_envb addresses the cells of a box with 32-bit offsets: a larger box runs on the per-slot kernel + k_glue_lean,
+        // which share its state layout)
+        h->fp.envw = 0; h->fp.env_fused = 0;
+    }
     h->fp.bnx = nx; h->fp.bny = ny; h->fp.bnz = nz; h->fp.box_cells = (long long)n_cells;
     h->fp.box_pow2 = ((nx & (nx - 1)) == 0) && ((ny & (ny - 1)) == 0) && ((nz & (nz - 1)) == 0);
     h->fp.coarse = (nx % 4 == 0 && ny % 4 == 0 && nz % 4 == 0 && nx >= 8 && ny >= 8 && nz >= 8);
@@ -803,6 +832,8 @@ extern "C" int wg_set_turbulence_boxes(wg_handle h, const float* const* boxes_de
         h->fd.box4c = (const float4*)h->box4c;
     }
     h->fp.inv_bdx = 1.0 / dx; h->fp.inv_bdy = 1.0 / dy; h->fp.inv_bdz = 1.0 / dz;
+    h->fp.inv_bn[0] = 1.0 / nx; h->fp.inv_bn[1] = 1.0 / ny; h->fp.inv_bn[2] = 1.0 / nz;
+    if (int rc = build_stencil_records(h, &h->box8, &h->fd.box8, h->box4, n_boxes, nx, ny, nz)) return rc;
     return sync_dev_params(h);
 }
 
@@ -813,16 +844,20 @@ extern "C" int wg_set_added_turbulence_box(wg_handle h, const float* box_dev, in
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
     drop_step_graphs(h);
-    h->fd.abox4 = nullptr;
+    h->fd.abox4 = nullptr; h->fd.abox8 = nullptr;
+    if (h->abox8) { void* q = h->abox8; h->abox8 = nullptr; HIPCHK(hipFree(q)); }
     if (h->abox4) { void* q = h->abox4; h->abox4 = nullptr; HIPCHK(hipFree(q)); }
     const size_t n_cells = (size_t)nx * ny * nz;
     HIPCHK(hipMalloc(&h->abox4, n_cells * 16));
     wg_launch_box_repack(box_dev, h->abox4, nx, ny, nz, nullptr);
     HIPCHK(hipDeviceSynchronize());
     h->fd.abox4 = (const float4*)h->abox4;
+    if (h->fp.envw && h->fp.turb_mode != WG_TURB_NONE && n_cells >= ((size_t)1 << 28)) { h->fp.envw = 0; h->fp.env_fused = 0; }
     h->fp.anx = nx; h->fp.any = ny; h->fp.anz = nz;
     h->fp.abox_pow2 = ((nx & (nx - 1)) == 0) && ((ny & (ny - 1)) == 0) && ((nz & (nz - 1)) == 0);
     h->fp.inv_adx = 1.0 / dx; h->fp.inv_ady = 1.0 / dy; h->fp.inv_adz = 1.0 / dz;
+    h->fp.inv_an[0] = 1.0 / nx; h->fp.inv_an[1] = 1.0 / ny; h->fp.inv_an[2] = 1.0 / nz;
+    if (int rc = build_stencil_records(h, &h->abox8, &h->fd.abox8, h->abox4, 1, nx, ny, nz)) return rc;
     return 0;
 }
 

@@ -115,6 +115,24 @@ __device__ __forceinline__ void envb_box_corners(const int bnx, const int bny, c
     o[0] = X0 + Y0 + Z0; o[1] = X1 + Y0 + Z0; o[2] = X0 + Y1 + Z0; o[3] = X1 + Y1 + Z0;
     o[4] = X0 + Y0 + Z1; o[5] = X1 + Y0 + Z1; o[6] = X0 + Y1 + Z1; o[7] = X1 + Y1 + Z1;
 }
+// Stencil records (FlowPtrs::box8): the record of a point = its cell origin, wrapped periodically — in double, exact for any
+// dimension: r = i - floor(i / n) n with one correction step each way (i / n is taken as i * (1 / n), which can be off by one
+// at multiples of n).  Same cells and weights as envb_box_corners; the 8 corners are the record's 8 consecutive float4.
+__device__ __forceinline__ unsigned envb_wrap(const double i, const int n, const double inv_n) {
+    double r = i - floor(i * inv_n) * (double)n;
+    if (r < 0.0) r += (double)n;
+    if (r >= (double)n) r -= (double)n;
+    return (unsigned)(int)r;
+}
+__device__ __forceinline__ unsigned envb_stencil_record(const int bnx, const int bny, const int bnz, const double inv_dx, const double inv_dy,
+                                                        const double inv_dz, const double inx, const double iny, const double inz,
+                                                        const double x, const double y, const double z, float& tx, float& ty, float& tz) {
+    const double fx = x * inv_dx, fy = y * inv_dy, fz = z * inv_dz;
+    const double ix = floor(fx), iy = floor(fy), iz = floor(fz);
+    tx = (float)(fx - ix); ty = (float)(fy - iy); tz = (float)(fz - iz);
+    const unsigned i0 = envb_wrap(ix, bnx, inx), j0 = envb_wrap(iy, bny, iny), k0 = envb_wrap(iz, bnz, inz);
+    return (i0 * (unsigned)bny + j0) * (unsigned)bnz + k0;
+}
 // (v[0..7] = v000 v100 v010 v110 v001 v101 v011 v111; the association of box_lookup_dims / the oracle: x, then y, then z)
 __device__ __forceinline__ void envb_tri3(const float4 (&v)[8], const float tx, const float ty, const float tz, float* __restrict__ out) {
 #define WG_TRI(f)                                                         \
@@ -736,6 +754,9 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
                         constexpr bool APOW2 = decltype(apow2_tag)::value;
                         const KArgsPtr kb = wg_cold_args();
                         const float4* const abox = kb->d.abox4;
+                        // stencil records: one aligned 128-byte record per point instead of 8 cells of the brick-ordered box
+                        const float4* const box8 = kb->d.box8;
+                        const float4* const abox8 = kb->d.abox8;
                         for (int r0 = rho_lo; r0 < rho_hi; r0 += rpp) {
                             const int rho = r0 + (tid >> sshift);
                             const bool live = rho < rho_hi && s < S;
@@ -754,17 +775,34 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
                                 const double by = yr + (double)(rdy_s * cgt) + q.oy, bz = hub_d + (double)rdz_s;
                                 // the 8 + 8 cells of the point are requested first; the wakes of the row's target are summed while they
                                 // are in flight (the sums need nothing of the lookups: the wake-added share is (sum of weights) x field)
-                                const float4* const fb = kb->d.box4 + (WPE == 2 ? ucell0 : q.box_cell0);
-                                unsigned oa[8], ob[8];
+                                const long long cell0 = WPE == 2 ? ucell0 : q.box_cell0;
                                 float4 va[8], vb[8];
                                 float ax, ay, az, gx = 0.f, gy_ = 0.f, gz = 0.f;
-                                envb_box_corners<POW2>(kb->p.bnx, kb->p.bny, kb->p.bnz, kb->p.inv_bdx, kb->p.inv_bdy, kb->p.inv_bdz, bx, by, bz, oa, ax, ay, az);
+                                if (box8) {
+                                    const unsigned ra_ = envb_stencil_record(kb->p.bnx, kb->p.bny, kb->p.bnz, kb->p.inv_bdx, kb->p.inv_bdy, kb->p.inv_bdz,
+                                                                             kb->p.inv_bn[0], kb->p.inv_bn[1], kb->p.inv_bn[2], bx, by, bz, ax, ay, az);
+                                    const float4* const rec = box8 + cell0 * 8;
 #pragma unroll
-                                for (int i = 0; i < 8; ++i) va[i] = (WG_ENVB_ABLATE & 2) ? make_float4(ax, ay, az, (float)oa[i]) : fb[oa[i]];
+                                    for (int i = 0; i < 8; ++i) va[i] = (WG_ENVB_ABLATE & 2) ? make_float4(ax, ay, az, (float)ra_) : rec[ra_ * 8u + (unsigned)i];
+                                } else {
+                                    const float4* const fb = kb->d.box4 + cell0;
+                                    unsigned oa[8];
+                                    envb_box_corners<POW2>(kb->p.bnx, kb->p.bny, kb->p.bnz, kb->p.inv_bdx, kb->p.inv_bdy, kb->p.inv_bdz, bx, by, bz, oa, ax, ay, az);
+#pragma unroll
+                                    for (int i = 0; i < 8; ++i) va[i] = (WG_ENVB_ABLATE & 2) ? make_float4(ax, ay, az, (float)oa[i]) : fb[oa[i]];
+                                }
                                 if (addl) {
-                                    envb_box_corners<APOW2>(kb->p.anx, kb->p.any, kb->p.anz, kb->p.inv_adx, kb->p.inv_ady, kb->p.inv_adz, bx, by, bz, ob, gx, gy_, gz);
+                                    if (abox8) {
+                                        const unsigned rb_ = envb_stencil_record(kb->p.anx, kb->p.any, kb->p.anz, kb->p.inv_adx, kb->p.inv_ady, kb->p.inv_adz,
+                                                                                 kb->p.inv_an[0], kb->p.inv_an[1], kb->p.inv_an[2], bx, by, bz, gx, gy_, gz);
 #pragma unroll
-                                    for (int i = 0; i < 8; ++i) vb[i] = (WG_ENVB_ABLATE & 4) ? make_float4(gx, gy_, gz, (float)ob[i]) : abox[ob[i]];
+                                        for (int i = 0; i < 8; ++i) vb[i] = (WG_ENVB_ABLATE & 4) ? make_float4(gx, gy_, gz, (float)rb_) : abox8[rb_ * 8u + (unsigned)i];
+                                    } else {
+                                        unsigned ob[8];
+                                        envb_box_corners<APOW2>(kb->p.anx, kb->p.any, kb->p.anz, kb->p.inv_adx, kb->p.inv_ady, kb->p.inv_adz, bx, by, bz, ob, gx, gy_, gz);
+#pragma unroll
+                                        for (int i = 0; i < 8; ++i) vb[i] = (WG_ENVB_ABLATE & 4) ? make_float4(gx, gy_, gz, (float)ob[i]) : abox[ob[i]];
+                                    }
                                 }
                                 const float ys = (float)yr + rdy_s * cgt, zs = hub + rdz_s;
                                 for (int cq = cr.x; cq < cr.x + cr.y; ++cq) {       // ascending source order

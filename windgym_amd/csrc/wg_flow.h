@@ -107,6 +107,7 @@ struct FlowP {
     float km1, km2r;
     float sg_af, sg_bf, sg_cf;    // super-Gaussian order n(x) = af exp(bf x/D) + cf (deficit_model = 1)
     double inv_adx, inv_ady, inv_adz;
+    double inv_bn[3], inv_an[3];  // 1 / (cells per dimension) of the fine / wake-added box: index wrap in double (stencil records)
     // deficit_model 2: tabulated eddy-viscosity (Ainslie / DWM) deficit, FlowPtrs::dtab [an_ct][an_ti][an_x][an_r] (wg_set_deficit_table):
     // Ct uniform from an_ct0, TI log-uniform from exp(an_lti0), x / D and r / R uniform from 0
     int an_ct, an_ti, an_x, an_r;
@@ -120,6 +121,13 @@ struct FlowPtrs {
     const float4* box4;          // interleaved copy of the turbulence box: [Nx][Ny][Nz] x (u, v, w, 0)
     const float4* box4c;         // the same block-averaged over 4x4x4 cells
     const float4* abox4;         // isotropic box of the wake-added turbulence, interleaved like box4
+    // STENCIL RECORDS (k_flow_envb's rotor-point lookups): for every cell origin (i, j, k) the 8 corners of its trilinear stencil,
+    // periodic wrap included, as ONE aligned 128-byte record — float4[8] = v000 v100 v010 v110 v001 v101 v011 v111, record
+    // (i ny + j) nz + k.  8 x the float4 box in HBM (8.6 GB for the reference's 2048 x 512 x 64 box: the card has 288), and a rotor
+    // point costs ONE 128-byte line instead of the ~3.3 lines its 2 x 2 x 2 stencil straddles in the brick-ordered box — the
+    // lookups were 62 % of cfg5's fetched bytes.  Null when the pool is too large for it (wg_set_turbulence_boxes).
+    const float4* box8;
+    const float4* abox8;
     const float* dtab;           // deficit_model 2: the deficit table (see FlowP::an_*)
     float *yaw, *u, *v, *w, *ti_loc, *power, *ct;
     float* bnd;                   // [n_slots][N][4] conservative chain bounds (excursion, k, eps) + last moving emission (uint bits)

@@ -758,6 +758,24 @@ extern "C" void wg_launch_box_coarsen(const void* fine, void* out, int nx, int n
     hipLaunchKernelGGL(k_box_coarsen, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float4*)fine, (float4*)out, nx, ny, nz);
 }
 
+// stencil records (FlowPtrs::box8): record (i ny + j) nz + k = the 8 corners of cell origin (i, j, k), periodic wrap included
+__global__ void k_box_stencil(const float4* __restrict__ fine, float4* __restrict__ out, const int nx, const int ny, const int nz) {
+    const size_t n_cells = (size_t)nx * ny * nz;
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_cells) return;
+    const int k = (int)(r % nz), j = (int)((r / nz) % ny), i = (int)(r / ((size_t)nz * ny));
+    const int i1 = i + 1 == nx ? 0 : i + 1, j1 = j + 1 == ny ? 0 : j + 1, k1 = k + 1 == nz ? 0 : k + 1;
+    float4* o = out + r * 8;
+    o[0] = fine[wg_box_cell(i, j, k, nx, ny, nz)];   o[1] = fine[wg_box_cell(i1, j, k, nx, ny, nz)];
+    o[2] = fine[wg_box_cell(i, j1, k, nx, ny, nz)];  o[3] = fine[wg_box_cell(i1, j1, k, nx, ny, nz)];
+    o[4] = fine[wg_box_cell(i, j, k1, nx, ny, nz)];  o[5] = fine[wg_box_cell(i1, j, k1, nx, ny, nz)];
+    o[6] = fine[wg_box_cell(i, j1, k1, nx, ny, nz)]; o[7] = fine[wg_box_cell(i1, j1, k1, nx, ny, nz)];
+}
+extern "C" void wg_launch_box_stencil(const void* fine, void* out, int nx, int ny, int nz, hipStream_t st) {
+    const size_t n_cells = (size_t)nx * ny * nz;
+    hipLaunchKernelGGL(k_box_stencil, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, st, (const float4*)fine, (float4*)out, nx, ny, nz);
+}
+
 // host-visible launch helpers (defined here so that the <<<>>> syntax stays in one translation unit)
 extern "C" void wg_launch_glue(const WgParams* p, const WgPtrs* d, int phase, const uint8_t* mask, float* obs,
                                float* reward, uint8_t* trunc, float* final_obs, hipStream_t st, const WgParams* gp,
