@@ -752,12 +752,14 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
                     auto rows = [&](auto pow2_tag, auto apow2_tag) __attribute__((always_inline)) {
                         constexpr bool POW2 = decltype(pow2_tag)::value;
                         constexpr bool APOW2 = decltype(apow2_tag)::value;
-                        const KArgsPtr kb = wg_cold_args();
-                        const float4* const abox = kb->d.abox4;
-                        // stencil records: one aligned 128-byte record per point instead of 8 cells of the brick-ordered box
-                        const float4* const box8 = kb->d.box8;
-                        const float4* const abox8 = kb->d.abox8;
                         for (int r0 = rho_lo; r0 < rho_hi; r0 += rpp) {
+                            // (the box geometry — 30 scalars — is fetched through a fresh kernarg pointer every trip: held across the
+                            // loop it is what spills)
+                            const KArgsPtr kb = wg_cold_args();
+                            const float4* const abox = kb->d.abox4;
+                            // stencil records: one aligned 128-byte record per point instead of 8 cells of the brick-ordered box
+                            const float4* const box8 = kb->d.box8;
+                            const float4* const abox8 = kb->d.abox8;
                             const int rho = r0 + (tid >> sshift);
                             const bool live = rho < rho_hi && s < S;
                             const int gt = Lrow[min(rho, max(rho_hi - 1, 0))];

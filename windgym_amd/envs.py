@@ -946,40 +946,85 @@ class WindFarmEnvMulti(_ParallelEnvBase):
 class RecordEpisodeVals:
     """Episode statistics of a :class:`WindFarmVecEnv` (wrappers/recordEpisodeVals.py:8-64): per-env running
     sum of ``infos["Power agent"]``, pushed as ``sum / episode_length`` into ``mean_power_queue`` when the
-    episode ends; also ``return_queue`` / ``length_queue`` like gymnasium's RecordEpisodeStatistics."""
+    episode ends; also ``return_queue`` / ``length_queue`` like gymnasium's RecordEpisodeStatistics.
 
-    def __init__(self, env: WindFarmVecEnv, buffer_length=100):
+    On a CUDA-tensor env (``as_torch=True``) the wrapper does not synchronise with the device every step (that alone made
+    a 55 us step take 135 us, bench.py --api): the step's rewards, truncation flags and farm powers are parked in a device
+    ring of ``flush_every`` steps and replayed on the host, in order, when the ring is full or a queue is read — the same
+    arithmetic on the same values, a bounded number of steps later."""
+
+    def __init__(self, env: WindFarmVecEnv, buffer_length=100, flush_every=64):
         self.env = env
         self.num_envs = env.num_envs
-        self.mean_power_queue = deque(maxlen=buffer_length)
-        self.return_queue = deque(maxlen=buffer_length)
-        self.length_queue = deque(maxlen=buffer_length)
+        self._mean_power_queue = deque(maxlen=buffer_length)
+        self._return_queue = deque(maxlen=buffer_length)
+        self._length_queue = deque(maxlen=buffer_length)
         self.episode_powers = np.zeros(self.num_envs)
         self.episode_returns = np.zeros(self.num_envs)
         self.episode_lengths = np.zeros(self.num_envs, dtype=np.int64)
+        self._ring = None                    # device ring [flush_every, 3, B] float32 (reward, truncated, power) + fill count
+        self._n_parked = 0
+        self._flush_every = int(flush_every)
 
     def __getattr__(self, name):
         return getattr(self.env, name)
 
+    # the queues: reading one first replays whatever is still parked on the device
+    @property
+    def mean_power_queue(self):
+        self._flush()
+        return self._mean_power_queue
+
+    @property
+    def return_queue(self):
+        self._flush()
+        return self._return_queue
+
+    @property
+    def length_queue(self):
+        self._flush()
+        return self._length_queue
+
     def reset(self, **kw):
+        self._flush()
         out = self.env.reset(**kw)
         self.episode_powers[:] = 0
         self.episode_returns[:] = 0
         self.episode_lengths[:] = 0
         return out
 
-    def step(self, actions):
-        obs, rew, term, trunc, infos = self.env.step(actions)
-        to_np = (lambda x: _np(x)) if self.env.as_torch else np.asarray
-        r, d, p = to_np(rew), to_np(trunc).astype(bool), to_np(infos["Power agent"])
+    def _account(self, r, d, p):
+        """one step of the reference wrapper's bookkeeping (recordEpisodeVals.py:43-56) on host arrays"""
         self.episode_powers += p
         self.episode_returns += r
         self.episode_lengths += 1
         for i in np.nonzero(d)[0]:
-            self.mean_power_queue.append(self.episode_powers[i] / self.episode_lengths[i])
-            self.return_queue.append(self.episode_returns[i])
-            self.length_queue.append(int(self.episode_lengths[i]))
+            self._mean_power_queue.append(self.episode_powers[i] / self.episode_lengths[i])
+            self._return_queue.append(self.episode_returns[i])
+            self._length_queue.append(int(self.episode_lengths[i]))
         self.episode_powers[d] = 0
         self.episode_returns[d] = 0
         self.episode_lengths[d] = 0
+
+    def _flush(self):
+        if self._n_parked:
+            blk = _np(self._ring[:self._n_parked])          # ONE device-to-host copy for all parked steps
+            n, self._n_parked = self._n_parked, 0
+            for k in range(n):
+                self._account(blk[k, 0].astype(np.float64), blk[k, 1] != 0, blk[k, 2].astype(np.float64))
+
+    def step(self, actions):
+        obs, rew, term, trunc, infos = self.env.step(actions)
+        if getattr(self.env, "as_torch", False) and hasattr(rew, "is_cuda") and rew.is_cuda:
+            t = self.env.torch
+            if self._ring is None:
+                self._ring = t.empty((self._flush_every, 3, self.num_envs), dtype=t.float32, device=rew.device)
+            row = self._ring[self._n_parked]
+            row[0].copy_(rew); row[1].copy_(trunc); row[2].copy_(infos["Power agent"])
+            self._n_parked += 1
+            if self._n_parked == self._flush_every:
+                self._flush()
+            return obs, rew, term, trunc, infos
+        to_np = (lambda x: _np(x)) if self.env.as_torch else np.asarray
+        self._account(to_np(rew), to_np(trunc).astype(bool), to_np(infos["Power agent"]))
         return obs, rew, term, trunc, infos
