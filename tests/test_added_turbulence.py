@@ -76,8 +76,8 @@ def test_oracle_ti_fold_switch(small_box):
 
 
 # (k_flow's instantiations under both turbulent inflows; "envb" / "envb1" = k_flow_envb, the one-launch frozen-box kernel, with two
-# waves / one wave per env — it serves the box inflow only)
-HIP_CASES = [(t, b) for t in ("MannFixed", "Random") for b in (64, 128, 256)] + [("MannFixed", "envb"), ("MannFixed", "envb1")]
+# waves / one wave per env ("envb4": four, one per farm slot) — it serves the box inflow only)
+HIP_CASES = [(t, b) for t in ("MannFixed", "Random") for b in (64, 128, 256)] + [("MannFixed", "envb4"), ("MannFixed", "envb"), ("MannFixed", "envb1")]
 
 
 @pytest.mark.gpu
@@ -90,7 +90,7 @@ def test_hip_matches_oracle_with_added_turbulence(turbtype, block, small_box):
     envk = isinstance(block, str)
     hooks = {"WG_FLOW_BLOCK": "64" if envk else str(block), "WG_FLOW_ENV": "1" if envk else "0"}
     if envk:
-        hooks["WG_ENV_WPE"] = "1" if block.endswith("1") else "2"
+        hooks["WG_ENV_WPE"] = block[-1] if block[-1] in "14" else "2"
     os.environ.update(hooks)
     try:
         env = binding.HipBatch(cfg)

@@ -30,7 +30,7 @@ BLOCKS = [64, 128, 256]
 # "env1" = the same kernel forced to ONE wave per env (WG_ENV_WPE=1: what a batch of more than 2048 envs runs — the headline)
 STEADY_BLOCKS = BLOCKS + ["env", "env1"]
 # frozen-box inflow: the per-slot instantiations and "envb" = k_flow_envb (wg_envb.hip), the one-launch env kernel cfg5 runs
-BOX_BLOCKS = BLOCKS + ["envb", "envb1"]
+BOX_BLOCKS = BLOCKS + ["envb4", "envb", "envb1"]      # (four waves per env = one per farm slot: what cfg5 x 1024 runs; two; one)
 
 
 def _make_env(hip, cfg, block=None):
@@ -41,7 +41,7 @@ def _make_env(hip, cfg, block=None):
     envk = isinstance(block, str) and block.startswith("env")
     hooks = {"WG_FLOW_BLOCK": "64" if envk else str(block), "WG_FLOW_ENV": "1" if envk else "0"}
     if envk:
-        hooks["WG_ENV_WPE"] = "1" if block.endswith("1") else "2"
+        hooks["WG_ENV_WPE"] = block[-1] if block[-1] in "14" else "2"
     os.environ.update(hooks)
     try:
         env = hip.HipBatch(cfg)

@@ -131,7 +131,7 @@ def test_fused_step_equals_two_launches_over_5000_steps(hip):
     assert n_tr >= 20 * 64
 
 
-@pytest.mark.parametrize("wpe", ["2", "1"])
+@pytest.mark.parametrize("wpe", ["4", "2", "1"])
 def test_box_env_kernel_agrees_with_the_per_slot_kernel(hip, wpe):
     """k_flow_envb (wg_envb.hip: one launch per step, lanes turbine-major, sample-major deficit phase) against k_flow<64, BOX>
     (one workgroup per farm slot + k_glue_lean) on the SAME state layout, seeds and actions, frozen Mann box with the

@@ -589,14 +589,31 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             // of S_pad <= 16 lanes; the wake-added field and TI folding are run-time options.
             bool envb_ok = f.res && small && f.block == 64 && !f.gl && p.turb_mode >= WG_TURB_BOX && NL <= 64 && p.N <= 32 &&
                            p.P <= 4096 && f.S_pad <= 16 && h->deficit_model == 0;
+            // waves per env of k_flow_envb: four (one per farm slot; two farms of at most 16 turbines) while every env's four waves are
+            // resident at once (1024 envs = the chip's 4096 wave slots), else two (one per context) up to 2048 envs, else one
+            // (four waves per env — one per farm slot, WG_ENV_WPE=4 — is built and tested but NOT the default: measured 104.3 vs 101.7 us
+            // per step on cfg5 x 1024, the launch is bound by the bytes it moves, not by a wave's chain of trips)
+            int envb_wpe = (p.B <= 2048) ? 2 : 1;
+            if (const char* ev = wg_hook("WG_ENV_WPE")) {
+                const int w = atoi(ev);
+                envb_wpe = (w == 4 && p.F == 2 && p.N <= 16) ? 4 : (w == 2 ? 2 : (w == 4 ? 2 : 1));
+            }
             if (envb_ok) {
-                f.env_cap = 256;
-                size_t ob = WG_ENVB_FIXED_LDS_BYTES + (size_t)20 * f.env_cap;
-                f.envb_off_cl = (int)ob;
-                ob = (ob + clb + 15) & ~(size_t)15;
-                f.env_off_tab = (int)ob;
-                ob += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S);
-                f.env_lds = (int)((ob + 15) & ~(size_t)15);
+                auto carve_b = [&](const int wpe) -> size_t {
+                    const int nlp = wpe == 4 ? 16 : 64;
+                    const int nl_w = (wpe == 4 ? 1 : (wpe == 2 ? p.F : 2 * p.F)) * p.N;      // lanes a wave serves
+                    f.env_cap = wpe == 4 ? 128 : 256;
+                    size_t ob = WG_ENVB_FIXED_LDS_BYTES(nlp) + (size_t)20 * f.env_cap;
+                    f.envb_off_cl = (int)ob;
+                    ob = (ob + (size_t)2 * nl_w * (p.N > 1 ? p.N - 1 : 1) + 15) & ~(size_t)15;      // candidate list: every ordered pair of a slot
+                    f.env_off_tab = (int)ob;
+                    ob += sizeof(float) * (2 * (size_t)nu + 2 * (size_t)p.S);
+                    return (ob + 15) & ~(size_t)15;
+                };
+                size_t lb = carve_b(envb_wpe);
+                if (envb_wpe > 1 && envb_wpe * lb + 64 > (size_t)lds_limit) { envb_wpe = envb_wpe == 4 ? 2 : 1; lb = carve_b(envb_wpe); }
+                if (envb_wpe > 1 && envb_wpe * lb + 64 > (size_t)lds_limit) { envb_wpe = 1; lb = carve_b(1); }
+                f.env_lds = (int)lb;
                 if (f.env_lds > 32768 || f.env_lds > lds_limit) envb_ok = false;
             }
             env_ok = env_ok || envb_ok;
@@ -611,6 +628,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             // 0.0360 / 0.0322, 2048: 0.0340 / 0.0411 / 0.0435, 4096: 0.0643 / 0.0624 / 0.0682)
             f.env_wpe = (p.B <= 2048 && 2 * f.env_lds <= lds_limit) ? 2 : 1;
             if (const char* ev = wg_hook("WG_ENV_WPE")) f.env_wpe = (atoi(ev) == 2 && 2 * f.env_lds <= lds_limit) ? 2 : 1;
+            if (envb_ok) f.env_wpe = envb_wpe;
         }
         // packed emission record: two arrays, or one interleaved (ct|k, eps|hv) array for the GL variant
         f.rec_il = f.gl ? 1 : 0;

@@ -26,6 +26,9 @@
 
 #include "wg_env_common.h"
 
+#ifndef WG_ENV_ABLATE
+#define WG_ENV_ABLATE 0     // profiling builds only
+#endif
 #ifndef WG_ENV_S_UNROLL
 #define WG_ENV_S_UNROLL 0   // 1: the rotor-point loop of the pair evaluation unrolled by 4
 #endif
@@ -74,7 +77,8 @@ static_assert(sizeof(EnvSlotLds) == WG_ENV_SLOT_LDS_BYTES, "keep WG_ENV_SLOT_LDS
 #define WG_ENV_OFF_XR 3072
 #define WG_ENV_OFF_SRC2 3584
 #define WG_ENV_OFF_SL 4096
-#define WG_ENV_OFF_STAGE (WG_ENV_OFF_SL + 4 * WG_ENV_SLOT_LDS_BYTES)
+#define WG_ENV_OFF_HDR (WG_ENV_OFF_SL + 4 * WG_ENV_SLOT_LDS_BYTES)      // int[32]  the env header as the prologue loaded it (the glue tail's copy)
+#define WG_ENV_OFF_STAGE (WG_ENV_OFF_HDR + 128)
 static_assert(WG_ENV_OFF_STAGE == WG_ENV_FIXED_LDS_BYTES, "keep WG_ENV_FIXED_LDS_BYTES in sync (wg_flow.h)");
 
 // Sum of a per-lane value over the lanes of the lane's OWN slot, for all slots of the env at once, in the association
@@ -147,6 +151,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
         // the scalar cache does not see this launch's vector stores).
         static_assert(sizeof(WgEnv) == 128, "the env header is loaded as 32 words");
         const int hw = reinterpret_cast<const int*>(k0->d.env + e)[tid & 31];
+        if (GLUE != 0 && tid < 32) reinterpret_cast<int*>(smem + WG_ENV_OFF_HDR)[tid] = hw;      // (handed to the glue tail: no second load)
         out.bg_init_pending = 0; out.rounds = 0; out.first_obs = 0;
         const bool use_mask = mode == WG_MODE_RESET && mask != nullptr;
         const uint8_t mask_byte = *(use_mask ? mask + e : reinterpret_cast<const uint8_t*>(k0->d.env + e));
@@ -492,7 +497,14 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
                 if (cd.jp0 < 0) r0 = 0;           // (released in this step: nothing to fetch — any slot of the ring will do)
                 if (cd.jp0 + 1 < 0) r1 = 0;
                 const unsigned sb = (unsigned)rg.w * pstride + (unsigned)rg.x;
+#if WG_ENV_ABLATE & 1      // (profiling builds, wrong results: no record-copy gathers for the brackets of MOVING chains)
+                if (cd.rest) { cd.q0 = r4_env[sb + (unsigned)r0]; cd.q1 = r4_env[sb + (unsigned)r1]; }
+                else { cd.q0 = Lrec4[gs]; cd.q1 = cd.q0; cd.q1.x += (unsigned)r1 & 1u; }
+#elif WG_ENV_ABLATE & 2    // (no record-copy gathers at all)
+                cd.q0 = Lrec4[gs]; cd.q1 = cd.q0; cd.q1.x += (unsigned)r1 & 1u;
+#else
                 cd.q0 = r4_env[sb + (unsigned)r0]; cd.q1 = r4_env[sb + (unsigned)r1];
+#endif
                 cd.y0 = 0.f; cd.y1 = 0.f;
                 if (!cd.rest) { cd.y0 = py_env[sb + (unsigned)r0]; cd.y1 = py_env[sb + (unsigned)r1]; }
                 cd.ok = true;
@@ -1021,6 +1033,7 @@ k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __res
             fz.work = work;
             fz.bg_init_pending = WPE == 2 ? 0 : fo.bg_init_pending;
             fz.plan_elsewhere = WPE == 2;
+            fz.hw = reinterpret_cast<const int*>(sm + WG_ENV_OFF_HDR)[threadIdx.x & 31];
             WG_STAMP(12);
             lean_step<GLUE == 2, false, true>(*(const WgParams*)&kg->gp, *(const WgPtrs*)&kg->gd, kg->d.gp, kg->d.gd, (int)blockIdx.x,
                                               (int)(threadIdx.x & 63), kg->obs, kg->reward, kg->trunc, kg->final_obs, nullptr, fz);

@@ -60,22 +60,41 @@ struct __attribute__((aligned(16))) EnvbSlotLds {
     unsigned c_add;
     int bg_init, add_acc, stepping, L;           // L: ring slots of the farm (roff[N] of its context)
 };
-static_assert(sizeof(EnvbSlotLds) == 208, "EnvbSlotLds layout (WG_ENVB_OFF_* below)");
+static_assert(sizeof(EnvbSlotLds) == 208, "EnvbSlotLds layout (EnvbLds below)");
 
-// fixed LDS layout (compile-time offsets from the wave's region), indexed by lane g = t * NS + k
-#define WG_ENVB_OFF_XR 0          // double[64]  downwind position
-#define WG_ENVB_OFF_YR 512        // double[64]  lateral position
-#define WG_ENVB_OFF_SRC4 1024     // float4[64]  (x, y as floats, bk, be): candidate pass
-#define WG_ENVB_OFF_REC4 2048     // uint4[64]   this step's emission record: (rec_a, rec_b, bits of u_e, bits of cos yaw)
-#define WG_ENVB_OFF_RING 3072     // int4[64]    (roff, rlen, head before, head after this step's release)
-#define WG_ENVB_OFF_UVW 4096      // float4[64]  rotor inflow of the step (u, v, w, ti): written by the rotor-point phase
-#define WG_ENVB_OFF_BD 5120       // float[64]   excursion bound of the chain (raised by the particle pass with LDS atomics)
-#define WG_ENVB_OFF_CR 5376       // int2[64]    (first entry, entries) of the target's slice of the candidate list
-#define WG_ENVB_OFF_ROW 5888      // u8[64]      lane of the i-th stepping (slot, turbine) row
-#define WG_ENVB_OFF_SL 5952       // EnvbSlotLds[4]
-#define WG_ENVB_OFF_PARK (WG_ENVB_OFF_SL + 4 * 208)       // float4[3][64]  the lane's turbine registers, parked across the particle / rotor phases
-#define WG_ENVB_OFF_STAGE (WG_ENVB_OFF_PARK + 3 * 1024)   // staged wakes: float4[cap] | added TI float[cap] | candidate list u16[..]
-static_assert(WG_ENVB_OFF_STAGE == WG_ENVB_FIXED_LDS_BYTES, "keep WG_ENVB_FIXED_LDS_BYTES in sync (wg_flow.h)");
+// LDS layout of a wave's region: compile-time offsets, the per-lane arrays sized for NLP lanes (64; 16 with four waves per env:
+// a wave then serves ONE farm slot of at most 16 turbines), indexed by lane g = t * NS + k
+//   XR / YR  double[NLP]   position        SRC4 float4[NLP] (x, y as floats, bk, be): candidate pass
+//   REC4     uint4[NLP]    this step's emission record: (rec_a, rec_b, bits of u_e, bits of cos yaw)
+//   RING     int4[NLP]     (roff, rlen, head before, head after this step's release)
+//   UVW      float4[NLP]   rotor inflow of the step (u, v, w, ti): written by the rotor-point phase
+//   BD       float[NLP]    excursion bound of the chain (raised by the particle pass with LDS atomics)
+//   CR       int2[NLP]     (first entry, entries) of the target's slice of the candidate list
+//   ROW      u8[NLP]       lane of the i-th stepping (slot, turbine) row
+//   SL       EnvbSlotLds[4] | PARK float4[3][NLP] the lane's turbine registers, parked across the particle / rotor phases
+//   HDR      int[32]       the env header as the prologue loaded it (the glue tail's copy)
+//   STAGE    staged wakes: float4[cap] | added TI float[cap] | candidate list u16[..] | tables (FlowP::env_off_tab)
+template <int NLP> struct EnvbLds {
+    static constexpr int XR = 0, YR = 8 * NLP, SRC4 = 16 * NLP, REC4 = 32 * NLP, RING = 48 * NLP, UVW = 64 * NLP, BD = 80 * NLP,
+                         CR = 84 * NLP, ROW = 92 * NLP, SL = 93 * NLP, PARK = SL + 4 * 208, HDR = PARK + 48 * NLP, STAGE = HDR + 128;
+    static_assert(STAGE == WG_ENVB_FIXED_LDS_BYTES(NLP), "keep WG_ENVB_FIXED_LDS_BYTES in sync (wg_flow.h)");
+};
+// cross-wave flags of a workgroup of four waves (behind the waves' regions): [w] = wave w's flow part is complete and its stores
+// have left the wave; [4 + c] = context c's episode set-up (run by its agent-farm wave) is complete
+#define WG_ENVB_FLAG_BYTES 64
+__device__ __forceinline__ void envb_flag_set(int* const f) {
+    __atomic_store_n(f, 1, __ATOMIC_RELAXED);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+// (bounded: a protocol error must not hang the GPU — the caller latches WG_STATUS_BIT_STATE on a time-out)
+__device__ __forceinline__ bool envb_flag_wait(int* const f) {
+    for (int n = 0; n < (1 << 22); ++n) {
+        if (__atomic_load_n(f, __ATOMIC_RELAXED) != 0) { asm volatile("" ::: "memory"); return true; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
+
 
 __device__ __forceinline__ long long envb_uni64(const long long v) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
@@ -192,33 +211,36 @@ __device__ __forceinline__ float envb_slot_sums(float v, const int NS) {
 }
 
 template <bool NOISE, int WPE, int GLUE>
-__device__ __forceinline__ void envb_flow(char* const smem, const int wv, const int mode, const float* __restrict__ actions,
+__device__ __forceinline__ void envb_flow(char* const smem, char* const wg_shared, const int wv, const int mode, const float* __restrict__ actions,
                                           const uint8_t* __restrict__ mask, const int chunk, EnvFlowOut& out) {
     const int tid = threadIdx.x & 63, e = blockIdx.x;
     int N, F, NS, NL, nsh;
     {
         const KArgsPtr ka = wg_cold_args();
         N = ka->p.N; F = ka->p.F;
-        NS = WPE == 2 ? F : 2 * F; NL = NS * N;              // slots / lanes served by THIS wave
+        NS = WPE == 4 ? 1 : (WPE == 2 ? F : 2 * F); NL = NS * N;      // slots / lanes served by THIS wave
         nsh = NS == 4 ? 2 : (NS == 2 ? 1 : 0);
     }
-    const int kbase = WPE == 2 ? wv * F : 0;                // the wave's first slot of the env
+    const int kbase = WPE == 4 ? wv : (WPE == 2 ? wv * F : 0);      // the wave's first slot of the env
     const bool valid = tid < NL;
     const int g = valid ? tid : 0;
     const int t = g >> nsh, k = g & (NS - 1);               // turbine, slot of the wave (WPE 1: of the env = ctx * F + farm)
-    const int c = WPE == 2 ? wv : (F == 2 ? (k >> 1) : k), farm = F == 2 ? (k & 1) : 0;
+    // (four waves per env: wave w = farm slot w = context w >> 1, farm w & 1 — the host selects it for F = 2 only)
+    const int c = WPE == 4 ? (wv >> 1) : (WPE == 2 ? wv : (F == 2 ? (k >> 1) : k)), farm = WPE == 4 ? (wv & 1) : (F == 2 ? (k & 1) : 0);
+    constexpr int NLP = WPE == 4 ? 16 : 64;
+    typedef EnvbLds<NLP> LO;
 
-    double* const Lxr = reinterpret_cast<double*>(smem + WG_ENVB_OFF_XR);
-    double* const Lyr = reinterpret_cast<double*>(smem + WG_ENVB_OFF_YR);
-    float4* const Lsrc4 = reinterpret_cast<float4*>(smem + WG_ENVB_OFF_SRC4);
-    uint4* const Lrec4 = reinterpret_cast<uint4*>(smem + WG_ENVB_OFF_REC4);
-    int4* const Lring = reinterpret_cast<int4*>(smem + WG_ENVB_OFF_RING);
-    float4* const Luvw = reinterpret_cast<float4*>(smem + WG_ENVB_OFF_UVW);
-    float* const Lbd = reinterpret_cast<float*>(smem + WG_ENVB_OFF_BD);
-    int2* const Lcr = reinterpret_cast<int2*>(smem + WG_ENVB_OFF_CR);
-    unsigned char* const Lrow = reinterpret_cast<unsigned char*>(smem + WG_ENVB_OFF_ROW);
-    EnvbSlotLds* const SL = reinterpret_cast<EnvbSlotLds*>(smem + WG_ENVB_OFF_SL);
-    float4* const Lpark = reinterpret_cast<float4*>(smem + WG_ENVB_OFF_PARK);
+    double* const Lxr = reinterpret_cast<double*>(smem + LO::XR);
+    double* const Lyr = reinterpret_cast<double*>(smem + LO::YR);
+    float4* const Lsrc4 = reinterpret_cast<float4*>(smem + LO::SRC4);
+    uint4* const Lrec4 = reinterpret_cast<uint4*>(smem + LO::REC4);
+    int4* const Lring = reinterpret_cast<int4*>(smem + LO::RING);
+    float4* const Luvw = reinterpret_cast<float4*>(smem + LO::UVW);
+    float* const Lbd = reinterpret_cast<float*>(smem + LO::BD);
+    int2* const Lcr = reinterpret_cast<int2*>(smem + LO::CR);
+    unsigned char* const Lrow = reinterpret_cast<unsigned char*>(smem + LO::ROW);
+    EnvbSlotLds* const SL = reinterpret_cast<EnvbSlotLds*>(smem + LO::SL);
+    float4* const Lpark = reinterpret_cast<float4*>(smem + LO::PARK);
     EnvbSlotLds& my = SL[k];
 
     // ---- prologue: every independent global load up front (one exposed round trip) ----------------------------------
@@ -231,6 +253,7 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
         // (the env header as one coalesced load from the global address space: see env_flow, wg_env.hip)
         static_assert(sizeof(WgEnv) == 128, "the env header is loaded as 32 words");
         const int hw = reinterpret_cast<const int*>(k0->d.env + e)[tid & 31];
+        if (GLUE != 0 && tid < 32) reinterpret_cast<int*>(smem + LO::HDR)[tid] = hw;     // (handed to the glue tail: no second load)
         out.bg_init_pending = 0; out.rounds = 0; out.first_obs = 0;
         const bool use_mask = mode == WG_MODE_RESET && mask != nullptr;
         const uint8_t mask_byte = *(use_mask ? mask + e : reinterpret_cast<const uint8_t*>(k0->d.env + e));
@@ -278,9 +301,10 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
         int env_done = WG_HDR_I(done), env_shadow_iters = WG_HDR_I(shadow_iters), env_steps_done = WG_HDR_I(steps_done);
         int env_timestep = WG_HDR_I(timestep), env_time_max_live = WG_HDR_I(time_max_live);
 #undef WG_HDR_I
-        if (WPE == 2) {      // (both waves hold their copy of the header before either can rewrite it: see env_flow)
+        if (WPE >= 2) {      // (every wave holds its copy of the header before any can rewrite it: see env_flow)
             asm volatile("" : "+s"(env_live), "+s"(env_done), "+s"(env_shadow_iters), "+s"(env_steps_done), "+s"(env_timestep), "+s"(env_time_max_live) : : "memory");
-            asm volatile("s_barrier" ::: "memory");
+            // (lgkmcnt: with four waves, wave 0's zeroing of the workgroup's flags has landed before anyone can set one)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         out.env_live = env_live;
         out.truncates = env_timestep >= env_time_max_live;
@@ -289,12 +313,12 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
         // ---- roles (as env_flow: running episode = one env step, background episode = its share of development) -------
         const bool is_live_c = (c == env_live);
         const int autoreset = k0->p.autoreset;
-        const int bg_lane = WPE == 2 ? 0 : (env_live ^ 1) * F;          // lane of the background context's agent farm, turbine 0
+        const int bg_lane = WPE >= 2 ? 0 : (env_live ^ 1) * F;          // lane of the background context's agent farm, turbine 0
         int budget = 0;
         if (mode == WG_MODE_STEP) {
             role_live = is_live_c && !env_done;
             role_dev = !is_live_c && autoreset != 0;
-            const int bg_pending = WPE == 2 ? (is_live_c ? 0 : __shfl(init_pending, 0, 64)) : __shfl(init_pending, bg_lane, 64);
+            const int bg_pending = WPE >= 2 ? (is_live_c ? 0 : __shfl(init_pending, 0, 64)) : __shfl(init_pending, bg_lane, 64);
             out.bg_init_pending = autoreset && bg_pending;
             if (autoreset && bg_pending && WPE == 1 && (WG_ENV_DEFER_INIT != 0) && !out.truncates) {
                 defer_init = true;      // rare path: the retired context's next episode is set up AFTER this wave's step (env_flow)
@@ -302,10 +326,18 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
             } else if (autoreset && bg_pending) {
                 const KArgsPtr ki = wg_cold_args();
                 const WgParams& gp = *ki->d.gp;
-                env_init_episode<GLUE != 0>(e, env_live ^ 1, tid);
-                full_barrier<64>();
+                if (WPE == 4) {
+                    // the context's agent-farm wave sets BOTH farms up; the baseline farm's wave waits for it (same CU: the
+                    // stores need no cache maintenance to be seen, only to have left the wave)
+                    int* const fl = reinterpret_cast<int*>(wg_shared) + 4 + c;
+                    if (farm == 0) { env_init_episode<GLUE != 0>(e, env_live ^ 1, tid); full_barrier<64>(); if (tid == 0) envb_flag_set(fl); }
+                    else if (!envb_flag_wait(fl)) atomicOr(ki->d.status, WG_STATUS_BIT_STATE);
+                } else {
+                    env_init_episode<GLUE != 0>(e, env_live ^ 1, tid);
+                    full_barrier<64>();
+                }
                 load_state();
-                const int tm = WPE == 2 ? ki->d.ctx[e * 2 + env_live].time_max : __shfl(time_max_c, env_live * F, 64);
+                const int tm = WPE >= 2 ? ki->d.ctx[e * 2 + env_live].time_max : __shfl(time_max_c, env_live * F, 64);
                 const int inc = 1 + (gp.extra_inc ? 1 : 0);
                 const long total = (long)((tm + inc - 1) / inc) + 1;
                 budget = wg_shadow_share(dev_rem + gp.K * fill_rem, total - env_steps_done, env_steps_done, e, farm ? 0x80000000u : 0u);
@@ -320,13 +352,13 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
             budget = chunk;
         }
         (void)env_shadow_iters;
-        if (WPE == 2 && valid && t == 0) {      // (what the other wave's glue reads of this one, also if it has nothing to do)
+        if (WPE >= 2 && valid && t == 0) {      // (what the other waves' glue / plan reads of this one, also if it has nothing to do)
             my.dev_rem = dev_rem; my.fill_rem = fill_rem; my.bg_init = out.bg_init_pending; my.n_flow = 0; my.out_pw = 0.f;
         }
         {   // nothing to do for the whole wave (masked out in RESET mode, finished env without autoreset, idle background)
             const bool any_work = valid && (role_live || (role_dev && budget > 0 && (dev_rem > 0 || fill_rem > 0)));
             if (!__ballot(any_work)) {
-                if (WPE == 2 && (WG_ENV_FIRST_OBS_LATER != 0) && mode == WG_MODE_STEP && !is_live_c && autoreset) {
+                if (WPE >= 2 && (WPE == 2 || farm == 0) && (WG_ENV_FIRST_OBS_LATER != 0) && mode == WG_MODE_STEP && !is_live_c && autoreset) {
                     const int d0 = __shfl(dev_rem, 0, 64), f0 = __shfl(fill_rem, 0, 64), np0 = __shfl(n_pushed, 0, 64);
                     const KArgsPtr kf = wg_cold_args();
                     if (d0 == 0 && f0 == 0 && kf->d.gd->next_obs_ok != nullptr && kf->d.gd->next_obs_ok[ctx_id] == 0) {
@@ -480,9 +512,11 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
         // Register discipline: nothing of the lane's turbine is needed until the tail — parked in LDS across the two phases
         // that want the registers for loads in flight (particle pass: streamed words + box cells of two trips; rotor points:
         // 16 box cells per lane).  The rotor inflow (u, v, w, ti) lives in Luvw anyway.
-        Lpark[tid] = make_float4(yaw, oyaw, mvl_bits, sg);
-        Lpark[64 + tid] = make_float4(sws, swd, syaw, sp_);
-        Lpark[128 + tid] = make_float4(tpow, tct, __int_as_float(part_acc), cg);
+        if (valid) {
+            Lpark[g] = make_float4(yaw, oyaw, mvl_bits, sg);
+            Lpark[NLP + g] = make_float4(sws, swd, syaw, sp_);
+            Lpark[2 * NLP + g] = make_float4(tpow, tct, __int_as_float(part_acc), cg);
+        }
         lds_barrier<64>();
 
         // (2) particle pass: every valid particle of the stepping farms meanders with the low-pass filtered transverse inflow at
@@ -493,10 +527,10 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
             const KArgsPtr kp = wg_cold_args();
             const unsigned pstride = (unsigned)kp->p.pstride;
             const float dpart_f = kp->p.dpart_f, inv_D = kp->p.inv_D, dt = kp->p.dt, hub = kp->p.hub;
-            const int n_ctx_w = WPE == 2 ? 1 : 2;
+            const int n_ctx_w = WPE >= 2 ? 1 : 2;
             for (int cc = 0; cc < ((WG_ENVB_ABLATE & 16) ? 0 : n_ctx_w); ++cc) {
-                const int k0s = WPE == 2 ? 0 : cc * F;                         // the context's first slot of the wave
-                const int st0 = SL[k0s].stepping, st1 = F == 2 ? SL[k0s + 1].stepping : 0;
+                const int k0s = WPE >= 2 ? 0 : cc * F;                         // the context's first slot of the wave
+                const int st0 = SL[k0s].stepping, st1 = (F == 2 && WPE != 4) ? SL[k0s + 1].stepping : 0;
                 if (!(st0 | st1)) continue;
                 const bool both = st0 && st1;
                 const int lpf = both ? 32 : 64;
@@ -506,7 +540,7 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
                 const int L = q.L, n_emit = q.n_emit, n_valid = q.n_valid;
                 const float sof = q.s_off_f, sig = q.sig, alpha = q.alpha;
                 const double xshift = q.xshift, oy = q.oy;
-                const unsigned ctxw = (unsigned)(e * 2 + (WPE == 2 ? wv : cc));
+                const unsigned ctxw = (unsigned)(e * 2 + (WPE >= 2 ? c : cc));
                 // (particle addresses: the env's block as a wave-uniform base + a 32-bit offset per lane — an env's 2 F slots span
                 // less than 4 GB — so every access carries a scalar base and one address register)
                 const size_t pbe = (size_t)(e * 2 * F) * pstride;
@@ -656,7 +690,7 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
         {
             const KArgsPtr kp = wg_cold_args();
             const int cap = kp->p.env_cap;
-            float4* const pp = reinterpret_cast<float4*>(smem + WG_ENVB_OFF_STAGE);
+            float4* const pp = reinterpret_cast<float4*>(smem + LO::STAGE);
             float* const tiap = reinterpret_cast<float*>(pp + cap);
             const int S = kp->p.S, S_pad = kp->p.S_pad, sshift = kp->p.S_shift;
             const bool ADDED = kp->p.added != 0;
@@ -748,7 +782,7 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
                     const float hub = kp->p.hub, inv_S = kp->p.inv_S, km1 = kp->p.km1, km2r = kp->p.km2r;
                     const double hub_d = kp->p.hub_d;
                     // (two waves per env: the wave serves ONE episode — a wave-uniform base pointer of its box)
-                    const long long ucell0 = WPE == 2 ? envb_uni64(SL[0].box_cell0) : 0;
+                    const long long ucell0 = WPE >= 2 ? envb_uni64(SL[0].box_cell0) : 0;
                     auto rows = [&](auto pow2_tag, auto apow2_tag) __attribute__((always_inline)) {
                         constexpr bool POW2 = decltype(pow2_tag)::value;
                         constexpr bool APOW2 = decltype(apow2_tag)::value;
@@ -777,7 +811,7 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
                                 const double by = yr + (double)(rdy_s * cgt) + q.oy, bz = hub_d + (double)rdz_s;
                                 // the 8 + 8 cells of the point are requested first; the wakes of the row's target are summed while they
                                 // are in flight (the sums need nothing of the lookups: the wake-added share is (sum of weights) x field)
-                                const long long cell0 = WPE == 2 ? ucell0 : q.box_cell0;
+                                const long long cell0 = WPE >= 2 ? ucell0 : q.box_cell0;
                                 float4 va[8], vb[8];
                                 float ax, ay, az, gx = 0.f, gy_ = 0.f, gz = 0.f;
                                 if (box8) {
@@ -857,7 +891,7 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
         const float inv_k = 1.0f / (float)K;
         const unsigned ctx_id = (unsigned)(e * 2 + c);
         {   // the lane's turbine back from LDS; its rotor inflow as the rotor-point phase left it (a resting slot's: unchanged)
-            const float4 pa = Lpark[tid], pb = Lpark[64 + tid], pc = Lpark[128 + tid], r = Luvw[g];
+            const float4 pa = Lpark[g], pb = Lpark[NLP + g], pc = Lpark[2 * NLP + g], r = Luvw[g];
             yaw = pa.x; oyaw = pa.y; mvl_bits = pa.z; sg = pa.w;
             sws = pb.x; swd = pb.y; syaw = pb.z; sp_ = pb.w;
             tpow = pc.x; tct = pc.y; part_acc = __float_as_int(pc.z); cg = pc.w;
@@ -983,8 +1017,8 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
         }
     }
     // a background episode whose development is complete: window sums + first observation for the swap (see env_flow)
-    if (mode == WG_MODE_STEP && (WPE == 1 || c != env_live) && !defer_init) {
-        const EnvbSlotLds& bs = SL[WPE == 2 ? 0 : (env_live ^ 1) * F];      // the background context's agent farm
+    if (mode == WG_MODE_STEP && (WPE == 1 || (c != env_live && (WPE == 2 || farm == 0))) && !defer_init) {
+        const EnvbSlotLds& bs = SL[WPE >= 2 ? 0 : (env_live ^ 1) * F];      // the background context's agent farm
         const int bctx = e * 2 + (env_live ^ 1);
         bool build = false;
         if (ke->p.autoreset && bs.dev_rem == 0 && bs.fill_rem == 0) {
@@ -1012,6 +1046,10 @@ __device__ __forceinline__ void envb_flow(char* const smem, const int wv, const 
 // k_flow_envb<NOISE, 0, WPE>: the flow step alone (RESET-mode development; handles whose glue is a separate launch).
 // k_flow_envb<NOISE, 1 / 2, WPE>: step() as ONE launch — the glue (lean_step; 2 = with the per-agent observation buffer) as the
 // tail of the flow step, exactly as k_flow_env runs it.
+// WPE = waves per env: 1 (one wave serves the env's 2 F slots), 2 (one wave per context), 4 (one wave per FARM SLOT, F = 2, at most
+// 16 turbines, up to 1024 envs = the chip's 4096 wave slots): the loops of a farm step — particle trips, rotor-point passes — are
+// then spread over four waves instead of two, and the wave that runs the glue (the running episode's agent farm) meets its
+// baseline farm's wave through a flag in LDS; the background context's waves meet the same way to plan their next share.
 template <bool NOISE, int GLUE, int WPE>
 __global__ void __launch_bounds__(64 * WPE, WG_ENVB_WAVES)
 k_flow_envb(const FlowP p_, const FlowPtrs d_, const int mode, const float* __restrict__ actions,
@@ -1019,46 +1057,70 @@ k_flow_envb(const FlowP p_, const FlowPtrs d_, const int mode, const float* __re
             float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out,
             float* __restrict__ final_obs_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wv = WPE == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-    const int lds_wave = WPE == 2 ? wg_cold_args()->p.env_lds : 0;
+    typedef EnvbLds<(WPE == 4 ? 16 : 64)> LO;
+    const int wv = WPE >= 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int lds_wave = WPE >= 2 ? wg_cold_args()->p.env_lds : 0;
     char* const sm = smem + wv * lds_wave;
+    char* const shared = smem + WPE * lds_wave;             // (WPE 4: the workgroup's flags)
+    int* const flags = reinterpret_cast<int*>(shared);
+    if (WPE == 4 && threadIdx.x < 8) flags[threadIdx.x] = 0;      // (before the prologue's workgroup barrier: nobody sets one earlier)
     EnvFlowOut fo;
-    envb_flow<NOISE, WPE, GLUE>(sm, wv, mode, actions, mask, chunk, fo);
+    envb_flow<NOISE, WPE, GLUE>(sm, shared, wv, mode, actions, mask, chunk, fo);
     if (GLUE != 0) {
         full_barrier<64>();
-        if (WPE == 2) {
-            // (two waves per env meet at a workgroup barrier only when the env truncates: see k_flow_env)
-            if (wv != fo.env_live) {
-                const EnvKArgsPtr kb = (EnvKArgsPtr)wg_cold_args();
-                const int e = (int)blockIdx.x;
-                if (kb->p.autoreset && !fo.truncates && (threadIdx.x & 63) == 0) {
-                    const int F = kb->p.F, K = kb->p.K;
-                    const EnvbSlotLds* const SLb = reinterpret_cast<const EnvbSlotLds*>(sm + WG_ENVB_OFF_SL);
+        const EnvKArgsPtr kb = (EnvKArgsPtr)wg_cold_args();
+        const int e = (int)blockIdx.x, F = kb->p.F, K = kb->p.K;
+        const int c_w = WPE == 4 ? (wv >> 1) : wv, farm_w = WPE == 4 ? (wv & 1) : 0;      // this wave's context / farm (WPE >= 2)
+        const bool lane0 = (threadIdx.x & 63) == 0;
+        if (WPE == 4 && lane0) envb_flag_set(flags + wv);      // this wave's flow part is complete, its stores have left the wave
+        if (WPE >= 2) {
+            // The glue needs nothing of the background context's waves unless the env truncates in this step (then it swaps that
+            // context in): the waves meet at a workgroup barrier ONLY then — all know from the env's header — and otherwise run to
+            // their ends side by side: the background context plans its own next share and clears its set-up flag.
+            if (c_w != fo.env_live && farm_w == 0) {
+                if (kb->p.autoreset && !fo.truncates && lane0) {
                     int work = 0;
-                    for (int f = 0; f < F; ++f) work = max(work, SLb[f].dev_rem + K * SLb[f].fill_rem);
+                    if (WPE == 4) {
+                        if (!envb_flag_wait(flags + wv + 1)) atomicOr(kb->d.status, WG_STATUS_BIT_STATE);
+                        for (int f = 0; f < F; ++f) {
+                            const EnvbSlotLds* const s_ = reinterpret_cast<const EnvbSlotLds*>(smem + (wv + f) * lds_wave + LO::SL);
+                            work = max(work, s_->dev_rem + K * s_->fill_rem);
+                        }
+                    } else {
+                        const EnvbSlotLds* const SLb = reinterpret_cast<const EnvbSlotLds*>(sm + LO::SL);
+                        for (int f = 0; f < F; ++f) work = max(work, SLb[f].dev_rem + K * SLb[f].fill_rem);
+                    }
                     const int steps_done = fo.steps_done + 1, time_max = fo.time_max_live;      // (as the glue sees them)
                     const int inc = 1 + (kb->gp.extra_inc ? 1 : 0);
                     const long total = (long)((time_max + inc - 1) / inc) + 1;
                     kb->d.env_rw[e].shadow_iters = work == 0 ? 0 : wg_shadow_share(work, total - steps_done, steps_done, e);
                 }
-                if (fo.bg_init_pending && (threadIdx.x & 63) == 0) kb->d.ctx[e * 2 + wv].init_pending = 0;
-                if (fo.truncates) __builtin_amdgcn_s_waitcnt(0x0070);       // (its last stores, before the barrier releases the glue)
+                if (fo.bg_init_pending && lane0) kb->d.ctx[e * 2 + c_w].init_pending = 0;
             }
+            if (c_w != fo.env_live && fo.truncates) __builtin_amdgcn_s_waitcnt(0x0070);       // (its last stores, before the barrier releases the glue)
             if (fo.truncates) __syncthreads();
         }
-        if (WPE == 1 || wv == fo.env_live) {
+        if (WPE == 1 || (c_w == fo.env_live && farm_w == 0)) {
             const EnvKArgsPtr kg = (EnvKArgsPtr)wg_cold_args();
-            const int F = kg->p.F, K = kg->p.K;
-            const EnvbSlotLds* const SLa = reinterpret_cast<const EnvbSlotLds*>(sm + WG_ENVB_OFF_SL);      // the live context's slots
-            const int la = WPE == 2 ? 0 : fo.env_live * F, lb = (fo.env_live ^ 1) * F;
             LeanFused fz;
-            fz.fp = SLa[la].out_pw;
-            fz.bp = F == 2 ? SLa[la + 1].out_pw : 0.f;
-            int work = 0;
-            if (WPE == 1) for (int f = 0; f < F; ++f) work = max(work, SLa[lb + f].dev_rem + K * SLa[lb + f].fill_rem);
-            fz.work = work;
-            fz.bg_init_pending = WPE == 2 ? 0 : fo.bg_init_pending;
-            fz.plan_elsewhere = WPE == 2;
+            if (WPE == 4) {
+                // the running episode's agent-farm wave: its baseline farm's wave is the next one
+                if (F == 2 && !envb_flag_wait(flags + wv + 1)) { if (lane0) atomicOr(kg->d.status, WG_STATUS_BIT_STATE); }
+                fz.fp = reinterpret_cast<const EnvbSlotLds*>(sm + LO::SL)->out_pw;
+                fz.bp = F == 2 ? reinterpret_cast<const EnvbSlotLds*>(sm + lds_wave + LO::SL)->out_pw : 0.f;
+                fz.work = 0;
+            } else {
+                const EnvbSlotLds* const SLa = reinterpret_cast<const EnvbSlotLds*>(sm + LO::SL);      // the live context's slots
+                const int la = WPE == 2 ? 0 : fo.env_live * F, lb = (fo.env_live ^ 1) * F;
+                fz.fp = SLa[la].out_pw;
+                fz.bp = F == 2 ? SLa[la + 1].out_pw : 0.f;
+                int work = 0;
+                if (WPE == 1) for (int f = 0; f < F; ++f) work = max(work, SLa[lb + f].dev_rem + K * SLa[lb + f].fill_rem);
+                fz.work = work;
+            }
+            fz.bg_init_pending = WPE >= 2 ? 0 : fo.bg_init_pending;
+            fz.plan_elsewhere = WPE >= 2;
+            fz.hw = reinterpret_cast<const int*>(sm + LO::HDR)[threadIdx.x & 31];
             lean_step<GLUE == 2, false, true>(*(const WgParams*)&kg->gp, *(const WgPtrs*)&kg->gd, kg->d.gp, kg->d.gd, (int)blockIdx.x,
                                               (int)(threadIdx.x & 63), kg->obs, kg->reward, kg->trunc, kg->final_obs, nullptr, fz);
         }
@@ -1067,13 +1129,14 @@ k_flow_envb(const FlowP p_, const FlowPtrs d_, const int mode, const float* __re
 
 extern "C" void wg_launch_flow_envb(const FlowP* p, const FlowPtrs* d, int mode, const float* actions, const uint8_t* mask,
                                     int chunk, hipStream_t st) {
-    const int grid = p->B, wpe = p->env_wpe == 2 ? 2 : 1;
-    const size_t lds = (size_t)p->env_lds * wpe;
+    const int grid = p->B, wpe = p->env_wpe == 4 ? 4 : (p->env_wpe == 2 ? 2 : 1);
+    const size_t lds = (size_t)p->env_lds * wpe + (wpe == 4 ? WG_ENVB_FLAG_BYTES : 0);
     static const WgParams gp0{};
     static const WgPtrs gd0{};
 #define WG_FLOW_ENVB(NZ, W) hipLaunchKernelGGL((k_flow_envb<NZ, 0, W>), dim3(grid), dim3(64 * W), lds, st, *p, *d, mode, actions, mask, chunk, gp0, gd0, \
                                                (float*)nullptr, (float*)nullptr, (uint8_t*)nullptr, (float*)nullptr)
-    if (wpe == 2) { if (p->noise) WG_FLOW_ENVB(true, 2); else WG_FLOW_ENVB(false, 2); }
+    if (wpe == 4) { if (p->noise) WG_FLOW_ENVB(true, 4); else WG_FLOW_ENVB(false, 4); }
+    else if (wpe == 2) { if (p->noise) WG_FLOW_ENVB(true, 2); else WG_FLOW_ENVB(false, 2); }
     else { if (p->noise) WG_FLOW_ENVB(true, 1); else WG_FLOW_ENVB(false, 1); }
 #undef WG_FLOW_ENVB
 }
@@ -1081,11 +1144,11 @@ extern "C" void wg_launch_flow_envb(const FlowP* p, const FlowPtrs* d, int mode,
 // step() as one launch (wg_api.hip: launch_step, handles with FlowP::env_fused and frozen-box inflow)
 extern "C" void wg_launch_step_envb(const FlowP* p, const FlowPtrs* d, const WgParams* gp, const WgPtrs* gd, const float* actions,
                                     float* obs, float* reward, uint8_t* trunc, float* final_obs, hipStream_t st) {
-    const int grid = p->B, wpe = p->env_wpe == 2 ? 2 : 1;
-    const size_t lds = (size_t)p->env_lds * wpe;
+    const int grid = p->B, wpe = p->env_wpe == 4 ? 4 : (p->env_wpe == 2 ? 2 : 1);
+    const size_t lds = (size_t)p->env_lds * wpe + (wpe == 4 ? WG_ENVB_FLAG_BYTES : 0);
 #define WG_STEP_ENVB(NZ, G, W) hipLaunchKernelGGL((k_flow_envb<NZ, G, W>), dim3(grid), dim3(64 * W), lds, st, *p, *d, (int)WG_MODE_STEP, actions, \
                                                   (const uint8_t*)nullptr, 0, *gp, *gd, obs, reward, trunc, final_obs)
-#define WG_STEP_ENVB_W(NZ, G) do { if (wpe == 2) WG_STEP_ENVB(NZ, G, 2); else WG_STEP_ENVB(NZ, G, 1); } while (0)
+#define WG_STEP_ENVB_W(NZ, G) do { if (wpe == 4) WG_STEP_ENVB(NZ, G, 4); else if (wpe == 2) WG_STEP_ENVB(NZ, G, 2); else WG_STEP_ENVB(NZ, G, 1); } while (0)
     if (gd->multi_out) { if (p->noise) WG_STEP_ENVB_W(true, 2); else WG_STEP_ENVB_W(false, 2); }
     else { if (p->noise) WG_STEP_ENVB_W(true, 1); else WG_STEP_ENVB_W(false, 1); }
 #undef WG_STEP_ENVB_W

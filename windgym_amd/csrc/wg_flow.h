@@ -154,11 +154,11 @@ struct FlowPtrs {
 // then four slot records) | staging: per-candidate deficit, added TI (WG_ENV_CAP floats each), candidate list (u16), aliased by
 // the quad list | tables (FlowP::env_off_tab)
 #define WG_ENV_SLOT_LDS_BYTES 160
-#define WG_ENV_FIXED_LDS_BYTES (3 * 64 * 16 + 2 * 64 * 8 + 4 * WG_ENV_SLOT_LDS_BYTES)
+#define WG_ENV_FIXED_LDS_BYTES (3 * 64 * 16 + 2 * 64 * 8 + 4 * WG_ENV_SLOT_LDS_BYTES + 128)      // (+ the env header's 32 words)
 #define WG_ENV_CAP 256
 // k_flow_envb's LDS carve (wg_envb.hip): fixed part (per-lane turbine fields + row table + four slot records of 208 bytes + the lanes' parked registers) |
 // staged wakes float4[env_cap] | added TI float[env_cap] | candidate list (u16) | tables (FlowP::env_off_tab)
-#define WG_ENVB_FIXED_LDS_BYTES (5952 + 4 * 208 + 3 * 1024)
+#define WG_ENVB_FIXED_LDS_BYTES(nlp) ((93 + 48) * (nlp) + 4 * 208 + 128)      // nlp = lanes the per-lane arrays are sized for: 64, or 16 (four waves per env)
 // sizeof(TurbLds) in wg_flow.hip; kept here so the host can size the dynamic LDS
 #define WG_TURB_LDS_BYTES 120
 // landing zone of the LDS-DMA gathers, per candidate lane: the 16-byte record copy (rec_a, rec_b, u_e, 0) of the two

@@ -308,6 +308,8 @@ struct LeanFused {
     int work;                 // remaining development work of the background episode: max over its farms of dev + K * fill
     int bg_init_pending;      // the background context's set-up flag was pending at the head of this launch
     int plan_elsewhere;       // the background context's own wave plans its next share (WgEnv::shadow_iters) unless the env truncates
+    int hw;                   // word (lane & 31) of the env's 128-byte header as the flow part's prologue loaded it: nothing this wave
+                              // reads of it has changed since (the header is rewritten only below) — the glue needs no second trip for it
 };
 
 // One env's glue after its flow step: power deques, window sums -> observation, reward, penalty, truncation, metrics, the
@@ -330,7 +332,7 @@ __device__ __forceinline__ void lean_step(const WgParams& p, const WgPtrs& d, co
     // The env's 128-byte header in ONE coalesced load: lane i (< 32) fetches 32-bit word i, the fields are broadcast with
     // v_readlane (-> scalar registers).  A plain global load: ordered against this wave's own stores to the header below.
     static_assert(sizeof(WgEnv) == 128, "lean_step loads the env header as 32 words");
-    const int hw = reinterpret_cast<const int*>(&env)[lane & 31];
+    const int hw = FUSED ? fz.hw : reinterpret_cast<const int*>(&env)[lane & 31];
 #define WG_HDR_I(f) __builtin_amdgcn_readlane(hw, (int)(offsetof(WgEnv, f) / 4))
 #define WG_HDR_F(f) __int_as_float(WG_HDR_I(f))
 #define WG_HDR_D(f) __hiloint2double(__builtin_amdgcn_readlane(hw, (int)(offsetof(WgEnv, f) / 4) + 1), WG_HDR_I(f))
