@@ -585,7 +585,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             f.env_lds = (int)((o + 15) & ~(size_t)15);
             if (f.env_lds > 32768 || f.env_lds > lds_limit) env_ok = false;
             // k_flow_envb (wg_envb.hip): the same pattern for frozen-box inflow (cfg5) on the turbulent small-farm layout (SoA
-            // record + u_e, what k_flow<64, BOX> runs on: the two are interchangeable).  Gaussian deficit; rotor points in rows
+            // record, what k_flow<64, BOX> runs on: the two are interchangeable).  Gaussian deficit; rotor points in rows
             // of S_pad <= 16 lanes; the wake-added field and TI folding are run-time options.
             bool envb_ok = f.res && small && f.block == 64 && !f.gl && p.turb_mode >= WG_TURB_BOX && NL <= 64 && p.N <= 32 &&
                            p.P <= 4096 && f.S_pad <= 16 && h->deficit_model == 0;
@@ -630,8 +630,9 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             if (const char* ev = wg_hook("WG_ENV_WPE")) f.env_wpe = (atoi(ev) == 2 && 2 * f.env_lds <= lds_limit) ? 2 : 1;
             if (envb_ok) f.env_wpe = envb_wpe;
         }
-        // packed emission record: two arrays, or one interleaved (ct|k, eps|hv) array for the GL variant
-        f.rec_il = f.gl ? 1 : 0;
+        // packed emission record: two arrays, or one interleaved (ct|k, u_e|hv) array for the steady compact variants whose
+        // deficit phase gathers bracket pairs from it (GL / k_flow_env: 64 threads; LF: 256 threads)
+        f.rec_il = (f.gl || (f.res && f.block == 256 && p.turb_mode == WG_TURB_NONE && (WG_LF_PAIR != 0) && (WG_PAIR_FIRST != 0))) ? 1 : 0;
         if (f.rec_il) {
             if (!rc) rc = dev_alloc(h, &d.rec_a, 2 * n_slots * pstride_keep, true);
             d.rec_b = d.rec_a ? d.rec_a + 1 : nullptr;
@@ -639,10 +640,6 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             if (!rc) rc = dev_alloc(h, &d.rec_a, n_slots * pstride_keep, true);
             if (!rc) rc = dev_alloc(h, &d.rec_b, n_slots * pstride_keep, true);
         }
-        // frozen-record layout for the deficit gathers of the large-farm variant: 16-byte AoS copy (rec4)
-        // (GL handles too: their gathers read the 16-byte copy — one line per pair instead of record line + u_e line)
-        if (!f.res || !small || f.rec_il) { if (!rc) rc = dev_alloc(h, &d.rec4, n_slots * pstride_keep, true); }
-        else { if (!rc) rc = dev_alloc(h, &d.u_e, n_slots * pstride_keep, true); }
         if (rc) { wg_destroy(h); return rc; }
         f.lds_bytes = (int)((off + 15) & ~(size_t)15);
         f.dt = p.dt; f.D = p.D; f.inv_D = p.inv_D; f.hub = p.hub; f.dpart_f = (float)p.dpart; f.R_rot = 0.5f * p.D;
@@ -653,6 +650,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         f.yaw_min = p.yaw_min; f.yaw_max = p.yaw_max; f.yaw_step = p.yaw_step;
         f.ka = p.ka; f.kb = p.kb; f.eps0 = p.eps0; f.hill = p.hill; f.tia = p.tia; f.tib = p.tib; f.tic = p.tic; f.tid = p.tid;
         f.tab_x0 = (float)x0; f.tab_inv_dx = (float)(1.0 / dxu);
+        f.ue_scale = p.turb_mode == WG_TURB_NONE ? 1.0f : 2.0f;
         for (int i = 0; i < WG_N_CH; ++i) {
             // (the flow kernels only push: what they call the history length is the rings' physical capacity)
             f.hlen[i] = p.ring_cap[i]; f.ring_off[i] = p.ring_off[i]; f.fring_off[i] = p.fring_off[i];
@@ -674,7 +672,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         }
         FlowPtrs& g = h->fd;
         memset(&g, 0, sizeof(g));
-        g.py = d.py; g.rec_a = d.rec_a; g.rec_b = d.rec_b; g.u_e = d.u_e; g.rec4 = d.rec4;
+        g.py = d.py; g.rec_a = d.rec_a; g.rec_b = d.rec_b;
         g.pz = d.pz; g.vlp = d.vlp; g.wlp = d.wlp;
         g.bnd = d.bnd;
         g.dbg = nullptr;
@@ -1216,7 +1214,7 @@ struct StateHeader {
     int32_t res, reserved0, pstride, n_boxes;      // particle-ring layout (uniform / compact rings); reserved0: always 0 (was: k_flow_duo)
     uint64_t payload;
 };
-static const uint32_t WG_STATE_MAGIC = 0x53474757u;   // "WGGS"
+static const uint32_t WG_STATE_MAGIC = 0x32474757u;   // "WGG2" (round 6: u_e lives in the packed record; blobs of the "WGGS" layout are refused)
 static StateHeader state_header(const wg_env_s* h) {
     StateHeader sh;
     memset(&sh, 0, sizeof(sh));

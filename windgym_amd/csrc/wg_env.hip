@@ -26,9 +26,6 @@
 
 #include "wg_env_common.h"
 
-#ifndef WG_ENV_ABLATE
-#define WG_ENV_ABLATE 0     // profiling builds only
-#endif
 #ifndef WG_ENV_S_UNROLL
 #define WG_ENV_S_UNROLL 0   // 1: the rotor-point loop of the pair evaluation unrolled by 4
 #endif
@@ -67,7 +64,7 @@ static_assert(sizeof(EnvSlotLds) == WG_ENV_SLOT_LDS_BYTES, "keep WG_ENV_SLOT_LDS
 // by lane g, then the slot records, then the staging region (per-candidate deficit | added TI | candidate list, aliased by the
 // quad list), then the tables (FlowP::env_off_tab)
 //   Lsrc4 (float x, float y, bk, be)   positions as floats + running bounds of the chain (candidate pass)
-//   Lrec4 (ra, rb, u_e, cos yaw)       this step's emission record, packed (pack_a / pack_b), rotor wind speed, cos(yaw)
+//   Lrec4 (ra, rb, -, cos yaw)         this step's emission record, packed (pack_a / pack_b: u_e is in rb), cos(yaw)
 //   Lring (roff, rlen, head, -)        the chain's compact ring
 //   Lxr                                downwind position in double (brackets are decided in double)
 //   Lsrc2 (bd, mvl)                    excursion bound (raised by the advection pass with LDS atomics), last moving emission
@@ -458,13 +455,14 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
         // step are ages jp0 = j - n_emit, jp0 + 1 before it; negative: released in this step — the turbine's record, at the
         // turbine.  A resting chain's particles sit where they were released: their py is not fetched.
         // (particle addresses: the env's block as a uniform base + 32-bit offsets — an env's 2 F slots span < 4 GB)
-        struct Cand { uint4 q0, q1; float y0, y1, xd, wgt; int en, jp0; bool ok, rest; };      // (en: list entry = target lane << 5 | source turbine)
+        struct Cand { uint2 q0, q1; float y0, y1, xd, wgt; int en, jp0; bool ok, rest; };      // (en: list entry = target lane << 5 | source turbine)
         float dsum = 0.f, tia_max = 0.f;
         {
             const KArgsPtr kp = wg_cold_args();
             const unsigned pstride = (unsigned)kp->p.pstride;
             const size_t pb_env = (size_t)(e * 2 * F + kbase) * pstride;      // particle block of the wave's slot 0 (slot k: + k * pstride)
-            const uint4* const r4_env = kp->d.rec4 + pb_env;
+            // (the brackets' records come from the interleaved record array the advection pass streams: the same lines)
+            const uint2* const rc_env = reinterpret_cast<const uint2*>(kp->d.rec_a + 2 * pb_env);
             const float* const py_env = kp->d.py + pb_env;
             const double inv_dpart = kp->p.inv_dpart;
             const float inv_D = kp->p.inv_D;
@@ -497,14 +495,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
                 if (cd.jp0 < 0) r0 = 0;           // (released in this step: nothing to fetch — any slot of the ring will do)
                 if (cd.jp0 + 1 < 0) r1 = 0;
                 const unsigned sb = (unsigned)rg.w * pstride + (unsigned)rg.x;
-#if WG_ENV_ABLATE & 1      // (profiling builds, wrong results: no record-copy gathers for the brackets of MOVING chains)
-                if (cd.rest) { cd.q0 = r4_env[sb + (unsigned)r0]; cd.q1 = r4_env[sb + (unsigned)r1]; }
-                else { cd.q0 = Lrec4[gs]; cd.q1 = cd.q0; cd.q1.x += (unsigned)r1 & 1u; }
-#elif WG_ENV_ABLATE & 2    // (no record-copy gathers at all)
-                cd.q0 = Lrec4[gs]; cd.q1 = cd.q0; cd.q1.x += (unsigned)r1 & 1u;
-#else
-                cd.q0 = r4_env[sb + (unsigned)r0]; cd.q1 = r4_env[sb + (unsigned)r1];
-#endif
+cd.q0 = rc_env[sb + (unsigned)r0]; cd.q1 = rc_env[sb + (unsigned)r1];
                 cd.y0 = 0.f; cd.y1 = 0.f;
                 if (!cd.rest) { cd.y0 = py_env[sb + (unsigned)r0]; cd.y1 = py_env[sb + (unsigned)r1]; }
                 cd.ok = true;
@@ -530,7 +521,8 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
                 const float rhv = -kq->p.hill * sg * tu;
                 // the packed record saturates outside [0, WG_K_MAX] x [-WG_HV_MAX, WG_HV_MAX]: never silently (wg_check reports it)
                 if (rk > WG_K_MAX || fabsf(rhv) > WG_HV_MAX) atomicOr(kq->d.status, WG_STATUS_BIT_RANGE);
-                const unsigned na_ = pack_a(ctx, rk), nb_ = pack_b(reps, rhv);
+                // (steady inflow: u_e <= U — stored as their ratio)
+                const unsigned na_ = pack_a(ctx, rk), nb_ = pack_b(tu * __builtin_amdgcn_rcpf(kq->p.ue_scale * my.ws_f), rhv);
                 float4 s4 = Lsrc4[g];
                 s4.z = fmaxf(s4.z, rk + WG_K_MAX / 65535.0f);
                 s4.w = fmaxf(s4.w, reps + 1.0f / 65535.0f);
@@ -544,7 +536,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
 
             // exact evaluation, one candidate per lane and batch; results staged per candidate, WG_ENV_CAP at a time
             const KArgsPtr ke2 = wg_cold_args();
-            const float dpart_f = ke2->p.dpart_f, D = ke2->p.D, dt = ke2->p.dt, R_rot = ke2->p.R_rot;
+            const float dpart_f = ke2->p.dpart_f, D = ke2->p.D, dt = ke2->p.dt, R_rot = ke2->p.R_rot, eps0 = ke2->p.eps0, ue_scale = ke2->p.ue_scale;
             const float tia = ke2->p.no_ti_fold ? 0.f : ke2->p.tia, tib = ke2->p.tib, tid_ = ke2->p.tid, inv_S = ke2->p.inv_S;
             const int S = ke2->p.S;
             const float2* const rpt = reinterpret_cast<const float2*>(smem + ke2->p.env_off_tab + 8 * ke2->p.n_tab);
@@ -562,24 +554,25 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
                     const int jp0 = cd.jp0, jp1 = jp0 + 1;
                     float py0 = cd.rest ? ysrc : cd.y0, py1 = cd.rest ? ysrc : cd.y1;
                     unsigned a0 = cd.q0.x, b0_ = cd.q0.y, a1 = cd.q1.x, b1_ = cd.q1.y;
-                    float u0 = __uint_as_float(cd.q0.z), u1 = __uint_as_float(cd.q1.z);
                     if (jp0 < 0) {      // (jp1 < 0 implies jp0 < 0)
                         const uint4 rn = Lrec4[gs];
-                        py0 = ysrc; u0 = __uint_as_float(rn.z); a0 = rn.x; b0_ = rn.y;
-                        if (jp1 < 0) { py1 = ysrc; u1 = __uint_as_float(rn.z); a1 = rn.x; b1_ = rn.y; }
+                        py0 = ysrc; a0 = rn.x; b0_ = rn.y;
+                        if (jp1 < 0) { py1 = ysrc; a1 = rn.x; b1_ = rn.y; }
                     }
+                    const float ue_max = ue_scale * q.ws_f;
+                    const float u0 = rec_uf(b0_) * ue_max, u1 = rec_uf(b1_) * ue_max;
                     {
                         const int nv = q.n_valid;
                         const float sof = q.s_off_f;
-                        if (jp0 >= 0 && jp0 < nv) py0 = m0_advect(py0, a0, b0_, jp0, sof, dpart_f, inv_D, dt);
-                        if (jp1 >= 0 && jp1 < nv) py1 = m0_advect(py1, a1, b1_, jp1, sof, dpart_f, inv_D, dt);
+                        if (jp0 >= 0 && jp0 < nv) py0 = m0_advect(py0, a0, b0_, jp0, sof, dpart_f, inv_D, dt, eps0);
+                        if (jp1 >= 0 && jp1 < nv) py1 = m0_advect(py1, a1, b1_, jp1, sof, dpart_f, inv_D, dt, eps0);
                     }
                     // interpolation, lateral cut-off, Gaussian deficit at the S rotor points (k_flow: eval_pair)
                     const float wgt = cd.wgt;
                     const float w0 = 1.0f - wgt, w1 = wgt;
                     const float yc = w0 * py0 + w1 * py1;
                     const float kv = w0 * rec_k(a0) + w1 * rec_k(a1);
-                    const float epv = w0 * rec_eps(b0_) + w1 * rec_eps(b1_);
+                    const float epv = w0 * rec_eps(a0, eps0) + w1 * rec_eps(a1, eps0);
                     const float xd = cd.xd;
                     const float sp = kv * xd + epv;
                     const float sig = sp * D;
@@ -657,7 +650,6 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
             const size_t pb_env = (size_t)(e * 2 * F + kbase) * pstride;
             float* const py_env = kp->d.py + pb_env;
             unsigned* const ra_env = kp->d.rec_a + 2 * pb_env;        // interleaved (ct|k, eps|hv) record
-            uint4* const r4_env = kp->d.rec4 + pb_env;
             // (2) quad list of the chains that move (TurbLds::mvl, k_flow): a chain is listed whole while it may hold a particle
             // of a yawed turbine; a resting chain only receives this step's new particles, stored straight to their ring slots
             int nlist;
@@ -684,7 +676,6 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
                                 const unsigned ix = sb + (unsigned)r;
                                 py_env[ix] = y0;
                                 reinterpret_cast<uint2*>(ra_env)[ix] = make_uint2(rn.x, rn.y);
-                                r4_env[ix] = make_uint4(rn.x, rn.y, rn.z, 0u);
                             }
                         }
                     }
@@ -706,7 +697,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
             // advection pass, software-pipelined: a lane requests its next listed quad before it computes the current one
             // (vmcnt counts loads and stores in ONE in-order queue: a plain load-compute-store loop waits for the previous
             // trip's stores whenever it waits for its loads)
-            const float dpart_f = kp->p.dpart_f, inv_D = kp->p.inv_D, dt = kp->p.dt;
+            const float dpart_f = kp->p.dpart_f, inv_D = kp->p.inv_D, dt = kp->p.dt, eps0 = kp->p.eps0;
             struct QuadReq { float4 py; uint4 ra, rb; int g, kq; unsigned q; };
             auto request = [&](QuadReq& r, const int cidx) __attribute__((always_inline)) {
                 const bool v = cidx < nlist;
@@ -740,7 +731,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     int j = j0 - i; if (j < 0) j += R;
-                    const float adv = m0_advect(pyv[i], rav[i], rbv[i], j, sof, dpart_f, inv_D, dt);
+                    const float adv = m0_advect(pyv[i], rav[i], rbv[i], j, sof, dpart_f, inv_D, dt, eps0);
                     pyv[i] = j < n_valid_q ? adv : pyv[i];
                 }
                 const float y0 = Lsrc4[gq].y;
@@ -751,7 +742,6 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
                         int ei = e0 + i; if (ei >= R) ei -= R;
                         if (ei < n_emit_q) {
                             pyv[i] = y0; rav[i] = rn.x; rbv[i] = rn.y;
-                            r4_env[4u * q + (unsigned)i] = make_uint4(rn.x, rn.y, rn.z, 0u);
                         }
                     }
                     reinterpret_cast<uint4*>(ra_env)[2u * q] = make_uint4(rav[0], rbv[0], rav[1], rbv[1]);

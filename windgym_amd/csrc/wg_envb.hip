@@ -18,7 +18,7 @@
 // ambient and the wake-added field at ITS point and sums the staged wakes of its target in ascending source order.  No
 // per-point field staging in LDS, one pass over the rotor points instead of two.
 //
-// State layout: exactly k_flow<64, BOX, RES>'s (SoA py / pz / vlp / wlp / rec_a / rec_b / u_e over compact rings, slot-major
+// State layout: exactly k_flow<64, BOX, RES>'s (SoA py / pz / vlp / wlp / rec_a / rec_b over compact rings, slot-major
 // turbine arrays) — the two kernels are interchangeable launch by launch on one handle (tests/test_gpu_variant_ab.py); values
 // agree to float rounding (different summation order over the rotor points), both are held to the oracle's bars.
 // Order of a flow step (k_flow's for turbulent inflow): clocks -> emission records -> particle pass (meandering through the
@@ -65,7 +65,7 @@ static_assert(sizeof(EnvbSlotLds) == 208, "EnvbSlotLds layout (EnvbLds below)");
 // LDS layout of a wave's region: compile-time offsets, the per-lane arrays sized for NLP lanes (64; 16 with four waves per env:
 // a wave then serves ONE farm slot of at most 16 turbines), indexed by lane g = t * NS + k
 //   XR / YR  double[NLP]   position        SRC4 float4[NLP] (x, y as floats, bk, be): candidate pass
-//   REC4     uint4[NLP]    this step's emission record: (rec_a, rec_b, bits of u_e, bits of cos yaw)
+//   REC4     uint4[NLP]    this step's emission record: (rec_a, rec_b, -, bits of cos yaw)
 //   RING     int4[NLP]     (roff, rlen, head before, head after this step's release)
 //   UVW      float4[NLP]   rotor inflow of the step (u, v, w, ti): written by the rotor-point phase
 //   BD       float[NLP]    excursion bound of the chain (raised by the particle pass with LDS atomics)
@@ -495,7 +495,9 @@ __device__ __forceinline__ void envb_flow(char* const smem, char* const wg_share
             const float rhv = -kq->p.hill * sg * tu;
             // the packed record saturates outside [0, WG_K_MAX] x [-WG_HV_MAX, WG_HV_MAX]: never silently (wg_check reports it)
             if (rk > WG_K_MAX || fabsf(rhv) > WG_HV_MAX) atomicOr(kq->d.status, WG_STATUS_BIT_RANGE);
-            const unsigned na_ = pack_a(ctx, rk), nb_ = pack_b(reps, rhv);
+            const float ue_max = kq->p.ue_scale * my.ws_f;        // (turbulent inflow: 2 U)
+            if (tu > ue_max) atomicOr(kq->d.status, WG_STATUS_BIT_RANGE);
+            const unsigned na_ = pack_a(ctx, rk), nb_ = pack_b(tu * __builtin_amdgcn_rcpf(ue_max), rhv);
             float4 s4 = Lsrc4[g];
             s4.z = fmaxf(s4.z, rk + WG_K_MAX / 65535.0f);
             s4.w = fmaxf(s4.w, reps + 1.0f / 65535.0f);
@@ -526,7 +528,7 @@ __device__ __forceinline__ void envb_flow(char* const smem, char* const wg_share
         {
             const KArgsPtr kp = wg_cold_args();
             const unsigned pstride = (unsigned)kp->p.pstride;
-            const float dpart_f = kp->p.dpart_f, inv_D = kp->p.inv_D, dt = kp->p.dt, hub = kp->p.hub;
+            const float dpart_f = kp->p.dpart_f, inv_D = kp->p.inv_D, dt = kp->p.dt, hub = kp->p.hub, eps0 = kp->p.eps0;
             const int n_ctx_w = WPE >= 2 ? 1 : 2;
             for (int cc = 0; cc < ((WG_ENVB_ABLATE & 16) ? 0 : n_ctx_w); ++cc) {
                 const int k0s = WPE >= 2 ? 0 : cc * F;                         // the context's first slot of the wave
@@ -548,7 +550,6 @@ __device__ __forceinline__ void envb_flow(char* const smem, char* const wg_share
                 float* const py_ = kp->d.py + pbe; float* const pz_ = kp->d.pz + pbe;
                 float* const vl_ = kp->d.vlp + pbe; float* const wl_ = kp->d.wlp + pbe;
                 unsigned* const ra_ = kp->d.rec_a + pbe; unsigned* const rb_ = kp->d.rec_b + pbe;
-                float* const ue_ = kp->d.u_e + pbe;
                 const uint8_t* const own_ = kp->d.qown + (size_t)ctxw * (unsigned)(kp->p.NP >> 2);
                 // (the two farms of a context read the same box of the pool: a wave-uniform base pointer)
                 const float4* const cbox = kp->d.box4c ? kp->d.box4c + envb_uni64(SL[k0s].cbox_cell0) : nullptr;
@@ -619,7 +620,7 @@ __device__ __forceinline__ void envb_flow(char* const smem, char* const wg_share
                             const unsigned rav = cu[u].ra, rbv = cu[u].rb;
                             if (j < n_valid) {
                                 const float xrel = sof + (float)j * dpart_f;
-                                const float sp = rec_k(rav) * (xrel * inv_D) + rec_eps(rbv);
+                                const float sp = rec_k(rav) * (xrel * inv_D) + rec_eps(rav, eps0);
                                 vlv += alpha * (sig * fv - vlv);
                                 wlv += alpha * (sig * fw - wlv);
                                 pyv += (rec_hv(rbv) * m0_cfrac(rec_ct(rav), sp) + vlv) * dt;
@@ -629,7 +630,7 @@ __device__ __forceinline__ void envb_flow(char* const smem, char* const wg_share
                             if (R - 1 - j < n_emit) {                                 // (= (r - head - 1) mod R: emission index of this slot)
                                 const uint4 rn = Lrec4[gq];
                                 pyv = y0; pzv = hub; vlv = 0.f; wlv = 0.f;
-                                ra_[ia] = rn.x; rb_[ia] = rn.y; ue_[ia] = __uint_as_float(rn.z);
+                                ra_[ia] = rn.x; rb_[ia] = rn.y;
                             }
                             const float ex = j < n_valid ? fabsf(pyv - y0) + fabsf(pzv - hub) : 0.f;   // (valid particles only)
                             if (ex > Lbd[gq]) atomicMax(reinterpret_cast<int*>(&Lbd[gq]), __float_as_int(ex));   // ex >= 0: int order == float order
@@ -706,7 +707,8 @@ __device__ __forceinline__ void envb_flow(char* const smem, char* const wg_share
                     const float inv_D = kp->p.inv_D, D = kp->p.D, hub = kp->p.hub, R_rot = kp->p.R_rot;
                     const float tia = kp->p.no_ti_fold ? 0.f : kp->p.tia, tib = kp->p.tib, tid_ = kp->p.tid;
                     const size_t pbe = (size_t)(e * 2 * F) * pstride;
-                    const float* const py_e = kp->d.py + pbe; const float* const pz_e = kp->d.pz + pbe; const float* const ue_e = kp->d.u_e + pbe;
+                    const float* const py_e = kp->d.py + pbe; const float* const pz_e = kp->d.pz + pbe;
+                    const float eps0 = kp->p.eps0;
                     const unsigned* const ra_e = kp->d.rec_a + pbe; const unsigned* const rb_e = kp->d.rec_b + pbe;
                     for (int cb = base; cb < top; cb += 64) {
                         const int cidx = cb + tid;
@@ -736,18 +738,18 @@ __device__ __forceinline__ void envb_flow(char* const smem, char* const wg_share
 #if WG_ENVB_ABLATE & 8
                                 const uint4 rr = Lrec4[gs];
                                 const float py0 = Lsrc4[gs].y + 1e-9f * (float)i0, py1 = py0 + 1e-9f * (float)i1, pz0 = hub, pz1 = hub;
-                                const float u0 = __uint_as_float(rr.z), u1 = u0;
                                 const unsigned a0 = rr.x, a1 = rr.x, b0_ = rr.y, b1_ = rr.y;
 #else
                                 const float py0 = py_e[i0], py1 = py_e[i1], pz0 = pz_e[i0], pz1 = pz_e[i1];
-                                const float u0 = ue_e[i0], u1 = ue_e[i1];
                                 const unsigned a0 = ra_e[i0], a1 = ra_e[i1], b0_ = rb_e[i0], b1_ = rb_e[i1];
 #endif
+                                const float ue_max = kp->p.ue_scale * q.ws_f;
+                                const float u0 = rec_uf(b0_) * ue_max, u1 = rec_uf(b1_) * ue_max;
                                 const float w0 = 1.0f - wgt, w1 = wgt;
                                 const float yc = w0 * py0 + w1 * py1;
                                 const float zc = w0 * pz0 + w1 * pz1;
                                 const float kv = w0 * rec_k(a0) + w1 * rec_k(a1);
-                                const float epv = w0 * rec_eps(b0_) + w1 * rec_eps(b1_);
+                                const float epv = w0 * rec_eps(a0, eps0) + w1 * rec_eps(a1, eps0);
                                 const float xd = (float)dx * inv_D;
                                 const float sp = kv * xd + epv;
                                 const float sig = sp * D;

@@ -70,8 +70,9 @@ struct FlowP {
     int target_chunk;             // targets whose pair parameters are staged in LDS at once
     int lf_cap;                   // large-farm steady variant (WG_LF_PAIR): candidates whose results fit the staging region at once
     int lds_off_turb, lds_off_tab, lds_bytes;
-    int rec_il;                   // the packed emission record is ONE interleaved array (rec_a[2 i] = ct|k, rec_a[2 i + 1] = eps|hv; rec_b = rec_a + 1):
-                                  // GL handles — a pair's gathers touch one record line instead of two, an emission writes one sector
+    int rec_il;                   // the packed emission record is ONE interleaved array (rec_a[2 i] = ct|k, rec_a[2 i + 1] = u_e|hv; rec_b = rec_a + 1):
+                                  // steady compact handles (GL / k_flow_env, LF) — a bracket pair is 16 contiguous bytes of the array
+                                  // the advection pass streams, an emission writes one sector
     int gl;                       // the launch runs the GL variant of k_flow (LDS-DMA gathers; no per-target source masks in LDS)
     int lds_off_ql, lds_off_gat;  // single-wave steady compact variant: quad list of its own (0 = aliases the pair staging) and the
                                   // landing zone of the deficit phase's LDS-DMA gathers (WG_GAT_BYTES)
@@ -89,6 +90,7 @@ struct FlowP {
     double dt_d, dpart, inv_dpart;
     float yaw_min, yaw_max, yaw_step;
     float ka, kb, eps0, hill, tia, tib, tic, tid;
+    float ue_scale;               // a particle's u_e is stored as a 16-bit fraction of ue_scale x the episode's free-stream speed (wg_flow_dev.h)
     float tab_x0, tab_inv_dx;     // uniform-grid turbine table
     int hlen[WG_N_CH], ring_off[WG_N_CH], fring_off[WG_N_CH];
     float inv_hlen[WG_N_CH], inv_power_avg;   // reciprocals for the division-free ring positions (fast_mod)
@@ -115,9 +117,8 @@ struct FlowP {
 };
 
 struct FlowPtrs {
-    float *py, *u_e, *pz, *vlp, *wlp;
-    uint4* rec4;                  // gather copy of the frozen record per particle: (rec_a, rec_b, bits of u_e, 0); used instead of u_e when block == 256
-    unsigned *rec_a, *rec_b;      // packed emission record (see wg_flow.hip)
+    float *py, *pz, *vlp, *wlp;
+    unsigned *rec_a, *rec_b;      // packed emission record incl. u_e (wg_flow_dev.h: pack_a / pack_b)
     const float4* box4;          // interleaved copy of the turbulence box: [Nx][Ny][Nz] x (u, v, w, 0)
     const float4* box4c;         // the same block-averaged over 4x4x4 cells
     const float4* abox4;         // isotropic box of the wake-added turbulence, interleaved like box4

@@ -53,11 +53,15 @@ struct SlotRegs {
 // A farm's particle state in the compact-ring layout (small farms): SoA over the concatenated per-turbine rings of
 // the farm slot, in global memory
 struct PartLds {
-    float* py; unsigned* ra; unsigned* rb; float* ue;
+    float* py; unsigned* ra; unsigned* rb;      // (interleaved record, FlowP::rec_il: rb == ra + 1 and particle i's words are ra[2 i], ra[2 i + 1])
     float *pz, *vl, *wl;        // turbulent inflow only
     const uint8_t* own;         // [L/4] owner turbine of a quad
-    uint4* r4;                  // large farms: 16-byte gather copy of the frozen record (rec_a, rec_b, bits of u_e, 0) or null
     int L;                      // ring slots of the farm = roff[N]
+    int il;                     // 1: interleaved record
+    // the packed emission record (rec_a, rec_b) of ring slot i, whichever way it is stored
+    __device__ __forceinline__ uint2 rec(const int i) const {
+        return il ? *reinterpret_cast<const uint2*>(ra + 2 * i) : make_uint2(ra[i], rb[i]);
+    }
 };
 
 // per-episode inflow context (uniform over the workgroup)
@@ -141,7 +145,11 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     // rings; a pair close enough to be bracketed by a particle released in this step is a candidate unconditionally.)
     constexpr bool PRE = RES && TURB == WG_TURB_NONE && (WG_PAIR_FIRST != 0);
     constexpr bool GL = PRE && NT == WG_WAVE && (WG_GLDS != 0);
+    // interleaved record array (FlowP::rec_il; the host sets it for exactly these variants): a bracket pair is 16 contiguous
+    // bytes of the array the advection pass streams
+    constexpr bool IL = GL || LF;
     const float ws_f = (float)ws;
+    const float ue_max = p.ue_scale * ws_f, ue_inv = __builtin_amdgcn_rcpf(ue_max);      // (scale of the record's u_e field)
     float* gat = reinterpret_cast<float*>(reinterpret_cast<char*>(pair) + p.lds_off_gat);
     typedef const __attribute__((address_space(1))) void* GPtr;
     typedef __attribute__((address_space(3))) void* LPtr;
@@ -191,15 +199,16 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         }
         // (a resting chain's particles sit where they were released — at the turbine: their py is not fetched; the request
         // points into the rec_a line the lane fetches anyway and the consumer substitutes y_t)
-        // (the 16-byte record copy rec4 = (rec_a, rec_b, u_e, 0), written once at emission: one request and — for the two
-        // adjacent bracketing particles — one line per pair; the interleaved rec_a / rec_b array is what the advection
-        // pass streams)
-        const uint4* q0p = pl.r4 + i0;
-        const uint4* q1p = pl.r4 + i1;
-        __builtin_amdgcn_global_load_lds((GPtr)q0p, (LPtr)(gat + 0 * 256), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((GPtr)q1p, (LPtr)(gat + 1 * 256), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((GPtr)(rest ? (const float*)q0p : pl.py + i0), (LPtr)(gat + 512), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((GPtr)(rest ? (const float*)q1p : pl.py + i1), (LPtr)(gat + 512 + 64), 4, 0, 0);
+        // (the records come from the interleaved (rec_a, rec_b) array the advection pass streams — the same lines; round 6: u_e
+        // is in rec_b, the 16-byte gather copy of rounds 2-5 is gone.  4-byte requests: one word per lane and request.)
+        const unsigned* q0p = pl.ra + 2 * i0;
+        const unsigned* q1p = pl.ra + 2 * i1;
+        __builtin_amdgcn_global_load_lds((GPtr)q0p, (LPtr)(gat + 0 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(q0p + 1), (LPtr)(gat + 1 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)q1p, (LPtr)(gat + 2 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(q1p + 1), (LPtr)(gat + 3 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(rest ? (const float*)q0p : pl.py + i0), (LPtr)(gat + 4 * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GPtr)(rest ? (const float*)q1p : pl.py + i1), (LPtr)(gat + 5 * 64), 4, 0, 0);
         return rest;
     };
     bool gl_rest = false;
@@ -276,8 +285,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
         q.reps = p.eps0 * __builtin_amdgcn_sqrtf(beta);
         q.rhv = -p.hill * sg * q.u;
         // the packed record saturates outside [0, WG_K_MAX] x [-WG_HV_MAX, WG_HV_MAX]: never silently (wg_check reports it)
-        if (q.rk > WG_K_MAX || fabsf(q.rhv) > WG_HV_MAX) atomicOr(wg_cold_args()->d.status, WG_STATUS_BIT_RANGE);
         q.rue = q.u;
+        if (q.rk > WG_K_MAX || fabsf(q.rhv) > WG_HV_MAX || q.rue > ue_max) atomicOr(wg_cold_args()->d.status, WG_STATUS_BIT_RANGE);
         q.cg = cg;
         q.sg = sg;
         q.bk = fmaxf(q.bk, q.rk + WG_K_MAX / 65535.0f);
@@ -288,7 +297,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 if (n_emit >= q.rlen) hn %= q.rlen; else if (hn >= q.rlen) hn -= q.rlen;
                 q.head_n = hn;
             }
-            if (n_emit > 0 && rec_moves(pack_b(q.reps, q.rhv))) q.mvl = sr.n_emitted + (unsigned)n_emit;
+            if (n_emit > 0 && rec_moves(pack_b(q.rue * ue_inv, q.rhv))) q.mvl = sr.n_emitted + (unsigned)n_emit;
         }
     }
     if (!GL) for (int i = tid; i < TC * WG_MASK_WORDS; i += NT) tmask[i] = 0u;
@@ -299,13 +308,14 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     // cut-off, deficit at the S rotor points -> def[i], tiav[i] (, addv) and the source's bit in the target's mask
     auto eval_pair = [&](const int i, const int tl, const int s2, const int t, const double dx, const float wgt,
                          const float py0, const float py1, const float pz0, const float pz1, const unsigned a0, const unsigned a1,
-                         const unsigned b0_, const unsigned b1_, const float u0, const float u1) __attribute__((always_inline)) {
+                         const unsigned b0_, const unsigned b1_) __attribute__((always_inline)) {
+            const float u0 = rec_uf(b0_) * ue_max, u1 = rec_uf(b1_) * ue_max;      // (rotor wind speed at emission: in the record)
             const float w0 = 1.0f - wgt, w1 = wgt;
             const float yc = w0 * py0 + w1 * py1;
             float zc = p.hub;
             if (TURB != WG_TURB_NONE) zc = w0 * pz0 + w1 * pz1;
             const float kv = w0 * rec_k(a0) + w1 * rec_k(a1);
-            const float epv = w0 * rec_eps(b0_) + w1 * rec_eps(b1_);
+            const float epv = w0 * rec_eps(a0, p.eps0) + w1 * rec_eps(a1, p.eps0);
             const float xd = (float)dx * p.inv_D;
             const float sp = kv * xd + epv;
             const float sig = sp * p.D;
@@ -569,7 +579,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             if (j < 0) { j = 0; wgt = 0.f; }
             if (j + 1 > new_valid - 1) continue;          // the chain has not reached the target yet
             const int Rs = src.rlen;
-            float py0, py1, u0, u1, pz0 = 0.f, pz1 = 0.f;
+            float py0, py1, pz0 = 0.f, pz1 = 0.f;
             unsigned a0, a1, b0_, b1_;
             if (PREV) {
                 // ages j, j + 1 after the step are ages jp, jp + 1 = j - n_emit, ... before it (negative: released in this
@@ -581,36 +591,30 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 if (jp1 < 0) r1 = 0;
                 const int i0 = (WG_ABLATE & 128) ? src.roff : src.roff + r0, i1 = (WG_ABLATE & 128) ? src.roff + 1 : src.roff + r1;   // (profiling: gathers that hit one line per chain)
                 const bool g0 = jp0 >= 0, g1 = jp1 >= 0;
-                py0 = py1 = (float)src.yr; u0 = u1 = src.rue;
-                a0 = a1 = pack_a(src.rct, src.rk); b0_ = b1_ = pack_b(src.reps, src.rhv);
-                if (pl.r4) {
+                py0 = py1 = (float)src.yr;
+                a0 = a1 = pack_a(src.rct, src.rk); b0_ = b1_ = pack_b(src.rue * ue_inv, src.rhv);
+                {
                     // (both brackets requested together, whether needed or not — i0 / i1 are valid ring slots either way:
                     // loads under `if (g0)` / `if (g1)` came out as two round trips, one behind the other)
-                    const uint4 q0 = pl.r4[i0], q1 = pl.r4[i1];
+                    const uint2 q0 = pl.rec(i0), q1 = pl.rec(i1);
                     const float y0l = pl.py[i0], y1l = pl.py[i1];
-                    if (g0) { a0 = q0.x; b0_ = q0.y; u0 = __uint_as_float(q0.z); py0 = y0l; }
-                    if (g1) { a1 = q1.x; b1_ = q1.y; u1 = __uint_as_float(q1.z); py1 = y1l; }
-                } else {
-                    if (g0) { py0 = pl.py[i0]; u0 = pl.ue[i0]; a0 = pl.ra[i0]; b0_ = pl.rb[i0]; }
-                    if (g1) { py1 = pl.py[i1]; u1 = pl.ue[i1]; a1 = pl.ra[i1]; b1_ = pl.rb[i1]; }
+                    if (g0) { a0 = q0.x; b0_ = q0.y; py0 = y0l; }
+                    if (g1) { a1 = q1.x; b1_ = q1.y; py1 = y1l; }
                 }
-                if (g0 && jp0 < n_valid) py0 = m0_advect(py0, a0, b0_, jp0, s_off_f, p.dpart_f, p.inv_D, p.dt);
-                if (g1 && jp1 < n_valid) py1 = m0_advect(py1, a1, b1_, jp1, s_off_f, p.dpart_f, p.inv_D, p.dt);
+                if (g0 && jp0 < n_valid) py0 = m0_advect(py0, a0, b0_, jp0, s_off_f, p.dpart_f, p.inv_D, p.dt, p.eps0);
+                if (g1 && jp1 < n_valid) py1 = m0_advect(py1, a1, b1_, jp1, s_off_f, p.dpart_f, p.inv_D, p.dt, p.eps0);
             } else {
                 int r0 = src.head_n - j; if (r0 < 0) r0 += Rs;
                 int r1 = r0 - 1; if (r1 < 0) r1 += Rs;
                 const int i0 = src.roff + r0, i1 = src.roff + r1;
                 py0 = pl.py[i0]; py1 = pl.py[i1];
                 if (TURB != WG_TURB_NONE) { pz0 = pl.pz[i0]; pz1 = pl.pz[i1]; }
-                if (pl.r4) {       // large farms: the two bracketing records are 32 contiguous bytes (one line, not three)
-                    const uint4 g0 = pl.r4[i0], g1 = pl.r4[i1];
-                    a0 = g0.x; b0_ = g0.y; u0 = __uint_as_float(g0.z); a1 = g1.x; b1_ = g1.y; u1 = __uint_as_float(g1.z);
-                } else {
-                    u0 = pl.ue[i0]; u1 = pl.ue[i1];
-                    a0 = pl.ra[i0]; a1 = pl.ra[i1]; b0_ = pl.rb[i0]; b1_ = pl.rb[i1];
+                {
+                    const uint2 g0 = pl.rec(i0), g1 = pl.rec(i1);
+                    a0 = g0.x; b0_ = g0.y; a1 = g1.x; b1_ = g1.y;
                 }
             }
-            eval_pair(i, tl, s2, t, dx, wgt, py0, py1, pz0, pz1, a0, a1, b0_, b1_, u0, u1);
+            eval_pair(i, tl, s2, t, dx, wgt, py0, py1, pz0, pz1, a0, a1, b0_, b1_);
         }
         lds_barrier<NT>();
         // thread t: superposition in ascending source order
@@ -723,7 +727,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             // (3) software-pipelined: a thread's NEXT candidate is decoded and its gathers requested before the current one
             // is evaluated (cfg3: ~520 candidates on 256 threads — two or three trips, whose gather round trips would
             // otherwise add up)
-            struct Cand { int t, s2, jp0; float wgt; double dx; uint4 q0, q1; float y0, y1; bool ok; };
+            struct Cand { int t, s2, jp0; float wgt; double dx; uint2 q0, q1; float y0, y1; bool ok; };
             auto lf_issue = [&](Cand& k, const int c) __attribute__((always_inline)) {
                 k.ok = false;
                 if (c >= c1) return;
@@ -749,7 +753,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 if (k.jp0 < 0) r0 = 0;          // (released in this step: nothing to fetch — any slot of the ring will do)
                 if (k.jp0 + 1 < 0) r1 = 0;
                 const int i0 = src.roff + r0, i1 = src.roff + r1;
-                k.q0 = pl.r4[i0]; k.q1 = pl.r4[i1];
+                k.q0 = pl.rec(i0); k.q1 = pl.rec(i1);      // (the interleaved record the advection pass streams: the pair is 16 contiguous bytes)
                 k.y0 = pl.py[i0]; k.y1 = pl.py[i1];
                 k.ok = true;
             };
@@ -763,13 +767,12 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 const int jp0 = k.jp0, jp1 = jp0 + 1;
                 float py0 = k.y0, py1 = k.y1;
                 unsigned a0 = k.q0.x, b0_ = k.q0.y, a1 = k.q1.x, b1_ = k.q1.y;
-                float u0 = __uint_as_float(k.q0.z), u1 = __uint_as_float(k.q1.z);
-                if (jp0 < 0) { py0 = (float)src.yr; u0 = src.rue; a0 = pack_a(src.rct, src.rk); b0_ = pack_b(src.reps, src.rhv); }
-                if (jp1 < 0) { py1 = (float)src.yr; u1 = src.rue; a1 = pack_a(src.rct, src.rk); b1_ = pack_b(src.reps, src.rhv); }
-                if (jp0 >= 0 && jp0 < n_valid) py0 = m0_advect(py0, a0, b0_, jp0, s_off_f, p.dpart_f, p.inv_D, p.dt);
-                if (jp1 >= 0 && jp1 < n_valid) py1 = m0_advect(py1, a1, b1_, jp1, s_off_f, p.dpart_f, p.inv_D, p.dt);
+                if (jp0 < 0) { py0 = (float)src.yr; a0 = pack_a(src.rct, src.rk); b0_ = pack_b(src.rue * ue_inv, src.rhv); }
+                if (jp1 < 0) { py1 = (float)src.yr; a1 = pack_a(src.rct, src.rk); b1_ = pack_b(src.rue * ue_inv, src.rhv); }
+                if (jp0 >= 0 && jp0 < n_valid) py0 = m0_advect(py0, a0, b0_, jp0, s_off_f, p.dpart_f, p.inv_D, p.dt, p.eps0);
+                if (jp1 >= 0 && jp1 < n_valid) py1 = m0_advect(py1, a1, b1_, jp1, s_off_f, p.dpart_f, p.inv_D, p.dt, p.eps0);
                 if (c == 0) WG_STAMP(12);
-                eval_pair(c - c0, 0, k.s2, k.t, k.dx, k.wgt, py0, py1, 0.f, 0.f, a0, a1, b0_, b1_, u0, u1);
+                eval_pair(c - c0, 0, k.s2, k.t, k.dx, k.wgt, py0, py1, 0.f, 0.f, a0, a1, b0_, b1_);
                 if (c == 0) WG_STAMP(13);
             }
             lds_barrier<NT>();
@@ -803,13 +806,10 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
     unsigned* __restrict__ gra = d.rec_a + pbase;
     unsigned* __restrict__ grb = d.rec_b + pbase;
     // large farms (256-thread workgroups): the frozen record is gathered from a 16-byte AoS copy, see phase A
-    constexpr bool AOS = (NT == 256);
     // chain pruning is compiled into the large-farm variant only: there the advection pass is traffic-bound and a
     // skipped quad saves real time; in the small-farm variants the extra predicate cost registers (spills at the 96
     // VGPR budget: +26 % on cfg2) and was measured slower even with two thirds of the particles skipped
     constexpr bool PRUNE = (NT == 256);
-    uint4* __restrict__ gr4 = d.rec4 + pbase;
-    float* __restrict__ gue = d.u_e + pbase;
     if (RES && TURB == WG_TURB_NONE) {
         // compact rings, steady inflow: the unit of work is a quad of 4 consecutive ring slots (one owner turbine per
         // quad: ring lengths are multiples of 4).  Only chains that hold a particle of a yawed turbine move (hv != 0),
@@ -846,12 +846,12 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 if (full) cnt = nqd;
                 else if (kl == 0) {
                     // A resting chain only receives this step's new particles (at most 3 here).  They are written straight to
-                    // their ring slots — py, the interleaved record, the record copy: three small stores per particle, no load —
+                    // their ring slots — py and the interleaved record: two small stores per particle, no load —
                     // instead of listing their quads for the advection pass, which read-modify-writes whole quads (two or three
                     // lines fetched to change 28 bytes).  The slots hold the chain's oldest particles (pre-step ages >= R -
                     // n_emit), which no bracket of this step can touch, so the stores need not wait for the gathers in flight.
                     const float y0 = (float)tq.yr;
-                    const unsigned na = pack_a(tq.rct, tq.rk), nb = pack_b(tq.reps, tq.rhv);
+                    const unsigned na = pack_a(tq.rct, tq.rk), nb = pack_b(tq.rue * ue_inv, tq.rhv);
 #pragma unroll
                     for (int e = 0; e < 3; ++e) {
                         if (e < n_emit) {
@@ -859,7 +859,6 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                             const int ix = tq.roff + r;
                             pl.py[ix] = y0;
                             reinterpret_cast<uint2*>(pl.ra)[ix] = make_uint2(na, nb);
-                            pl.r4[ix] = make_uint4(na, nb, __float_as_uint(tq.rue), 0u);
                         }
                     }
                 }
@@ -962,8 +961,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             r.t = (int)(ent >> qsh); r.kq = (int)(ent & ((1u << qsh) - 1u));
             r.q = valid ? (T[r.t].roff >> 2) + r.kq : 0;
             r.py = reinterpret_cast<const float4*>(pl.py)[r.q];
-            r.ra = reinterpret_cast<const uint4*>(pl.ra)[GL ? 2 * r.q : r.q];
-            r.rb = GL ? reinterpret_cast<const uint4*>(pl.ra)[2 * r.q + 1] : reinterpret_cast<const uint4*>(pl.rb)[r.q];
+            r.ra = reinterpret_cast<const uint4*>(pl.ra)[IL ? 2 * r.q : r.q];
+            r.rb = IL ? reinterpret_cast<const uint4*>(pl.ra)[2 * r.q + 1] : reinterpret_cast<const uint4*>(pl.rb)[r.q];
         };
         constexpr bool GLP2 = (GL && (WG_ADV_PIPE >= 2)) || (LFP && (WG_ADV_PIPE_LF >= 2));
         if (GL) {
@@ -976,9 +975,9 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             // reads below the wait)
             const int l = tid & 63;
             wg_wait_vmem();
-            const uint4* gat4 = reinterpret_cast<const uint4*>(gat);
-            uint4 g_q0 = gat4[l], g_q1 = gat4[64 + l];
-            float g_py0 = gat[512 + l], g_py1 = gat[512 + 64 + l];
+            const unsigned* gatu = reinterpret_cast<const unsigned*>(gat);
+            uint2 g_q0 = make_uint2(gatu[l], gatu[64 + l]), g_q1 = make_uint2(gatu[128 + l], gatu[192 + l]);
+            float g_py0 = gat[256 + l], g_py1 = gat[320 + l];
             // (GLP: the first quad of the advection pass is requested now — its round trip runs under the deficit
             // evaluation below)
             if (GLP) adv_request_to(nq_, tid, tid < nlist_pre);
@@ -989,8 +988,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     lds_barrier<NT>();
                     gl_rest = gl_issue(c, gl_nc);
                     wg_wait_vmem();
-                    g_q0 = gat4[l]; g_q1 = gat4[64 + l];
-                    g_py0 = gat[512 + l]; g_py1 = gat[512 + 64 + l];
+                    g_q0 = make_uint2(gatu[l], gatu[64 + l]); g_q1 = make_uint2(gatu[128 + l], gatu[192 + l]);
+                    g_py0 = gat[256 + l]; g_py1 = gat[320 + l];
                 }
                 if (b_ok) {
                     const int i = b_i, tl = b_tl, s2 = b_s2, j = b_j;
@@ -998,15 +997,15 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     const float wgt = b_wgt;
                     const TurbLds& src = T[s2];
                     const int jp0 = j - n_emit, jp1 = jp0 + 1;
-                    float py0 = g_py0, u0 = __uint_as_float(g_q0.z), py1 = g_py1, u1 = __uint_as_float(g_q1.z);
+                    float py0 = g_py0, py1 = g_py1;
                     if (gl_rest) { py0 = (float)src.yr; py1 = py0; }      // (not fetched: see gl_issue)
                     unsigned a0 = g_q0.x, b0_ = g_q0.y, a1 = g_q1.x, b1_ = g_q1.y;
                     // released in this step: the turbine's record, at the turbine
-                    if (jp0 < 0) { py0 = (float)src.yr; u0 = src.rue; a0 = pack_a(src.rct, src.rk); b0_ = pack_b(src.reps, src.rhv); }
-                    if (jp1 < 0) { py1 = (float)src.yr; u1 = src.rue; a1 = pack_a(src.rct, src.rk); b1_ = pack_b(src.reps, src.rhv); }
-                    if (jp0 >= 0 && jp0 < n_valid) py0 = m0_advect(py0, a0, b0_, jp0, s_off_f, p.dpart_f, p.inv_D, p.dt);
-                    if (jp1 >= 0 && jp1 < n_valid) py1 = m0_advect(py1, a1, b1_, jp1, s_off_f, p.dpart_f, p.inv_D, p.dt);
-                    eval_pair(i, tl, s2, tl, dx, wgt, py0, py1, 0.f, 0.f, a0, a1, b0_, b1_, u0, u1);
+                    if (jp0 < 0) { py0 = (float)src.yr; a0 = pack_a(src.rct, src.rk); b0_ = pack_b(src.rue * ue_inv, src.rhv); }
+                    if (jp1 < 0) { py1 = (float)src.yr; a1 = pack_a(src.rct, src.rk); b1_ = pack_b(src.rue * ue_inv, src.rhv); }
+                    if (jp0 >= 0 && jp0 < n_valid) py0 = m0_advect(py0, a0, b0_, jp0, s_off_f, p.dpart_f, p.inv_D, p.dt, p.eps0);
+                    if (jp1 >= 0 && jp1 < n_valid) py1 = m0_advect(py1, a1, b1_, jp1, s_off_f, p.dpart_f, p.inv_D, p.dt, p.eps0);
+                    eval_pair(i, tl, s2, tl, dx, wgt, py0, py1, 0.f, 0.f, a0, a1, b0_, b1_);
                 }
             }
             lds_barrier<NT>();
@@ -1045,8 +1044,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 t = (int)(ent >> qsh); kq = (int)(ent & ((1u << qsh) - 1u));
                 q = (T[t].roff >> 2) + kq;
                 py = reinterpret_cast<const float4*>(pl.py)[q];
-                ra = reinterpret_cast<const uint4*>(pl.ra)[GL ? 2 * q : q];
-                rb = GL ? reinterpret_cast<const uint4*>(pl.ra)[2 * q + 1] : reinterpret_cast<const uint4*>(pl.rb)[q];
+                ra = reinterpret_cast<const uint4*>(pl.ra)[IL ? 2 * q : q];
+                rb = IL ? reinterpret_cast<const uint4*>(pl.ra)[2 * q + 1] : reinterpret_cast<const uint4*>(pl.rb)[q];
             }
             TurbLds& tq = T[t];
             const int R = tq.rlen, hd = tq.head;
@@ -1055,13 +1054,13 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             int e0 = r0 - hd - 1; if (e0 < 0) e0 += R;         // emission index of slot r0 (r0+i: e0+i)
             const bool emits = (e0 < n_emit) || (n_emit > 0 && e0 + 3 >= R);   // wraps past R-1 -> 0
             float pyv[4] = {py.x, py.y, py.z, py.w};
-            // (GL: `ra` / `rb` hold the quad's interleaved records (a0 b0 a1 b1) (a2 b2 a3 b3))
-            unsigned rav[4] = {ra.x, GL ? ra.z : ra.y, GL ? rb.x : ra.z, GL ? rb.z : ra.w};
-            unsigned rbv[4] = {GL ? ra.y : rb.x, GL ? ra.w : rb.y, GL ? rb.y : rb.z, rb.w};
+            // (IL: `ra` / `rb` hold the quad's interleaved records (a0 b0 a1 b1) (a2 b2 a3 b3))
+            unsigned rav[4] = {ra.x, IL ? ra.z : ra.y, IL ? rb.x : ra.z, IL ? rb.z : ra.w};
+            unsigned rbv[4] = {IL ? ra.y : rb.x, IL ? ra.w : rb.y, IL ? rb.y : rb.z, rb.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int j = j0 - i; if (j < 0) j += R;
-                if (j < n_valid) pyv[i] = m0_advect(pyv[i], rav[i], rbv[i], j, s_off_f, p.dpart_f, p.inv_D, p.dt);
+                if (j < n_valid) pyv[i] = m0_advect(pyv[i], rav[i], rbv[i], j, s_off_f, p.dpart_f, p.inv_D, p.dt, p.eps0);
             }
             const float y0 = (float)tq.yr;
             if (emits) {
@@ -1069,12 +1068,10 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 for (int i = 0; i < 4; ++i) {
                     int ei = e0 + i; if (ei >= R) ei -= R;
                     if (ei < n_emit) {
-                        pyv[i] = y0; rav[i] = pack_a(tq.rct, tq.rk); rbv[i] = pack_b(tq.reps, tq.rhv);
-                        if (pl.r4) pl.r4[4 * q + i] = make_uint4(rav[i], rbv[i], __float_as_uint(tq.rue), 0u);
-                        else pl.ue[4 * q + i] = tq.rue;
+                        pyv[i] = y0; rav[i] = pack_a(tq.rct, tq.rk); rbv[i] = pack_b(tq.rue * ue_inv, tq.rhv);
                     }
                 }
-                if (GL) {
+                if (IL) {
                     reinterpret_cast<uint4*>(pl.ra)[2 * q] = make_uint4(rav[0], rbv[0], rav[1], rbv[1]);
                     reinterpret_cast<uint4*>(pl.ra)[2 * q + 1] = make_uint4(rav[2], rbv[2], rav[3], rbv[3]);
                 } else {
@@ -1153,7 +1150,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     const unsigned rav = ras[u], rbv = rbs[u];
                     if (j < n_valid) {
                         const float xrel = s_off_f + (float)j * p.dpart_f;
-                        const float sp = rec_k(rav) * (xrel * p.inv_D) + rec_eps(rbv);
+                        const float sp = rec_k(rav) * (xrel * p.inv_D) + rec_eps(rav, p.eps0);
                         if (TURB == WG_TURB_RANDOM) {
                             int rfull = hfull - j; if (rfull < 0) rfull += P;
                             const uint32_t key = (uint32_t)(tv[u] * P + rfull);
@@ -1168,10 +1165,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     const float y0 = (float)tq.yr;
                     if (ev[u] < n_emit) {
                         pyv[u] = y0; pzv[u] = p.hub; vlv = 0.f; wlv = 0.f;
-                        const unsigned na = pack_a(tq.rct, tq.rk), nb = pack_b(tq.reps, tq.rhv);
+                        const unsigned na = pack_a(tq.rct, tq.rk), nb = pack_b(tq.rue * ue_inv, tq.rhv);
                         pl.ra[ix] = na; pl.rb[ix] = nb;
-                        if (pl.r4) pl.r4[ix] = make_uint4(na, nb, __float_as_uint(tq.rue), 0u);
-                        else pl.ue[ix] = tq.rue;
                     }
                     const float ex = j < n_valid ? fabsf(pyv[u] - y0) + fabsf(pzv[u] - p.hub) : 0.f;   // (valid particles only)
                     if (ex > tq.bd) atomicMax(reinterpret_cast<int*>(&tq.bd), __float_as_int(ex));
@@ -1267,7 +1262,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 TurbLds& tq = T[t];
                 if (j < n_valid) {
                     const float xrel = s_off_f + (float)j * p.dpart_f;
-                    const float sp = rec_k(rav[u]) * (xrel * p.inv_D) + rec_eps(rbv[u]);
+                    const float sp = rec_k(rav[u]) * (xrel * p.inv_D) + rec_eps(rav[u], p.eps0);
                     if (TURB == WG_TURB_RANDOM) {
                         fv[u] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)ix, 1u, 0x50u);
                         fw[u] = wg_turb_normal(tc.seed, sr.istep, (uint32_t)ix, 2u, 0x50u);
@@ -1281,10 +1276,8 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 const float y0 = (float)tq.yr;
                 if (e < n_emit) {
                     pyv[u] = y0; pzv[u] = p.hub; vlv[u] = 0.f; wlv[u] = 0.f;
-                    const unsigned na = pack_a(tq.rct, tq.rk), nb = pack_b(tq.reps, tq.rhv);
+                    const unsigned na = pack_a(tq.rct, tq.rk), nb = pack_b(tq.rue * ue_inv, tq.rhv);
                     gra[ix] = na; grb[ix] = nb;
-                    if (AOS) gr4[ix] = make_uint4(na, nb, __float_as_uint(tq.rue), 0u);
-                    else gue[ix] = tq.rue;
                 }
                 const float ex = j < n_valid ? fabsf(pyv[u] - y0) + fabsf(pzv[u] - p.hub) : 0.f;   // (valid particles only)
                 if (ex > tq.bd) atomicMax(reinterpret_cast<int*>(&tq.bd), __float_as_int(ex));
@@ -1360,7 +1353,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     int j = j0s[q] - i; if (j < 0) j += P;
                     if (j < n_valid) {
                         const float xrel = s_off_f + (float)j * p.dpart_f;
-                        const float sp = rec_k(rav[i]) * (xrel * p.inv_D) + rec_eps(rbv[i]);
+                        const float sp = rec_k(rav[i]) * (xrel * p.inv_D) + rec_eps(rav[i], p.eps0);
                         pyv[i] += rec_hv(rbv[i]) * m0_cfrac(rec_ct(rav[i]), sp) * p.dt;
                     }
                 }
@@ -1371,9 +1364,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     for (int i = 0; i < 4; ++i) {
                         int ei = e0s[q] + i; if (ei >= P) ei -= P;
                         if (ei < n_emit) {
-                            pyv[i] = y0; rav[i] = pack_a(tq.rct, tq.rk); rbv[i] = pack_b(tq.reps, tq.rhv);
-                            if (AOS) gr4[i4 + i] = make_uint4(rav[i], rbv[i], __float_as_uint(tq.rue), 0u);
-                            else gue[i4 + i] = tq.rue;
+                            pyv[i] = y0; rav[i] = pack_a(tq.rct, tq.rk); rbv[i] = pack_b(tq.rue * ue_inv, tq.rhv);
                         }
                     }
                     *reinterpret_cast<uint4*>(gra + i4) = make_uint4(rav[0], rav[1], rav[2], rav[3]);
@@ -1444,26 +1435,17 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                     int r1 = r0 - 1; if (r1 < 0) r1 += Rs;
                     const unsigned sb = RES ? (unsigned)T[s2].roff : (unsigned)(s2 * P);
                     const unsigned i0 = sb + (unsigned)r0, i1 = sb + (unsigned)r1;
-                    // one round of gathers.  Small farms: the lines were streamed by this workgroup a moment ago (L2
-                    // hits).  Large farms (AOS): the particle state of the resident workgroups exceeds L2, every gather
-                    // line comes from HBM and these gathers were half of the kernel's traffic -> the frozen record is
-                    // read from its 16-byte copy (written once, at emission): the two bracketing particles are 32
-                    // contiguous bytes, a pair touches two lines (record, py) instead of four (py, u_e, rec_a, rec_b)
+                    // one round of gathers: the lines were streamed by this workgroup a moment ago (py, the record words —
+                    // round 6: the record carries u_e, there is no separate copy to fetch)
                     const float py0 = RES ? pl.py[i0] : gpy[i0], py1 = RES ? pl.py[i1] : gpy[i1];
-                    float u0, u1;
                     unsigned a0, a1, b0_, b1_;
-                    if (RES) {      // the farm's particle state is in LDS: no global gathers at all
-                        u0 = pl.ue[i0]; u1 = pl.ue[i1];
+                    if (RES) {
                         a0 = pl.ra[i0]; a1 = pl.ra[i1]; b0_ = pl.rb[i0]; b1_ = pl.rb[i1];
-                    } else if (AOS) {
-                        const uint4 q0 = gr4[i0], q1 = gr4[i1];
-                        u0 = __uint_as_float(q0.z); u1 = __uint_as_float(q1.z);
-                        a0 = q0.x; a1 = q1.x; b0_ = q0.y; b1_ = q1.y;
                     } else {
-                        u0 = gue[i0]; u1 = gue[i1];
                         a0 = gra[i0]; a1 = gra[i1]; b0_ = grb[i0]; b1_ = grb[i1];
                     }
-                    const float k0 = rec_k(a0), k1 = rec_k(a1), e0 = rec_eps(b0_), e1 = rec_eps(b1_);
+                    const float u0 = rec_uf(b0_) * ue_max, u1 = rec_uf(b1_) * ue_max;
+                    const float k0 = rec_k(a0), k1 = rec_k(a1), e0 = rec_eps(a0, p.eps0), e1 = rec_eps(a1, p.eps0);
                     const float c0 = rec_ct(a0), c1 = rec_ct(a1);
                     const float w0 = 1.0f - wgt, w1 = wgt;
                     const float yc = w0 * py0 + w1 * py1;
@@ -1798,7 +1780,7 @@ k_flow(const FlowP p, const FlowPtrs d, const int mode, const float* __restrict_
         pl.py = d.py + pbase;
         if (p.rec_il) { pl.ra = d.rec_a + 2 * pbase; pl.rb = pl.ra + 1; }      // interleaved record (GL handles)
         else { pl.ra = d.rec_a + pbase; pl.rb = d.rec_b + pbase; }
-        pl.ue = d.u_e ? d.u_e + pbase : nullptr; pl.r4 = d.rec4 ? d.rec4 + pbase : nullptr;
+        pl.il = p.rec_il;
         pl.pz = TURB != WG_TURB_NONE ? d.pz + pbase : nullptr;
         pl.vl = TURB != WG_TURB_NONE ? d.vlp + pbase : nullptr;
         pl.wl = TURB != WG_TURB_NONE ? d.wlp + pbase : nullptr;
@@ -2196,22 +2178,17 @@ k_windspeed(const FlowP p, const FlowPtrs d, const int e, const int farm, const 
             int r1 = r0 - 1; if (r1 < 0) r1 += P;
             i0 = pbase + (size_t)s2 * P + r0; i1 = pbase + (size_t)s2 * P + r1;
         }
-        unsigned a0, a1, b0, b1;
-        float ue0, ue1;
-        if (d.rec4) {
-            const uint4 q0 = d.rec4[i0], q1 = d.rec4[i1];
-            a0 = q0.x; a1 = q1.x; b0 = q0.y; b1 = q1.y; ue0 = __uint_as_float(q0.z); ue1 = __uint_as_float(q1.z);
-        } else {
-            const size_t rs = p.rec_il ? 2 : 1;      // (interleaved record: rec_b = rec_a + 1)
-            a0 = d.rec_a[i0 * rs]; a1 = d.rec_a[i1 * rs]; b0 = d.rec_b[i0 * rs]; b1 = d.rec_b[i1 * rs]; ue0 = d.u_e[i0]; ue1 = d.u_e[i1];
-        }
+        const size_t rs = p.rec_il ? 2 : 1;      // (interleaved record: rec_b = rec_a + 1)
+        const unsigned a0 = d.rec_a[i0 * rs], a1 = d.rec_a[i1 * rs], b0 = d.rec_b[i0 * rs], b1 = d.rec_b[i1 * rs];
+        const float ue_max_ = p.ue_scale * (float)cx.ws;
+        const float ue0 = rec_uf(b0) * ue_max_, ue1 = rec_uf(b1) * ue_max_;
         const float w0 = 1.0f - wgt, w1 = wgt;
         const float yc = w0 * d.py[i0] + w1 * d.py[i1];
         float zc = p.hub;
         if (p.turb_mode != WG_TURB_NONE) zc = w0 * d.pz[i0] + w1 * d.pz[i1];
         const float ctv = w0 * rec_ct(a0) + w1 * rec_ct(a1);
         const float kv = w0 * rec_k(a0) + w1 * rec_k(a1);
-        const float epv = w0 * rec_eps(b0) + w1 * rec_eps(b1);
+        const float epv = w0 * rec_eps(a0, p.eps0) + w1 * rec_eps(a1, p.eps0);
         const float uev = w0 * ue0 + w1 * ue1;
         const float sp = kv * ((float)dx * p.inv_D) + epv;
         const float sig = sp * p.D;

@@ -15,11 +15,19 @@ __device__ __forceinline__ float m0_cfrac(float ct, float sp) {
 }
 
 // Frozen emission record of a wake particle, packed into two 32-bit words (16-bit fixed point):
-//   rec_a = ct (unorm16 over [0,1])   | k  (unorm16 over [0,0.25]) << 16
-//   rec_b = eps (unorm16 over [0,1])  | hv (snorm16 over [-16,16] m/s) << 16
-// Quantisation steps (1.5e-5, 3.8e-6, 1.5e-5, 4.9e-4 m/s) are an order of magnitude below the fp32 parity
-// tolerances; the streaming pass reads 8 instead of 16 record bytes per particle, and the
-// "does this particle move" test needs only rec_b.
+//   rec_a = ct (unorm16 over [0,1])              | k  (unorm16 over [0,0.25]) << 16
+//   rec_b = u_e / u_max (unorm16 over [0,1])     | hv (snorm16 over [-16,16] m/s) << 16
+// (round 6) u_e — the rotor wind speed at emission, the scale of the particle's deficit — lives IN the record: the brackets of
+// a (target, source) pair are then read from the very lines the advection pass streams (record + py), and the separate
+// 16-byte gather copy of rounds 2-5 (rec4: one more 128-byte line per candidate pair, 29 % of what a cfg2 step fetched, +14 %
+// env-steps/s without it) is gone.  Its place was the initial wake width eps, which is a function of ct alone (model M0:
+// eps = eps0 sqrt(beta), beta = (1 + sqrt(1 - ct)) / (2 sqrt(1 - ct))) and is recomputed where it is needed (m0_eps).
+// u_e is stored relative to u_max = FlowP::ue_scale x the episode's free-stream speed: 1 x under steady inflow (the deficits
+// only lower u: u_e <= U exactly), 2 x with turbulence — a step of U / 65535 ~ 2e-4 m/s, i.e. <= 5e-5 m/s of deficit per wake.
+// Quantisation steps (1.5e-5, 3.8e-6, ~2e-4 m/s, 4.9e-4 m/s) are an order of magnitude below the fp32 parity tolerances
+// (DESIGN.md §6).  (Tried first: u_e in 18 bits over [0, 32) m/s and hv in 14 — hv's 2e-3 m/s step moves a particle 5 cm in
+// 50 s, which the steepest flank of a wake turns into 1e-3 m/s at a rotor: 24 oracle tests 30 % over their bar.)
+// The streaming pass reads 8 record bytes per particle, and the "does this particle move" test needs only rec_b.
 #define WG_K_MAX 0.25f
 #define WG_HV_MAX 16.0f
 __device__ __forceinline__ unsigned pack_a(float ct, float k) {
@@ -27,26 +35,37 @@ __device__ __forceinline__ unsigned pack_a(float ct, float k) {
     const unsigned qk = (unsigned)(fminf(fmaxf(k, 0.f), WG_K_MAX) * (65535.0f / WG_K_MAX) + 0.5f);
     return qc | (qk << 16);
 }
-__device__ __forceinline__ unsigned pack_b(float eps, float hv) {
-    const unsigned qe = (unsigned)(fminf(fmaxf(eps, 0.f), 1.f) * 65535.0f + 0.5f);
+// (uf = u_e / u_max)
+__device__ __forceinline__ unsigned pack_b(float uf, float hv) {
+    const unsigned qu = (unsigned)(fminf(fmaxf(uf, 0.f), 1.f) * 65535.0f + 0.5f);
     const int qh = (int)rintf(fminf(fmaxf(hv, -WG_HV_MAX), WG_HV_MAX) * (32767.0f / WG_HV_MAX));
-    return qe | ((unsigned)(qh & 0xffff) << 16);
+    return qu | ((unsigned)(qh & 0xffff) << 16);
 }
 __device__ __forceinline__ float rec_ct(unsigned a) { return (float)(a & 0xffffu) * (1.0f / 65535.0f); }
 __device__ __forceinline__ float rec_k(unsigned a) { return (float)(a >> 16) * (WG_K_MAX / 65535.0f); }
-__device__ __forceinline__ float rec_eps(unsigned b) { return (float)(b & 0xffffu) * (1.0f / 65535.0f); }
+__device__ __forceinline__ float rec_uf(unsigned b) { return (float)(b & 0xffffu) * (1.0f / 65535.0f); }      // u_e / u_max
 __device__ __forceinline__ float rec_hv(unsigned b) { return (float)((int)b >> 16) * (WG_HV_MAX / 32767.0f); }
 __device__ __forceinline__ bool rec_moves(unsigned b) { return (b >> 16) != 0u; }
+// initial wake width of a particle whose (clamped) thrust coefficient is ct: eps0 sqrt(beta(ct)) — the value the emission computes,
+// recomputed from the record's ct (quantised to 1.5e-5: d eps <= 5e-6)
+__device__ __forceinline__ float m0_eps(float ct, float eps0) {
+    // beta = (1 + rq) / (2 rq) = 0.5 + 0.5 / rq, rq = sqrt(1 - ct): two transcendental instructions (v_rsq, v_sqrt) on the advection
+    // pass's per-particle chain
+    const float beta = __builtin_fmaf(0.5f, __builtin_amdgcn_rsqf(1.0f - ct), 0.5f);
+    return eps0 * __builtin_amdgcn_sqrtf(beta);
+}
+__device__ __forceinline__ float rec_eps(unsigned a, float eps0) { return m0_eps(rec_ct(a), eps0); }
 
 // lateral position of a wake particle of age j (pre-step clock s_off) after one step of Hill-vortex deflection.  ONE
 // definition with explicit fused operations: the advection pass stores this value and the deficit phase of the steady
 // compact variant recomputes it for the particles it brackets (see flow_step) — both must produce the same bits
 // whatever the surrounding code lets the compiler contract.
 __device__ __forceinline__ float m0_advect(float py, unsigned ra, unsigned rb, int j, float s_off_f, float dpart_f,
-                                           float inv_D, float dt) {
+                                           float inv_D, float dt, float eps0) {
     const float xrel = __builtin_fmaf((float)j, dpart_f, s_off_f);
-    const float sp = __builtin_fmaf(rec_k(ra), xrel * inv_D, rec_eps(rb));
-    return __builtin_fmaf(rec_hv(rb) * m0_cfrac(rec_ct(ra), sp), dt, py);
+    const float ct = rec_ct(ra);
+    const float sp = __builtin_fmaf(rec_k(ra), xrel * inv_D, m0_eps(ct, eps0));
+    return __builtin_fmaf(rec_hv(rb) * m0_cfrac(ct, sp), dt, py);
 }
 
 // x^y for x >= 0 via v_log_f32 / v_exp_f32 (HIP's __powf expands to the full-precision routine)

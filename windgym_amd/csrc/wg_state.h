@@ -7,9 +7,8 @@
 //
 //   particle SoA, fp32, [n_slots][N*P] each, ring index fastest -> a workgroup streams contiguous memory:
 //       py                      transverse position of the wake particle (r/w every step)
-//       rec_a, rec_b            frozen emission record ct|k, eps|hv as 16-bit fixed point (read by the advection pass)
-//       u_e | rec4              rotor wind speed at emission (small farms) | 16-byte gather copy of the frozen record incl.
-//                               u_e (farms whose workgroups have 256 threads: their deficit gathers miss L2)
+//       rec_a, rec_b            frozen emission record ct|k, u_e|hv as fixed point (read by the advection pass AND by the deficit
+//                               phase's bracket gathers: round 6 — rounds 2-5 kept u_e in a separate array / a 16-byte gather copy)
 //       pz, vlp, wlp            vertical position + low-pass filtered transverse turbulence (box inflow only)
 //   turbine SoA, fp32, [n_slots][N]: yaw, u, v, w, ti_loc, power, ct
 //   sensors, fp32, per ctx: ring[ch][N][H_ch], farm ring[ch][H_ch]   (MesClass deques)
@@ -169,9 +168,8 @@ struct WgEnv {
 
 struct WgPtrs {
     // particles
-    float *py, *u_e, *pz, *vlp, *wlp;   // u_e: rotor wind speed at emission (small farms; NULL when rec4 is used)
-    uint4* rec4;               // gather copy of the frozen emission record: (rec_a, rec_b, bits of u_e, 0), written at emission
-    unsigned *rec_a, *rec_b;   // packed emission record: ct|k and eps|hv as 16-bit fixed point
+    float *py, *pz, *vlp, *wlp;
+    unsigned *rec_a, *rec_b;   // packed emission record: ct|k (16 + 16 bits) and u_e|hv (18 + 14 bits) as fixed point
     // turbines [n_slots][N]
     float *yaw, *u, *v, *w, *ti_loc, *power, *ct;
     float* bnd;               // [n_slots][N][4]: running maxima over a chain: excursion, k, eps (pruning bounds); [3] = bits of the emission count at the chain's last moving emission (TurbLds::mvl)
