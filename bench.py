@@ -422,7 +422,7 @@ def main():
         # algorithmic bytes of one k_flow launch, from two counts made on the device: the wake
         # particles the advection passes streamed (chain pruning: a particle behind the last turbine is not touched)
         # and the farm flow-steps executed (live farms + background development of the next episodes).
-        # per particle: py read+write (8) + packed record ct|k, eps|hv read (8); per turbine: state r/w + positions;
+        # per particle: py read+write (8) + packed record ct|k, u_e|hv read (8); per turbine: state r/w + positions;
         # box: + pz,vlp,wlp r/w (24) + 8 corners x (v, w) of the meandering box per particle (64), 8 corners x
         # (u, v, w) of the fine box per rotor point (96); wake-added turbulence (row a7): 8 corners x (u, v, w) of the
         # isotropic box at the rotor points of every target with a candidate source wake (96 each), counted on the device
@@ -478,8 +478,8 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el_med / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "storage": "state fp32; the frozen emission record of a wake particle (ct, k, eps, hv) is stored as 4 x 16-bit "
-                       "fixed point (8 B per particle), positions in fp64",
+            "storage": "state fp32; the frozen emission record of a wake particle (ct, k, u_e / U, hv) is stored as 4 x 16-bit "
+                       "fixed point (8 B per particle; eps is recomputed from ct), positions in fp64",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload][1]} "
                                    f"(O={env.obs_dim}), {B} envs/GPU, F={F} farms/env "
                                    f"({'Baseline reward' if F == 2 else 'Power_avg reward'}), P={cfg.n_particles}, "

@@ -47,7 +47,9 @@ typedef enum wg_status {
     WG_ERR_NOMEM = -6,
     WG_ERR_RANGE = -7         /* a wake particle's emission record left the range of its 16-bit fixed-point storage
                                * (wake-growth rate k > 0.25, i.e. local TI > 0.65, or deflection speed |hv| > 16 m/s,
-                               * i.e. rotor wind speed > 40 m/s): the value was saturated; reported by wg_check      */
+                               * i.e. rotor wind speed > 40 m/s, or — turbulent inflow only — a rotor wind speed above twice
+                               * the episode's free-stream speed, the scale of the record's u_e field): the value was
+                               * saturated; reported by wg_check                                                      */
 } wg_status;
 
 /* sensor channels, order fixed by MesClass.turb_mes.get_measurements (MesClass.py:328-351) */

@@ -135,9 +135,9 @@ def _extreme_cfg(ti, ws, n_envs=2, **kw):
 
 def test_u16_record_at_the_edge_of_its_range_matches_the_oracle(hip):
     """Largest values the config validation admits: TI = 0.5 (k = 0.38 sqrt(0.5^2 + added^2) + 0.004 up to 0.23 of the
-    0.25 the unorm16 covers), 25 m/s with the yaws driven to +-45 deg (|hv| = 0.4 sin(45) 25 = 7.1 of 16 m/s; eps up to
-    0.2 sqrt(beta)).  The quantisation steps (1.5e-5, 3.8e-6, 1.5e-5, 4.9e-4 m/s) must keep the stated tolerances there
-    too, and nothing saturates (wg_check)."""
+    0.25 the unorm16 covers), 25 m/s with the yaws driven to +-45 deg (|hv| = 0.4 sin(45) 25 = 7.1 of 16 m/s; u_e as a
+    16-bit fraction of 25 m/s: a step of 3.8e-4 m/s).  The quantisation steps (ct 1.5e-5, k 3.8e-6, u_e U / 65535, hv 4.9e-4 m/s)
+    must keep the stated tolerances there too, and nothing saturates (wg_check)."""
     import torch
     from oracle import oracle as om
     cfg = _extreme_cfg(0.5, 25.0)

@@ -51,3 +51,22 @@ def test_turbulence_box_files_round_trip(tmp_path):
     import pytest
     with pytest.raises(NotImplementedError):
         load_box(str(d / "TF_hdf5.nc"), dxyz=(3, 3, 3))
+
+
+def test_v80_table_against_the_numbers_the_reference_tree_holds():
+    """SURVEY Appendix D restated the V80 power / Ct table "from recall" (py_wake is not in the container).  What the reference
+    tree itself pins of it: MesClass's default power_max = 2 000 000 W (MesClass.py:165, 400) is the turbine's rated power, and
+    WindFarmEnv derives the same scale as max(turbine.power(arange(10, 25))) (Wind_Farm_Env.py:112) — the table must give
+    exactly that; D = 80 m and hub height 70 m are used by the example layouts (4 D spacing = 320 m, README).  The notebook's
+    per-turbine powers (Example 1, cell 4: 1.14 / 0.71 / 1.09 / 0.10 MW at rotor speeds 9.04 / 8.66 / 9.55 / 4.63 m/s) are single
+    draws under "Random" turbulence — the speeds are instantaneous outputs of the same stochastic run, not table nodes — so
+    they can only BRACKET the table: each power must lie between the table's values at +-10 % of its rotor wind speed."""
+    import numpy as np
+    from windgym_amd.turbine import V80
+    v = V80()
+    assert v.diameter() == 80.0 and v.hub_height() == 70.0
+    assert float(max(v.power(np.arange(10, 25, 1)))) == 2_000_000.0
+    assert float(v.power(np.array([25.0]))[0]) == 2_000_000.0 and float(v.power(np.array([2.9]))[0]) == 0.0
+    for ws, p_mw in ((9.04, 1.14), (8.66, 0.71), (9.55, 1.09), (4.63, 0.10)):
+        lo, hi = float(v.power(np.array([0.9 * ws]))[0]) / 1e6, float(v.power(np.array([1.1 * ws]))[0]) / 1e6
+        assert lo <= p_mw <= hi, (ws, p_mw, lo, hi)

@@ -24,6 +24,9 @@
 // farm_mes.add_measurements (Wind_Farm_Env.py:480-495, 822-864, 943-979; BasicControllers.py:10-73; MesClass.py:568-591).
 #include <hip/hip_runtime.h>
 
+#ifndef WG_ENV_ABLATE
+#define WG_ENV_ABLATE 0     // profiling builds only: 1 = no bracket gathers, 2 = no advection pass, 4 = trivial advection arithmetic, 8 = no rotor-point loop
+#endif
 #include "wg_env_common.h"
 
 #ifndef WG_ENV_S_UNROLL
@@ -495,9 +498,12 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
                 if (cd.jp0 < 0) r0 = 0;           // (released in this step: nothing to fetch — any slot of the ring will do)
                 if (cd.jp0 + 1 < 0) r1 = 0;
                 const unsigned sb = (unsigned)rg.w * pstride + (unsigned)rg.x;
-cd.q0 = rc_env[sb + (unsigned)r0]; cd.q1 = rc_env[sb + (unsigned)r1];
+                cd.q0 = rc_env[sb + (unsigned)r0]; cd.q1 = rc_env[sb + (unsigned)r1];
                 cd.y0 = 0.f; cd.y1 = 0.f;
                 if (!cd.rest) { cd.y0 = py_env[sb + (unsigned)r0]; cd.y1 = py_env[sb + (unsigned)r1]; }
+#if WG_ENV_ABLATE & 1      // (profiling builds, wrong results: no bracket gathers)
+                cd.q0 = make_uint2(Lrec4[gs].x, Lrec4[gs].y); cd.q1 = cd.q0; cd.y0 = cd.y1 = Lsrc4[gs].y;
+#endif
                 cd.ok = true;
             };
             Cand ca, cb_;
@@ -595,7 +601,7 @@ cd.q0 = rc_env[sb + (unsigned)r0]; cd.q1 = rc_env[sb + (unsigned)r1];
                     const float ninv = -inv2s2;
                     float acc = 0.f;
 #pragma unroll 4
-                    for (int sI = 0; sI < S; ++sI) {
+                    for (int sI = 0; sI < ((WG_ENV_ABLATE & 8) ? 1 : S); ++sI) {
                         const float2 rp = rpt[sI];
                         const float dy = yt + rp.x * cgt - yc;
                         acc += amp * __expf((dy * dy + rp.y) * ninv);
@@ -681,7 +687,7 @@ cd.q0 = rc_env[sb + (unsigned)r0]; cd.q1 = rc_env[sb + (unsigned)r1];
                     }
                 }
                 const int inc = env_scan(cnt, tid);
-                nlist = __builtin_amdgcn_readlane(inc, 63);
+                nlist = (WG_ENV_ABLATE & 2) ? 0 : __builtin_amdgcn_readlane(inc, 63);
                 if (full) {
                     const int base = inc - cnt;
                     const unsigned tag = (unsigned)g << 10;

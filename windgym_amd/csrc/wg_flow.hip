@@ -752,7 +752,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 int r1 = src.head - k.jp0 - 1; if (r1 < 0) r1 += Rs;
                 if (k.jp0 < 0) r0 = 0;          // (released in this step: nothing to fetch — any slot of the ring will do)
                 if (k.jp0 + 1 < 0) r1 = 0;
-                const int i0 = src.roff + r0, i1 = src.roff + r1;
+                const int i0 = (WG_ABLATE & 128) ? src.roff : src.roff + r0, i1 = (WG_ABLATE & 128) ? src.roff + 1 : src.roff + r1;   // (profiling: gathers that hit one line per chain)
                 k.q0 = pl.rec(i0); k.q1 = pl.rec(i1);      // (the interleaved record the advection pass streams: the pair is 16 contiguous bytes)
                 k.y0 = pl.py[i0]; k.y1 = pl.py[i1];
                 k.ok = true;

@@ -62,6 +62,9 @@ __device__ __forceinline__ float rec_eps(unsigned a, float eps0) { return m0_eps
 // whatever the surrounding code lets the compiler contract.
 __device__ __forceinline__ float m0_advect(float py, unsigned ra, unsigned rb, int j, float s_off_f, float dpart_f,
                                            float inv_D, float dt, float eps0) {
+#if defined(WG_ENV_ABLATE) && (WG_ENV_ABLATE & 4)      // (profiling builds, wrong results: what the advection arithmetic costs)
+    return py + dt * rec_hv(rb) * 0.5f;
+#endif
     const float xrel = __builtin_fmaf((float)j, dpart_f, s_off_f);
     const float ct = rec_ct(ra);
     const float sp = __builtin_fmaf(rec_k(ra), xrel * inv_D, m0_eps(ct, eps0));
