@@ -642,6 +642,7 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
         }
         if (rc) { wg_destroy(h); return rc; }
         f.lds_bytes = (int)((off + 15) & ~(size_t)15);
+        if (const char* ev = wg_hook("WG_LDS_PAD")) f.lds_bytes = std::min(lds_limit, f.lds_bytes + atoi(ev));      // (measurement: what a workgroup's LDS size alone costs)
         f.dt = p.dt; f.D = p.D; f.inv_D = p.inv_D; f.hub = p.hub; f.dpart_f = (float)p.dpart; f.R_rot = 0.5f * p.D;
         f.inv_N = 1.0f / (float)p.N; f.inv_S = 1.0f / (float)p.S; f.inv_P = 1.0f / (float)p.P;
         f.inv_power_avg = 1.0f / (float)(p.power_avg > 0 ? p.power_avg : 1);

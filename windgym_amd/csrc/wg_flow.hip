@@ -589,7 +589,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 int r1 = src.head - jp1; if (r1 < 0) r1 += Rs;
                 if (jp0 < 0) r0 = 0;      // (released in this step: nothing to fetch — any slot of the ring will do)
                 if (jp1 < 0) r1 = 0;
-                const int i0 = (WG_ABLATE & 128) ? src.roff : src.roff + r0, i1 = (WG_ABLATE & 128) ? src.roff + 1 : src.roff + r1;   // (profiling: gathers that hit one line per chain)
+                const int i0 = src.roff + r0, i1 = src.roff + r1;
                 const bool g0 = jp0 >= 0, g1 = jp1 >= 0;
                 py0 = py1 = (float)src.yr;
                 a0 = a1 = pack_a(src.rct, src.rk); b0_ = b1_ = pack_b(src.rue * ue_inv, src.rhv);
@@ -752,7 +752,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 int r1 = src.head - k.jp0 - 1; if (r1 < 0) r1 += Rs;
                 if (k.jp0 < 0) r0 = 0;          // (released in this step: nothing to fetch — any slot of the ring will do)
                 if (k.jp0 + 1 < 0) r1 = 0;
-                const int i0 = (WG_ABLATE & 128) ? src.roff : src.roff + r0, i1 = (WG_ABLATE & 128) ? src.roff + 1 : src.roff + r1;   // (profiling: gathers that hit one line per chain)
+                const int i0 = src.roff + r0, i1 = src.roff + r1;
                 k.q0 = pl.rec(i0); k.q1 = pl.rec(i1);      // (the interleaved record the advection pass streams: the pair is 16 contiguous bytes)
                 k.y0 = pl.py[i0]; k.y1 = pl.py[i1];
                 k.ok = true;
@@ -887,12 +887,20 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 tag = (unsigned)t << qsh;
                 full = moving || n_emit >= 4 || n_emit >= R;
                 if (full) cnt = nqd;
-                else {
-                    int prev = -1;
-                    for (int e = 0; e < n_emit; ++e) {
-                        int r = tq.head + 1 + e; if (r >= R) r -= R;
-                        if ((r >> 2) != prev) ++cnt;
-                        prev = r >> 2;
+                else if (kl == 0) {
+                    // (a resting chain only receives this step's new particles: stored straight to their ring slots, as in the
+                    // single-wave variant above — no load, no trip through the pass; cfg3: +4 %, the baseline farms' workgroups
+                    // are the tail of the launch and their pass was one exposed round trip)
+                    const float y0 = (float)tq.yr;
+                    const unsigned na = pack_a(tq.rct, tq.rk), nb = pack_b(tq.rue * ue_inv, tq.rhv);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        if (e < n_emit) {
+                            int r = tq.head + 1 + e; if (r >= R) r -= R;
+                            const int ix = tq.roff + r;
+                            pl.py[ix] = y0;
+                            reinterpret_cast<uint2*>(pl.ra)[ix] = make_uint2(na, nb);
+                        }
                     }
                 }
             }
@@ -908,15 +916,6 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             const int base = woff + __shfl(inc - mine, (tid & 63) & ~(lpt - 1), 64);
             if (full) {
                 for (int i = kl; i < nqd; i += lpt) ql[base + i] = (unsigned short)(tag | (unsigned)i);
-            } else if (kl == 0 && cnt > 0) {
-                const TurbLds& tq = T[t];
-                const int R = tq.rlen;
-                int prev = -1, o = base;
-                for (int e = 0; e < n_emit; ++e) {
-                    int r = tq.head + 1 + e; if (r >= R) r -= R;
-                    if ((r >> 2) != prev) ql[o++] = (unsigned short)(tag | (unsigned)(r >> 2));
-                    prev = r >> 2;
-                }
             }
         } else {
         if (tid == 0) *nq = 0;
