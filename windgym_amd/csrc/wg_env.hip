@@ -107,8 +107,17 @@ __device__ __forceinline__ float env_slot_sums(const float v, const int N, const
 // paths of the background context (episode set-up, a second flow step, the first observation) are off the live wave's chain;
 // the waves meet at ONE workgroup barrier before the live context's wave runs the glue (k_flow_env).  `smem` is the wave's
 // own region, `wv` its context.
-template <bool NOISE, int WPE, int GLUE>
-__device__ __forceinline__ void env_flow(char* const smem, const int wv, const int mode, const float* __restrict__ actions,
+// SPLIT (small batches: every wave of 4 per env resident with at most two per SIMD): each context has a SECOND wave (role 1, the
+// "pass wave") that runs the quad list and the advection pass of a launch in which its context takes exactly one flow step —
+// a fifth of the main wave's instructions, and at these sizes a wave's life is its instruction chain (one dependent issue per
+// ~7 cycles, EXPERIMENTS.md).  The pass wave repeats the prologue and the emission records from the same inputs (deterministic:
+// the same records), lists the moving chains, requests its first trip and then waits for an LDS flag the main wave raises when
+// the evaluation's gathers — which read the particles in their PRE-step state — have landed; only then does it store.  It
+// writes the particles and the chains' excursion bounds (WgBnd.x), the main wave everything else; neither reads what the
+// other writes in the same launch.  Launches in which the context sets an episode up or takes two or more flow steps run
+// unsplit (both waves decide that from the same words), the pass wave rests.
+template <bool NOISE, int WPE, int GLUE, bool SPLIT>
+__device__ __forceinline__ void env_flow(char* const smem, const int wv, const int role, const int mode, const float* __restrict__ actions,
                                          const uint8_t* __restrict__ mask, const int chunk, EnvFlowOut& out) {
     const int tid = threadIdx.x & 63, e = blockIdx.x;
     int N, F, NS, NL;
@@ -141,7 +150,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
     // ---- prologue: every independent global load up front (one exposed round trip) ----------------------------------
     typedef const __attribute__((address_space(4))) WgEnv* CEnvPtr;
     int env_live;
-    bool role_live = false, role_dev = false, defer_init = false;
+    bool role_live = false, role_dev = false, defer_init = false, split_on = false;
     float yaw, tu, tti, oyaw;
     {
         const KArgsPtr k0 = wg_cold_args();
@@ -198,6 +207,12 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
         int env_done = WG_HDR_I(done), env_shadow_iters = WG_HDR_I(shadow_iters), env_steps_done = WG_HDR_I(steps_done);
         int env_timestep = WG_HDR_I(timestep), env_time_max_live = WG_HDR_I(time_max_live);
 #undef WG_HDR_I
+        if (SPLIT && role == 1) {
+            // (the pass wave: its flag down, and every word it has requested in its registers, before the barrier lets the main
+            // waves go on — they rewrite some of those words at their ends)
+            if (tid == 0) *reinterpret_cast<int*>(smem + WG_ENV_OFF_HDR) = 0;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
         if (WPE == 2) {
             // Two waves per env read the same header, and the live context's wave rewrites it in its glue tail.  Both waves hold
             // their copies BEFORE either passes this barrier, so neither can see a word the other has already advanced, whatever
@@ -226,6 +241,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
             // background context's wave sees its own, the live wave gets it through LDS after the barrier)
             const int bg_pending = WPE == 2 ? (is_live_c ? 0 : __shfl(init_pending, 0, 64)) : __shfl(init_pending, (env_live ^ 1) * F * N, 64);
             out.bg_init_pending = autoreset && bg_pending;
+            if (SPLIT && role == 1 && out.bg_init_pending) return;      // (an episode set-up in this launch: the context runs unsplit)
             if (autoreset && bg_pending && WPE == 1 && (WG_ENV_DEFER_INIT != 0) && !out.truncates) {
                 // rare path (one context per truncation): the retired context's next episode is set up AFTER this wave's step
                 // (below) — its background lanes rest in this launch, the set-up needs no reload of the wave's state, and the
@@ -265,6 +281,12 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
             role_dev = is_live_c && !masked_out;
             budget = chunk;
         }
+        if (SPLIT) {
+            // exactly one flow step for every slot of the wave that steps at all, no episode set-up in this launch
+            const bool two = valid && role_dev && budget >= 2;
+            split_on = mode == WG_MODE_STEP && k0->p.K == 1 && !out.bg_init_pending && !defer_init && !__ballot(two);
+            if (role == 1 && !split_on) return;
+        }
         if (WPE == 2 && valid && t == 0) {      // (what the other wave's glue reads of this one, also if it has nothing to do)
             my.dev_rem = dev_rem; my.fill_rem = fill_rem; my.bg_init = out.bg_init_pending; my.n_flow = 0; my.out_pw = 0.f;
         }
@@ -273,7 +295,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
             if (!__ballot(any_work)) {
                 // (two waves per env: the resting background wave of an episode completed in an EARLIER launch prepares its
                 // first observation now — see the end of this function)
-                if (WPE == 2 && (WG_ENV_FIRST_OBS_LATER != 0) && mode == WG_MODE_STEP && !is_live_c && autoreset) {
+                if (WPE == 2 && (WG_ENV_FIRST_OBS_LATER != 0) && mode == WG_MODE_STEP && !is_live_c && autoreset && role == 0) {
                     const int d0 = __shfl(dev_rem, 0, 64), f0 = __shfl(fill_rem, 0, 64), np0 = __shfl(n_pushed, 0, 64);
                     const KArgsPtr kf = wg_cold_args();
                     if (d0 == 0 && f0 == 0 && kf->d.gd->next_obs_ok != nullptr && kf->d.gd->next_obs_ok[ctx_id] == 0) {
@@ -437,7 +459,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
                 const bool cd = (s2 != t) & (dxf >= 0.f) & (gap <= lim0);
                 cmask |= cd ? (1u << s2) : 0u;
             }
-            if (!stepping) cmask = 0u;
+            if (!stepping || (SPLIT && role == 1)) cmask = 0u;
         }
         // this target's range of the list: ascending (target lane, source) order by construction
         int cbeg, nc;
@@ -641,6 +663,19 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
                 }
             }
         }
+        if (SPLIT && split_on && role == 0) {
+            // every gather of this step has landed (the evaluation consumed them): the pass wave may store
+            __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0)
+            if (tid == 0) env_flag_set(reinterpret_cast<int*>(smem + 2 * wg_cold_args()->p.env_lds + WG_ENV_OFF_HDR));
+            // (roofline accounting of the pass this wave does not run: particles the step reads or writes)
+            if (stepping) {
+                const int4 rg = Lring[g];
+                const unsigned mvl = __float_as_uint(Lsrc2[g].y);
+                const int n_emit = my.n_emit;
+                const bool full = (mvl != 0u && (int)(my.n_emitted - mvl) < rg.y) || n_emit >= 4 || n_emit >= rg.y;
+                stream_acc += full ? rg.y : n_emit;
+            }
+        }
         if (stepping) {
             const float ti_f = my.ti_f;
             tu = my.ws_f;
@@ -650,7 +685,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
         lds_barrier<64>();          // (the quad list below aliases the staging arrays)
         WG_STAMP(9);
 
-        {
+        if (!(SPLIT && split_on && role == 0)) {
             const KArgsPtr kp = wg_cold_args();
             const unsigned pstride = (unsigned)kp->p.pstride;
             const size_t pb_env = (size_t)(e * 2 * F + kbase) * pstride;
@@ -767,6 +802,9 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
             QuadReq qa, qb;
             qa.py = qb.py = make_float4(0.f, 0.f, 0.f, 0.f); qa.ra = qa.rb = qb.ra = qb.rb = make_uint4(0u, 0u, 0u, 0u);
             request(qa, tid);
+            if (SPLIT && role == 1) {      // (its first trip is in flight; no store before the main wave's gathers have landed)
+                if (!env_flag_wait(reinterpret_cast<int*>(smem + WG_ENV_OFF_HDR))) atomicOr(kp->d.status, WG_STATUS_BIT_STATE);
+            }
 #if WG_ENV_PP & 1
             for (int base = 0; base < nlist; base += 128) {
                 request(qb, base + 64 + tid);
@@ -785,6 +823,10 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
         }
         lds_barrier<64>();
         WG_STAMP(3);
+        if (SPLIT && role == 1) {      // the pass wave: the chains' excursion bounds, nothing else
+            if (stepping) reinterpret_cast<float4*>(wg_cold_args()->d.bnd)[(unsigned)((e * 2 * F + kbase) * N + g)].x = Lsrc2[g].x;
+            return;
+        }
 
         // per-turbine tail: the step's emissions are in the ring now; power / thrust with the current yaw (model M0 step 5),
         // WindFarmEnv._take_measurements (Wind_Farm_Env.py:480-495) accumulated over the K sub-steps and, at the end of the env
@@ -908,7 +950,10 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
         const float2 s2 = Lsrc2[g];
         ke->d.yaw[tb] = yaw; ke->d.u[tb] = tu; ke->d.v[tb] = 0.f; ke->d.w[tb] = 0.f;
         ke->d.ti_loc[tb] = tti; ke->d.power[tb] = tpow; ke->d.ct[tb] = tct;
-        reinterpret_cast<float4*>(ke->d.bnd)[tb] = make_float4(s2.x, s4.z, s4.w, s2.y);
+        if (SPLIT && split_on) {      // (the excursion bound is the pass wave's)
+            float4* const bp = reinterpret_cast<float4*>(ke->d.bnd) + tb;
+            bp->y = s4.z; bp->z = s4.w; bp->w = s2.y;
+        } else reinterpret_cast<float4*>(ke->d.bnd)[tb] = make_float4(s2.x, s4.z, s4.w, s2.y);
         if (role_live && farm == 0) ke->d.old_yaw[(unsigned)(e * N + t)] = oyaw;
         if (t == 0) {
             const int n_flow = my.n_flow, P = ke->p.P;
@@ -969,8 +1014,8 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
 // k_flow_env<NOISE, 1 / 2>: step() as ONE launch — the env's wave runs its glue (lean_step: sums-mode handles without TI /
 // farm-level entries; 2 = with the per-agent observation buffer of the PettingZoo facade) as the tail of its flow step.  No
 // cross-workgroup dependency: the wave owns both contexts of its env.  (Wind_Farm_Env.py:920-1034 in one kernel.)
-template <bool NOISE, int GLUE, int WPE>
-__global__ void __launch_bounds__(64 * WPE, WG_ENV_WAVES)
+template <bool NOISE, int GLUE, int WPE, bool SPLIT = false>
+__global__ void __launch_bounds__(64 * WPE * (SPLIT ? 2 : 1), WG_ENV_WAVES)
 k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __restrict__ actions,
            const uint8_t* __restrict__ mask, const int chunk, const WgParams gp_, const WgPtrs gd_,
            float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out,
@@ -981,11 +1026,16 @@ k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __res
     __syncthreads();
 #endif
     // (WPE 2: wave c of the workgroup serves context c of the env, in its own LDS region)
-    const int wv = WPE == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int wv4 = WPE == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int wv = SPLIT ? (wv4 & 1) : wv4, role = SPLIT ? (wv4 >> 1) : 0;      // (SPLIT: waves 2, 3 = the pass waves of contexts 0, 1)
     const int lds_wave = WPE == 2 ? wg_cold_args()->p.env_lds : 0;
-    char* const sm = smem + wv * lds_wave;
+    char* const sm = smem + wv4 * lds_wave;
     EnvFlowOut fo;
-    env_flow<NOISE, WPE, GLUE>(sm, wv, mode, actions, mask, chunk, fo);
+    env_flow<NOISE, WPE, GLUE, SPLIT>(sm, wv, role, mode, actions, mask, chunk, fo);
+    if (SPLIT && role == 1) {      // (a pass wave: the workgroup barrier of a truncating step, nothing else)
+        if (GLUE != 0 && fo.truncates) { __builtin_amdgcn_s_waitcnt(0x0070); __syncthreads(); }
+        return;
+    }
     if (GLUE != 0) {
         // (every store of the flow part — rings, turbine state, headers, a prepared first observation — has left the wave
         // before anything reads it back; LDS still holds the slots' records)
@@ -1072,9 +1122,12 @@ extern "C" void wg_launch_step_env(const FlowP* p, const FlowPtrs* d, const WgPa
     const size_t lds = (size_t)p->env_lds * wpe;
 #define WG_STEP_ENV(NZ, G, W) hipLaunchKernelGGL((k_flow_env<NZ, G, W>), dim3(grid), dim3(64 * W), lds, st, *p, *d, (int)WG_MODE_STEP, actions, \
                                                  (const uint8_t*)nullptr, 0, *gp, *gd, obs, reward, trunc, final_obs)
-#define WG_STEP_ENV_W(NZ, G) do { if (wpe == 2) WG_STEP_ENV(NZ, G, 2); else WG_STEP_ENV(NZ, G, 1); } while (0)
+#define WG_STEP_ENV_S(NZ, G) hipLaunchKernelGGL((k_flow_env<NZ, G, 2, true>), dim3(grid), dim3(256), 2 * lds, st, *p, *d, (int)WG_MODE_STEP, actions, \
+                                                (const uint8_t*)nullptr, 0, *gp, *gd, obs, reward, trunc, final_obs)
+#define WG_STEP_ENV_W(NZ, G) do { if (wpe == 2 && p->env_split) WG_STEP_ENV_S(NZ, G); else if (wpe == 2) WG_STEP_ENV(NZ, G, 2); else WG_STEP_ENV(NZ, G, 1); } while (0)
     if (gd->multi_out) { if (p->noise) WG_STEP_ENV_W(true, 2); else WG_STEP_ENV_W(false, 2); }
     else { if (p->noise) WG_STEP_ENV_W(true, 1); else WG_STEP_ENV_W(false, 1); }
 #undef WG_STEP_ENV_W
+#undef WG_STEP_ENV_S
 #undef WG_STEP_ENV
 }

@@ -168,6 +168,20 @@ __device__ __forceinline__ void env_first_obs(const int ctx_id, const int n_push
     if (lane == 0) d.next_obs_ok[ctx_id] = 1;
 }
 
+// LDS flag between two waves of a workgroup (k_flow_env's pass waves).  The wait is bounded: a protocol error must not hang the
+// GPU — the caller latches WG_STATUS_BIT_STATE on a time-out.
+__device__ __forceinline__ void env_flag_set(int* const f) {
+    __atomic_store_n(f, 1, __ATOMIC_RELAXED);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ bool env_flag_wait(int* const f) {
+    for (int n = 0; n < (1 << 22); ++n) {
+        if (__atomic_load_n(f, __ATOMIC_RELAXED) != 0) { asm volatile("" ::: "memory"); return true; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
+
 struct EnvFlowOut {          // what the flow part hands to the glue tail of k_step_env
     int env_live, bg_init_pending;
     int truncates;            // the env truncates in this step (known from its header): the only case in which the glue needs the
