@@ -3,8 +3,9 @@ never runs).  Every pair runs the SAME handle configuration through two kernel v
 
   fused   step() as ONE launch (k_flow_env with the glue as its tail)  vs  flow launch + k_glue_lean      -> bit-identical
   wpe     two waves per env (one per context)                          vs  one wave per env               -> bit-identical
-  split   a second wave per context runs the advection pass            vs  the same two-wave kernel       -> bit-identical,
-          (default at <= 512 envs for farms with long chains)              without it                        state blobs too
+  split   a third wave per env runs the advection pass of the          vs  the same two-wave kernel       -> bit-identical,
+          running episode's context (default at <= 1024 envs for              without it                        state blobs too
+          farms with long chains)
   gl      k_flow_env (lane = farm slot x turbine)                      vs  k_flow GL (one farm slot per workgroup)
           same state layout, arithmetic and summation orders; the compiler contracts a few products differently, so the
           flow values agree to the last bits (held to 1e-5 relative over hundreds of steps), decisions (truncation) exactly

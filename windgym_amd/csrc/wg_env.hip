@@ -107,18 +107,17 @@ __device__ __forceinline__ float env_slot_sums(const float v, const int N, const
 // paths of the background context (episode set-up, a second flow step, the first observation) are off the live wave's chain;
 // the waves meet at ONE workgroup barrier before the live context's wave runs the glue (k_flow_env).  `smem` is the wave's
 // own region, `wv` its context.
-// SPLIT (small batches: every wave of 4 per env resident with at most two per SIMD): each context has a SECOND wave (role 1, the
-// "pass wave") that runs the quad list and the advection pass of a launch in which its context takes exactly one flow step —
-// a fifth of the main wave's instructions, and at these sizes a wave's life is its instruction chain (one dependent issue per
-// ~7 cycles, EXPERIMENTS.md).  The pass wave repeats the prologue and the emission records from the same inputs (deterministic:
-// the same records), lists the moving chains, requests its first trip and then waits for an LDS flag the main wave raises when
-// the evaluation's gathers — which read the particles in their PRE-step state — have landed; only then does it store.  It
-// writes the particles and the chains' excursion bounds (WgBnd.x), the main wave everything else; neither reads what the
-// other writes in the same launch.  Launches in which the context sets an episode up or takes two or more flow steps run
-// unsplit (both waves decide that from the same words), the pass wave rests.
+// SPLIT (small batches, WPE 2: three waves per env): the running episode's context has a SECOND wave (role 1, the "pass wave")
+// that runs the quad list and the advection pass of its step — a fifth of the main wave's instructions, and at these sizes a
+// wave's life is its instruction chain (one dependent issue per ~7 cycles, EXPERIMENTS.md); the background context's wave has
+// no glue behind its step and is not the env's last wave.  The pass wave repeats the prologue and the emission records from the
+// same inputs (deterministic: the same records), lists the moving chains, requests its first trip and then waits for an LDS flag
+// the main wave raises when the evaluation's gathers — which read the particles in their PRE-step state — have landed; only then
+// does it store.  It writes the particles and the chains' excursion bounds (WgBnd.x), the main wave everything else; neither
+// reads what the other writes in the same launch.  `smem_pass`: the pass wave's LDS region, whose header slot holds the flag.
 template <bool NOISE, int WPE, int GLUE, bool SPLIT>
-__device__ __forceinline__ void env_flow(char* const smem, const int wv, const int role, const int mode, const float* __restrict__ actions,
-                                         const uint8_t* __restrict__ mask, const int chunk, EnvFlowOut& out) {
+__device__ __forceinline__ void env_flow(char* const smem, char* const smem_pass, const int wv, const int role, const int mode,
+                                         const float* __restrict__ actions, const uint8_t* __restrict__ mask, const int chunk, EnvFlowOut& out) {
     const int tid = threadIdx.x & 63, e = blockIdx.x;
     int N, F, NS, NL;
     float inv_N;
@@ -241,7 +240,6 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
             // background context's wave sees its own, the live wave gets it through LDS after the barrier)
             const int bg_pending = WPE == 2 ? (is_live_c ? 0 : __shfl(init_pending, 0, 64)) : __shfl(init_pending, (env_live ^ 1) * F * N, 64);
             out.bg_init_pending = autoreset && bg_pending;
-            if (SPLIT && role == 1 && out.bg_init_pending) return;      // (an episode set-up in this launch: the context runs unsplit)
             if (autoreset && bg_pending && WPE == 1 && (WG_ENV_DEFER_INIT != 0) && !out.truncates) {
                 // rare path (one context per truncation): the retired context's next episode is set up AFTER this wave's step
                 // (below) — its background lanes rest in this launch, the set-up needs no reload of the wave's state, and the
@@ -284,7 +282,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
         if (SPLIT) {
             // exactly one flow step for every slot of the wave that steps at all, no episode set-up in this launch
             const bool two = valid && role_dev && budget >= 2;
-            split_on = mode == WG_MODE_STEP && k0->p.K == 1 && !out.bg_init_pending && !defer_init && !__ballot(two);
+            split_on = mode == WG_MODE_STEP && k0->p.K == 1 && is_live_c && !defer_init && !__ballot(two);
             if (role == 1 && !split_on) return;
         }
         if (WPE == 2 && valid && t == 0) {      // (what the other wave's glue reads of this one, also if it has nothing to do)
@@ -666,7 +664,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
         if (SPLIT && split_on && role == 0) {
             // every gather of this step has landed (the evaluation consumed them): the pass wave may store
             __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0)
-            if (tid == 0) env_flag_set(reinterpret_cast<int*>(smem + 2 * wg_cold_args()->p.env_lds + WG_ENV_OFF_HDR));
+            if (tid == 0) env_flag_set(reinterpret_cast<int*>(smem_pass + WG_ENV_OFF_HDR));
             // (roofline accounting of the pass this wave does not run: particles the step reads or writes)
             if (stepping) {
                 const int4 rg = Lring[g];
@@ -1015,7 +1013,7 @@ __device__ __forceinline__ void env_flow(char* const smem, const int wv, const i
 // farm-level entries; 2 = with the per-agent observation buffer of the PettingZoo facade) as the tail of its flow step.  No
 // cross-workgroup dependency: the wave owns both contexts of its env.  (Wind_Farm_Env.py:920-1034 in one kernel.)
 template <bool NOISE, int GLUE, int WPE, bool SPLIT = false>
-__global__ void __launch_bounds__(64 * WPE * (SPLIT ? 2 : 1), WG_ENV_WAVES)
+__global__ void __launch_bounds__(64 * (WPE + (SPLIT ? 1 : 0)), WG_ENV_WAVES)
 k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __restrict__ actions,
            const uint8_t* __restrict__ mask, const int chunk, const WgParams gp_, const WgPtrs gd_,
            float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out,
@@ -1027,11 +1025,18 @@ k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __res
 #endif
     // (WPE 2: wave c of the workgroup serves context c of the env, in its own LDS region)
     const int wv4 = WPE == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-    const int wv = SPLIT ? (wv4 & 1) : wv4, role = SPLIT ? (wv4 >> 1) : 0;      // (SPLIT: waves 2, 3 = the pass waves of contexts 0, 1)
+    // (SPLIT: wave 2 = the pass wave of the running episode's context — which one, it reads from the env's header first: the main
+    // waves cannot rewrite it before the prologue's workgroup barrier, where this wave arrives with its loads done)
+    int wv = wv4, role = 0;
+    if (SPLIT && wv4 == 2) {
+        role = 1;
+        wv = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(wg_cold_args()->d.env + blockIdx.x)[offsetof(WgEnv, live) / 4]) & 1;
+    }
     const int lds_wave = WPE == 2 ? wg_cold_args()->p.env_lds : 0;
     char* const sm = smem + wv4 * lds_wave;
+    char* const sm_pass = smem + 2 * lds_wave;
     EnvFlowOut fo;
-    env_flow<NOISE, WPE, GLUE, SPLIT>(sm, wv, role, mode, actions, mask, chunk, fo);
+    env_flow<NOISE, WPE, GLUE, SPLIT>(sm, sm_pass, wv, role, mode, actions, mask, chunk, fo);
     if (SPLIT && role == 1) {      // (a pass wave: the workgroup barrier of a truncating step, nothing else)
         if (GLUE != 0 && fo.truncates) { __builtin_amdgcn_s_waitcnt(0x0070); __syncthreads(); }
         return;
@@ -1122,7 +1127,7 @@ extern "C" void wg_launch_step_env(const FlowP* p, const FlowPtrs* d, const WgPa
     const size_t lds = (size_t)p->env_lds * wpe;
 #define WG_STEP_ENV(NZ, G, W) hipLaunchKernelGGL((k_flow_env<NZ, G, W>), dim3(grid), dim3(64 * W), lds, st, *p, *d, (int)WG_MODE_STEP, actions, \
                                                  (const uint8_t*)nullptr, 0, *gp, *gd, obs, reward, trunc, final_obs)
-#define WG_STEP_ENV_S(NZ, G) hipLaunchKernelGGL((k_flow_env<NZ, G, 2, true>), dim3(grid), dim3(256), 2 * lds, st, *p, *d, (int)WG_MODE_STEP, actions, \
+#define WG_STEP_ENV_S(NZ, G) hipLaunchKernelGGL((k_flow_env<NZ, G, 2, true>), dim3(grid), dim3(192), (size_t)p->env_lds * 3, st, *p, *d, (int)WG_MODE_STEP, actions, \
                                                 (const uint8_t*)nullptr, 0, *gp, *gd, obs, reward, trunc, final_obs)
 #define WG_STEP_ENV_W(NZ, G) do { if (wpe == 2 && p->env_split) WG_STEP_ENV_S(NZ, G); else if (wpe == 2) WG_STEP_ENV(NZ, G, 2); else WG_STEP_ENV(NZ, G, 1); } while (0)
     if (gd->multi_out) { if (p->noise) WG_STEP_ENV_W(true, 2); else WG_STEP_ENV_W(false, 2); }

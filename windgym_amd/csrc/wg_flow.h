@@ -83,7 +83,7 @@ struct FlowP {
     int envw, env_lds, env_off_tab;
     int env_cap, envb_off_cl;         // k_flow_envb (wg_envb.hip, frozen-box inflow): staged wakes per chunk of targets; offset of the candidate list
     int env_wpe;                      // waves per env: 1, or 2 (a workgroup of two waves, one per context, each with its own LDS region of env_lds bytes)
-    int env_split;                    // k_flow_env's small-batch instantiation: a second wave per context runs the advection pass
+    int env_split;                    // k_flow_env's small-batch instantiation: a third wave per env runs the advection pass of the running episode's context
     int env_fused;                    // step() as ONE launch: the env's wave runs its glue (lean_step) as the tail of its flow step
     int env_inc;                      // env time steps per step(): 1 + extra_timestep_inc (the background plan's steps left)
     float env_eps_max;                // widest initial wake width a record can hold: min(1, eps0 sqrt(beta(ct = 0.96)))
