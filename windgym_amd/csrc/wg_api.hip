@@ -747,9 +747,10 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
     }
     if (const char* ev = wg_hook("WG_STEP_GRAPH")) h->graph_mode = atoi(ev) != 0;
     if (wg_hook("WG_DEBUG"))
-        fprintf(stderr, "[windgym] k_flow variant: %s, %d threads, LDS %d B per workgroup, slot stride %d floats\n",
+        fprintf(stderr, "[windgym] k_flow variant: %s%s, %d threads, LDS %d B per workgroup, slot stride %d floats\n",
                 h->fp.envw ? (h->fp.turb_mode == WG_TURB_NONE ? "compact rings / pair-major, one wave per env (k_flow_env)" : "compact rings / sample-major, one wave per env (k_flow_envb)")
                           : (h->fp.res ? "compact rings / pair-major" : "uniform rings / sample-major"),
+                h->fp.envw && h->fp.env_split ? " + a pass wave for the running episode's context" : "",
                 h->fp.block, h->fp.envw ? h->fp.env_lds : h->fp.lds_bytes, h->fp.pstride);
     *out = h;
     return 0;
