@@ -1,6 +1,7 @@
 """Oracle spot checks AT BENCH BATCH SIZE.  The step-for-step oracle tests of test_gpu_parity.py run a handful
 of envs; the soaks at BASELINE's batch sizes check properties only.  Here the FULL batch of each GPU config runs on the HIP
-path — the kernels, block orders and occupancies the bench line times (cfg2: one wave per env with the glue fused, 4096 envs;
+path — the kernels, block orders and occupancies the bench line times (cfg2: one wave per env with the glue fused, 4096 envs,
+and the three-waves-per-env instantiation of 512 / 1024 envs;
 cfg3: 256-thread large-farm variant, 512 envs; cfg4: per-agent buffer, 2048 envs; cfg5: k_flow_envb, the one-launch frozen-box
 kernel, 1024 envs on a small box) — and the CPU oracle replays 16 of its envs, spread over the batch, on the same global seeds and actions: every step
 for 300 steps, through at least one rollover of each sampled env where the episode length allows, with the bars of DESIGN.md §6.
@@ -92,6 +93,13 @@ def test_cfg2_4096_envs_on_the_bench_schedule(hip, oracle_lib):
     steps, background development spread over them: a fifth of the share per launch the 1.0 runs above give it) — 1250 steps, so
     that every sampled env rolls over under that schedule; the oracle replays its 16 envs at the same length."""
     _run(hip, oracle_lib, "cfg2", 4096, 5.0, (64, True, 2), steps=1250)
+
+
+@pytest.mark.parametrize("B", [512, 1024])
+def test_cfg2_small_batches_with_the_pass_wave(hip, oracle_lib, B):
+    """the small-batch instantiation (three waves per env: the running episode's advection pass on a wave of its own, its stores
+    behind an LDS flag) at the two batch sizes VERDICT r5 item 6 names, against the oracle through rollovers"""
+    _run(hip, oracle_lib, "cfg2", B, 1.0, (64, True, 2))
 
 
 def test_cfg3_512_envs_large_farm_variant(hip, oracle_lib):
