@@ -4,8 +4,10 @@ never runs).  Every pair runs the SAME handle configuration through two kernel v
   fused   step() as ONE launch (k_flow_env with the glue as its tail)  vs  flow launch + k_glue_lean      -> bit-identical
   wpe     two waves per env (one per context)                          vs  one wave per env               -> bit-identical
   split   a third wave per env runs the advection pass of the          vs  the same two-wave kernel       -> bit-identical,
-          running episode's context (default at <= 1024 envs for              without it                        state blobs too
-          farms with long chains)
+          running episode's context and fetches the glue's step-              without it                        state blobs too
+          independent inputs ahead (default at 513 .. 1024 envs for
+          farms with long chains); split_both: a fourth wave does the
+          background context's pass (default at <= 512 envs)
   gl      k_flow_env (lane = farm slot x turbine)                      vs  k_flow GL (one farm slot per workgroup)
           same state layout, arithmetic and summation orders; the compiler contracts a few products differently, so the
           flow values agree to the last bits (held to 1e-5 relative over hundreds of steps), decisions (truncation) exactly
@@ -52,9 +54,9 @@ def _pair(mode):
         return {"WG_FLOW_ENV": "1", "WG_STEP_FUSED": "1"}, {"WG_FLOW_ENV": "1", "WG_STEP_FUSED": "0"}, True
     if mode == "wpe":
         return {"WG_FLOW_ENV": "1", "WG_ENV_WPE": "2"}, {"WG_FLOW_ENV": "1", "WG_ENV_WPE": "1"}, True
-    if mode == "split":
-        return ({"WG_FLOW_ENV": "1", "WG_ENV_WPE": "2", "WG_ENV_SPLIT": "1"}, {"WG_FLOW_ENV": "1", "WG_ENV_WPE": "2", "WG_ENV_SPLIT": "0"},
-                True)
+    if mode in ("split", "split_both"):      # (a pass wave for the running episode's context / for both contexts)
+        return ({"WG_FLOW_ENV": "1", "WG_ENV_WPE": "2", "WG_ENV_SPLIT": "1" if mode == "split" else "2"},
+                {"WG_FLOW_ENV": "1", "WG_ENV_WPE": "2", "WG_ENV_SPLIT": "0"}, True)
     return {"WG_FLOW_ENV": "1"}, {"WG_FLOW_ENV": "0"}, False
 
 
@@ -109,7 +111,7 @@ def _ab(hip, mode, case, B, steps):
         if s % 50 == 49:
             same_fields(f"step {s}")
     a_env.check(); b_env.check()
-    if mode in ("fused", "split"):
+    if mode in ("fused", "split", "split_both"):
         # particles, rings, headers, window sums: the whole state.  (Not for "wpe": one wave per env defers a retired context's
         # episode set-up behind its step, so the BACKGROUND context's development runs a launch behind the two-wave schedule —
         # every output is equal, the not-yet-live episode's intermediate state is not.)
@@ -122,7 +124,8 @@ def _ab(hip, mode, case, B, steps):
 # every case at B = 64; the two bench shapes also at the large odd batch
 PAIRS = [(m, c, 64) for m in ("fused", "wpe", "gl") for c in ("cfg2_4x4", "cfg4_3x3_per_agent_buffer", "two_turb_noise_K", "cfg2_one_farm")]
 PAIRS += [(m, c, 389) for m in ("fused", "wpe", "gl") for c in ("cfg2_4x4", "cfg4_3x3_per_agent_buffer")]
-PAIRS += [("split", c, B) for c in ("cfg2_4x4", "cfg4_3x3_per_agent_buffer", "two_turb_noise_K", "cfg2_one_farm") for B in (64, 389)]
+PAIRS += [(m, c, B) for m in ("split", "split_both") for c in ("cfg2_4x4", "cfg4_3x3_per_agent_buffer", "two_turb_noise_K", "cfg2_one_farm")
+          for B in (64, 389)]
 
 
 @pytest.mark.parametrize("mode,case,B", PAIRS)

@@ -631,9 +631,9 @@ extern "C" int wg_create(const wg_config* c, int device, wg_handle* out) {
             // small batches: a pass wave for the running episode's context (wg_env.hip, SPLIT: three waves per env) while they sit at
             // most three to a SIMD (1024 envs) and a farm's pass is four trips or more (cfg2 x 256 / 512 / 1024: +19 / +18 / +10 %; x 2048:
             // -21 %, more than one dispatch round; cfg4's 3 x 3 farm: two trips, -3 to -6 %: the wave costs more than it takes over)
-            f.env_split = (env_ok && !envb_ok && f.env_wpe == 2 && p.B <= 1024 && qf >= 256 && p.K == 1 && 3 * f.env_lds <= lds_limit) ? 1 : 0;
+            f.env_split = (env_ok && !envb_ok && f.env_wpe == 2 && p.B <= 1024 && qf >= 256 && p.K == 1 && 4 * f.env_lds + 4096 <= lds_limit) ? (p.B <= 512 ? 2 : 1) : 0;
             if (const char* ev = wg_hook("WG_ENV_SPLIT"))
-                f.env_split = (atoi(ev) != 0 && env_ok && !envb_ok && f.env_wpe == 2 && p.B <= 2048 && p.K == 1 && 3 * f.env_lds <= lds_limit) ? 1 : 0;
+                f.env_split = (atoi(ev) != 0 && env_ok && !envb_ok && f.env_wpe == 2 && p.B <= 2048 && p.K == 1 && 4 * f.env_lds + 4096 <= lds_limit) ? (atoi(ev) == 2 ? 2 : 1) : 0;
             if (envb_ok) f.env_wpe = envb_wpe;
         }
         // packed emission record: two arrays, or one interleaved (ct|k, u_e|hv) array for the steady compact variants whose

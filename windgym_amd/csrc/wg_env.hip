@@ -107,7 +107,8 @@ __device__ __forceinline__ float env_slot_sums(const float v, const int N, const
 // paths of the background context (episode set-up, a second flow step, the first observation) are off the live wave's chain;
 // the waves meet at ONE workgroup barrier before the live context's wave runs the glue (k_flow_env).  `smem` is the wave's
 // own region, `wv` its context.
-// SPLIT (small batches, WPE 2: three waves per env): the running episode's context has a SECOND wave (role 1, the "pass wave")
+// SPLIT (small batches, WPE 2; 1: three waves per env, 2: four — a pass wave for the background context too, whose step has no glue
+// behind it but the longer pass: both its farms' chains move): the running episode's context has a SECOND wave (role 1, the "pass wave")
 // that runs the quad list and the advection pass of its step — a fifth of the main wave's instructions, and at these sizes a
 // wave's life is its instruction chain (one dependent issue per ~7 cycles, EXPERIMENTS.md); the background context's wave has
 // no glue behind its step and is not the env's last wave.  The pass wave repeats the prologue and the emission records from the
@@ -115,8 +116,9 @@ __device__ __forceinline__ float env_slot_sums(const float v, const int N, const
 // the main wave raises when the evaluation's gathers — which read the particles in their PRE-step state — have landed; only then
 // does it store.  It writes the particles and the chains' excursion bounds (WgBnd.x), the main wave everything else; neither
 // reads what the other writes in the same launch.  `smem_pass`: the pass wave's LDS region, whose header slot holds the flag.
-template <bool NOISE, int WPE, int GLUE, bool SPLIT>
-__device__ __forceinline__ void env_flow(char* const smem, char* const smem_pass, const int wv, const int role, const int mode,
+// `zone`: LDS of the glue inputs the pass wave fetches ahead (LEAN_PRE_*, wg_glue_lean.h).
+template <bool NOISE, int WPE, int GLUE, int SPLIT>
+__device__ __forceinline__ void env_flow(char* const smem, char* const smem_pass, float* const zone, const int wv, const int role, const int mode,
                                          const float* __restrict__ actions, const uint8_t* __restrict__ mask, const int chunk, EnvFlowOut& out) {
     const int tid = threadIdx.x & 63, e = blockIdx.x;
     int N, F, NS, NL;
@@ -209,7 +211,7 @@ __device__ __forceinline__ void env_flow(char* const smem, char* const smem_pass
         if (SPLIT && role == 1) {
             // (the pass wave: its flag down, and every word it has requested in its registers, before the barrier lets the main
             // waves go on — they rewrite some of those words at their ends)
-            if (tid == 0) *reinterpret_cast<int*>(smem + WG_ENV_OFF_HDR) = 0;
+            if (tid == 0) { *reinterpret_cast<int*>(smem + WG_ENV_OFF_HDR) = 0; if (GLUE != 0 && (SPLIT == 1 || wv == 0)) reinterpret_cast<int*>(zone)[LEAN_PRE_FLAG] = 0; }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
         if (WPE == 2) {
@@ -219,6 +221,30 @@ __device__ __forceinline__ void env_flow(char* const smem, char* const smem_pass
             // background plan — must agree).  Every prologue load has been requested by now: the barrier adds no round trip.
             asm volatile("" : "+s"(env_live), "+s"(env_done), "+s"(env_shadow_iters), "+s"(env_steps_done), "+s"(env_timestep), "+s"(env_time_max_live) : : "memory");
             asm volatile("s_barrier" ::: "memory");
+        }
+        if (SPLIT && role == 1 && GLUE != 0 && c == env_live) {
+            // The glue's step-independent inputs, fetched now — the main wave's glue then has no load on its common path: the old
+            // window sums and leaving samples of the glue lane's turbine, the deque entries this step's powers replace, the
+            // metrics.  Nothing in this launch writes them before the glue does (the rings' leaving slots are not the slot the
+            // step pushes into: a ring holds one sample more than its deque).
+            const EnvKArgsPtr kz = (EnvKArgsPtr)wg_cold_args();
+            const WgParams& zp = *(const WgParams*)&kz->gp;
+            const WgPtrs& zd = *(const WgPtrs*)&kz->gd;
+#define WG_HDR_Z(f) __builtin_amdgcn_readlane(hw, (int)(offsetof(WgEnv, f) / 4))
+            const int z_np = WG_HDR_Z(n_pushed_live), z_fn = WG_HDR_Z(farm_pow_n), z_bn = WG_HDR_Z(base_pow_n);
+#undef WG_HDR_Z
+            const int PA = zp.power_avg;
+            const SumsRaw zr = wg_sums_load<false, false>(zp, zd, e, e * 2 + env_live, tid < N ? tid : 0, z_np);
+            const float z_fo = zd.farm_pow[(size_t)e * PA + z_fn % PA];
+            const float z_bo = F == 2 ? zd.base_pow[(size_t)e * PA + z_bn % PA] : 0.f;
+            const float z_met = tid < WG_N_METRICS ? zd.metrics[(size_t)e * WG_N_METRICS + tid] : 0.f;
+            double* const zs = reinterpret_cast<double*>(zone);
+#pragma unroll
+            for (int sI = 0; sI < WG_N_CH; ++sI) { zs[LEAN_PRE_S(sI, tid)] = zr.S[sI]; zone[LEAN_PRE_LV(sI, tid)] = zr.lv[sI]; }
+            zone[LEAN_PRE_MET(tid)] = z_met;
+            if (tid == 0) { zone[LEAN_PRE_FOLD] = z_fo; zone[LEAN_PRE_BOLD] = z_bo; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (tid == 0) env_flag_set(reinterpret_cast<int*>(zone) + LEAN_PRE_FLAG);
         }
         out.env_live = env_live;
         out.truncates = env_timestep >= env_time_max_live;
@@ -240,6 +266,7 @@ __device__ __forceinline__ void env_flow(char* const smem, char* const smem_pass
             // background context's wave sees its own, the live wave gets it through LDS after the barrier)
             const int bg_pending = WPE == 2 ? (is_live_c ? 0 : __shfl(init_pending, 0, 64)) : __shfl(init_pending, (env_live ^ 1) * F * N, 64);
             out.bg_init_pending = autoreset && bg_pending;
+            if (SPLIT == 2 && role == 1 && out.bg_init_pending) return;      // (an episode set-up in this launch: the context runs unsplit)
             if (autoreset && bg_pending && WPE == 1 && (WG_ENV_DEFER_INIT != 0) && !out.truncates) {
                 // rare path (one context per truncation): the retired context's next episode is set up AFTER this wave's step
                 // (below) — its background lanes rest in this launch, the set-up needs no reload of the wave's state, and the
@@ -282,7 +309,7 @@ __device__ __forceinline__ void env_flow(char* const smem, char* const smem_pass
         if (SPLIT) {
             // exactly one flow step for every slot of the wave that steps at all, no episode set-up in this launch
             const bool two = valid && role_dev && budget >= 2;
-            split_on = mode == WG_MODE_STEP && k0->p.K == 1 && is_live_c && !defer_init && !__ballot(two);
+            split_on = mode == WG_MODE_STEP && k0->p.K == 1 && (is_live_c || (SPLIT == 2 && !out.bg_init_pending)) && !defer_init && !__ballot(two);
             if (role == 1 && !split_on) return;
         }
         if (WPE == 2 && valid && t == 0) {      // (what the other wave's glue reads of this one, also if it has nothing to do)
@@ -878,6 +905,10 @@ __device__ __forceinline__ void env_flow(char* const smem, char* const smem_pass
                         const int H = kc->p.hlen[ch];
                         rbase[(unsigned)(kc->p.ring_off[ch] + fast_mod(n_pushed, H, kc->p.inv_hlen[ch]) * N + t)] = val[ch];      // (time-major: WgRing)
                     }
+                    if (SPLIT) {      // (what the glue would read back from the rings)
+#pragma unroll
+                        for (int ch = 0; ch < WG_N_CH; ++ch) out.g_nw[ch] = val[ch];
+                    }
                     // stage the pushed values for the farm-level mean / mean / sum
                     sws = val[0]; swd = val[1]; sp_ = val[3];
                 } else {
@@ -973,6 +1004,10 @@ __device__ __forceinline__ void env_flow(char* const smem, char* const smem_pass
             if (farm == F - 1) cx.pend_base_n = my.pend_base_n;
         }
     }
+    if (SPLIT) {      // (the running episode's main wave: lane t of the agent farm is the glue's lane t)
+        out.g_yaw = yaw; out.g_old = oyaw; out.g_pw = tpow;
+        out.g_pwb = F == 2 ? __shfl(tpow, min(tid + N, 63), 64) : 0.f;
+    }
     WG_STAMP(8);
     // A background episode whose development is complete: its window sums and first observation are prepared for the swap
     // (wg_first_obs, see k_flow) — in the launch AFTER the one that completed it (WG_ENV_FIRST_OBS_LATER; development ends
@@ -1012,8 +1047,8 @@ __device__ __forceinline__ void env_flow(char* const smem, char* const smem_pass
 // k_flow_env<NOISE, 1 / 2>: step() as ONE launch — the env's wave runs its glue (lean_step: sums-mode handles without TI /
 // farm-level entries; 2 = with the per-agent observation buffer of the PettingZoo facade) as the tail of its flow step.  No
 // cross-workgroup dependency: the wave owns both contexts of its env.  (Wind_Farm_Env.py:920-1034 in one kernel.)
-template <bool NOISE, int GLUE, int WPE, bool SPLIT = false>
-__global__ void __launch_bounds__(64 * (WPE + (SPLIT ? 1 : 0)), WG_ENV_WAVES)
+template <bool NOISE, int GLUE, int WPE, int SPLIT = 0>
+__global__ void __launch_bounds__(64 * (WPE + SPLIT), WG_ENV_WAVES)
 k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __restrict__ actions,
            const uint8_t* __restrict__ mask, const int chunk, const WgParams gp_, const WgPtrs gd_,
            float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out,
@@ -1027,16 +1062,19 @@ k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __res
     const int wv4 = WPE == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     // (SPLIT: wave 2 = the pass wave of the running episode's context — which one, it reads from the env's header first: the main
     // waves cannot rewrite it before the prologue's workgroup barrier, where this wave arrives with its loads done)
+    // (SPLIT 2: waves 2, 3 = the pass waves of contexts 0, 1)
     int wv = wv4, role = 0;
-    if (SPLIT && wv4 == 2) {
+    if (SPLIT == 1 && wv4 == 2) {
         role = 1;
         wv = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(wg_cold_args()->d.env + blockIdx.x)[offsetof(WgEnv, live) / 4]) & 1;
     }
+    if (SPLIT == 2) { wv = wv4 & 1; role = wv4 >> 1; }
     const int lds_wave = WPE == 2 ? wg_cold_args()->p.env_lds : 0;
     char* const sm = smem + wv4 * lds_wave;
-    char* const sm_pass = smem + 2 * lds_wave;
+    char* const sm_pass = smem + (SPLIT == 2 ? 2 + wv : 2) * lds_wave;
+    float* const zone = SPLIT ? reinterpret_cast<float*>(smem + (2 + SPLIT) * lds_wave) : nullptr;
     EnvFlowOut fo;
-    env_flow<NOISE, WPE, GLUE, SPLIT>(sm, sm_pass, wv, role, mode, actions, mask, chunk, fo);
+    env_flow<NOISE, WPE, GLUE, SPLIT>(sm, sm_pass, zone, wv, role, mode, actions, mask, chunk, fo);
     if (SPLIT && role == 1) {      // (a pass wave: the workgroup barrier of a truncating step, nothing else)
         if (GLUE != 0 && fo.truncates) { __builtin_amdgcn_s_waitcnt(0x0070); __syncthreads(); }
         return;
@@ -1085,6 +1123,16 @@ k_flow_env(const FlowP p_, const FlowPtrs d_, const int mode, const float* __res
             fz.bg_init_pending = WPE == 2 ? 0 : fo.bg_init_pending;
             fz.plan_elsewhere = WPE == 2;
             fz.hw = reinterpret_cast<const int*>(sm + WG_ENV_OFF_HDR)[threadIdx.x & 31];
+            fz.pre = nullptr;
+            if (SPLIT) {
+                // the glue's inputs: the step's own from this wave's registers, the rest from the pass wave's fetch (long done)
+                if (!env_flag_wait(reinterpret_cast<int*>(zone) + LEAN_PRE_FLAG)) atomicOr(kg->d.status, WG_STATUS_BIT_STATE);
+                const int gl = (int)(threadIdx.x & 63), own = gl < kg->p.N ? gl : 0;
+                fz.pre = zone;
+#pragma unroll
+                for (int ch = 0; ch < WG_N_CH; ++ch) fz.nw[ch] = __shfl(fo.g_nw[ch], own, 64);
+                fz.yaw = fo.g_yaw; fz.old_yaw = fo.g_old; fz.pw = fo.g_pw; fz.pwb = fo.g_pwb;
+            }
             WG_STAMP(12);
             lean_step<GLUE == 2, false, true>(*(const WgParams*)&kg->gp, *(const WgPtrs*)&kg->gd, kg->d.gp, kg->d.gd, (int)blockIdx.x,
                                               (int)(threadIdx.x & 63), kg->obs, kg->reward, kg->trunc, kg->final_obs, nullptr, fz);
@@ -1127,9 +1175,10 @@ extern "C" void wg_launch_step_env(const FlowP* p, const FlowPtrs* d, const WgPa
     const size_t lds = (size_t)p->env_lds * wpe;
 #define WG_STEP_ENV(NZ, G, W) hipLaunchKernelGGL((k_flow_env<NZ, G, W>), dim3(grid), dim3(64 * W), lds, st, *p, *d, (int)WG_MODE_STEP, actions, \
                                                  (const uint8_t*)nullptr, 0, *gp, *gd, obs, reward, trunc, final_obs)
-#define WG_STEP_ENV_S(NZ, G) hipLaunchKernelGGL((k_flow_env<NZ, G, 2, true>), dim3(grid), dim3(192), (size_t)p->env_lds * 3, st, *p, *d, (int)WG_MODE_STEP, actions, \
-                                                (const uint8_t*)nullptr, 0, *gp, *gd, obs, reward, trunc, final_obs)
-#define WG_STEP_ENV_W(NZ, G) do { if (wpe == 2 && p->env_split) WG_STEP_ENV_S(NZ, G); else if (wpe == 2) WG_STEP_ENV(NZ, G, 2); else WG_STEP_ENV(NZ, G, 1); } while (0)
+#define WG_STEP_ENV_S(NZ, G, SP) hipLaunchKernelGGL((k_flow_env<NZ, G, 2, SP>), dim3(grid), dim3(64 * (2 + SP)), (size_t)p->env_lds * (2 + SP) + LEAN_PRE_BYTES, st, \
+                                                    *p, *d, (int)WG_MODE_STEP, actions, (const uint8_t*)nullptr, 0, *gp, *gd, obs, reward, trunc, final_obs)
+#define WG_STEP_ENV_W(NZ, G) do { if (wpe == 2 && p->env_split == 2) WG_STEP_ENV_S(NZ, G, 2); else if (wpe == 2 && p->env_split == 1) WG_STEP_ENV_S(NZ, G, 1); \
+                                  else if (wpe == 2) WG_STEP_ENV(NZ, G, 2); else WG_STEP_ENV(NZ, G, 1); } while (0)
     if (gd->multi_out) { if (p->noise) WG_STEP_ENV_W(true, 2); else WG_STEP_ENV_W(false, 2); }
     else { if (p->noise) WG_STEP_ENV_W(true, 1); else WG_STEP_ENV_W(false, 1); }
 #undef WG_STEP_ENV_W

@@ -189,4 +189,7 @@ struct EnvFlowOut {          // what the flow part hands to the glue tail of k_s
     int steps_done, time_max_live;   // the env header as the prologue read it (before any wave of this launch can have written it): what
                               // the background context's wave plans its next share from (WPE 2)
     int rounds, first_obs;    // (WG_TIMELINE builds: flow rounds taken, first observation of a completed background episode built)
+    // (k_flow_env with a pass wave, the running episode's main wave) per-lane values of the step for the glue: the samples the lane's
+    // agent-farm turbine pushed into its rings, its yaw before / after, its power and its baseline twin's
+    float g_nw[WG_N_CH], g_yaw, g_old, g_pw, g_pwb;
 };

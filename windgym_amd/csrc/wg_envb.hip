@@ -1105,6 +1105,7 @@ k_flow_envb(const FlowP p_, const FlowPtrs d_, const int mode, const float* __re
         if (WPE == 1 || (c_w == fo.env_live && farm_w == 0)) {
             const EnvKArgsPtr kg = (EnvKArgsPtr)wg_cold_args();
             LeanFused fz;
+            fz.pre = nullptr;
             if (WPE == 4) {
                 // the running episode's agent-farm wave: its baseline farm's wave is the next one
                 if (F == 2 && !envb_flag_wait(flags + wv + 1)) { if (lane0) atomicOr(kg->d.status, WG_STATUS_BIT_STATE); }

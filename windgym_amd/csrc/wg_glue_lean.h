@@ -310,7 +310,21 @@ struct LeanFused {
     int plan_elsewhere;       // the background context's own wave plans its next share (WgEnv::shadow_iters) unless the env truncates
     int hw;                   // word (lane & 31) of the env's 128-byte header as the flow part's prologue loaded it: nothing this wave
                               // reads of it has changed since (the header is rewritten only below) — the glue needs no second trip for it
+    // k_flow_env with a pass wave: NO load left on the glue's common path.  What the step produced comes in the flow part's
+    // registers (the lane's pushed samples, yaw before / after, power: own and baseline turbine), what it did not touch — old
+    // window sums, leaving samples, oldest deque entries, metrics — was fetched by the pass wave while the step ran and waits in
+    // LDS (`pre`, layout LEAN_PRE_*; nullptr: the glue loads everything itself).
+    const float* pre;
+    float nw[WG_N_CH], yaw, old_yaw, pw, pwb;
 };
+// LDS zone of the pre-fetched glue inputs (floats; lane = the glue's lane): S[s] as doubles | lv[s] | metrics | deque entries | flag
+#define LEAN_PRE_S(s, lane) ((s) * 64 + (lane))                    // index into (const double*)pre
+#define LEAN_PRE_LV(s, lane) (512 + (s) * 64 + (lane))
+#define LEAN_PRE_MET(lane) (768 + (lane))
+#define LEAN_PRE_FOLD 832
+#define LEAN_PRE_BOLD 833
+#define LEAN_PRE_FLAG 834
+#define LEAN_PRE_BYTES 3584
 
 // One env's glue after its flow step: power deques, window sums -> observation, reward, penalty, truncation, metrics, the
 // background episode's next share, and — at truncation — the swap.  One wave; `lane` 0 .. 63.
@@ -367,19 +381,40 @@ __device__ __forceinline__ void lean_step(const WgParams& p, const WgPtrs& d, co
         nx_prep = d.next_obs_ok != nullptr && wg_uni(d.next_obs_ok[e * 2 + nxt]) != 0;
     }
     // ---- every load of the step, issued together ----
-    const SumsRaw raw = wg_sums_load<GEN>(p, d, e, ctx_id, own, n_pushed_live);
+    const bool pre = FUSED && !GEN && fz.pre != nullptr;
+    SumsRaw raw;
     const size_t tb_a = (size_t)(ctx_id * F) * N;
     float l_yaw = 0.f, l_old = 0.f, l_pow = 0.f, l_powb = 0.f;
-    if (lane < N) {
-        l_yaw = d.yaw[tb_a + lane]; l_old = d.old_yaw[(size_t)e * N + lane]; l_pow = d.power[tb_a + lane];
-        if (F == 2) l_powb = d.power[tb_a + N + lane];
-    }
     const float fp = FUSED ? fz.fp : wg_uni(d.step_farm_pow[e]);
     const float bp = F == 2 ? (FUSED ? fz.bp : wg_uni(d.step_base_pow[e])) : 0.f;
     const int fslot = ev.farm_pow_n % PA, bslot = ev.base_pow_n % PA;      // (counts run over all episodes)
-    const float f_old = wg_uni(fq[fslot]), b_old = F == 2 ? wg_uni(bq[bslot]) : 0.f;
     float* met = d.metrics + (size_t)e * WG_N_METRICS;
-    const float l_met = lane < WG_N_METRICS ? met[lane] : 0.f;
+    float f_old, b_old, l_met;
+    if (pre) {
+        // (the same values the loads below would return: the registers hold what this wave has just stored, the LDS zone what
+        // nothing in this launch writes before the glue does)
+        const double* const zs = reinterpret_cast<const double*>(fz.pre);
+        const unsigned msk = p.sum_mask_t | p.cur_mask_t;
+#pragma unroll
+        for (int s = 0; s < WG_N_SUMS; ++s) { raw.S[s] = 0.0; raw.lv[s] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < WG_N_CH; ++s) {
+            if ((p.sum_mask_t >> s) & 1u) { raw.S[s] = zs[LEAN_PRE_S(s, lane)]; raw.lv[s] = fz.pre[LEAN_PRE_LV(s, lane)]; }
+        }
+#pragma unroll
+        for (int ch = 0; ch < WG_N_CH; ++ch) raw.nw[ch] = ((msk >> ch) & 1u) ? fz.nw[ch] : 0.f;
+        if (lane < N) { l_yaw = fz.yaw; l_old = fz.old_yaw; l_pow = fz.pw; if (F == 2) l_powb = fz.pwb; }
+        f_old = wg_uni(fz.pre[LEAN_PRE_FOLD]); b_old = F == 2 ? wg_uni(fz.pre[LEAN_PRE_BOLD]) : 0.f;
+        l_met = lane < WG_N_METRICS ? fz.pre[LEAN_PRE_MET(lane)] : 0.f;
+    } else {
+        raw = wg_sums_load<GEN>(p, d, e, ctx_id, own, n_pushed_live);
+        if (lane < N) {
+            l_yaw = d.yaw[tb_a + lane]; l_old = d.old_yaw[(size_t)e * N + lane]; l_pow = d.power[tb_a + lane];
+            if (F == 2) l_powb = d.power[tb_a + N + lane];
+        }
+        f_old = wg_uni(fq[fslot]); b_old = F == 2 ? wg_uni(bq[bslot]) : 0.f;
+        l_met = lane < WG_N_METRICS ? met[lane] : 0.f;
+    }
     // background episode: remaining work of its farms (plan of the next step's share), pending set-up flag
     int work = 0;
     if (p.autoreset) {

@@ -227,7 +227,9 @@ __device__ __forceinline__ SumsEnt wg_sums_ent(const WgParams& p, const WgPtrs& 
     return q;
 }
 // the loads of one step's update: `np` pushes are in the sums, the flow kernel has pushed sample number np since
-template <bool GEN>
+// (NEWEST = false: only what does not depend on the step in flight — the old sums and the leaving samples; k_flow_env's pass wave
+// fetches those while the step runs)
+template <bool GEN, bool NEWEST = true>
 __device__ inline SumsRaw wg_sums_load(const WgParams& p, const WgPtrs& d, const int e, const int ctx_id, const int ent, const int np) {
     constexpr int NSL = GEN ? WG_N_SUMS : WG_N_CH;        // (without TI entries only the four window slots exist)
     SumsRaw r;
@@ -239,7 +241,7 @@ __device__ inline SumsRaw wg_sums_load(const WgParams& p, const WgPtrs& d, const
     for (int ch = 0; ch < WG_N_CH; ++ch) {
         const bool need = (((q.sm | q.cm) >> ch) & 1u) || (ch == WG_CH_WS && ti);
         const int off = q.farm ? p.fring_off[ch] : p.ring_off[ch];
-        r.nw[ch] = need ? q.rb[off + wg_umod(np, p.ring_cap[ch], p.ring_magic[ch]) * q.stride] : 0.f;
+        r.nw[ch] = (NEWEST && need) ? q.rb[off + wg_umod(np, p.ring_cap[ch], p.ring_magic[ch]) * q.stride] : 0.f;
     }
 #pragma unroll
     for (int s = 0; s < WG_N_SUMS; ++s) { r.S[s] = 0.0; r.lv[s] = 0.f; }
