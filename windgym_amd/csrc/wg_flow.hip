@@ -727,7 +727,7 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
             // (3) software-pipelined: a thread's NEXT candidate is decoded and its gathers requested before the current one
             // is evaluated (cfg3: ~520 candidates on 256 threads — two or three trips, whose gather round trips would
             // otherwise add up)
-            struct Cand { int t, s2, jp0; float wgt; double dx; uint2 q0, q1; float y0, y1; bool ok; };
+            struct Cand { int t, s2, jp0; float wgt; double dx; uint2 q0, q1; float y0, y1; bool ok, rest; };
             auto lf_issue = [&](Cand& k, const int c) __attribute__((always_inline)) {
                 k.ok = false;
                 if (c >= c1) return;
@@ -754,7 +754,12 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 if (k.jp0 + 1 < 0) r1 = 0;
                 const int i0 = src.roff + r0, i1 = src.roff + r1;
                 k.q0 = pl.rec(i0); k.q1 = pl.rec(i1);      // (the interleaved record the advection pass streams: the pair is 16 contiguous bytes)
-                k.y0 = pl.py[i0]; k.y1 = pl.py[i1];
+                // (a resting chain's particles sit where they were released — at the turbine — and do not move in this step either:
+                // their py is not fetched, as in the single-wave variants; the baseline farms' workgroups gather one line per
+                // candidate instead of two)
+                k.rest = gl_resting(src);
+                k.y0 = 0.f; k.y1 = 0.f;
+                if (!k.rest) { k.y0 = pl.py[i0]; k.y1 = pl.py[i1]; }
                 k.ok = true;
             };
             Cand nxt;
@@ -765,12 +770,12 @@ __device__ __forceinline__ void flow_step(const FlowP& p, const FlowPtrs& d, Tur
                 if (!k.ok) continue;
                 const TurbLds& src = T[k.s2];
                 const int jp0 = k.jp0, jp1 = jp0 + 1;
-                float py0 = k.y0, py1 = k.y1;
+                float py0 = k.rest ? (float)src.yr : k.y0, py1 = k.rest ? (float)src.yr : k.y1;
                 unsigned a0 = k.q0.x, b0_ = k.q0.y, a1 = k.q1.x, b1_ = k.q1.y;
                 if (jp0 < 0) { py0 = (float)src.yr; a0 = pack_a(src.rct, src.rk); b0_ = pack_b(src.rue * ue_inv, src.rhv); }
                 if (jp1 < 0) { py1 = (float)src.yr; a1 = pack_a(src.rct, src.rk); b1_ = pack_b(src.rue * ue_inv, src.rhv); }
-                if (jp0 >= 0 && jp0 < n_valid) py0 = m0_advect(py0, a0, b0_, jp0, s_off_f, p.dpart_f, p.inv_D, p.dt, p.eps0);
-                if (jp1 >= 0 && jp1 < n_valid) py1 = m0_advect(py1, a1, b1_, jp1, s_off_f, p.dpart_f, p.inv_D, p.dt, p.eps0);
+                if (!k.rest && jp0 >= 0 && jp0 < n_valid) py0 = m0_advect(py0, a0, b0_, jp0, s_off_f, p.dpart_f, p.inv_D, p.dt, p.eps0);
+                if (!k.rest && jp1 >= 0 && jp1 < n_valid) py1 = m0_advect(py1, a1, b1_, jp1, s_off_f, p.dpart_f, p.inv_D, p.dt, p.eps0);
                 if (c == 0) WG_STAMP(12);
                 eval_pair(c - c0, 0, k.s2, k.t, k.dx, k.wgt, py0, py1, 0.f, 0.f, a0, a1, b0_, b1_);
                 if (c == 0) WG_STAMP(13);
