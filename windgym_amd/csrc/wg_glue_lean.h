@@ -383,6 +383,10 @@ __device__ __forceinline__ void lean_step(const WgParams& p, const WgPtrs& d, co
     // ---- every load of the step, issued together ----
     const bool pre = FUSED && !GEN && fz.pre != nullptr;
     SumsRaw raw;
+    // (farms with more than 64 turbines, cfg3: the lane's SECOND turbine is requested with the first — the observation loop
+    // below would otherwise take a second memory round trip for it)
+    const bool have2 = !FUSED && lane + WG_WAVE < N;
+    SumsRaw raw2 = {};
     const size_t tb_a = (size_t)(ctx_id * F) * N;
     float l_yaw = 0.f, l_old = 0.f, l_pow = 0.f, l_powb = 0.f;
     const float fp = FUSED ? fz.fp : wg_uni(d.step_farm_pow[e]);
@@ -408,6 +412,7 @@ __device__ __forceinline__ void lean_step(const WgParams& p, const WgPtrs& d, co
         l_met = lane < WG_N_METRICS ? fz.pre[LEAN_PRE_MET(lane)] : 0.f;
     } else {
         raw = wg_sums_load<GEN>(p, d, e, ctx_id, own, n_pushed_live);
+        if (have2) raw2 = wg_sums_load<GEN>(p, d, e, ctx_id, lane + WG_WAVE, n_pushed_live);
         if (lane < N) {
             l_yaw = d.yaw[tb_a + lane]; l_old = d.old_yaw[(size_t)e * N + lane]; l_pow = d.power[tb_a + lane];
             if (F == 2) l_powb = d.power[tb_a + N + lane];
@@ -551,7 +556,10 @@ __device__ __forceinline__ void lean_step(const WgParams& p, const WgPtrs& d, co
     {
         float* o1 = swap_obs ? fin : obs;
         if (o1) {
-            auto get = [&](const int ent) { return wg_sums_apply<GEN>(p, d, ctx_id, ent, wg_sums_load<GEN>(p, d, e, ctx_id, ent, np_step), !swap_obs); };
+            auto get = [&](const int ent) {
+                if (have2 && ent == lane + WG_WAVE) return wg_sums_apply<GEN>(p, d, ctx_id, ent, raw2, !swap_obs);
+                return wg_sums_apply<GEN>(p, d, ctx_id, ent, wg_sums_load<GEN>(p, d, e, ctx_id, ent, np_step), !swap_obs);
+            };
             const ObsIn oi = wg_sums_apply<GEN>(p, d, ctx_id, own, raw, lane < N && !swap_obs);
             build_obs_sums<MULTI, GEN>(p, lane, o1, swap_obs ? nullptr : fin, swap_obs ? nullptr : om, np_step + 1, mscr, oi, get);
         }
