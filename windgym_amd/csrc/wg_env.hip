@@ -617,8 +617,9 @@ __device__ __forceinline__ void env_flow(char* const smem, char* const smem_pass
                     {
                         const int nv = q.n_valid;
                         const float sof = q.s_off_f;
-                        if (jp0 >= 0 && jp0 < nv) py0 = m0_advect(py0, a0, b0_, jp0, sof, dpart_f, inv_D, dt, eps0);
-                        if (jp1 >= 0 && jp1 < nv) py1 = m0_advect(py1, a1, b1_, jp1, sof, dpart_f, inv_D, dt, eps0);
+                        // (a resting chain's particles do not move in this step either: hv = 0 in every record)
+                        if (!cd.rest && jp0 >= 0 && jp0 < nv) py0 = m0_advect(py0, a0, b0_, jp0, sof, dpart_f, inv_D, dt, eps0);
+                        if (!cd.rest && jp1 >= 0 && jp1 < nv) py1 = m0_advect(py1, a1, b1_, jp1, sof, dpart_f, inv_D, dt, eps0);
                     }
                     // interpolation, lateral cut-off, Gaussian deficit at the S rotor points (k_flow: eval_pair)
                     const float wgt = cd.wgt;
